@@ -1,0 +1,269 @@
+/*
+ * srrg2_slam_amd.h -- C ABI of the MI355X-native multi-cue aligner hot path.
+ *
+ * This header is the drop-in boundary of the build.  The reference has no C ABI:
+ * its boundary is a set of C++ classes found by name in the BOSS registry
+ * (S/instances.cpp:21-23,28-84) and configured through PARAM()s.  Every entry
+ * point below cites the reference interface it replaces, using the path
+ * abbreviations of SURVEY.md:
+ *   S/ = srrg2_slam_interfaces/src/srrg2_slam_interfaces/
+ *   T/ = srrg2_slam_interfaces/tests/
+ *
+ * Conventions
+ *  - every function returns an int: 0 on success, <0 on error (replaces the
+ *    reference's `throw std::runtime_error`, e.g. S/registration/aligners/
+ *    multi_aligner_impl.cpp:30,40,49).  srrg2_amd_last_error() returns the text.
+ *  - handles are opaque; one handle = one non-thread-safe object (the reference
+ *    objects are single threaded, SURVEY.md section 8b "Threading").
+ *  - transforms: SE(3) = row-major 3x4 float [R|t] (12 floats);
+ *                SE(2) = row-major 3x3 homogeneous float (9 floats).
+ *    `moving_in_fixed` maps moving-frame points into the fixed frame
+ *    (S/registration/aligners/aligner.h:103-109).
+ *  - clouds are borrowed for the duration of the call only: set_fixed/set_moving
+ *    ingest (copy + reorder) the data into HBM, so the caller may free or reuse
+ *    its buffer on return.  `mem` says where the caller's pointer lives.
+ *  - all arithmetic is float32 / int32 at the interface.
+ */
+#ifndef SRRG2_SLAM_AMD_H
+#define SRRG2_SLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRRG2_AMD_ABI_VERSION 1
+#define SRRG2_MAX_SLICES 8
+
+/* ---- enums -------------------------------------------------------------- */
+
+/* variable flavours of S/registration/aligners/multi_aligner.h:152-158 */
+enum srrg2_variable_kind {
+  SRRG2_SE2_RIGHT       = 0, /* MultiAligner2D   = MultiAlignerBase_<VariableSE2RightAD>           */
+  SRRG2_SE3_EULER_RIGHT = 1, /* MultiAligner3D   = MultiAlignerBase_<VariableSE3EulerRightAD>      */
+  SRRG2_SE3_QUAT_RIGHT  = 2  /* MultiAligner3DQR = MultiAlignerBase_<VariableSE3QuaternionRightAD> */
+};
+
+/* AlignerBase::Status, S/registration/aligners/aligner.h:23-28 (values identical) */
+enum srrg2_status {
+  SRRG2_SUCCESS                    = 0,
+  SRRG2_NOT_ENOUGH_CORRESPONDENCES = 1,
+  SRRG2_NOT_ENOUGH_INLIERS         = 2,
+  SRRG2_FAIL                       = 3
+};
+
+/* which factor a slice linearises (FactorCorrespondenceDriven_ subclasses used through
+ * S/registration/aligners/aligner_slice_processor.h:7,29,44; prior factors through
+ * S/registration/aligners/aligner_slice_odometry_prior.h:9,33) */
+enum srrg2_slice_kind {
+  SRRG2_SLICE_P2P          = 0, /* point-to-point   (SE2: 2x3 J, SE3: 3x6 J)            */
+  SRRG2_SLICE_P2PLANE      = 1, /* point-to-plane   (1x3 / 1x6 J), needs fixed normals  */
+  SRRG2_SLICE_REPROJECTION = 2, /* pinhole reprojection error (2x6 J), SE3 only         */
+  SRRG2_SLICE_PRIOR        = 3  /* unary prior on the estimate (AlignerSliceProcessorPrior_) */
+};
+
+/* concrete CorrespondenceFinder_ behind S/registration/correspondence_finder.h:56 */
+enum srrg2_finder_kind {
+  SRRG2_FINDER_NONE       = 0, /* prior slices                                        */
+  SRRG2_FINDER_NN_GATED   = 1, /* exact nearest neighbour within max_distance         */
+  SRRG2_FINDER_PROJECTIVE = 2  /* pinhole projection into the organised fixed cloud   */
+};
+
+/* robustifier bound per slice (S/registration/aligners/aligner_slice_processor_base.h:34-38,
+ * RobustifierClamp swap in multi_aligner_impl.cpp:184-201) */
+enum srrg2_robustifier_kind {
+  SRRG2_ROBUST_NONE      = 0,
+  SRRG2_ROBUST_CLAMP     = 1, /* w = 0            for chi >= threshold */
+  SRRG2_ROBUST_SATURATED = 2, /* w = thr/chi      for chi >= threshold */
+  SRRG2_ROBUST_CAUCHY    = 3  /* w = 1/(1+chi/thr) for chi >= threshold */
+};
+
+/* FactorStats::Status as used by multi_aligner_impl.cpp:244 */
+enum srrg2_factor_status {
+  SRRG2_FACTOR_INLIER     = 0,
+  SRRG2_FACTOR_KERNELIZED = 1, /* robustifier fired: counted in num_outliers */
+  SRRG2_FACTOR_SUPPRESSED = 2  /* residual could not be evaluated            */
+};
+
+enum srrg2_mem { SRRG2_MEM_HOST = 0, SRRG2_MEM_DEVICE = 1 };
+
+/* error codes (<0) */
+enum srrg2_error {
+  SRRG2_OK            = 0,
+  SRRG2_E_INVALID     = -1, /* bad argument / misuse (reference: std::runtime_error) */
+  SRRG2_E_NO_DEVICE   = -2, /* no usable HIP device: the product path never falls back to CPU */
+  SRRG2_E_HIP         = -3, /* a HIP runtime call failed */
+  SRRG2_E_UNSUPPORTED = -4,
+  SRRG2_E_STATE       = -5  /* e.g. compute() before clouds were set */
+};
+
+/* ---- PODs --------------------------------------------------------------- */
+
+/* srrg2_core::Correspondence: {int fixed_idx; int moving_idx; float response}
+ * (field names S/trackers/tracker_slice_processor_impl.cpp:51-55, ctor order
+ * S/registration/loop_detector/multi_loop_detector_hbst_impl.cpp:183-191). 12 bytes. */
+typedef struct srrg2_correspondence {
+  int32_t fixed_idx;
+  int32_t moving_idx;
+  float   response; /* NN finder: squared distance; projective finder: depth difference */
+} srrg2_correspondence;
+
+/* srrg2_solver::IterationStats, the fields the reference reads:
+ * num_inliers/num_outliers/chi_inliers (multi_aligner_impl.cpp:81-82,
+ * aligner_termination_criteria_impl.cpp:30-32, multi_loop_detector_hbst_impl.cpp:388-391). */
+typedef struct srrg2_iteration_stats {
+  int32_t iteration;           /* index in the stats vector of this compute()             */
+  int32_t num_inliers;         /* factors whose robustifier did not fire (priors included) */
+  int32_t num_outliers;        /* factors whose robustifier fired                          */
+  int32_t num_suppressed;      /* factors whose residual was not evaluable                 */
+  int32_t num_correspondences; /* MultiAlignerBase_::numCorrespondences() at that iteration */
+  int32_t solver_status;       /* 0 = SolverBase::Success, 1 = linear system not solvable  */
+  float   chi_inliers;
+  float   chi_outliers;
+} srrg2_iteration_stats;
+
+/* PARAMs of AlignerBase + MultiAlignerBase_ (aligner.h:30; multi_aligner.h:45-57) */
+typedef struct srrg2_aligner_params {
+  int32_t max_iterations;                   /* default 10 */
+  int32_t min_num_inliers;                  /* default 10 */
+  int32_t enable_inlier_only_runs;          /* default 0  */
+  int32_t keep_only_inlier_correspondences; /* default 0  */
+} srrg2_aligner_params;
+
+/* PARAMs of AlignerTerminationCriteriaStandard_ (aligner_termination_criteria.h:40-56) */
+typedef struct srrg2_termination_params {
+  int32_t window_size;               /* default 5   */
+  int32_t num_correspondences_range; /* default 20  */
+  int32_t num_inliers_range;         /* default 20  */
+  int32_t num_outliers_range;        /* default 20  */
+  float   chi_epsilon;               /* default 0.2 */
+} srrg2_termination_params;
+
+/* One AlignerSliceProcessor_ / AlignerSliceProcessorPrior_ with its finder and robustifier
+ * (aligner_slice_processor.h:56-66,133-150; aligner_slice_processor_base.h:34-53;
+ * aligner_slice_odometry_prior.h:17-21,41-45). */
+typedef struct srrg2_slice_config {
+  int32_t kind;                      /* srrg2_slice_kind */
+  int32_t finder;                    /* srrg2_finder_kind */
+  int32_t robustifier;               /* srrg2_robustifier_kind */
+  float   robustifier_chi_threshold;
+  int32_t min_num_correspondences;   /* strict '>' test, aligner_slice_processor_impl.cpp:77-79 */
+  float   finder_max_distance;       /* NN gate [m]; projective: max |depth difference| [m] */
+  float   finder_normal_cos;         /* accept only if n_f . (R n_m) > this; <= -1 disables */
+  float   finder_cell_size;          /* search-grid cell edge [m]; 0 = choose automatically */
+  float   sensor_in_robot[12];       /* setSensorInRobot (aligner_slice_processor.h:149); SE2: first 9 */
+  float   camera_matrix[9];          /* row-major K, projective finder / reprojection factor */
+  int32_t image_rows;
+  int32_t image_cols;
+  float   depth_min;                 /* projective finder: accepted depth range of the moving point */
+  float   depth_max;
+  float   prior_information_diag[6]; /* diagonal_info_matrix; SE2 uses the first 3 */
+  int32_t prior_sets_initial_guess;  /* init() overrides the guess (aligner_slice_odometry_prior.cpp:19,34) */
+} srrg2_slice_config;
+
+/* result record of one alignment of a batch (loop body of
+ * S/registration/loop_detector/multi_loop_detector_brute_force_impl.cpp:64-91) */
+typedef struct srrg2_batch_result {
+  float   moving_in_fixed[12];
+  int32_t status;              /* srrg2_status */
+  int32_t num_iterations;      /* IterationStats entries produced */
+  srrg2_iteration_stats last;  /* iterationStats().back() */
+} srrg2_batch_result;
+
+typedef struct srrg2_aligner_s* srrg2_aligner_h;
+
+/* ---- library ------------------------------------------------------------ */
+
+int         srrg2_amd_abi_version(void);
+const char* srrg2_amd_last_error(void);
+/* number of visible HIP devices (<0 on error) */
+int         srrg2_amd_device_count(void);
+
+/* ---- aligner: MultiAlignerBase_<Variable> -------------------------------- */
+
+/* ctor of MultiAlignerBase_ (multi_aligner.h:60-66): one variable, graph id 0,
+ * solver max_iterations forced to [1].  `device` = HIP device ordinal. */
+int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out);
+int srrg2_aligner_destroy(srrg2_aligner_h h);
+
+void srrg2_aligner_default_params(srrg2_aligner_params* p);
+void srrg2_termination_default_params(srrg2_termination_params* p);
+void srrg2_slice_default_config(srrg2_slice_config* c, int variable_kind);
+
+/* param_max_iterations / min_num_inliers / enable_inlier_only_runs /
+ * keep_only_inlier_correspondences (aligner.h:30, multi_aligner.h:45-57) */
+int srrg2_aligner_set_params(srrg2_aligner_h h, const srrg2_aligner_params* p);
+/* param_termination_criteria (aligner.h:31-35); NULL = run max_iterations */
+int srrg2_aligner_set_termination(srrg2_aligner_h h, const srrg2_termination_params* p);
+/* param_slice_processors.pushBack (multi_aligner.h:34-37); sets _slices_changed_flag */
+int srrg2_aligner_add_slice(srrg2_aligner_h h, const srrg2_slice_config* c, int* slice_idx_out);
+int srrg2_aligner_clear_slices(srrg2_aligner_h h);
+/* swap a slice's robustifier (slice->param_robustifier.setValue, multi_aligner_impl.cpp:197) */
+int srrg2_aligner_set_robustifier(srrg2_aligner_h h, int slice_idx, int kind, float chi_threshold);
+
+/* MultiAlignerBase_::setFixed / setMoving -> slice->bindFixed/bindMoving
+ * (multi_aligner_impl.cpp:8-24; aligner_slice_processor_impl.cpp:82-93).
+ * coords: n points of dim floats (dim 2 for SE2, 3 for SE3) `coord_stride_bytes` apart;
+ * normals may be NULL.  Marks the finder's search structure stale
+ * (correspondence_finder.h:80-91). */
+int srrg2_aligner_set_fixed(srrg2_aligner_h h, int slice_idx, const float* coords,
+                            int coord_stride_bytes, const float* normals,
+                            int normal_stride_bytes, int n, int mem);
+int srrg2_aligner_set_moving(srrg2_aligner_h h, int slice_idx, const float* coords,
+                             int coord_stride_bytes, const float* normals,
+                             int normal_stride_bytes, int n, int mem);
+
+/* prior slices: the measurement the factor gets in setupFactor()
+ * (aligner_slice_odometry_prior.cpp:6-14,23-29; aligner_slice_motion_model.hpp:75-79) */
+int srrg2_aligner_set_prior_measurement(srrg2_aligner_h h, int slice_idx, const float* T);
+
+/* setMovingInFixed / movingInFixed (multi_aligner_impl.cpp:27-44) */
+int srrg2_aligner_set_moving_in_fixed(srrg2_aligner_h h, const float* T);
+int srrg2_aligner_get_moving_in_fixed(srrg2_aligner_h h, float* T_out);
+
+/* MultiAlignerBase_::compute() (multi_aligner_impl.cpp:47-95): blocking; on return the
+ * estimate, status and iteration stats are host visible. */
+int srrg2_aligner_compute(srrg2_aligner_h h, int* status_out);
+/* AlignerBase::status() (aligner.h:51-53) */
+int srrg2_aligner_status(srrg2_aligner_h h, int* status_out);
+
+/* Aligner_::iterationStats() (aligner.h:115-117): all iterations of the last compute().
+ * *n_inout: capacity of buf on entry, number of entries on return (buf may be NULL to query). */
+int srrg2_aligner_get_iteration_stats(srrg2_aligner_h h, srrg2_iteration_stats* buf, int* n_inout);
+
+/* MultiAlignerBase_::numCorrespondences() (multi_aligner_impl.cpp:275-285): priors count 1 */
+int srrg2_aligner_num_correspondences(srrg2_aligner_h h, int* n_out);
+/* slice->correspondences() (aligner_slice_processor.h:92-98), after pruning if enabled;
+ * ascending moving_idx. */
+int srrg2_aligner_get_correspondences(srrg2_aligner_h h, int slice_idx, srrg2_correspondence* buf,
+                                      int* n_inout);
+/* solver->measurementStats() of the last iteration for one cue slice
+ * (multi_aligner_impl.cpp:215,244): one srrg2_factor_status byte per correspondence of the
+ * un-pruned vector of the last iteration. */
+int srrg2_aligner_get_factor_status(srrg2_aligner_h h, int slice_idx, uint8_t* buf, int* n_inout);
+
+/* K independent alignments against the fixed scene already set on `h`
+ * (MultiLoopDetectorBruteForce_::compute, multi_loop_detector_brute_force_impl.cpp:63-91;
+ * MultiRelocalizer_::compute, multi_relocalizer_impl.cpp:74-88).  Semantically equal to K x
+ * { set_moving(slice 0, k); set_moving_in_fixed(guess k); compute() }.  All moving clouds are
+ * given as one concatenated array with offsets[K+1] (in points). */
+int srrg2_aligner_compute_batch(srrg2_aligner_h h, int K, const float* coords,
+                                int coord_stride_bytes, const float* normals,
+                                int normal_stride_bytes, const int32_t* offsets, int mem,
+                                const float* guesses /* K x 12 (or 9) */,
+                                srrg2_batch_result* results);
+
+/* ---- measurement hooks (no reference counterpart: the reference profiles with
+ * PROFILE_TIME scopes outside the aligner) ------------- */
+
+/* When enabled, every launch of the fused ICP step kernel is bracketed by a pair of HIP events
+ * on the launch stream; get returns the accumulated time and launch count since the last reset. */
+int srrg2_aligner_profile_enable(srrg2_aligner_h h, int enable);
+int srrg2_aligner_profile_get(srrg2_aligner_h h, double* step_kernel_ms, int64_t* step_kernel_launches,
+                              int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRRG2_SLAM_AMD_H */

@@ -1,0 +1,218 @@
+"""Python host-side mirror of the reference aligner interface over the C ABI.
+
+``MultiAligner`` follows ``MultiAlignerBase_`` (S/registration/aligners/multi_aligner.h:19-150,
+multi_aligner_impl.cpp:8-303): same method names (snake_case), argument meaning and error
+behaviour (misuse raises ``RuntimeError`` where the reference throws ``std::runtime_error``;
+algorithmic outcomes are ``status`` values 0..3 of aligner.h:23-28).
+
+The class is a thin marshalling layer: every call goes straight through the C ABI declared in
+include/srrg2_slam_amd.h.  It is parametrised by a *backend* (a loaded shared library plus the
+symbol prefix) so that the test-side oracle binding can reuse the marshalling code; the product
+backend is ``_capi.backend()`` and raises if the HIP library is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+
+
+class Backend:
+    """A loaded C library exporting the aligner call surface under ``prefix``."""
+
+    def __init__(self, lib, prefix, err_fn, needs_device):
+        self.lib = lib
+        self.prefix = prefix
+        self._err = err_fn
+        self.needs_device = needs_device
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def last_error(self):
+        msg = self._err()
+        return msg.decode() if msg else ""
+
+
+def _as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class MultiAligner:
+    """One ``MultiAlignerBase_<Variable>``: one estimate, N slices, one Gauss-Newton solver."""
+
+    def __init__(self, backend, variable_kind=abi.SE3_QUAT_RIGHT, device=0):
+        self._b = backend
+        self.variable_kind = variable_kind
+        self.dim = abi.point_dim(variable_kind)
+        self.tsize = abi.transform_size(variable_kind)
+        self._h = C.c_void_p()
+        if backend.needs_device:
+            rc = backend.fn("create")(C.c_int(variable_kind), C.c_int(device), C.byref(self._h))
+        else:
+            rc = backend.fn("create")(C.c_int(variable_kind), C.byref(self._h))
+        self._check(rc)
+        self.slices = []
+
+    # -- plumbing -----------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("%s (code %d)" % (self._b.last_error(), rc))
+
+    def close(self):
+        if self._h:
+            self._b.fn("destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration (PARAMs) -----------------------------------------------------
+    def set_params(self, max_iterations=10, min_num_inliers=10, enable_inlier_only_runs=False,
+                   keep_only_inlier_correspondences=False):
+        p = abi.AlignerParams(max_iterations, min_num_inliers, int(enable_inlier_only_runs),
+                              int(keep_only_inlier_correspondences))
+        self._check(self._b.fn("set_params")(self._h, C.byref(p)))
+
+    def set_termination_criteria(self, params):
+        """``params``: abi.TerminationParams or None (param_termination_criteria, aligner.h:31-35)."""
+        if params is None:
+            self._check(self._b.fn("set_termination")(self._h, None))
+        else:
+            self._check(self._b.fn("set_termination")(self._h, C.byref(params)))
+
+    def add_slice(self, config):
+        idx = C.c_int(-1)
+        self._check(self._b.fn("add_slice")(self._h, C.byref(config), C.byref(idx)))
+        self.slices.append(config)
+        return idx.value
+
+    def clear_slices(self):
+        self._check(self._b.fn("clear_slices")(self._h))
+        self.slices = []
+
+    def set_robustifier(self, slice_idx, kind, chi_threshold):
+        self._check(self._b.fn("set_robustifier")(self._h, C.c_int(slice_idx), C.c_int(kind),
+                                                  C.c_float(chi_threshold)))
+
+    # -- data ---------------------------------------------------------------------
+    def _set_cloud(self, which, slice_idx, coords, normals):
+        coords = _as_f32(coords)
+        assert coords.ndim == 2 and coords.shape[1] == self.dim, coords.shape
+        n = coords.shape[0]
+        nptr, nstride = None, 0
+        if normals is not None:
+            normals = _as_f32(normals)
+            assert normals.shape == coords.shape
+            nptr, nstride = _fptr(normals), normals.strides[0]
+        self._check(self._b.fn(which)(self._h, C.c_int(slice_idx), _fptr(coords), C.c_int(coords.strides[0]),
+                                      nptr, C.c_int(nstride), C.c_int(n), C.c_int(abi.MEM_HOST)))
+
+    def set_fixed(self, slice_idx, coords, normals=None):
+        self._set_cloud("set_fixed", slice_idx, coords, normals)
+
+    def set_moving(self, slice_idx, coords, normals=None):
+        self._set_cloud("set_moving", slice_idx, coords, normals)
+
+    def set_cloud_device(self, which, slice_idx, coords_ptr, coord_stride, normals_ptr, normal_stride, n):
+        """Device-resident input (``which`` = 'set_fixed' | 'set_moving'); pointers are raw ints."""
+        self._check(self._b.fn(which)(self._h, C.c_int(slice_idx), C.cast(coords_ptr, C.POINTER(C.c_float)),
+                                      C.c_int(coord_stride),
+                                      C.cast(normals_ptr, C.POINTER(C.c_float)) if normals_ptr else None,
+                                      C.c_int(normal_stride), C.c_int(n), C.c_int(abi.MEM_DEVICE)))
+
+    def set_prior_measurement(self, slice_idx, T):
+        T = _as_f32(T).reshape(-1)
+        assert T.size == self.tsize
+        self._check(self._b.fn("set_prior_measurement")(self._h, C.c_int(slice_idx), _fptr(T)))
+
+    def set_moving_in_fixed(self, T):
+        T = _as_f32(T).reshape(-1)
+        assert T.size == self.tsize
+        self._check(self._b.fn("set_moving_in_fixed")(self._h, _fptr(T)))
+
+    def moving_in_fixed(self):
+        T = np.zeros(self.tsize, dtype=np.float32)
+        self._check(self._b.fn("get_moving_in_fixed")(self._h, _fptr(T)))
+        return T.reshape(3, 3) if self.dim == 2 else T.reshape(3, 4)
+
+    # -- compute --------------------------------------------------------------------
+    def compute(self):
+        st = C.c_int(-1)
+        self._check(self._b.fn("compute")(self._h, C.byref(st)))
+        return st.value
+
+    def status(self):
+        st = C.c_int(-1)
+        self._check(self._b.fn("status")(self._h, C.byref(st)))
+        return st.value
+
+    def iteration_stats(self):
+        n = C.c_int(0)
+        self._check(self._b.fn("get_iteration_stats")(self._h, None, C.byref(n)))
+        buf = (abi.IterationStats * max(n.value, 1))()
+        n2 = C.c_int(n.value)
+        self._check(self._b.fn("get_iteration_stats")(self._h, buf, C.byref(n2)))
+        return [buf[i].as_dict() for i in range(n2.value)]
+
+    def num_correspondences(self):
+        n = C.c_int(0)
+        self._check(self._b.fn("num_correspondences")(self._h, C.byref(n)))
+        return n.value
+
+    def correspondences(self, slice_idx):
+        """(C,) structured array with fields fixed_idx, moving_idx, response."""
+        n = C.c_int(0)
+        self._check(self._b.fn("get_correspondences")(self._h, C.c_int(slice_idx), None, C.byref(n)))
+        dt = np.dtype([("fixed_idx", np.int32), ("moving_idx", np.int32), ("response", np.float32)])
+        out = np.zeros(max(n.value, 1), dtype=dt)
+        n2 = C.c_int(n.value)
+        self._check(self._b.fn("get_correspondences")(self._h, C.c_int(slice_idx),
+                                                      out.ctypes.data_as(C.POINTER(abi.Correspondence)),
+                                                      C.byref(n2)))
+        return out[:n2.value]
+
+    def factor_status(self, slice_idx):
+        n = C.c_int(0)
+        self._check(self._b.fn("get_factor_status")(self._h, C.c_int(slice_idx), None, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint8)
+        n2 = C.c_int(n.value)
+        self._check(self._b.fn("get_factor_status")(self._h, C.c_int(slice_idx),
+                                                    out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n2)))
+        return out[:n2.value]
+
+    def compute_batch(self, moving_clouds, guesses, moving_normals=None):
+        """K independent alignments against the fixed scene (multi_loop_detector_brute_force_impl.cpp:63-91)."""
+        K = len(moving_clouds)
+        sizes = [int(np.asarray(m).shape[0]) for m in moving_clouds]
+        offsets = np.zeros(K + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum(sizes)
+        coords = _as_f32(np.concatenate([_as_f32(m) for m in moving_clouds], axis=0)) if K else np.zeros(
+            (0, self.dim), np.float32)
+        nptr, nstride = None, 0
+        if moving_normals is not None:
+            normals = _as_f32(np.concatenate([_as_f32(m) for m in moving_normals], axis=0))
+            nptr, nstride = _fptr(normals), normals.strides[0]
+        g = _as_f32(np.asarray(guesses)).reshape(K, self.tsize)
+        res = (abi.BatchResult * max(K, 1))()
+        self._check(self._b.fn("compute_batch")(self._h, C.c_int(K), _fptr(coords), C.c_int(coords.strides[0]),
+                                                nptr, C.c_int(nstride),
+                                                offsets.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                C.c_int(abi.MEM_HOST), _fptr(g), res))
+        out = []
+        for k in range(K):
+            T = np.array(res[k].moving_in_fixed[:self.tsize], dtype=np.float32)
+            out.append({
+                "moving_in_fixed": T.reshape(3, 3) if self.dim == 2 else T.reshape(3, 4),
+                "status": res[k].status,
+                "num_iterations": res[k].num_iterations,
+                "last": res[k].last.as_dict(),
+            })
+        return out

@@ -1,0 +1,221 @@
+"""Seeded synthetic workloads of BASELINE.json's configs.
+
+The reference ships no data files (its tests generate inputs in-test, T/test_motion_model.cpp:24,
+SURVEY.md section 4), so every workload here is generated from a SplitMix64 stream: the same seed
+gives bit-identical float32 arrays on every machine, which is what lets the CPU oracle and the HIP
+path be compared index-for-index.
+
+C1  scan_pair_2d      1000-beam 270deg scan of a 10 m x 8 m room with two boxes, SE(2)
+C2  cloud_pair_3d     100k-pt cloud on an analytic surface + 4 walls, with normals, SE(3)
+C4  batch_3d          K independent C2-style problems (loop-closure candidates)
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed, n):
+    """n uint64 values of the SplitMix64 stream started at ``seed``."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = (np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed, n, lo=0.0, hi=1.0):
+    u = (splitmix64(seed, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return lo + (hi - lo) * u
+
+
+def normal(seed, n, sigma=1.0):
+    """Box-Muller on two SplitMix64 streams."""
+    u1 = np.maximum(uniform(seed, n), 1e-300)
+    u2 = uniform(seed ^ 0x5DEECE66D, n)
+    return sigma * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# ---- transforms (float64 helpers for building ground truth) ---------------------------
+def rpy_to_R(roll, pitch, yaw):
+    cr, sr = np.cos(roll), np.sin(roll)
+    cp, sp = np.cos(pitch), np.sin(pitch)
+    cy, sy = np.cos(yaw), np.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def se3(t, rpy):
+    T = np.zeros((3, 4))
+    T[:, :3] = rpy_to_R(*rpy)
+    T[:, 3] = t
+    return T
+
+
+def se3_inv(T):
+    Ti = np.zeros((3, 4))
+    Ti[:, :3] = T[:, :3].T
+    Ti[:, 3] = -T[:, :3].T @ T[:, 3]
+    return Ti
+
+
+def se3_mul(A, B):
+    C = np.zeros((3, 4))
+    C[:, :3] = A[:, :3] @ B[:, :3]
+    C[:, 3] = A[:, :3] @ B[:, 3] + A[:, 3]
+    return C
+
+
+def se2(tx, ty, theta):
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, -s, tx], [s, c, ty], [0, 0, 1.0]])
+
+
+def identity(dim):
+    return np.eye(3, dtype=np.float32) if dim == 2 else np.eye(3, 4, dtype=np.float32)
+
+
+# ---- C2: analytic surface + walls -----------------------------------------------------
+def _surface(x, y):
+    return 0.3 * np.sin(1.3 * x) * np.cos(0.9 * y)
+
+
+def _surface_normal(x, y):
+    dzdx = 0.3 * 1.3 * np.cos(1.3 * x) * np.cos(0.9 * y)
+    dzdy = -0.3 * 0.9 * np.sin(1.3 * x) * np.sin(0.9 * y)
+    n = np.stack([-dzdx, -dzdy, np.ones_like(x)], axis=1)
+    return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+
+def scene_3d(n, seed, noise_sigma=0.0):
+    """n points (+unit normals) on z = 0.3 sin(1.3x) cos(0.9y), (x,y) in [-5,5]^2, plus 4 walls.
+
+    80 % of the points lie on the surface (stratified jitter), 5 % on each wall
+    (x = +-5, y = +-5, z in [-0.5, 2])."""
+    n_wall = n // 20
+    n_surf = n - 4 * n_wall
+    g = int(np.ceil(np.sqrt(n_surf)))
+    cell = np.arange(n_surf)
+    jx = uniform(seed * 7919 + 1, n_surf)
+    jy = uniform(seed * 7919 + 2, n_surf)
+    x = -5.0 + 10.0 * ((cell % g) + jx) / g
+    y = -5.0 + 10.0 * ((cell // g) + jy) / g
+    y = np.minimum(y, 5.0)
+    pts = [np.stack([x, y, _surface(x, y)], axis=1)]
+    nrm = [_surface_normal(x, y)]
+    walls = [((-5.0, None), (1.0, 0.0, 0.0)), ((5.0, None), (-1.0, 0.0, 0.0)),
+             ((None, -5.0), (0.0, 1.0, 0.0)), ((None, 5.0), (0.0, -1.0, 0.0))]
+    for w, ((wx, wy), nvec) in enumerate(walls):
+        a = uniform(seed * 7919 + 10 + 2 * w, n_wall, -5.0, 5.0)
+        z = uniform(seed * 7919 + 11 + 2 * w, n_wall, -0.5, 2.0)
+        if wx is not None:
+            p = np.stack([np.full(n_wall, wx), a, z], axis=1)
+        else:
+            p = np.stack([a, np.full(n_wall, wy), z], axis=1)
+        pts.append(p)
+        nrm.append(np.tile(np.array(nvec), (n_wall, 1)))
+    P = np.concatenate(pts, axis=0)
+    N = np.concatenate(nrm, axis=0)
+    if noise_sigma > 0:
+        P = P + N * normal(seed * 7919 + 99, P.shape[0], noise_sigma)[:, None]
+    return P, N
+
+
+def cloud_pair_3d(n=100_000, seed=2000, t=(0.05, -0.03, 0.02), rpy_deg=(1.0, -1.5, 2.0), noise_sigma=0.0):
+    """C2: returns dict(fixed, fixed_normals, moving, moving_normals, X_gt) as float32 (X_gt 3x4).
+
+    fixed and moving sample the same scene with different seeds; moving is expressed in the
+    moving frame, i.e. fixed ~= X_gt * moving."""
+    X_gt = se3(np.array(t), np.deg2rad(np.array(rpy_deg)))
+    Pf, Nf = scene_3d(n, seed, noise_sigma)
+    Pm_w, Nm_w = scene_3d(n, seed + 1, noise_sigma)
+    Xi = se3_inv(X_gt)
+    Pm = Pm_w @ Xi[:, :3].T + Xi[:, 3]
+    Nm = Nm_w @ Xi[:, :3].T
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"fixed": f32(Pf), "fixed_normals": f32(Nf), "moving": f32(Pm), "moving_normals": f32(Nm),
+            "X_gt": f32(X_gt)}
+
+
+def batch_3d(K=256, n=50_000, seed=4000, shared_fixed_group=8, t_max=0.2, rpy_max_deg=5.0):
+    """C4: K alignment problems.  The fixed cloud is shared per group of ``shared_fixed_group``
+    problems (setFixed once per query map, multi_loop_detector_brute_force_impl.cpp:63);
+    0 or 1 => all distinct.  Ground truths: t ~ U[-t_max,t_max]^3, rpy ~ U[-rpy_max,rpy_max]^3."""
+    out = []
+    fixed_cache = {}
+    for k in range(K):
+        grp = k // shared_fixed_group if shared_fixed_group > 1 else k
+        if grp not in fixed_cache:
+            Pf, Nf = scene_3d(n, seed + 10 * grp)
+            fixed_cache = {grp: (np.ascontiguousarray(Pf, np.float32), np.ascontiguousarray(Nf, np.float32))}
+        t = uniform(seed * 31 + 3 * k, 3, -t_max, t_max)
+        rpy = np.deg2rad(uniform(seed * 31 + 3 * k + 1, 3, -rpy_max_deg, rpy_max_deg))
+        X_gt = se3(t, rpy)
+        Pm_w, Nm_w = scene_3d(n, seed + 10 * grp + 1 + (k % max(shared_fixed_group, 1)))
+        Xi = se3_inv(X_gt)
+        Pm = Pm_w @ Xi[:, :3].T + Xi[:, 3]
+        Nm = Nm_w @ Xi[:, :3].T
+        out.append({"group": grp, "fixed": fixed_cache[grp][0], "fixed_normals": fixed_cache[grp][1],
+                    "moving": np.ascontiguousarray(Pm, np.float32),
+                    "moving_normals": np.ascontiguousarray(Nm, np.float32),
+                    "X_gt": np.ascontiguousarray(X_gt, np.float32)})
+    return out
+
+
+# ---- C1: 2D laser scan -------------------------------------------------------------------
+def _room_segments():
+    segs = []
+
+    def box(x0, y0, x1, y1):
+        segs.extend([((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1)), ((x0, y1), (x0, y0))])
+
+    box(-5.0, -4.0, 5.0, 4.0)  # 10 m x 8 m room
+    box(1.5, 1.0, 2.5, 2.2)  # interior boxes
+    box(-3.2, -2.6, -2.0, -1.2)
+    return np.array(segs, dtype=np.float64)  # (S, 2, 2)
+
+
+def scan_2d(pose, beams=1000, fov_deg=270.0, sigma=0.0, seed=0):
+    """Ray-cast scan taken from SE(2) ``pose`` (3x3, sensor in world); returns points and unit
+    normals in the sensor frame.  Beams that hit nothing are dropped (none in a closed room)."""
+    segs = _room_segments()
+    ang = np.deg2rad(np.linspace(-fov_deg / 2, fov_deg / 2, beams))
+    c, s = pose[0, 0], pose[1, 0]
+    o = pose[:2, 2]
+    d = np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    dw = d @ np.array([[c, s], [-s, c]])  # rotate directions into the world
+    a = segs[:, 0, :]
+    e = segs[:, 1, :] - a
+    # solve o + r*dw = a + u*e for every (beam, segment)
+    den = dw[:, None, 0] * e[None, :, 1] - dw[:, None, 1] * e[None, :, 0]
+    ao = a[None, :, :] - o[None, None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = (ao[..., 0] * e[None, :, 1] - ao[..., 1] * e[None, :, 0]) / den
+        u = (ao[..., 0] * dw[:, None, 1] - ao[..., 1] * dw[:, None, 0]) / den
+    ok = (np.abs(den) > 1e-12) & (r > 1e-6) & (u >= 0.0) & (u <= 1.0)
+    r = np.where(ok, r, np.inf)
+    hit = np.argmin(r, axis=1)
+    rng = r[np.arange(beams), hit]
+    valid = np.isfinite(rng)
+    if sigma > 0:
+        rng = rng + normal(seed * 104729 + 5, beams, sigma)
+    pts = d * rng[:, None]
+    ew = e[hit]
+    nw = np.stack([-ew[:, 1], ew[:, 0]], axis=1)
+    nw = nw / np.linalg.norm(nw, axis=1, keepdims=True)
+    flip = np.sum(nw * dw, axis=1) > 0  # normals face the sensor
+    nw[flip] *= -1
+    ns = nw @ np.array([[c, -s], [s, c]])  # world -> sensor frame
+    return pts[valid], ns[valid]
+
+
+def scan_pair_2d(beams=1000, t=(0.10, 0.05), theta_deg=3.0, sigma=0.0, seed=1000):
+    """C1: fixed scan from the origin, moving scan from pose X_gt; fixed ~= X_gt * moving."""
+    X_gt = se2(t[0], t[1], np.deg2rad(theta_deg))
+    Pf, Nf = scan_2d(se2(0, 0, 0), beams, sigma=sigma, seed=seed)
+    Pm, Nm = scan_2d(X_gt, beams, sigma=sigma, seed=seed + 1)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"fixed": f32(Pf), "fixed_normals": f32(Nf), "moving": f32(Pm), "moving_normals": f32(Nm),
+            "X_gt": f32(X_gt)}
