@@ -1,2 +1,10 @@
 """MI355X-native multi-cue aligner hot path of srrg2_slam_interfaces."""
 from . import _abi as abi  # noqa: F401
+
+
+def MultiAligner(variable_kind=abi.SE3_QUAT_RIGHT, device=0):
+    """Product aligner on the HIP library (raises if the library or a HIP device is missing)."""
+    from . import _capi
+    from .aligner import MultiAligner as _MA
+
+    return _MA(_capi.backend(), variable_kind, device)

@@ -1,0 +1,861 @@
+// aligner_host.hip -- host driver + C ABI of the aligner (include/srrg2_slam_amd.h).
+//
+// The host side owns configuration, HBM buffers and the launch sequence; every per-iteration
+// decision of MultiAlignerBase_::compute() (multi_aligner_impl.cpp:47-128) is taken on the device
+// by the control kernels, so one compute() is one stream of launches followed by ONE small
+// device->host copy.  There is no CPU fallback: without a HIP device every entry point that needs
+// one fails with SRRG2_E_NO_DEVICE / SRRG2_E_HIP.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "det_math.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      return fail(SRRG2_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    }                                                                                              \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p       = nullptr;
+  size_t cap = 0;  // elements
+  int reserve(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void) hipFree(p);
+    p   = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 16;
+    hipError_t e = hipMalloc((void**) &p, want * sizeof(T));
+    if (e != hipSuccess) return fail(SRRG2_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void) hipFree(p);
+    p   = nullptr;
+    cap = 0;
+  }
+};
+
+struct Slice {
+  srrg2_slice_config cfg;
+  // fixed cloud + search grid
+  DevBuf<float4> fixed_raw, fixed_nrm_raw;   // ingest order
+  DevBuf<float4> fixed_sorted, fixed_nrm_sorted;
+  DevBuf<int> cell_start, cursor, scan_sums;
+  DevBuf<unsigned> scalars;  // [0..2] bbox min keys, [3..5] bbox max keys, [6] nvalid, [7] ninf bits, [8] scan total
+  GridDev grid{};
+  int nf          = 0;
+  bool has_fixed  = false;
+  bool fixed_has_normals = false;
+  // moving cloud(s)
+  DevBuf<float4> moving, moving_nrm;
+  DevBuf<unsigned> pinf;  // per problem
+  int nm_total            = 0;
+  bool has_moving         = false;
+  bool moving_has_normals = false;
+  // outputs
+  DevBuf<int> corr_fixed;
+  DevBuf<float> corr_resp;
+  DevBuf<uint8_t> corr_stat;
+  DevBuf<unsigned long long> acc;
+  // prior
+  float prior_Z[12]{};
+  bool has_prior = false;
+  void release() {
+    fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
+    cell_start.release(); cursor.release(); scan_sums.release(); scalars.release();
+    moving.release(); moving_nrm.release(); pinf.release();
+    corr_fixed.release(); corr_resp.release(); corr_stat.release(); acc.release();
+  }
+};
+
+}  // namespace
+
+struct srrg2_aligner_s {
+  int kind = 0, dim = 3, dof = 6, tsize = 12, device = 0;
+  hipStream_t stream = nullptr;
+  srrg2_aligner_params params{10, 10, 0, 0};
+  bool has_term = false;
+  srrg2_termination_params term{5, 20, 20, 20, 0.2f};
+  std::vector<Slice*> slices;
+  float X[12]{};
+  int status = SRRG2_FAIL;
+  // problems of the current batch (K = 1 for compute())
+  int K = 1;
+  std::vector<ProblemDev> probs_host;
+  DevBuf<ProblemDev> probs;
+  DevBuf<ProblemState> states;
+  DevBuf<ProblemOut> outs;
+  DevBuf<srrg2_iteration_stats> stats;
+  DevBuf<float> guesses;
+  DevBuf<char> staging;  // raw strided input staged on the device
+  // pinned host mirrors
+  ProblemOut* outs_host = nullptr; size_t outs_host_cap = 0;
+  srrg2_iteration_stats* stats_host = nullptr; size_t stats_host_cap = 0;
+  float* guesses_host = nullptr; size_t guesses_host_cap = 0;
+  int max_stats = 0;
+  std::vector<srrg2_iteration_stats> last_stats;  // of problem K-1 (== the only one for compute())
+  int last_ncorr[SRRG2_MAX_SLICES]{};
+  bool computed = false;
+  // profiling
+  bool profile = false;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+};
+
+namespace {
+
+using srrg2_aligner = srrg2_aligner_s;
+
+void identity(int kind, float* T) {
+  if (kind == SRRG2_SE2_RIGHT) {
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(T, I, sizeof(I));
+  } else {
+    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    std::memcpy(T, I, sizeof(I));
+  }
+}
+
+int set_device(srrg2_aligner* a) {
+  HIP_TRY(hipSetDevice(a->device));
+  return 0;
+}
+
+template <typename T>
+int ensure_pinned(T*& p, size_t& cap, size_t n) {
+  if (n <= cap) return 0;
+  if (p) (void) hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+  HIP_TRY(hipHostMalloc((void**) &p, (n + 16) * sizeof(T), hipHostMallocDefault));
+  cap = n + 16;
+  return 0;
+}
+
+// stage `n` records of `dim` floats, `stride_bytes` apart, from host or device memory; returns a device
+// pointer to floats and the stride in floats
+int stage_input(srrg2_aligner* a, const float* src, int stride_bytes, int n, int dim, int mem, const float** dev_ptr,
+                int* stride_floats, size_t staging_offset) {
+  if (stride_bytes % 4 != 0 || stride_bytes < dim * 4) return fail(SRRG2_E_INVALID, "stride must be a multiple of 4 and >= dim*4");
+  if (mem == SRRG2_MEM_DEVICE) {
+    *dev_ptr       = src;
+    *stride_floats = stride_bytes / 4;
+    return 0;
+  }
+  if (mem != SRRG2_MEM_HOST) return fail(SRRG2_E_INVALID, "bad mem kind");
+  char* dst = a->staging.p + staging_offset;
+  if (stride_bytes == dim * 4) {
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t) n * dim * 4, hipMemcpyHostToDevice, a->stream));
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t) dim * 4, src, (size_t) stride_bytes, (size_t) dim * 4, (size_t) n,
+                             hipMemcpyHostToDevice, a->stream));
+  }
+  *dev_ptr       = (const float*) dst;
+  *stride_floats = dim;
+  return 0;
+}
+
+float key_to_float(unsigned k) {
+  unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  float f;
+  std::memcpy(&f, &b, 4);
+  return f;
+}
+
+float bound2_of_host(int r, float h) {
+  float b = ((float) r - 0.01f) * h;
+  return (b * b) * 0.9999f;
+}
+
+// (re)build the finder's search grid of one slice; called from set_fixed
+int build_grid(srrg2_aligner* a, Slice* s) {
+  const int n = s->nf;
+  int rc;
+  if ((rc = s->scalars.reserve(16))) return rc;
+  unsigned init[16];
+  for (int i = 0; i < 3; ++i) { init[i] = 0xffffffffu; init[3 + i] = 0u; }
+  init[6] = 0; init[7] = 0; init[8] = 0;
+  for (int i = 9; i < 16; ++i) init[i] = 0;
+  // ninf (init[7]) is accumulated by the normal ingest which already ran: keep it
+  HIP_TRY(hipMemcpyAsync(s->scalars.p, init, 7 * sizeof(unsigned), hipMemcpyHostToDevice, a->stream));
+  srrg2amd::launch_bbox(s->fixed_raw.p, n, s->scalars.p, s->scalars.p + 3, (int*) (s->scalars.p + 6), a->stream);
+  unsigned back[8];
+  HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  const int nvalid = (int) back[6];
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  if (nvalid > 0) {
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = key_to_float(back[d]);
+      mx[d] = key_to_float(back[3 + d]);
+    }
+  }
+  const float gate = s->cfg.finder_max_distance;
+  float h          = s->cfg.finder_cell_size > 0.f ? s->cfg.finder_cell_size : gate * 0.25f;
+  if (!(h > 0.f)) h = 1.f;
+  const int dim = a->dim;
+  for (;;) {
+    double cells = 1.0;
+    bool ok      = true;
+    for (int d = 0; d < dim; ++d) {
+      double nd = std::floor(((double) mx[d] - (double) mn[d]) / (double) h) + 1.0;
+      if (nd > 1024.0) ok = false;
+      cells *= nd;
+    }
+    if (ok && cells <= 4194304.0) break;
+    h *= 2.f;
+  }
+  GridDev& g = s->grid;
+  g.ox = mn[0]; g.oy = mn[1]; g.oz = dim == 3 ? mn[2] : 0.f;
+  g.h     = h;
+  g.inv_h = 1.0f / h;
+  auto ccoord = [&](float x, float o) {
+    float u = (x - o) * g.inv_h;
+    u       = std::fmin(std::fmax(u, -2048.f), 4096.f);
+    return (int) std::floor(u);
+  };
+  g.nx = nvalid > 0 ? ccoord(mx[0], g.ox) + 1 : 1;
+  g.ny = nvalid > 0 ? ccoord(mx[1], g.oy) + 1 : 1;
+  g.nz = (nvalid > 0 && dim == 3) ? ccoord(mx[2], g.oz) + 1 : 1;
+  g.gate2 = gate * gate;
+  int r   = 1;
+  while (bound2_of_host(r, h) < g.gate2 && r < 4096) ++r;
+  g.rmax          = r;
+  const int ncell = g.nx * g.ny * g.nz;
+  if ((rc = s->cell_start.reserve((size_t) ncell + 1))) return rc;
+  if ((rc = s->cursor.reserve((size_t) ncell + 1))) return rc;
+  if ((rc = s->scan_sums.reserve((size_t) srrg2amd::scan_num_blocks(ncell) + 1))) return rc;
+  if ((rc = s->fixed_sorted.reserve((size_t) std::max(n, 1)))) return rc;
+  if (s->fixed_has_normals && (rc = s->fixed_nrm_sorted.reserve((size_t) std::max(n, 1)))) return rc;
+  HIP_TRY(hipMemsetAsync(s->cell_start.p, 0, ((size_t) ncell + 1) * sizeof(int), a->stream));
+  srrg2amd::launch_grid_count(g, s->fixed_raw.p, n, s->cell_start.p, a->stream);
+  srrg2amd::launch_exclusive_scan(s->cell_start.p, ncell, s->scan_sums.p, (int*) (s->scalars.p + 8), a->stream);
+  HIP_TRY(hipMemcpyAsync(s->cursor.p, s->cell_start.p, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, a->stream));
+  srrg2amd::launch_grid_scatter(g, s->fixed_raw.p, s->fixed_has_normals ? s->fixed_nrm_raw.p : nullptr, n, s->cursor.p,
+                                s->fixed_sorted.p, s->fixed_has_normals ? s->fixed_nrm_sorted.p : nullptr, a->stream);
+  g.cell_start = s->cell_start.p;
+  g.pts        = s->fixed_sorted.p;
+  g.nrm        = s->fixed_has_normals ? s->fixed_nrm_sorted.p : nullptr;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int check_slice(srrg2_aligner* a, int si, const char* what) {
+  if (!a) return fail(SRRG2_E_INVALID, std::string(what) + ": null handle");
+  if (si < 0 || si >= (int) a->slices.size()) return fail(SRRG2_E_INVALID, std::string(what) + ": bad slice index");
+  return 0;
+}
+
+// upload the moving clouds of K problems (concatenated, offsets[K+1]) into slice `si`
+int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const float* normals, int ns,
+                  const int32_t* offsets, int K, int mem) {
+  Slice* s    = a->slices[si];
+  const int n = offsets[K] - offsets[0];
+  int rc;
+  if ((rc = s->moving.reserve((size_t) std::max(n, 1)))) return rc;
+  if (normals && (rc = s->moving_nrm.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->pinf.reserve((size_t) K))) return rc;
+  if ((rc = s->corr_fixed.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->corr_resp.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->corr_stat.reserve((size_t) std::max(n, 1)))) return rc;
+  const size_t bytes_c = (size_t) n * a->dim * 4;
+  if (mem == SRRG2_MEM_HOST && (rc = a->staging.reserve(2 * bytes_c + 64))) return rc;
+  HIP_TRY(hipMemsetAsync(s->pinf.p, 0, (size_t) K * sizeof(unsigned), a->stream));
+  const float* base_c = (const float*) ((const char*) coords + (size_t) offsets[0] * cs);
+  const float* dsrc;
+  int sf;
+  if ((rc = stage_input(a, base_c, cs, n, a->dim, mem, &dsrc, &sf, 0))) return rc;
+  const float* nsrc = nullptr;
+  int nsf = 0;
+  if (normals) {
+    const float* base_n = (const float*) ((const char*) normals + (size_t) offsets[0] * ns);
+    if ((rc = stage_input(a, base_n, ns, n, a->dim, mem, &nsrc, &nsf, (bytes_c + 63) / 64 * 64))) return rc;
+  }
+  for (int k = 0; k < K; ++k) {
+    const int off = offsets[k] - offsets[0], cnt = offsets[k + 1] - offsets[k];
+    srrg2amd::launch_ingest(dsrc + (size_t) off * sf, sf, cnt, a->dim, s->moving.p + off, s->pinf.p + k, 1, a->stream);
+    if (normals)
+      srrg2amd::launch_ingest(nsrc + (size_t) off * nsf, nsf, cnt, a->dim, s->moving_nrm.p + off, nullptr, 0, a->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  if (mem == SRRG2_MEM_HOST) HIP_TRY(hipStreamSynchronize(a->stream));  // caller may reuse its buffer on return
+  s->nm_total           = n;
+  s->has_moving         = true;
+  s->moving_has_normals = normals != nullptr;
+  return 0;
+}
+
+int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null for K == 1 */, const float* guesses) {
+  int rc;
+  if ((rc = set_device(a))) return rc;
+  const int nslices = (int) a->slices.size();
+  // sanity checks (reference: sanityCheck throws, aligner_slice_processor_impl.cpp:8-17;
+  // aligner_slice_processor_prior_impl.cpp:11-22)
+  int max_nm = 0;
+  std::vector<ProblemDev> probs((size_t) K);
+  for (int si = 0; si < nslices; ++si) {
+    Slice* s = a->slices[si];
+    if (s->cfg.kind == SRRG2_SLICE_PRIOR) {
+      if (!s->has_prior) return fail(SRRG2_E_STATE, "compute: prior slice without measurement");
+      continue;
+    }
+    if (!s->has_fixed) return fail(SRRG2_E_STATE, "compute: cue slice| no fixed");
+    if (!s->has_moving) return fail(SRRG2_E_STATE, "compute: cue slice| no moving");
+    if (s->cfg.kind == SRRG2_SLICE_P2PLANE && !s->fixed_has_normals)
+      return fail(SRRG2_E_STATE, "compute: point-to-plane slice needs fixed normals");
+  }
+  // problems: all cue slices share the problem layout of slice 0's batch; for K == 1 each slice has its own nm
+  const int slots = 2 * std::max(a->params.max_iterations, 1);
+  a->max_stats    = slots;
+  if ((rc = a->probs.reserve((size_t) K * std::max(nslices, 1)))) return rc;
+  if ((rc = a->states.reserve((size_t) K))) return rc;
+  if ((rc = a->outs.reserve((size_t) K))) return rc;
+  if ((rc = a->stats.reserve((size_t) K * slots))) return rc;
+  if ((rc = a->guesses.reserve((size_t) K * a->tsize))) return rc;
+  if ((rc = ensure_pinned(a->outs_host, a->outs_host_cap, (size_t) K))) return rc;
+  if ((rc = ensure_pinned(a->stats_host, a->stats_host_cap, (size_t) K * slots))) return rc;
+  if ((rc = ensure_pinned(a->guesses_host, a->guesses_host_cap, (size_t) K * a->tsize))) return rc;
+  std::memcpy(a->guesses_host, guesses, (size_t) K * a->tsize * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(a->guesses.p, a->guesses_host, (size_t) K * a->tsize * sizeof(float), hipMemcpyHostToDevice,
+                         a->stream));
+  // per-slice problem tables live back to back in a->probs: [slice][K]
+  std::vector<ProblemDev> all((size_t) K * std::max(nslices, 1));
+  for (int si = 0; si < nslices; ++si) {
+    Slice* s = a->slices[si];
+    for (int k = 0; k < K; ++k) {
+      ProblemDev pd{0, 0};
+      if (s->cfg.kind != SRRG2_SLICE_PRIOR) {
+        if (K == 1) {
+          pd.moff = 0;
+          pd.nm   = s->nm_total;
+        } else {
+          pd.moff = offsets[k] - offsets[0];
+          pd.nm   = offsets[k + 1] - offsets[k];
+        }
+        max_nm = std::max(max_nm, pd.nm);
+      }
+      all[(size_t) si * K + k] = pd;
+    }
+  }
+  if (nslices > 0)
+    HIP_TRY(hipMemcpyAsync(a->probs.p, all.data(), all.size() * sizeof(ProblemDev), hipMemcpyHostToDevice, a->stream));
+
+  CtlParams C{};
+  C.variable_kind = a->kind;
+  C.nslices       = nslices;
+  C.K             = K;
+  C.params        = a->params;
+  C.has_term      = a->has_term ? 1 : 0;
+  C.term          = a->term;
+  C.max_stats     = slots;
+  std::vector<SliceDev> sdev((size_t) nslices);
+  int first_cue = -1;
+  for (int si = 0; si < nslices; ++si) {
+    Slice* s     = a->slices[si];
+    SliceCtl& sc = C.slices[si];
+    sc.kind                     = s->cfg.kind;
+    sc.min_num_correspondences  = s->cfg.min_num_correspondences;
+    sc.robust_kind              = s->cfg.robustifier;
+    sc.robust_thr               = s->cfg.robustifier_chi_threshold;
+    sc.gate                     = s->cfg.finder_max_distance;
+    sc.has_prior                = s->has_prior ? 1 : 0;
+    sc.prior_sets_initial_guess = s->cfg.prior_sets_initial_guess;
+    std::memcpy(sc.prior_Z, s->prior_Z, sizeof(sc.prior_Z));
+    std::memcpy(sc.prior_info, s->cfg.prior_information_diag, sizeof(sc.prior_info));
+    sc.acc       = nullptr;
+    sc.slots     = slots;
+    sc.pinf_bits = nullptr;
+    sc.ninf_bits = nullptr;
+    if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+    if (first_cue < 0) first_cue = si;
+    if ((rc = s->acc.reserve((size_t) K * slots * ACC_N))) return rc;
+    HIP_TRY(hipMemsetAsync(s->acc.p, 0, (size_t) K * slots * ACC_N * sizeof(unsigned long long), a->stream));
+    sc.acc       = s->acc.p;
+    sc.pinf_bits = s->pinf.p;
+    sc.ninf_bits = s->scalars.p + 7;
+    SliceDev& d       = sdev[si];
+    d.grid            = s->grid;
+    d.mpts            = s->moving.p;
+    d.mnrm            = s->moving_has_normals ? s->moving_nrm.p : nullptr;
+    d.corr_fixed      = s->corr_fixed.p;
+    d.corr_resp       = s->corr_resp.p;
+    d.corr_stat       = s->corr_stat.p;
+    d.acc             = s->acc.p;
+    d.slots           = slots;
+    d.slice_idx       = si;
+    d.robust_kind     = s->cfg.robustifier;
+    d.robust_thr      = s->cfg.robustifier_chi_threshold;
+    d.normal_cos      = s->cfg.finder_normal_cos;
+    d.use_normal_gate = (s->cfg.finder_normal_cos > -1.f && s->fixed_has_normals && s->moving_has_normals) ? 1 : 0;
+    d.variable_kind   = a->kind;
+    if (a->dim == 3)
+      dm::se3_inverse(s->cfg.sensor_in_robot, d.Sinv);
+    else
+      dm::se2_inverse(s->cfg.sensor_in_robot, d.Sinv);
+  }
+  if (K > 1 && first_cue >= 0) {
+    for (int si = 0; si < nslices; ++si)
+      if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR && si != first_cue)
+        return fail(SRRG2_E_UNSUPPORTED, "compute_batch supports one cue slice (plus prior slices)");
+  }
+  // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
+  srrg2amd::launch_icp_init(C, a->probs.p, a->states.p, a->guesses.p, a->tsize, a->stream);
+
+  auto run_phase = [&](int slot0) -> int {
+    for (int it = 0; it < a->params.max_iterations; ++it) {
+      const int slot = slot0 + it;
+      for (int si = 0; si < nslices; ++si) {
+        Slice* s = a->slices[si];
+        if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+        const bool plane = s->cfg.kind == SRRG2_SLICE_P2PLANE;
+        int nm_max       = 0;
+        for (int k = 0; k < K; ++k) nm_max = std::max(nm_max, all[(size_t) si * K + k].nm);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (a->profile) {
+          if (a->prof_used == a->prof_events.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x));
+            HIP_TRY(hipEventCreate(&y));
+            a->prof_events.emplace_back(x, y);
+          }
+          e0 = a->prof_events[a->prof_used].first;
+          e1 = a->prof_events[a->prof_used].second;
+          a->prof_used++;
+          HIP_TRY(hipEventRecord(e0, a->stream));
+        }
+        srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, slot, K, nm_max,
+                                  a->stream);
+        if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
+      }
+      srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, slot, a->stream);
+    }
+    return 0;
+  };
+  if ((rc = run_phase(0))) return rc;
+  srrg2amd::launch_icp_post(C, a->states.p, a->stats.p, a->stream);
+  if (a->params.enable_inlier_only_runs) {
+    if ((rc = run_phase(a->params.max_iterations))) return rc;
+  }
+  srrg2amd::launch_icp_finalize(C, a->states.p, a->outs.p, a->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(a->outs_host, a->outs.p, (size_t) K * sizeof(ProblemOut), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipMemcpyAsync(a->stats_host, a->stats.p, (size_t) K * slots * sizeof(srrg2_iteration_stats),
+                         hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  if (a->profile) {
+    for (size_t i = 0; i < a->prof_used; ++i) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, a->prof_events[i].first, a->prof_events[i].second));
+      a->prof_ms += ms;
+      a->prof_launches++;
+    }
+    a->prof_used = 0;
+  }
+  a->K = K;
+  // the handle's observable state is that of the last alignment (sequential semantics)
+  const ProblemOut& o = a->outs_host[K - 1];
+  std::memcpy(a->X, o.X, sizeof(float) * a->tsize);
+  a->status = o.status;
+  int ns    = std::min(o.nstats, slots);
+  a->last_stats.assign(a->stats_host + (size_t) (K - 1) * slots, a->stats_host + (size_t) (K - 1) * slots + ns);
+  for (int si = 0; si < SRRG2_MAX_SLICES; ++si) a->last_ncorr[si] = o.ncorr[si];
+  a->computed = true;
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int srrg2_amd_abi_version(void) {
+  return SRRG2_AMD_ABI_VERSION;
+}
+
+const char* srrg2_amd_last_error(void) {
+  return g_err.c_str();
+}
+
+int srrg2_amd_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(SRRG2_E_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+void srrg2_aligner_default_params(srrg2_aligner_params* p) {
+  if (!p) return;
+  p->max_iterations = 10;  // aligner.h:30
+  p->min_num_inliers = 10; // multi_aligner.h:45
+  p->enable_inlier_only_runs = 0;
+  p->keep_only_inlier_correspondences = 0;
+}
+
+void srrg2_termination_default_params(srrg2_termination_params* p) {
+  if (!p) return;
+  p->window_size = 5;  // aligner_termination_criteria.h:40-56
+  p->num_correspondences_range = 20;
+  p->num_inliers_range = 20;
+  p->num_outliers_range = 20;
+  p->chi_epsilon = 0.2f;
+}
+
+void srrg2_slice_default_config(srrg2_slice_config* c, int variable_kind) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->kind = SRRG2_SLICE_P2P;
+  c->finder = SRRG2_FINDER_NN_GATED;
+  c->robustifier = SRRG2_ROBUST_NONE;
+  c->robustifier_chi_threshold = 1.f;
+  c->min_num_correspondences = 0;
+  c->finder_max_distance = 1.f;
+  c->finder_normal_cos = -2.f;
+  c->finder_cell_size = 0.f;
+  identity(variable_kind, c->sensor_in_robot);
+  for (int i = 0; i < 6; ++i) c->prior_information_diag[i] = variable_kind == SRRG2_SE2_RIGHT ? 100.f : 1.f;
+  c->prior_sets_initial_guess = 1;
+}
+
+int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
+  if (!out || variable_kind < 0 || variable_kind > 2) return fail(SRRG2_E_INVALID, "create: bad arguments");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(SRRG2_E_NO_DEVICE, "create: no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(SRRG2_E_INVALID, "create: bad device ordinal");
+  srrg2_aligner* a = new srrg2_aligner();
+  a->kind   = variable_kind;
+  a->dim    = variable_kind == SRRG2_SE2_RIGHT ? 2 : 3;
+  a->dof    = variable_kind == SRRG2_SE2_RIGHT ? 3 : 6;
+  a->tsize  = variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
+  a->device = device;
+  identity(variable_kind, a->X);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete a;
+    return fail(SRRG2_E_HIP, "create: cannot create stream");
+  }
+  *out = a;
+  return 0;
+}
+
+int srrg2_aligner_destroy(srrg2_aligner_h a) {
+  if (!a) return 0;
+  (void) hipSetDevice(a->device);
+  if (a->stream) (void) hipStreamSynchronize(a->stream);
+  for (Slice* s : a->slices) {
+    s->release();
+    delete s;
+  }
+  a->probs.release(); a->states.release(); a->outs.release(); a->stats.release(); a->guesses.release();
+  a->staging.release();
+  if (a->outs_host) (void) hipHostFree(a->outs_host);
+  if (a->stats_host) (void) hipHostFree(a->stats_host);
+  if (a->guesses_host) (void) hipHostFree(a->guesses_host);
+  for (auto& ev : a->prof_events) {
+    (void) hipEventDestroy(ev.first);
+    (void) hipEventDestroy(ev.second);
+  }
+  if (a->stream) (void) hipStreamDestroy(a->stream);
+  delete a;
+  return 0;
+}
+
+int srrg2_aligner_set_params(srrg2_aligner_h a, const srrg2_aligner_params* p) {
+  if (!a || !p || p->max_iterations < 0) return fail(SRRG2_E_INVALID, "set_params: bad arguments");
+  a->params = *p;
+  return 0;
+}
+
+int srrg2_aligner_set_termination(srrg2_aligner_h a, const srrg2_termination_params* p) {
+  if (!a) return fail(SRRG2_E_INVALID, "set_termination: null handle");
+  if (!p) {
+    a->has_term = false;
+    return 0;
+  }
+  if (p->window_size < 1 || p->window_size > TERM_WINDOW_MAX) return fail(SRRG2_E_INVALID, "set_termination: window_size");
+  a->has_term = true;
+  a->term     = *p;
+  return 0;
+}
+
+int srrg2_aligner_add_slice(srrg2_aligner_h a, const srrg2_slice_config* c, int* idx) {
+  if (!a || !c) return fail(SRRG2_E_INVALID, "add_slice: bad arguments");
+  if ((int) a->slices.size() >= SRRG2_MAX_SLICES) return fail(SRRG2_E_INVALID, "add_slice: too many slices");
+  if (c->kind == SRRG2_SLICE_REPROJECTION || c->finder == SRRG2_FINDER_PROJECTIVE)
+    return fail(SRRG2_E_UNSUPPORTED, "add_slice: projective finder / reprojection factor not built yet");
+  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED)
+    return fail(SRRG2_E_INVALID, "add_slice| no finder");  // aligner_slice_processor_impl.cpp:13-16
+  if (c->kind == SRRG2_SLICE_PRIOR && a->kind == SRRG2_SE3_EULER_RIGHT)
+    return fail(SRRG2_E_UNSUPPORTED, "add_slice: SE3 prior factors exist for the quaternion variable only "
+                                     "(SE3PriorErrorFactorAD, aligner_slice_odometry_prior.h:33)");
+  Slice* s = new Slice();
+  s->cfg   = *c;
+  if (idx) *idx = (int) a->slices.size();
+  a->slices.push_back(s);
+  return 0;
+}
+
+int srrg2_aligner_clear_slices(srrg2_aligner_h a) {
+  if (!a) return fail(SRRG2_E_INVALID, "clear_slices: null handle");
+  (void) hipSetDevice(a->device);
+  (void) hipStreamSynchronize(a->stream);
+  for (Slice* s : a->slices) {
+    s->release();
+    delete s;
+  }
+  a->slices.clear();
+  return 0;
+}
+
+int srrg2_aligner_set_robustifier(srrg2_aligner_h a, int si, int kind, float thr) {
+  int rc = check_slice(a, si, "set_robustifier");
+  if (rc) return rc;
+  a->slices[si]->cfg.robustifier               = kind;
+  a->slices[si]->cfg.robustifier_chi_threshold = thr;
+  return 0;
+}
+
+int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int cs, const float* normals, int ns, int n,
+                            int mem) {
+  int rc = check_slice(a, si, "set_fixed");
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && !coords)) return fail(SRRG2_E_INVALID, "set_fixed: bad cloud");
+  Slice* s = a->slices[si];
+  if (s->cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_fixed on a prior slice: use set_prior_measurement");
+  if ((rc = set_device(a))) return rc;
+  if ((rc = s->fixed_raw.reserve((size_t) std::max(n, 1)))) return rc;
+  if (normals && (rc = s->fixed_nrm_raw.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->scalars.reserve(16))) return rc;
+  const size_t bytes_c = (size_t) n * a->dim * 4;
+  if (mem == SRRG2_MEM_HOST && (rc = a->staging.reserve(2 * bytes_c + 64))) return rc;
+  HIP_TRY(hipMemsetAsync(s->scalars.p, 0, 16 * sizeof(unsigned), a->stream));
+  const float* dsrc;
+  int sf;
+  if ((rc = stage_input(a, coords, cs, n, a->dim, mem, &dsrc, &sf, 0))) return rc;
+  srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, nullptr, 1, a->stream);
+  if (normals) {
+    const float* nsrc;
+    int nsf;
+    if ((rc = stage_input(a, normals, ns, n, a->dim, mem, &nsrc, &nsf, (bytes_c + 63) / 64 * 64))) return rc;
+    srrg2amd::launch_ingest(nsrc, nsf, n, a->dim, s->fixed_nrm_raw.p, s->scalars.p + 7, 0, a->stream);
+  }
+  s->nf                = n;
+  s->fixed_has_normals = normals != nullptr;
+  if ((rc = build_grid(a, s))) return rc;
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  s->has_fixed = true;
+  return 0;
+}
+
+int srrg2_aligner_set_moving(srrg2_aligner_h a, int si, const float* coords, int cs, const float* normals, int ns, int n,
+                             int mem) {
+  int rc = check_slice(a, si, "set_moving");
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && !coords)) return fail(SRRG2_E_INVALID, "set_moving: bad cloud");
+  if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR)
+    return fail(SRRG2_E_INVALID, "set_moving on a prior slice: use set_prior_measurement");
+  if ((rc = set_device(a))) return rc;
+  const int32_t offsets[2] = {0, n};
+  return upload_moving(a, si, coords, cs, normals, ns, offsets, 1, mem);
+}
+
+int srrg2_aligner_set_prior_measurement(srrg2_aligner_h a, int si, const float* T) {
+  int rc = check_slice(a, si, "set_prior_measurement");
+  if (rc) return rc;
+  if (!T) return fail(SRRG2_E_INVALID, "set_prior_measurement: null transform");
+  Slice* s = a->slices[si];
+  if (s->cfg.kind != SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_prior_measurement: not a prior slice");
+  std::memcpy(s->prior_Z, T, sizeof(float) * a->tsize);
+  s->has_prior = true;
+  return 0;
+}
+
+int srrg2_aligner_set_moving_in_fixed(srrg2_aligner_h a, const float* T) {
+  if (!a || !T) return fail(SRRG2_E_INVALID, "set_moving_in_fixed: bad arguments");
+  std::memcpy(a->X, T, sizeof(float) * a->tsize);
+  return 0;
+}
+
+int srrg2_aligner_get_moving_in_fixed(srrg2_aligner_h a, float* T) {
+  if (!a || !T) return fail(SRRG2_E_INVALID, "get_moving_in_fixed: bad arguments");
+  std::memcpy(T, a->X, sizeof(float) * a->tsize);
+  return 0;
+}
+
+int srrg2_aligner_compute(srrg2_aligner_h a, int* status_out) {
+  if (!a) return fail(SRRG2_E_INVALID, "compute: null handle");
+  int rc = run_compute(a, 1, nullptr, a->X);
+  if (rc) return rc;
+  if (status_out) *status_out = a->status;
+  return 0;
+}
+
+int srrg2_aligner_status(srrg2_aligner_h a, int* s) {
+  if (!a || !s) return fail(SRRG2_E_INVALID, "status: bad arguments");
+  *s = a->status;
+  return 0;
+}
+
+int srrg2_aligner_get_iteration_stats(srrg2_aligner_h a, srrg2_iteration_stats* buf, int* n) {
+  if (!a || !n) return fail(SRRG2_E_INVALID, "get_iteration_stats: bad arguments");
+  const int have = (int) a->last_stats.size();
+  if (buf) std::memcpy(buf, a->last_stats.data(), sizeof(srrg2_iteration_stats) * (size_t) std::min(*n, have));
+  *n = have;
+  return 0;
+}
+
+int srrg2_aligner_num_correspondences(srrg2_aligner_h a, int* n) {
+  if (!a || !n) return fail(SRRG2_E_INVALID, "num_correspondences: bad arguments");
+  int tot = 0;  // multi_aligner_impl.cpp:275-285
+  for (size_t si = 0; si < a->slices.size(); ++si) {
+    int c = a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR ? 1 : (a->computed ? a->last_ncorr[si] : 0);
+    if (c >= 0) tot += c;
+  }
+  *n = tot;
+  return 0;
+}
+
+// dense per-point arrays of the LAST problem -> host, compacted in ascending moving index
+static int fetch_dense(srrg2_aligner* a, int si, std::vector<int>& cf, std::vector<float>& cr, std::vector<uint8_t>& cst,
+                       int* moff_out) {
+  Slice* s = a->slices[si];
+  int rc;
+  if ((rc = set_device(a))) return rc;
+  if (!a->computed || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving) {
+    cf.clear(); cr.clear(); cst.clear();
+    *moff_out = 0;
+    return 0;
+  }
+  // problem K-1 of the last run
+  int moff = 0, nm = s->nm_total;
+  if (a->K > 1) {
+    std::vector<ProblemDev> pd((size_t) a->K);
+    HIP_TRY(hipMemcpy(pd.data(), a->probs.p + (size_t) si * a->K, sizeof(ProblemDev) * (size_t) a->K, hipMemcpyDeviceToHost));
+    moff = pd[a->K - 1].moff;
+    nm   = pd[a->K - 1].nm;
+  }
+  cf.resize((size_t) nm); cr.resize((size_t) nm); cst.resize((size_t) nm);
+  if (nm > 0) {
+    HIP_TRY(hipMemcpy(cf.data(), s->corr_fixed.p + moff, sizeof(int) * (size_t) nm, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cr.data(), s->corr_resp.p + moff, sizeof(float) * (size_t) nm, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cst.data(), s->corr_stat.p + moff, (size_t) nm, hipMemcpyDeviceToHost));
+  }
+  *moff_out = moff;
+  return 0;
+}
+
+int srrg2_aligner_get_correspondences(srrg2_aligner_h a, int si, srrg2_correspondence* buf, int* n) {
+  int rc = check_slice(a, si, "get_correspondences");
+  if (rc) return rc;
+  if (!n) return fail(SRRG2_E_INVALID, "get_correspondences: null count");
+  std::vector<int> cf;
+  std::vector<float> cr;
+  std::vector<uint8_t> cst;
+  int moff;
+  if ((rc = fetch_dense(a, si, cf, cr, cst, &moff))) return rc;
+  const bool prune = a->params.keep_only_inlier_correspondences && a->status == SRRG2_SUCCESS;
+  int cnt = 0;
+  for (size_t i = 0; i < cf.size(); ++i) {
+    if (cf[i] < 0) continue;
+    if (prune && cst[i] != SRRG2_FACTOR_INLIER) continue;  // _pruneCorrespondences, multi_aligner_impl.cpp:243-250
+    if (buf && cnt < *n) {
+      buf[cnt].fixed_idx  = cf[i];
+      buf[cnt].moving_idx = (int) i;
+      buf[cnt].response   = cr[i];
+    }
+    ++cnt;
+  }
+  *n = cnt;
+  return 0;
+}
+
+int srrg2_aligner_get_factor_status(srrg2_aligner_h a, int si, uint8_t* buf, int* n) {
+  int rc = check_slice(a, si, "get_factor_status");
+  if (rc) return rc;
+  if (!n) return fail(SRRG2_E_INVALID, "get_factor_status: null count");
+  std::vector<int> cf;
+  std::vector<float> cr;
+  std::vector<uint8_t> cst;
+  int moff;
+  if ((rc = fetch_dense(a, si, cf, cr, cst, &moff))) return rc;
+  const bool prune = a->params.keep_only_inlier_correspondences && a->status == SRRG2_SUCCESS;
+  int cnt = 0;
+  for (size_t i = 0; i < cf.size(); ++i) {
+    if (cf[i] < 0) continue;
+    if (prune && cst[i] != SRRG2_FACTOR_INLIER) continue;
+    if (buf && cnt < *n) buf[cnt] = cst[i];
+    ++cnt;
+  }
+  *n = cnt;
+  return 0;
+}
+
+int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, int cs, const float* normals, int ns,
+                                const int32_t* offsets, int mem, const float* guesses, srrg2_batch_result* results) {
+  if (!a || K < 0 || !offsets || !guesses || !results) return fail(SRRG2_E_INVALID, "compute_batch: bad arguments");
+  if (K == 0) return 0;
+  if (a->slices.empty()) return fail(SRRG2_E_STATE, "compute_batch: no slices");
+  int cue = -1;
+  for (size_t si = 0; si < a->slices.size(); ++si)
+    if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR) {
+      cue = (int) si;
+      break;
+    }
+  if (cue != 0) return fail(SRRG2_E_UNSUPPORTED, "compute_batch: slice 0 must be the cue slice");
+  int rc;
+  if ((rc = set_device(a))) return rc;
+  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem))) return rc;
+  if ((rc = run_compute(a, K, offsets, guesses))) return rc;
+  const int slots = a->max_stats;
+  for (int k = 0; k < K; ++k) {
+    const ProblemOut& o = a->outs_host[k];
+    std::memset(&results[k], 0, sizeof(results[k]));
+    std::memcpy(results[k].moving_in_fixed, o.X, sizeof(float) * a->tsize);
+    results[k].status         = o.status;
+    results[k].num_iterations = o.nstats;
+    if (o.nstats > 0) results[k].last = a->stats_host[(size_t) k * slots + std::min(o.nstats, slots) - 1];
+  }
+  return 0;
+}
+
+int srrg2_aligner_profile_enable(srrg2_aligner_h a, int enable) {
+  if (!a) return fail(SRRG2_E_INVALID, "profile_enable: null handle");
+  a->profile = enable != 0;
+  return 0;
+}
+
+int srrg2_aligner_profile_get(srrg2_aligner_h a, double* ms, int64_t* launches, int reset) {
+  if (!a) return fail(SRRG2_E_INVALID, "profile_get: null handle");
+  if (ms) *ms = a->prof_ms;
+  if (launches) *launches = a->prof_launches;
+  if (reset) {
+    a->prof_ms       = 0.0;
+    a->prof_launches = 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

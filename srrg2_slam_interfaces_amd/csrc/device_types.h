@@ -1,0 +1,110 @@
+// device_types.h -- PODs shared by the HIP kernels and the host driver of the aligner.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srrg2_slam_amd.h"
+
+#define ACC_N 32          // int64 accumulators per (problem, slice, iteration slot)
+#define ACC_B 21          // b starts after the 21 upper-triangular entries of H
+#define ACC_CHI_IN 27
+#define ACC_CHI_OUT 28
+#define ACC_N_IN 29
+#define ACC_N_OUT 30
+#define ACC_N_CORR 31
+#define TERM_WINDOW_MAX 64
+#define NO_MATCH 0x7fffffff
+
+// upper-triangular index of H(a,b), a <= b, in a 6x6 layout (3-dof variables use the same table)
+__host__ __device__ __forceinline__ constexpr int hidx(int a, int b) {
+  return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
+
+// Search structure over the fixed cloud (CorrespondenceFinder_ state, rebuilt when
+// _fixed_changed_flag is set: S/registration/correspondence_finder.h:80-83,117).
+// Points are stored sorted by cell; pts[j] = {x, y, z, bits(original index)}.
+struct GridDev {
+  float ox, oy, oz;
+  float h, inv_h;
+  int nx, ny, nz;
+  int rmax;        // cube radius that covers the gate
+  float gate2;     // max_distance^2
+  const int* cell_start;  // ncell + 1
+  const float4* pts;
+  const float4* nrm;      // sorted like pts (w unused); null when the cloud has no normals
+};
+
+// One cue slice (AlignerSliceProcessor_) as the step kernel sees it.
+struct SliceDev {
+  GridDev grid;
+  const float4* mpts;   // moving points of all problems of the batch, concatenated
+  const float4* mnrm;   // moving normals or null
+  int* corr_fixed;      // per moving point: matched fixed index or -1
+  float* corr_resp;     // per moving point: response (squared distance)
+  uint8_t* corr_stat;   // per moving point: srrg2_factor_status of the last linearisation
+  unsigned long long* acc;  // [problem][slot][ACC_N]
+  int slots;
+  int slice_idx;
+  int robust_kind;
+  float robust_thr;
+  float normal_cos;
+  int use_normal_gate;
+  int variable_kind;
+  float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
+};
+
+struct ProblemDev {
+  int moff;  // offset of this problem's moving points in the concatenated arrays
+  int nm;
+};
+
+// device-resident state of one alignment (one MultiAlignerBase_::compute())
+struct ProblemState {
+  float X[12];      // moving_in_fixed; equals the `moving_in_fixed` backup of _runSolver (:102)
+  int status;       // srrg2_status
+  int done;         // current _runSolver loop left (break at :110 or :125)
+  int finished;     // compute() returned early (:75-78, :81-85)
+  int nstats;       // IterationStats appended so far
+  int phase;        // 0 = main run, 1 = inlier-only run (_postCompute :165-175)
+  int kexp[SRRG2_MAX_SLICES];   // fixed-point exponent per slice
+  int ncorr[SRRG2_MAX_SLICES];  // correspondences of the last finder pass per slice
+  int ninl[SRRG2_MAX_SLICES];   // inliers of the last linearisation per slice
+  int w_count;
+  double w_corr[TERM_WINDOW_MAX], w_inl[TERM_WINDOW_MAX], w_out[TERM_WINDOW_MAX], w_chi[TERM_WINDOW_MAX];
+  double last_H[36], last_b[6], last_dx[6];
+};
+
+// what the host reads back after compute()
+struct ProblemOut {
+  float X[12];
+  int status;
+  int nstats;
+  int ncorr[SRRG2_MAX_SLICES];
+};
+
+struct SliceCtl {
+  int kind;                 // srrg2_slice_kind
+  int min_num_correspondences;
+  int robust_kind;
+  float robust_thr;
+  float gate;               // finder_max_distance
+  int has_prior;
+  int prior_sets_initial_guess;
+  float prior_Z[12];
+  float prior_info[6];
+  const unsigned long long* acc;  // [problem][slot][ACC_N] (null for priors)
+  int slots;
+  const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
+  const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
+};
+
+struct CtlParams {
+  int variable_kind;
+  int nslices;
+  int K;
+  srrg2_aligner_params params;
+  int has_term;
+  srrg2_termination_params term;
+  int max_stats;  // capacity of the per-problem stats array
+  SliceCtl slices[SRRG2_MAX_SLICES];
+};

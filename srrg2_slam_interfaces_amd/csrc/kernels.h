@@ -1,0 +1,23 @@
+// kernels.h -- launchers of the HIP kernels in kernels.hip (C++ linkage, internal to the library)
+#pragma once
+#include "device_types.h"
+
+namespace srrg2amd {
+
+void launch_ingest(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits,
+                   int finite_per_point, hipStream_t s);
+void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s);
+void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s);
+int scan_num_blocks(int n);
+void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s);
+void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
+                         float4* out_nrm, hipStream_t s);
+void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int slot,
+                     int K, int max_nm, hipStream_t s);
+void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* states, const float* guesses, int tsize,
+                     hipStream_t s);
+void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, int slot, hipStream_t s);
+void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s);
+void launch_icp_finalize(const CtlParams& C, ProblemState* states, ProblemOut* outs, hipStream_t s);
+
+}  // namespace srrg2amd

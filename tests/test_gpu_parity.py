@@ -1,0 +1,162 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from helpers import assert_same_run, cue_config, prior_config, setup_pair
+from srrg2_slam_interfaces_amd import _abi as abi
+from srrg2_slam_interfaces_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(oracle, product, kind):
+    return oracle.OracleAligner(kind), product.MultiAligner(kind)
+
+
+@pytest.mark.parametrize("kind", [abi.SE3_QUAT_RIGHT, abi.SE3_EULER_RIGHT])
+@pytest.mark.parametrize("slice_kind", [abi.SLICE_P2PLANE, abi.SLICE_P2P])
+def test_se3_icp_parity(oracle, product, kind, slice_kind):
+    d = syn.cloud_pair_3d(n=20000, seed=2000)
+    a_ref, a_gpu = _run_both(oracle, product, kind, d,
+                             cue_config(kind, slice_kind, 0.25, abi.ROBUST_CAUCHY, 0.05, 0.8))
+    assert a_ref.status() == abi.SUCCESS
+    assert_same_run(a_ref, a_gpu)
+    # converged close to the ground truth (different samplings of the same surface)
+    assert np.max(np.abs(a_gpu.moving_in_fixed() - d["X_gt"])) < 5e-3
+
+
+def _run_both(oracle, product, kind, data, cfg, params=None, term=None, guess=None, moving_normals=True):
+    out = []
+    for al in _pair(oracle, product, kind):
+        if params:
+            al.set_params(**params)
+        if term is not None:
+            al.set_termination_criteria(term)
+        setup_pair(al, data, cfg, guess, moving_normals)
+        al.compute()
+        out.append(al)
+    return out
+
+
+def test_single_iteration_bitwise(oracle, product):
+    """One finder pass + one Gauss-Newton step from the initial guess."""
+    d = syn.cloud_pair_3d(n=30000, seed=2100)
+    cfg = cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_SATURATED, 0.01)
+    a_ref, a_gpu = _run_both(oracle, product, abi.SE3_QUAT_RIGHT, d, cfg, params=dict(max_iterations=1))
+    assert_same_run(a_ref, a_gpu)
+
+
+@pytest.mark.parametrize("slice_kind", [abi.SLICE_P2P, abi.SLICE_P2PLANE])
+@pytest.mark.parametrize("sigma", [0.0, 0.01])
+def test_se2_icp_parity_c1(oracle, product, slice_kind, sigma):
+    """BASELINE config C1: SE(2) ICP on a 1k-beam scan pair."""
+    d = syn.scan_pair_2d(beams=1000, sigma=sigma)
+    cfg = cue_config(abi.SE2_RIGHT, slice_kind, 0.5, abi.ROBUST_CAUCHY if sigma else abi.ROBUST_NONE, 0.05)
+    a_ref, a_gpu = _run_both(oracle, product, abi.SE2_RIGHT, d, cfg)
+    assert a_ref.status() == abi.SUCCESS
+    assert_same_run(a_ref, a_gpu)
+    if sigma == 0.0:
+        assert np.max(np.abs(a_gpu.moving_in_fixed() - d["X_gt"])) < 2e-2
+
+
+def test_termination_inlier_runs_and_pruning(oracle, product):
+    d = syn.cloud_pair_3d(n=15000, seed=2200, noise_sigma=0.01)
+    cfg = cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.0005)
+    params = dict(max_iterations=12, min_num_inliers=10, enable_inlier_only_runs=True,
+                  keep_only_inlier_correspondences=True)
+    a_ref, a_gpu = _run_both(oracle, product, abi.SE3_QUAT_RIGHT, d, cfg, params=params,
+                             term=abi.default_termination_params())
+    assert a_ref.status() == abi.SUCCESS
+    assert len(a_ref.iteration_stats()) < 24  # the criterion fired before 2 x 12 iterations
+    assert_same_run(a_ref, a_gpu)
+    assert np.all(a_gpu.factor_status(0) == abi.FACTOR_INLIER)
+
+
+def test_prior_plus_cue_slices(oracle, product):
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=10000, seed=2300)
+    Z = syn.se3(np.array([0.04, -0.02, 0.01]), np.deg2rad([0.5, -1.0, 1.5])).astype(np.float32)
+    runs = []
+    for al in _pair(oracle, product, kind):
+        setup_pair(al, d, cue_config(kind, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.05))
+        pi = al.add_slice(prior_config(kind, info=[10, 10, 10, 100, 100, 100]))
+        al.set_prior_measurement(pi, Z)
+        al.compute()
+        runs.append(al)
+    assert runs[0].status() == abi.SUCCESS
+    assert_same_run(runs[0], runs[1])
+
+
+def test_prior_only_slices(oracle, product):
+    for kind, Z in ((abi.SE3_QUAT_RIGHT, syn.se3(np.array([0.3, -0.2, 0.1]), np.deg2rad([20., -30., 45.]))),
+                    (abi.SE2_RIGHT, syn.se2(0.4, -0.1, 0.7))):
+        runs = []
+        for al in _pair(oracle, product, kind):
+            al.set_params(min_num_inliers=0)
+            pi = al.add_slice(prior_config(kind))
+            al.set_prior_measurement(pi, Z.astype(np.float32))
+            al.compute()
+            runs.append(al)
+        assert runs[0].status() == abi.SUCCESS
+        assert_same_run(runs[0], runs[1], slices=())
+
+
+def test_edge_cases(oracle, product):
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=4000, seed=2400)
+    # (a) nothing within the gate at the first iteration -> Fail
+    far = dict(d)
+    far["moving"] = d["moving"] + np.float32(50.0)
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.25)
+    a_ref, a_gpu = _run_both(oracle, product, kind, far, cfg)
+    assert a_ref.status() == abi.FAIL
+    assert_same_run(a_ref, a_gpu)
+    # (b) NaN / inf points on both sides are skipped
+    bad = {k: v.copy() for k, v in d.items()}
+    bad["moving"][::7, 1] = np.nan
+    bad["fixed"][::11, 0] = np.inf
+    a_ref, a_gpu = _run_both(oracle, product, kind, bad, cfg)
+    assert_same_run(a_ref, a_gpu)
+    # (c) empty moving cloud
+    emp = dict(d)
+    emp["moving"] = np.zeros((0, 3), np.float32)
+    emp["moving_normals"] = np.zeros((0, 3), np.float32)
+    a_ref, a_gpu = _run_both(oracle, product, kind, emp, cfg)
+    assert a_ref.status() == abi.FAIL
+    assert_same_run(a_ref, a_gpu)
+    # (d) too few inliers
+    a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, params=dict(min_num_inliers=10 ** 6))
+    assert a_ref.status() == abi.NOT_ENOUGH_INLIERS
+    assert_same_run(a_ref, a_gpu)
+    # (e) wide gate on a coarse cloud exercises the second search phase of the grid finder
+    cfg2 = cue_config(kind, abi.SLICE_P2P, 1.5)
+    sparse = {k: (v[::40] if v.ndim == 2 and v.shape[0] > 12 else v) for k, v in d.items()}
+    a_ref, a_gpu = _run_both(oracle, product, kind, sparse, cfg2)
+    assert_same_run(a_ref, a_gpu)
+
+
+def test_batch_matches_sequential_and_oracle(oracle, product):
+    kind = abi.SE3_QUAT_RIGHT
+    probs = syn.batch_3d(K=6, n=6000, seed=4100, shared_fixed_group=8)
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.35, abi.ROBUST_CAUCHY, 0.05)
+    res = []
+    for al in _pair(oracle, product, kind):
+        si = al.add_slice(cfg)
+        al.set_fixed(si, probs[0]["fixed"], probs[0]["fixed_normals"])
+        guesses = [syn.identity(3)] * len(probs)
+        res.append(al.compute_batch([p["moving"] for p in probs], guesses, [p["moving_normals"] for p in probs]))
+    for r, g in zip(*res):
+        assert r["status"] == g["status"] == abi.SUCCESS
+        assert r["num_iterations"] == g["num_iterations"]
+        assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes()
+        assert r["last"] == g["last"]
+    for p, g in zip(probs, res[1]):
+        assert np.max(np.abs(g["moving_in_fixed"] - p["X_gt"])) < 2e-2
+
+
+def test_errors_are_loud(product):
+    al = product.MultiAligner(abi.SE3_QUAT_RIGHT)
+    with pytest.raises(RuntimeError):
+        al.compute() if al.add_slice(cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2P, 0.1)) == 0 else None
+    with pytest.raises(RuntimeError):
+        al.set_fixed(5, np.zeros((1, 3), np.float32))
