@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the aligner hot path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one blocking MultiAligner::compute() (S/registration/aligners/multi_aligner_impl.cpp:47-95)
+= `iterations` ICP iterations (finder + linearise/reduce + 6x6 solve + update) on clouds that are already
+resident in HBM.  Workload at every N: BASELINE config C2 (SE(3) point-to-plane slice, 100k-pt synthetic
+cloud pair) per rank -- rank r aligns its own seeded pair, i.e. the loop-closure
+candidates of multi_loop_detector_brute_force_impl.cpp:64-91 sharded one per GPU (weak scaling, no
+collective on the data path; the per-alignment result records are all-gathered after every step).
+
+Prints ONE JSON line on rank 0.  `value` = ICP iterations/s summed over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=100_000)
+    ap.add_argument("--iterations", type=int, default=10)  # aligner.h:30
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4"])
+    ap.add_argument("--batch", type=int, default=32, help="c4: alignments per GPU per step")
+    ap.add_argument("--batch-points", type=int, default=50_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def make_aligner(pkg_or_oracle_ctor, abi, iterations):
+    al = pkg_or_oracle_ctor()
+    al.set_params(max_iterations=iterations, min_num_inliers=10)
+    c = abi.default_slice_config(abi.SE3_QUAT_RIGHT)
+    c.kind = abi.SLICE_P2PLANE
+    c.finder = abi.FINDER_NN_GATED
+    c.finder_max_distance = 0.25
+    c.finder_normal_cos = 0.8
+    c.robustifier = abi.ROBUST_CAUCHY
+    c.robustifier_chi_threshold = 0.05
+    al.add_slice(c)
+    return al
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import srrg2_slam_interfaces_amd as pkg
+    from srrg2_slam_interfaces_amd import _abi as abi
+    from srrg2_slam_interfaces_amd import _capi
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    ident = syn.identity(3)
+    al = make_aligner(lambda: pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=local_rank), abi, args.iterations)
+
+    if args.workload == "c2":
+        data = syn.cloud_pair_3d(n=args.points, seed=2000 + 10 * rank)
+        al.set_fixed(0, data["fixed"], data["fixed_normals"])
+        al.set_moving(0, data["moving"], data["moving_normals"])
+        units_per_step = args.iterations  # ICP iterations
+        alg_bytes_per_launch = 12 * args.points + 24 * args.points + 12 * args.points
+
+        def step():
+            al.set_moving_in_fixed(ident)
+            return al.compute()
+    else:
+        probs = syn.batch_3d(K=args.batch, n=args.batch_points, seed=4000 + 1000 * rank, shared_fixed_group=8)
+        # one fixed scene per group of 8 candidates: this bench keeps ONE fixed (group 0) resident
+        al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
+        movs = [p["moving"] for p in probs]
+        nrms = [p["moving_normals"] for p in probs]
+        guesses = [ident] * len(probs)
+        units_per_step = args.iterations * args.batch
+        alg_bytes_per_launch = args.batch * 48 * args.batch_points
+
+        def step():
+            return al.compute_batch(movs, guesses, nrms)
+
+    gather_in = torch.zeros(16, device="cuda")
+    gather_out = [torch.zeros(16, device="cuda") for _ in range(world)] if world > 1 else None
+
+    def full_step():
+        step()
+        if world > 1:  # all-gather of the per-alignment result records
+            gather_in[:12] = torch.from_numpy(al.moving_in_fixed().reshape(-1)).cuda()
+            gather_in[12] = float(al.status())
+            dist.all_gather(gather_out, gather_in)
+
+    for _ in range(args.warmup):
+        full_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    status = al.status()
+    stats = al.iteration_stats()
+
+    # roofline of the dominant kernel (k_icp_step): HIP events on the launch stream around every launch
+    lib = _capi.lib()
+    import ctypes as C
+
+    lib.srrg2_aligner_profile_enable(al._h, 1)
+    for _ in range(max(3, min(10, args.steps))):
+        step()
+    ms, launches = C.c_double(0), C.c_int64(0)
+    lib.srrg2_aligner_profile_get(al._h, C.byref(ms), C.byref(launches), 1)
+    lib.srrg2_aligner_profile_enable(al._h, 0)
+    kern_ms = ms.value / max(launches.value, 1)
+    achieved = alg_bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "icp_iterations_per_sec",
+        "value": units_per_step * args.steps * world / dt,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("C2: SE(3) point-to-plane AlignerSlice, %d-pt synthetic cloud pair per GPU, %d ICP "
+                         "iterations per compute(), gated NN 0.25 m + normal gate, Cauchy 0.05" %
+                         (args.points, args.iterations)) if args.workload == "c2" else
+                        ("C4-shard: %d x %d-pt SE(3) point-to-plane alignments per GPU per step, %d iterations" %
+                         (args.batch, args.batch_points, args.iterations)),
+            "points": args.points if args.workload == "c2" else args.batch_points,
+            "iterations_per_step": args.iterations,
+            "alignments_per_step_per_gpu": 1 if args.workload == "c2" else args.batch,
+            "last_status": status,
+            "last_num_inliers": stats[-1]["num_inliers"] if stats else None,
+            "parallelism": "1 alignment stream per GPU, results all-gathered" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_icp_step<3,true>",
+            "achieved": achieved,
+            "peak": 8000.0,
+            "unit": "GB/s",
+            "frac": achieved / 8000.0,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            "avg_launch_ms": kern_ms,
+            "launches_timed": launches.value,
+        },
+    }
+
+    if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
+        # CPU baseline = the oracle (a port: the reference cannot be built here), single
+        # thread like the reference, same clouds, same iteration count; bounded sample.
+        from oracle import pyoracle
+
+        ref = make_aligner(lambda: pyoracle.OracleAligner(abi.SE3_QUAT_RIGHT), abi, args.iterations)
+        ref.set_fixed(0, data["fixed"], data["fixed_normals"])
+        ref.set_moving(0, data["moving"], data["moving_normals"])
+        ref.set_moving_in_fixed(ident)
+        ref.compute()  # warm-up (builds the search grid)
+        # parity of this very workload before the CPU time is reported
+        al.set_moving_in_fixed(ident)
+        al.compute()
+        cr, cg = ref.correspondences(0), al.correspondences(0)
+        parity = (np.array_equal(cr["fixed_idx"], cg["fixed_idx"]) and np.array_equal(cr["moving_idx"], cg["moving_idx"])
+                  and float(np.max(np.abs(ref.moving_in_fixed() - al.moving_in_fixed()))) <= 1e-5)
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            ref.set_moving_in_fixed(ident)
+            ref.compute()
+            n += 1
+            if time.perf_counter() - t0 > args.cpu_seconds or n >= 200:
+                break
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": n * args.iterations / cdt,
+            "unit": "iterations/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "%d compute() calls x %d iterations on the full %d-pt C2 pair (%.1f s), oracle/liboracle.so "
+                      "-O3 -march=x86-64-v3 -ffp-contract=off, voxel-grid finder" % (n, args.iterations, args.points, cdt),
+            "host_cpus": os.cpu_count(),
+            "parity_indices_bit_exact_and_X_within_1e-5": bool(parity),
+        }
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

