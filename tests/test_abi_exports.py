@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads and exports every symbol include/srrg2_slam_amd.h declares; without a GPU
+it refuses to create an aligner (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "srrg2_slam_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(srrg2_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported():
+    from srrg2_slam_interfaces_amd import _capi
+
+    lib = _capi.lib()
+    names = _declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    assert lib.srrg2_amd_abi_version() == 1
+
+
+def test_oracle_mirrors_the_call_surface(oracle):
+    lib = oracle.lib()
+    for n in _declared_functions():
+        if n.startswith("srrg2_aligner_") and not n.startswith("srrg2_aligner_profile") and \
+                n not in ("srrg2_aligner_default_params",):
+            assert hasattr(lib, "oracle_" + n[len("srrg2_"):]), n
+
+
+def test_pod_layouts_match_ctypes():
+    from srrg2_slam_interfaces_amd import _abi as abi
+
+    assert C.sizeof(abi.Correspondence) == 12
+    assert C.sizeof(abi.IterationStats) == 32
+    assert C.sizeof(abi.AlignerParams) == 16
+    assert C.sizeof(abi.TerminationParams) == 20
+    assert C.sizeof(abi.SliceConfig) == 8 * 4 + 12 * 4 + 9 * 4 + 4 * 4 + 6 * 4 + 4
+    assert C.sizeof(abi.BatchResult) == 48 + 8 + 32
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    import srrg2_slam_interfaces_amd as pkg
+
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pkg.MultiAligner()

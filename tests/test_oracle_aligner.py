@@ -1,0 +1,162 @@
+"""CPU: the oracle's ICP state machine against the behaviours cited from the reference
+(S/registration/aligners/multi_aligner_impl.cpp, aligner_termination_criteria_impl.cpp)."""
+import numpy as np
+import pytest
+
+from helpers import cue_config, prior_config, setup_pair
+from srrg2_slam_interfaces_amd import _abi as abi
+from srrg2_slam_interfaces_amd import synthetic as syn
+
+
+def _exact_pair_3d(n=3000, seed=31):
+    """moving = X_gt^-1 * fixed exactly (same sampling): ICP must recover X_gt."""
+    P, N = syn.scene_3d(n, seed)
+    X = syn.se3(np.array([0.04, -0.03, 0.02]), np.deg2rad([1.0, -1.5, 2.0]))
+    Xi = syn.se3_inv(X)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    return {"fixed": f32(P), "fixed_normals": f32(N), "moving": f32(P @ Xi[:, :3].T + Xi[:, 3]),
+            "moving_normals": f32(N @ Xi[:, :3].T), "X_gt": f32(X)}
+
+
+@pytest.mark.parametrize("kind", [abi.SE3_QUAT_RIGHT, abi.SE3_EULER_RIGHT])
+def test_converges_to_ground_truth_on_noise_free_data(oracle, kind):
+    d = _exact_pair_3d()
+    al = oracle.OracleAligner(kind)
+    al.set_params(max_iterations=30)
+    setup_pair(al, d, cue_config(kind, abi.SLICE_P2PLANE, 0.25))
+    assert al.compute() == abi.SUCCESS
+    assert np.max(np.abs(al.moving_in_fixed() - d["X_gt"])) < 2e-5
+    st = al.iteration_stats()
+    assert len(st) == 30 and st[-1]["chi_inliers"] < 1e-6 < st[0]["chi_inliers"]
+
+
+def test_c1_se2_scan_matching(oracle):
+    """BASELINE config C1 (the reference's CPU-runnable case): SE(2) point-to-point ICP, 1k-pt scan pair."""
+    d = syn.scan_pair_2d(beams=1000)
+    al = oracle.OracleAligner(abi.SE2_RIGHT)
+    setup_pair(al, d, cue_config(abi.SE2_RIGHT, abi.SLICE_P2P, 0.5))
+    assert al.compute() == abi.SUCCESS
+    assert len(al.iteration_stats()) == 10  # aligner.h:30, no termination criterion
+    assert np.max(np.abs(al.moving_in_fixed() - d["X_gt"])) < 2e-2
+    al2 = oracle.OracleAligner(abi.SE2_RIGHT)
+    setup_pair(al2, d, cue_config(abi.SE2_RIGHT, abi.SLICE_P2PLANE, 0.5))
+    assert al2.compute() == abi.SUCCESS
+    assert np.max(np.abs(al2.moving_in_fixed() - d["X_gt"])) < 5e-3
+
+
+def test_status_logic_quirks(oracle):
+    kind = abi.SE3_QUAT_RIGHT
+    d = _exact_pair_3d(1500)
+    # first-iteration association failure ends as Fail, not NotEnoughCorrespondences (:75-78 overwrites :108)
+    far = dict(d)
+    far["moving"] = d["moving"] + np.float32(100)
+    al = oracle.OracleAligner(kind)
+    setup_pair(al, far, cue_config(kind, abi.SLICE_P2PLANE, 0.25))
+    assert al.compute() == abi.FAIL and al.iteration_stats() == []
+    # estimate is restored to the guess (:109)
+    assert np.array_equal(al.moving_in_fixed(), syn.identity(3))
+    # min_num_correspondences is a strict '>' (aligner_slice_processor_impl.cpp:77-79)
+    al = oracle.OracleAligner(kind)
+    setup_pair(al, d, cue_config(kind, abi.SLICE_P2PLANE, 0.25, min_corr=10 ** 7))
+    assert al.compute() == abi.FAIL
+    # not enough inliers (:81-85)
+    al = oracle.OracleAligner(kind)
+    al.set_params(min_num_inliers=10 ** 7)
+    setup_pair(al, d, cue_config(kind, abi.SLICE_P2PLANE, 0.25))
+    assert al.compute() == abi.NOT_ENOUGH_INLIERS
+    assert len(al.iteration_stats()) == 10
+    # a prior slice makes the association always good (aligner_slice_processor_prior.h:66-68)
+    al = oracle.OracleAligner(kind)
+    al.set_params(min_num_inliers=0)
+    setup_pair(al, far, cue_config(kind, abi.SLICE_P2PLANE, 0.25))
+    pi = al.add_slice(prior_config(kind))
+    al.set_prior_measurement(pi, syn.identity(3))
+    assert al.compute() == abi.SUCCESS
+    assert al.num_correspondences() == 1  # prior counts 1 (multi_aligner_impl.cpp:275-285)
+
+
+def test_misuse_raises(oracle):
+    al = oracle.OracleAligner(abi.SE3_QUAT_RIGHT)
+    al.add_slice(cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2P, 0.1))
+    with pytest.raises(RuntimeError):
+        al.compute()  # no fixed / moving
+    pi = al.add_slice(prior_config(abi.SE3_QUAT_RIGHT))
+    with pytest.raises(RuntimeError):
+        al.set_fixed(pi, np.zeros((3, 3), np.float32))
+    with pytest.raises(RuntimeError):
+        al.set_fixed(7, np.zeros((3, 3), np.float32))
+    c = cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2P, 0.1)
+    c.finder = abi.FINDER_NONE
+    with pytest.raises(RuntimeError):
+        al.add_slice(c)  # "| no finder", aligner_slice_processor_impl.cpp:13-16
+
+
+def test_termination_criterion_quirks(oracle):
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=4000, seed=33, noise_sigma=0.005)
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.01)
+    al = oracle.OracleAligner(kind)
+    al.set_params(max_iterations=40)
+    al.set_termination_criteria(abi.default_termination_params())
+    setup_pair(al, d, cfg)
+    assert al.compute() == abi.SUCCESS
+    n_default = len(al.iteration_stats())
+    assert 5 <= n_default < 40  # needs a full window of 5 before it may stop (:43-45)
+    # quirk (:46): the OUTLIER range is compared against num_correspondences_range
+    t = abi.default_termination_params()
+    t.num_correspondences_range = -1  # range() >= 0 > -1 -> never stops
+    al = oracle.OracleAligner(kind)
+    al.set_params(max_iterations=40)
+    al.set_termination_criteria(t)
+    setup_pair(al, d, cfg)
+    al.compute()
+    assert len(al.iteration_stats()) == 40
+    # chi_epsilon = 0 can only be met by an exactly constant chi window
+    t = abi.default_termination_params()
+    t.window_size = 2
+    al = oracle.OracleAligner(kind)
+    al.set_params(max_iterations=40)
+    al.set_termination_criteria(t)
+    setup_pair(al, d, cfg)
+    al.compute()
+    assert 2 <= len(al.iteration_stats()) <= n_default
+
+
+def test_inlier_only_runs_and_pruning(oracle):
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=4000, seed=34, noise_sigma=0.01)
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 3e-4)
+    base = oracle.OracleAligner(kind)
+    setup_pair(base, d, cfg)
+    base.compute()
+    n_all = len(base.correspondences(0))
+    fs = base.factor_status(0)
+    assert 0 < (fs == abi.FACTOR_KERNELIZED).sum() < n_all
+    al = oracle.OracleAligner(kind)
+    al.set_params(enable_inlier_only_runs=True, keep_only_inlier_correspondences=True)
+    setup_pair(al, d, cfg)
+    assert al.compute() == abi.SUCCESS
+    st = al.iteration_stats()
+    assert len(st) == 20  # 10 + 10 inlier-only iterations (multi_aligner_impl.cpp:170-171)
+    c = al.correspondences(0)
+    assert len(c) == st[-1]["num_inliers"] < n_all  # pruned to the inliers of the last iteration (:243-250)
+    assert np.all(al.factor_status(0) == abi.FACTOR_INLIER)
+    assert al.num_correspondences() == len(c)
+    assert np.all(np.diff(c["moving_idx"]) > 0)
+
+
+def test_batch_equals_sequential(oracle):
+    kind = abi.SE3_QUAT_RIGHT
+    probs = syn.batch_3d(K=3, n=2500, seed=4200)
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.35)
+    al = oracle.OracleAligner(kind)
+    si = al.add_slice(cfg)
+    al.set_fixed(si, probs[0]["fixed"], probs[0]["fixed_normals"])
+    res = al.compute_batch([p["moving"] for p in probs], [syn.identity(3)] * 3, [p["moving_normals"] for p in probs])
+    for p, r in zip(probs, res):
+        one = oracle.OracleAligner(kind)
+        setup_pair(one, p, cfg)
+        one.compute()
+        assert r["status"] == one.status() == abi.SUCCESS
+        assert np.array_equal(r["moving_in_fixed"], one.moving_in_fixed())
+        assert r["last"] == one.iteration_stats()[-1]
