@@ -35,12 +35,13 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c4"])
     ap.add_argument("--batch", type=int, default=32, help="c4: alignments per GPU per step")
     ap.add_argument("--batch-points", type=int, default=50_000)
+    ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
-def make_aligner(pkg_or_oracle_ctor, abi, iterations):
+def make_aligner(pkg_or_oracle_ctor, abi, iterations, cell_size=0.0):
     al = pkg_or_oracle_ctor()
     al.set_params(max_iterations=iterations, min_num_inliers=10)
     c = abi.default_slice_config(abi.SE3_QUAT_RIGHT)
@@ -48,6 +49,7 @@ def make_aligner(pkg_or_oracle_ctor, abi, iterations):
     c.finder = abi.FINDER_NN_GATED
     c.finder_max_distance = 0.25
     c.finder_normal_cos = 0.8
+    c.finder_cell_size = cell_size
     c.robustifier = abi.ROBUST_CAUCHY
     c.robustifier_chi_threshold = 0.05
     al.add_slice(c)
@@ -77,7 +79,7 @@ def main():
     from srrg2_slam_interfaces_amd import synthetic as syn
 
     ident = syn.identity(3)
-    al = make_aligner(lambda: pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=local_rank), abi, args.iterations)
+    al = make_aligner(lambda: pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=local_rank), abi, args.iterations, args.cell_size)
 
     if args.workload == "c2":
         data = syn.cloud_pair_3d(n=args.points, seed=2000 + 10 * rank)

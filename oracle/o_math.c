@@ -419,7 +419,11 @@ int o_fixed_point_exponent(int n_terms, double term_bound) {
   if (!(term_bound > 1e-30)) {
     term_bound = 1e-30;
   }
-  int k = 62 - ceil_log2_double((double) n_terms) - ceil_log2_double(term_bound);
+  int lb = ceil_log2_double(term_bound);
+  int k  = 62 - ceil_log2_double((double) n_terms) - lb;
+  if (k > 50 - lb) { /* every scaled term stays below 2^50: exact magic-number double->int conversion */
+    k = 50 - lb;
+  }
   if (k > 50) {
     k = 50;
   }

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,7 +67,11 @@ struct Slice {
   bool has_fixed  = false;
   bool fixed_has_normals = false;
   // moving cloud(s)
-  DevBuf<float4> moving, moving_nrm;
+  DevBuf<float4> moving, moving_nrm;          // Morton-sorted per problem, .w = caller's index
+  DevBuf<float4> moving_raw, moving_nrm_raw;  // ingest order
+  DevBuf<int> ms_counts, ms_cursor, ms_sums;
+  DevBuf<unsigned> ms_bb;
+  DevBuf<ProblemDev> ms_probs;
   DevBuf<unsigned> pinf;  // per problem
   int nm_total            = 0;
   bool has_moving         = false;
@@ -75,7 +80,7 @@ struct Slice {
   DevBuf<int> corr_fixed;
   DevBuf<float> corr_resp;
   DevBuf<uint8_t> corr_stat;
-  DevBuf<unsigned long long> acc;
+  DevBuf<long long> partials;
   // prior
   float prior_Z[12]{};
   bool has_prior = false;
@@ -83,7 +88,9 @@ struct Slice {
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
     cell_start.release(); cursor.release(); scan_sums.release(); scalars.release();
     moving.release(); moving_nrm.release(); pinf.release();
-    corr_fixed.release(); corr_resp.release(); corr_stat.release(); acc.release();
+    moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
+    ms_bb.release(); ms_probs.release();
+    corr_fixed.release(); corr_resp.release(); corr_stat.release(); partials.release();
   }
 };
 
@@ -251,7 +258,7 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   if ((rc = s->cell_start.reserve((size_t) ncell + 1))) return rc;
   if ((rc = s->cursor.reserve((size_t) ncell + 1))) return rc;
   if ((rc = s->scan_sums.reserve((size_t) srrg2amd::scan_num_blocks(ncell) + 1))) return rc;
-  if ((rc = s->fixed_sorted.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->fixed_sorted.reserve((size_t) std::max(n, 1) + 8))) return rc;  // scan_range over-reads <= 3 entries
   if (s->fixed_has_normals && (rc = s->fixed_nrm_sorted.reserve((size_t) std::max(n, 1)))) return rc;
   HIP_TRY(hipMemsetAsync(s->cell_start.p, 0, ((size_t) ncell + 1) * sizeof(int), a->stream));
   srrg2amd::launch_grid_count(g, s->fixed_raw.p, n, s->cell_start.p, a->stream);
@@ -297,12 +304,42 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     const float* base_n = (const float*) ((const char*) normals + (size_t) offsets[0] * ns);
     if ((rc = stage_input(a, base_n, ns, n, a->dim, mem, &nsrc, &nsf, (bytes_c + 63) / 64 * 64))) return rc;
   }
+  if ((rc = s->moving_raw.reserve((size_t) std::max(n, 1)))) return rc;
+  if (normals && (rc = s->moving_nrm_raw.reserve((size_t) std::max(n, 1)))) return rc;
+  std::vector<ProblemDev> pd((size_t) K);
+  int max_nm = 0;
   for (int k = 0; k < K; ++k) {
     const int off = offsets[k] - offsets[0], cnt = offsets[k + 1] - offsets[k];
-    srrg2amd::launch_ingest(dsrc + (size_t) off * sf, sf, cnt, a->dim, s->moving.p + off, s->pinf.p + k, 1, a->stream);
+    pd[k]  = ProblemDev{off, cnt};
+    max_nm = std::max(max_nm, cnt);
+    srrg2amd::launch_ingest(dsrc + (size_t) off * sf, sf, cnt, a->dim, s->moving_raw.p + off, s->pinf.p + k, 1, a->stream);
     if (normals)
-      srrg2amd::launch_ingest(nsrc + (size_t) off * nsf, nsf, cnt, a->dim, s->moving_nrm.p + off, nullptr, 0, a->stream);
+      srrg2amd::launch_ingest(nsrc + (size_t) off * nsf, nsf, cnt, a->dim, s->moving_nrm_raw.p + off, nullptr, 0,
+                              a->stream);
   }
+  // Morton sort per problem: 64^3 cells for one cloud, fewer per problem for big batches
+  const int bits = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
+  const size_t ncell = (size_t) K << (3 * bits);
+  if ((rc = s->ms_counts.reserve(ncell + 1))) return rc;
+  if ((rc = s->ms_cursor.reserve(ncell + 1))) return rc;
+  if ((rc = s->ms_sums.reserve((size_t) srrg2amd::scan_num_blocks((int) ncell) + 2))) return rc;
+  if ((rc = s->ms_bb.reserve((size_t) K * 6))) return rc;
+  if ((rc = s->ms_probs.reserve((size_t) K))) return rc;
+  {
+    std::vector<unsigned> bb((size_t) K * 6);
+    for (int k = 0; k < K; ++k)
+      for (int d = 0; d < 3; ++d) {
+        bb[(size_t) k * 6 + d]     = 0xffffffffu;
+        bb[(size_t) k * 6 + 3 + d] = 0u;
+      }
+    HIP_TRY(hipMemcpyAsync(s->ms_bb.p, bb.data(), bb.size() * sizeof(unsigned), hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(hipMemcpyAsync(s->ms_probs.p, pd.data(), pd.size() * sizeof(ProblemDev), hipMemcpyHostToDevice, a->stream));
+    HIP_TRY(hipMemsetAsync(s->ms_counts.p, 0, (ncell + 1) * sizeof(int), a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));  // bb / pd are stack-lifetime host buffers
+  }
+  srrg2amd::launch_msort(s->moving_raw.p, normals ? s->moving_nrm_raw.p : nullptr, s->ms_probs.p, K, max_nm, bits,
+                         s->ms_bb.p, s->ms_counts.p, s->ms_cursor.p, s->ms_sums.p, s->ms_sums.p + s->ms_sums.cap - 1,
+                         s->moving.p, normals ? s->moving_nrm.p : nullptr, a->stream);
   HIP_TRY(hipGetLastError());
   if (mem == SRRG2_MEM_HOST) HIP_TRY(hipStreamSynchronize(a->stream));  // caller may reuse its buffer on return
   s->nm_total           = n;
@@ -388,15 +425,20 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     sc.prior_sets_initial_guess = s->cfg.prior_sets_initial_guess;
     std::memcpy(sc.prior_Z, s->prior_Z, sizeof(sc.prior_Z));
     std::memcpy(sc.prior_info, s->cfg.prior_information_diag, sizeof(sc.prior_info));
-    sc.acc       = nullptr;
-    sc.slots     = slots;
+    sc.partials  = nullptr;
+    sc.nblocks   = 0;
     sc.pinf_bits = nullptr;
     sc.ninf_bits = nullptr;
     if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
     if (first_cue < 0) first_cue = si;
-    if ((rc = s->acc.reserve((size_t) K * slots * ACC_N))) return rc;
-    HIP_TRY(hipMemsetAsync(s->acc.p, 0, (size_t) K * slots * ACC_N * sizeof(unsigned long long), a->stream));
-    sc.acc       = s->acc.p;
+    int nm_max_s = 0;
+    for (int k = 0; k < K; ++k) nm_max_s = std::max(nm_max_s, all[(size_t) si * K + k].nm);
+    const int nblocks = std::max(srrg2amd::icp_step_blocks(nm_max_s), 1);
+    if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
+    if (nm_max_s == 0)  // no step launch will write the partials of an empty cloud
+      HIP_TRY(hipMemsetAsync(s->partials.p, 0, (size_t) K * nblocks * ACC_N * sizeof(long long), a->stream));
+    sc.partials  = s->partials.p;
+    sc.nblocks   = nblocks;
     sc.pinf_bits = s->pinf.p;
     sc.ninf_bits = s->scalars.p + 7;
     SliceDev& d       = sdev[si];
@@ -406,14 +448,14 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.corr_fixed      = s->corr_fixed.p;
     d.corr_resp       = s->corr_resp.p;
     d.corr_stat       = s->corr_stat.p;
-    d.acc             = s->acc.p;
-    d.slots           = slots;
+    d.partials        = s->partials.p;
     d.slice_idx       = si;
     d.robust_kind     = s->cfg.robustifier;
     d.robust_thr      = s->cfg.robustifier_chi_threshold;
     d.normal_cos      = s->cfg.finder_normal_cos;
     d.use_normal_gate = (s->cfg.finder_normal_cos > -1.f && s->fixed_has_normals && s->moving_has_normals) ? 1 : 0;
     d.variable_kind   = a->kind;
+    d.tune            = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
     if (a->dim == 3)
       dm::se3_inverse(s->cfg.sensor_in_robot, d.Sinv);
     else
@@ -429,7 +471,6 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
 
   auto run_phase = [&](int slot0) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
-      const int slot = slot0 + it;
       for (int si = 0; si < nslices; ++si) {
         Slice* s = a->slices[si];
         if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
@@ -449,11 +490,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           a->prof_used++;
           HIP_TRY(hipEventRecord(e0, a->stream));
         }
-        srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, slot, K, nm_max,
+        srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
                                   a->stream);
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }
-      srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, slot, a->stream);
+      srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
     }
     return 0;
   };

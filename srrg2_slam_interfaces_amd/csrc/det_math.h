@@ -267,31 +267,42 @@ DM_HD void box_plus(int variable_kind, float* X, const double* dx) {
 // Cholesky solve of H dx = -b, D in {3, 6}; H full row-major. returns 0 ok, 1 not positive definite
 template <int D>
 DM_HD int solve(const double* H, const double* b, double* dx) {
+  // fully unrolled so that L, y live in registers on the device
   double L[D * D];
   double y[D];
+#pragma unroll
   for (int i = 0; i < D * D; ++i) L[i] = 0.0;
+#pragma unroll
   for (int j = 0; j < D; ++j) {
     double s = H[j * D + j];
+#pragma unroll
     for (int k = 0; k < j; ++k) s = s - L[j * D + k] * L[j * D + k];
     if (!(s > 0.0)) return 1;
     double d     = sqrt(s);
     L[j * D + j] = d;
+#pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double v = H[i * D + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) v = v - L[i * D + k] * L[j * D + k];
       L[i * D + j] = v / d;
     }
   }
+#pragma unroll
   for (int i = 0; i < D; ++i) {
     double s = -b[i];
+#pragma unroll
     for (int k = 0; k < i; ++k) s = s - L[i * D + k] * y[k];
     y[i] = s / L[i * D + i];
   }
+#pragma unroll
   for (int i = D - 1; i >= 0; --i) {
     double s = y[i];
+#pragma unroll
     for (int k = i + 1; k < D; ++k) s = s - L[k * D + i] * dx[k];
     dx[i] = s / L[i * D + i];
   }
+#pragma unroll
   for (int i = 0; i < D; ++i) {
     if (!(dx[i] == dx[i]) || dx[i] > 1e300 || dx[i] < -1e300) return 1;
   }
@@ -310,7 +321,9 @@ DM_HD int ceil_log2(double v) {
 DM_HD int fixed_point_exponent(int n_terms, double term_bound) {
   if (n_terms < 1) n_terms = 1;
   if (!(term_bound > 1e-30)) term_bound = 1e-30;
-  int k = 62 - ceil_log2((double) n_terms) - ceil_log2(term_bound);
+  int lb = ceil_log2(term_bound);
+  int k  = 62 - ceil_log2((double) n_terms) - lb;
+  if (k > 50 - lb) k = 50 - lb;  // every scaled term stays below 2^50 (exact magic-number conversion)
   if (k > 50) k = 50;
   if (k < -64) k = -64;
   return k;

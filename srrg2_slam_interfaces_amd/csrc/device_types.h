@@ -42,14 +42,14 @@ struct SliceDev {
   int* corr_fixed;      // per moving point: matched fixed index or -1
   float* corr_resp;     // per moving point: response (squared distance)
   uint8_t* corr_stat;   // per moving point: srrg2_factor_status of the last linearisation
-  unsigned long long* acc;  // [problem][slot][ACC_N]
-  int slots;
+  long long* partials;  // [problem][gridDim.x][ACC_N]: per-block fixed-point partial sums (no atomics)
   int slice_idx;
   int robust_kind;
   float robust_thr;
   float normal_cos;
   int use_normal_gate;
   int variable_kind;
+  int tune;             // debug/tuning bit flags (env SRRG2_AMD_TUNE): 1 = skip phase 2 (WRONG results, timing only)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
 };
 
@@ -92,8 +92,8 @@ struct SliceCtl {
   int prior_sets_initial_guess;
   float prior_Z[12];
   float prior_info[6];
-  const unsigned long long* acc;  // [problem][slot][ACC_N] (null for priors)
-  int slots;
+  const long long* partials;  // [problem][nblocks][ACC_N] (null for priors)
+  int nblocks;                // gridDim.x of the slice's step launch
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
 };

@@ -12,11 +12,17 @@ int scan_num_blocks(int n);
 void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s);
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
                          float4* out_nrm, hipStream_t s);
-void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int slot,
-                     int K, int max_nm, hipStream_t s);
+// Morton sort of K moving clouds (counts/cursor: (K << 3*bits) + 1 ints; bb: K*6 keys initialised to
+// {0xffffffff x3, 0 x3}; counts zeroed)
+void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
+                  unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
+                  float4* out_nrm, hipStream_t s);
+void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                     int max_nm, hipStream_t s);
+int icp_step_blocks(int max_nm);
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* states, const float* guesses, int tsize,
                      hipStream_t s);
-void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, int slot, hipStream_t s);
+void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s);
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s);
 void launch_icp_finalize(const CtlParams& C, ProblemState* states, ProblemOut* outs, hipStream_t s);
 

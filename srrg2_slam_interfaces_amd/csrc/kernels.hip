@@ -204,41 +204,266 @@ __global__ void k_grid_scatter(GridDev g, const float4* __restrict__ pts, const 
 }
 
 // ============================================================================================
+// spatial sort of the moving cloud(s): Morton order inside each problem's bounding box, so that the 64
+// lanes of a wave query neighbouring cells of the fixed grid (L1/L2-coherent candidate loads).  The
+// order has no effect on results: outputs are addressed by the caller's index (kept in .w) and every
+// sum is exact.
+// ============================================================================================
+__device__ __forceinline__ unsigned spread3(unsigned v) {  // v < 64: insert two zero bits between bits
+  v = (v | (v << 8)) & 0x0000f00fu;
+  v = (v | (v << 4)) & 0x000c30c3u;
+  v = (v | (v << 2)) & 0x00249249u;
+  return v;
+}
+
+__device__ __forceinline__ unsigned morton_key(const float4 p, const unsigned* bb, int bits) {
+  const unsigned ncell = 1u << (3 * bits);
+  if (!finite3(p.x, p.y, p.z)) return ncell - 1;
+  const float res = (float) (1 << bits);
+  unsigned c[3];
+  const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    unsigned kmn = bb[d], kmx = bb[3 + d];
+    unsigned bmn = (kmn & 0x80000000u) ? (kmn & 0x7fffffffu) : ~kmn;
+    unsigned bmx = (kmx & 0x80000000u) ? (kmx & 0x7fffffffu) : ~kmx;
+    float mn = __uint_as_float(bmn), mx = __uint_as_float(bmx);
+    float ext = mx - mn;
+    float u   = ext > 0.f ? (v[d] - mn) / ext * res : 0.f;
+    int ci    = (int) u;
+    ci        = min(max(ci, 0), (1 << bits) - 1);
+    c[d]      = (unsigned) ci;
+  }
+  return spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+}
+
+__global__ void k_msort_bbox(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
+                             unsigned* __restrict__ bb /* [K][6] */) {
+  const ProblemDev pd = probs[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
+    float4 p = pts[pd.moff + i];
+    if (!finite3(p.x, p.y, p.z)) continue;
+    unsigned* b = bb + blockIdx.y * 6;
+    atomicMin(&b[0], fkey(p.x)); atomicMax(&b[3], fkey(p.x));
+    atomicMin(&b[1], fkey(p.y)); atomicMax(&b[4], fkey(p.y));
+    atomicMin(&b[2], fkey(p.z)); atomicMax(&b[5], fkey(p.z));
+  }
+}
+
+__global__ void k_msort_count(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
+                              const unsigned* __restrict__ bb, int bits, int* __restrict__ counts) {
+  const ProblemDev pd = probs[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
+    unsigned key = morton_key(pts[pd.moff + i], bb + blockIdx.y * 6, bits);
+    atomicAdd(&counts[((size_t) blockIdx.y << (3 * bits)) + key], 1);
+  }
+}
+
+__global__ void k_msort_scatter(const float4* __restrict__ pts, const float4* __restrict__ nrm,
+                                const ProblemDev* __restrict__ probs, const unsigned* __restrict__ bb, int bits,
+                                int* __restrict__ cursor, float4* __restrict__ out_pts, float4* __restrict__ out_nrm) {
+  const ProblemDev pd = probs[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
+    float4 p     = pts[pd.moff + i];
+    unsigned key = morton_key(p, bb + blockIdx.y * 6, bits);
+    int pos      = atomicAdd(&cursor[((size_t) blockIdx.y << (3 * bits)) + key], 1);
+    p.w          = __int_as_float(i);
+    out_pts[pos] = p;
+    if (nrm) out_nrm[pos] = nrm[pd.moff + i];
+  }
+}
+
+// ============================================================================================
 // the fused ICP step kernel
 // ============================================================================================
+namespace {
+
+// exact double -> 64-bit fixed point for |v| < 2^51: round-to-nearest-even integer of v, i.e. the value
+// llrint(v) returns; one f64 add instead of a ~10-instruction conversion.  The bound is guaranteed by
+// dm::fixed_point_exponent (every scaled term is <= 2^50).
+__device__ __forceinline__ long long to_fixed(double v) {
+  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+  return __double_as_longlong(v + MAGIC) - __double_as_longlong(MAGIC);
+}
+
 template <int DIM>
-__device__ __forceinline__ void scan_cube(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                          int r, float& best, int& bidx, int& bpos) {
-  int z0 = DIM == 3 ? max(cz - r, 0) : 0, z1 = DIM == 3 ? min(cz + r, g.nz - 1) : 0;
-  int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
-  int x0 = max(cx - r, 0), x1 = min(cx + r, g.nx - 1);
-  if (x0 > x1) return;
+__device__ __forceinline__ void test_candidate(const float4 f, float qx, float qy, float qz, int j, float& best,
+                                               int& bidx, int& bpos) {
+  float dx = f.x - qx, dy = f.y - qy;
+  float d2 = dx * dx + dy * dy;
+  if (DIM == 3) {
+    float dz = f.z - qz;
+    d2       = d2 + dz * dz;
+  }
+  const int idx = __float_as_int(f.w);
+  if (d2 < best || (d2 == best && idx < bidx)) {
+    best = d2;
+    bidx = idx;
+    bpos = j;
+  }
+}
+
+// scan the contiguous candidates [j, e) with four independent 16-byte loads in flight.  Reads up to 3 entries
+// past e (never tested): the sorted arrays are allocated with >= 4 entries of slack.
+template <int DIM>
+__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int j, int e, float qx, float qy, float qz,
+                                           float& best, int& bidx, int& bpos) {
+  for (; j < e; j += 4) {
+    const float4 f0 = pts[j];
+    const float4 f1 = pts[j + 1];
+    const float4 f2 = pts[j + 2];
+    const float4 f3 = pts[j + 3];
+    test_candidate<DIM>(f0, qx, qy, qz, j, best, bidx, bpos);
+    if (j + 1 < e) test_candidate<DIM>(f1, qx, qy, qz, j + 1, best, bidx, bpos);
+    if (j + 2 < e) test_candidate<DIM>(f2, qx, qy, qz, j + 2, best, bidx, bpos);
+    if (j + 3 < e) test_candidate<DIM>(f3, qx, qy, qz, j + 3, best, bidx, bpos);
+  }
+}
+
+// generic cube scan of radius r (unused fallback)
+// (arguments by value: a reference to the kernel-argument struct would force it into scratch memory)
+template <int DIM>
+__device__ __noinline__ int scan_cube(const int* __restrict__ cell_start, const float4* __restrict__ pts, int nx,
+                                       int ny, int nz, float qx, float qy, float qz, int cx, int cy, int cz, int r,
+                                       float best_in, int bidx_in, int bpos_in, float* best_out, int* bidx_out) {
+  float best = best_in;
+  int bidx = bidx_in, bpos = bpos_in;
+  int z0 = DIM == 3 ? max(cz - r, 0) : 0, z1 = DIM == 3 ? min(cz + r, nz - 1) : 0;
+  int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
+  int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
+  if (x0 > x1) {
+    *best_out = best;
+    *bidx_out = bidx;
+    return bpos;
+  }
   for (int z = z0; z <= z1; ++z) {
     for (int y = y0; y <= y1; ++y) {
-      int row = (z * g.ny + y) * g.nx;
-      int s = g.cell_start[row + x0], e = g.cell_start[row + x1 + 1];
-      for (int j = s; j < e; ++j) {
-        float4 f = g.pts[j];
-        float dx = f.x - qx, dy = f.y - qy;
-        float d2 = dx * dx + dy * dy;
-        if (DIM == 3) {
-          float dz = f.z - qz;
-          d2       = d2 + dz * dz;
-        }
-        int idx = __float_as_int(f.w);
-        if (d2 < best || (d2 == best && idx < bidx)) {
-          best = d2;
-          bidx = idx;
-          bpos = j;
-        }
-      }
+      int row = (z * ny + y) * nx;
+      int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+      for (int j = s; j < e; ++j) test_candidate<DIM>(pts[j], qx, qy, qz, j, best, bidx, bpos);
+    }
+  }
+  *best_out = best;
+  *bidx_out = bidx;
+  return bpos;
+}
+
+// first search phase: the 3^DIM cells around the query.  All row ranges are fetched up front
+// (independent loads), then the candidates of each row are streamed two at a time.
+template <int DIM>
+__device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                             float& best, int& bidx, int& bpos) {
+  constexpr int NROWS = DIM == 3 ? 9 : 3;
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+  if (x0 > x1) return;
+  int rs[NROWS], re[NROWS];
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+    const int y = cy + (r % 3) - 1;
+    const int z = DIM == 3 ? cz + (r / 3) - 1 : 0;
+    const bool ok = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+    const int row = ok ? (z * g.ny + y) * g.nx : 0;
+    rs[r] = ok ? g.cell_start[row + x0] : 0;
+    re[r] = ok ? g.cell_start[row + x1 + 1] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+    scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, best, bidx, bpos);
+  }
+}
+
+// radius-2 cube, one z-layer (5 rows) at a time: the 10 range fetches of a layer are independent, so a lane
+// pays one fetch latency per layer instead of one per row.  Re-visits the radius-1 block (harmless: the
+// minimum is idempotent).
+template <int DIM>
+__device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                             float& best, int& bidx, int& bpos) {
+  const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.nx - 1);
+  if (x0 > x1) return;
+  const int zlo = DIM == 3 ? cz - 2 : 0, zhi = DIM == 3 ? cz + 2 : 0;
+  for (int z = zlo; z <= zhi; ++z) {
+    if (z < 0 || z >= g.nz) continue;
+    int rs[5], re[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int y   = cy + r - 2;
+      const bool ok = y >= 0 && y < g.ny;
+      const int row = ok ? (z * g.ny + y) * g.nx : 0;
+      rs[r] = ok ? g.cell_start[row + x0] : 0;
+      re[r] = ok ? g.cell_start[row + x1 + 1] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, best, bidx, bpos);
     }
   }
 }
 
+// Sum 32 per-lane values over the 64 lanes of a wave with a transposing butterfly: at every step a lane
+// hands half of its values to its partner, so the reduction costs 32 exchanges instead of 32 x 6.  The two
+// widest steps use gfx950's v_permlane32_swap / v_permlane16_swap (pure VALU, no LDS crossbar, no selects).
+// On return lane L holds the wave total of value index
+//   16*bit5(L) + 8*bit4(L) + 4*bit3(L) + 2*bit2(L) + bit1(L);   lanes 2a and 2a+1 hold the same total.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ long long swap_add32(long long a, long long b) {
+  // a' = [a.lo32lanes, b.lo32lanes], b' = [a.hi32lanes, b.hi32lanes]; a' + b'
+  v2u lo = __builtin_amdgcn_permlane32_swap((unsigned) a, (unsigned) b, false, false);
+  v2u hi = __builtin_amdgcn_permlane32_swap((unsigned) ((unsigned long long) a >> 32),
+                                            (unsigned) ((unsigned long long) b >> 32), false, false);
+  long long x = (long long) (((unsigned long long) hi.x << 32) | lo.x);
+  long long y = (long long) (((unsigned long long) hi.y << 32) | lo.y);
+  return x + y;
+}
+__device__ __forceinline__ long long swap_add16(long long a, long long b) {
+  v2u lo = __builtin_amdgcn_permlane16_swap((unsigned) a, (unsigned) b, false, false);
+  v2u hi = __builtin_amdgcn_permlane16_swap((unsigned) ((unsigned long long) a >> 32),
+                                            (unsigned) ((unsigned long long) b >> 32), false, false);
+  long long x = (long long) (((unsigned long long) hi.x << 32) | lo.x);
+  long long y = (long long) (((unsigned long long) hi.y << 32) | lo.y);
+  return x + y;
+}
+
+__device__ __forceinline__ long long wave_transpose_reduce(long long (&v)[ACC_N], int lane, int& index_out) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = swap_add32(v[i], v[i + 16]);  // lanes <32 keep i, lanes >=32 keep i+16
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = swap_add16(v[i], v[i + 8]);    // bit4 == 0 keep i, bit4 == 1 keep i+8
+  {  // xor 8: 4 values kept
+    const bool upper = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long send = upper ? v[i] : v[i + 4];
+      const long long keep = upper ? v[i + 4] : v[i];
+      v[i]                 = keep + __shfl_xor(send, 8);
+    }
+  }
+  {  // xor 4: 2 values kept
+    const bool upper = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long long send = upper ? v[i] : v[i + 2];
+      const long long keep = upper ? v[i + 2] : v[i];
+      v[i]                 = keep + __shfl_xor(send, 4);
+    }
+  }
+  {  // xor 2: 1 value kept
+    const bool upper     = (lane & 2) != 0;
+    const long long send = upper ? v[0] : v[1];
+    const long long keep = upper ? v[1] : v[0];
+    v[0]                 = keep + __shfl_xor(send, 2);
+  }
+  v[0] += __shfl_xor(v[0], 1);
+  index_out = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 +
+              ((lane >> 1) & 1);
+  return v[0];
+}
+
+}  // namespace
+
 template <int DIM, bool PLANE>
 __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                  ProblemState* __restrict__ states, int slot) {
+                                                  ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   const int prob     = blockIdx.y;
@@ -248,12 +473,12 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 
   // finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35
   float T[12];
-  if (DIM == 3) {
+  if constexpr (DIM == 3) {
     dm::se3_compose(S.Sinv, st->X, T);
   } else {
     float t9[9];
     dm::se2_compose(S.Sinv, st->X, t9);
-    // spread the 3x3 into the 3x4 slots used below: rows [r0 r1 t]
+    // spread the 3x3 into the 3x4 slots used below: rows [r0 r1 . t]
     T[0] = t9[0]; T[1] = t9[1]; T[2] = 0.f; T[3] = t9[2];
     T[4] = t9[3]; T[5] = t9[4]; T[6] = 0.f; T[7] = t9[5];
     T[8] = 0.f; T[9] = 0.f; T[10] = 1.f; T[11] = 0.f;
@@ -270,44 +495,184 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 #pragma unroll
   for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
 
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
-    const int gi   = pd.moff + i;
-    const float4 p = S.mpts[gi];
-    int match      = -1;
-    float resp     = 0.f;
-    uint8_t fstat  = SRRG2_FACTOR_SUPPRESSED;
-    if (finite3(p.x, p.y, p.z)) {
-      float qx, qy, qz = 0.f;
-      if constexpr (DIM == 3) {
-        qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
-        qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
-        qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
-      } else {
-        qx = (T[0] * p.x + T[1] * p.y) + T[3];
-        qy = (T[4] * p.x + T[5] * p.y) + T[7];
+  // ONE moving point per thread: the 32 fixed-point terms of the point go straight into the wave
+  // reduction, so no accumulator registers are live during the search.
+  __shared__ int coop_flat[4][132];
+  __shared__ int coop_first[4][128];
+  const int i       = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane    = threadIdx.x & 63;
+  const int wid     = threadIdx.x >> 6;
+  const bool inrange = i < pd.nm;
+  const int gi      = pd.moff + (inrange ? i : 0);
+  float4 p          = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (inrange) p = S.mpts[gi];
+  // moving points are stored spatially sorted; p.w carries the caller's index within the problem
+  const int oi      = pd.moff + __float_as_int(p.w);
+  const bool active = inrange && finite3(p.x, p.y, p.z);
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  int cx = 0, cy = 0, cz = 0;
+  float best = INFINITY;
+  int bidx = NO_MATCH, bpos = 0;
+  int r2 = 0;  // > 1: this lane needs the second search phase with cube radius r2
+  if (active) {
+    if constexpr (DIM == 3) {
+      qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+      qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+      qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+    } else {
+      qx = (T[0] * p.x + T[1] * p.y) + T[3];
+      qy = (T[4] * p.x + T[5] * p.y) + T[7];
+    }
+    cx = cell_coord(qx, g.ox, g.inv_h);
+    cy = cell_coord(qy, g.oy, g.inv_h);
+    cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
+    const bool found1 = bidx != NO_MATCH && best <= g.gate2;
+    if (!(found1 && best <= b2_1) && g.rmax > 1) {
+      r2 = g.rmax;
+      if (found1) {
+        r2 = 1;
+        while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
       }
-      const int cx = cell_coord(qx, g.ox, g.inv_h);
-      const int cy = cell_coord(qy, g.oy, g.inv_h);
-      const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
-      float best   = INFINITY;
-      int bidx = NO_MATCH, bpos = 0;
-      scan_cube<DIM>(g, qx, qy, qz, cx, cy, cz, 1, best, bidx, bpos);
-      bool found = bidx != NO_MATCH && best <= g.gate2;
-      if (!(found && best <= b2_1) && g.rmax > 1) {
-        int r2 = g.rmax;
-        if (found) {
-          r2 = 1;
+    }
+  }
+  // Phase 1b: lanes that did not settle inside the 3^DIM block (sparser regions, or a misaligned first
+  // iteration) scan the radius-2 cube themselves; only what is still open afterwards goes to the
+  // cooperative scan below.
+  if (g.rmax >= 2 && !(S.tune & 2)) {
+    if (r2 > 1) {
+      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
+      const bool found2 = bidx != NO_MATCH && best <= g.gate2;
+      if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
+        r2 = 0;
+      } else {
+        r2 = g.rmax;
+        if (found2) {
+          r2 = 2;
           while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
         }
-        if (r2 > 1) scan_cube<DIM>(g, qx, qy, qz, cx, cy, cz, r2, best, bidx, bpos);
       }
-      found = bidx != NO_MATCH && best <= g.gate2;
+    }
+  }
+  // Second search phase, wave-cooperative: a lane whose nearest neighbour may lie outside the 3^DIM block
+  // (or that found nothing) needs a cube of radius r2 <= rmax; scanning it alone would stall its whole wave
+  // for up to (2 rmax + 1)^2 dependent row fetches.  Instead the 64 lanes split the rows of that cube, then
+  // take the lexicographic minimum of (d2, fixed index) across the wave.  Same cells, same exact result.
+  {
+    unsigned long long need = __ballot(r2 > 1);
+    if (S.tune & 1) need = 0;
+    while (need) {
+      const int src = __ffsll((long long) need) - 1;
+      need &= need - 1;
+      const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
+      const int scx = __shfl(cx, src), scy = __shfl(cy, src), scz = __shfl(cz, src);
+      const int sr = __shfl(r2, src);
+      const int z0 = DIM == 3 ? max(scz - sr, 0) : 0, z1 = DIM == 3 ? min(scz + sr, g.nz - 1) : 0;
+      const int y0 = max(scy - sr, 0), y1 = min(scy + sr, g.ny - 1);
+      const int x0 = max(scx - sr, 0), x1 = min(scx + sr, g.nx - 1);
+      float lbest = INFINITY;
+      int lidx = NO_MATCH, lpos = 0;
+      if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+        const int ny_r = y1 - y0 + 1;
+        const int rows = ny_r * (z1 - z0 + 1);
+        int* flat      = coop_flat[wid];  // flattened candidate offset at which each row starts (+ total)
+        int* first     = coop_first[wid]; // sorted-array index of each row's first candidate
+        for (int row0 = 0; row0 < rows; row0 += 128) {
+          // (1) every lane fetches the [start, end) ranges of two rows: all row fetches of the cube in flight at once
+          int sA = 0, eA = 0, sB = 0, eB = 0;
+          const int rA = row0 + lane, rB = row0 + 64 + lane;
+          if (rA < rows) {
+            const int row = ((z0 + rA / ny_r) * g.ny + (y0 + rA % ny_r)) * g.nx;
+            sA = g.cell_start[row + x0];
+            eA = g.cell_start[row + x1 + 1];
+          }
+          if (rB < rows) {
+            const int row = ((z0 + rB / ny_r) * g.ny + (y0 + rB % ny_r)) * g.nx;
+            sB = g.cell_start[row + x0];
+            eB = g.cell_start[row + x1 + 1];
+          }
+          // (2) wave prefix sum of both counts at once (packed in 64 bits)
+          const unsigned long long pk = (unsigned long long) (unsigned) (eA - sA) |
+                                        ((unsigned long long) (unsigned) (eB - sB) << 32);
+          unsigned long long inc = pk;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+          }
+          const unsigned long long tot = __shfl(inc, 63);
+          const int totA = (int) (unsigned) tot, totB = (int) (tot >> 32);
+          const unsigned long long exc = inc - pk;
+          flat[lane]       = (int) (unsigned) exc;
+          flat[64 + lane]  = totA + (int) (exc >> 32);
+          first[lane]      = sA;
+          first[64 + lane] = sB;
+          if (lane == 0) flat[128] = totA + totB;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // (3) every lane takes an equal contiguous share of the flattened candidate list
+          const int total = totA + totB;
+          const int share = (total + 63) >> 6;
+          int t           = lane * share;
+          const int tend  = min(t + share, total);
+          if (t < tend) {
+            int lo = 0, hi = 127;  // last row whose start offset is <= t
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+              const int mid = (lo + hi + 1) >> 1;
+              if (flat[mid] <= t) lo = mid; else hi = mid - 1;
+            }
+            int r = lo;
+            int next = flat[r + 1];
+            while (t < tend) {
+              while (t >= next) {
+                ++r;
+                next = flat[r + 1];
+              }
+              const int j = first[r] + (t - flat[r]);
+              const int run = min(next, tend) - t;  // candidates of this row in my share: consecutive in memory
+              scan_range<DIM>(g.pts, j, j + run, sqx, sqy, sqz, lbest, lidx, lpos);
+              t += run;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      // wave minimum of the 64-bit key (d2 bits, index): d2 >= 0 so the float bit pattern orders like the value
+      unsigned long long key = ((unsigned long long) __float_as_uint(lbest) << 32) | (unsigned) lidx;
+      unsigned long long kmin = key;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(kmin, off);
+        kmin = o < kmin ? o : kmin;
+      }
+      const unsigned long long who = __ballot(key == kmin);
+      const int wl   = __ffsll((long long) who) - 1;
+      const int wpos = __shfl(lpos, wl);
+      if (lane == src) {
+        const float wbest = __uint_as_float((unsigned) (kmin >> 32));
+        const int widx    = (int) (unsigned) kmin;
+        if (wbest < best || (wbest == best && widx < bidx)) {
+          best = wbest;
+          bidx = widx;
+          bpos = wpos;
+        }
+      }
+    }
+  }
+  int match     = -1;
+  float resp    = 0.f;
+  uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
+  if (inrange) {
+    if (active) {
+      bool found = bidx != NO_MATCH && best <= g.gate2;
       float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
       if (found && (PLANE || S.use_normal_gate)) nf = g.nrm[bpos];
       if (found && S.use_normal_gate) {
         const float4 nm = S.mnrm[gi];
         float dot;
-        if (DIM == 3) {
+        if constexpr (DIM == 3) {
           float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
           float ry = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
           float rz = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
@@ -386,7 +751,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
             kernelized = true;
             w = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
           }
-          const long long chi_fx = __double2ll_rn((double) chi * scale);
+          const long long chi_fx = to_fixed((double) chi * scale);
           if (kernelized) {
             fstat = SRRG2_FACTOR_KERNELIZED;
             acc[ACC_N_OUT] += 1;
@@ -397,47 +762,46 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
             acc[ACC_CHI_IN] += chi_fx;
           }
           if (w != 0.f) {
+            // (w * 2^k) is exact, (w * 2^k) * J is exact (24 x 24 bits): scaling commutes with the one
+            // rounding of the final product, so these are the specified terms times 2^k exactly.
+            const double ws = (double) w * scale;
 #pragma unroll
             for (int a = 0; a < D; ++a) {
               double wj[ROWS];
 #pragma unroll
-              for (int r = 0; r < ROWS; ++r) wj[r] = (double) w * (double) J[r][a];
+              for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
 #pragma unroll
               for (int b = a; b < D; ++b) {
                 double t = wj[0] * (double) J[0][b];
 #pragma unroll
                 for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) J[r][b];
-                acc[hidx(a, b)] += __double2ll_rn(t * scale);
+                acc[hidx(a, b)] += to_fixed(t);
               }
               double t = wj[0] * (double) e[0];
 #pragma unroll
               for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) e[r];
-              acc[ACC_B + a] += __double2ll_rn(t * scale);
+              acc[ACC_B + a] += to_fixed(t);
             }
           }
         }
       }
     }
-    S.corr_fixed[gi] = match;
-    S.corr_resp[gi]  = resp;
-    S.corr_stat[gi]  = fstat;
+    S.corr_fixed[oi] = match;
+    S.corr_resp[oi]  = resp;
+    S.corr_stat[oi]  = fstat;
   }
 
-  // block reduction: wave shuffles, then 4 waves through LDS, then one 64-bit atomic per entry
+  // block reduction: transposing butterfly per wave, 4 waves through LDS, then ONE plain 256-byte store of
+  // the block's partial sums.  (Device-scope atomics on 32 shared addresses serialise at ~10 ns each:
+  // 391 blocks x 32 atomics cost ~90 us at C2 -- profiles/r1a; the control kernel sums the partials instead.)
   __shared__ long long red[4][ACC_N];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-  for (int a = 0; a < ACC_N; ++a) {
-    long long v = wave_sum(acc[a]);
-    if (lane == 0) red[wid][a] = v;
-  }
+  int my_index;
+  const long long total = wave_transpose_reduce(acc, lane, my_index);
+  if ((lane & 1) == 0) red[wid][my_index] = total;
   __syncthreads();
   if (threadIdx.x < ACC_N) {
     long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (v != 0) {
-      unsigned long long* dst = S.acc + ((size_t) prob * S.slots + slot) * ACC_N + threadIdx.x;
-      atomicAdd(dst, (unsigned long long) v);
-    }
+    S.partials[((size_t) prob * gridDim.x + blockIdx.x) * ACC_N + threadIdx.x] = v;
   }
 }
 
@@ -568,7 +932,8 @@ __device__ bool has_to_stop(const CtlParams& C, ProblemState* st, const srrg2_it
 }
 
 template <int D>
-__device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob, int slot) {
+__device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob,
+                             const long long (*sums)[ACC_N]) {
   // association check: association_good |= slice->correspondencesGood(), multi_aligner.h:126-138
   bool good = false;
   for (int s = 0; s < C.nslices; ++s) {
@@ -577,8 +942,8 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
       good = true;  // aligner_slice_processor_prior.h:66-68
       continue;
     }
-    const unsigned long long* acc = sc.acc + ((size_t) prob * sc.slots + slot) * ACC_N;
-    int nc       = (int) (long long) acc[ACC_N_CORR];
+    const long long* acc = sums[s];
+    int nc               = (int) acc[ACC_N_CORR];
     st->ncorr[s] = nc;
     good |= nc > sc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
   }
@@ -589,7 +954,9 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   }
   // solver->compute(): one Gauss-Newton iteration over all slices' factors
   double H[D * D], b[D], dx[D];
+#pragma unroll
   for (int i = 0; i < D * D; ++i) H[i] = 0.0;
+#pragma unroll
   for (int i = 0; i < D; ++i) b[i] = 0.0;
   srrg2_iteration_stats cur;
   cur.iteration = st->nstats;
@@ -602,7 +969,9 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
       double pH[D * D], pb[D], pchi;
       int pstat;
       prior_linearize<D>(C.variable_kind, sc, rk, st->X, pH, pb, pchi, pstat);
+#pragma unroll
       for (int i = 0; i < D * D; ++i) H[i] = H[i] + pH[i];
+#pragma unroll
       for (int i = 0; i < D; ++i) b[i] = b[i] + pb[i];
       if (pstat == SRRG2_FACTOR_INLIER) {
         cur.num_inliers++;
@@ -616,23 +985,25 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
       st->ninl[s] = pstat == SRRG2_FACTOR_INLIER ? 1 : 0;
       continue;
     }
-    const unsigned long long* acc = sc.acc + ((size_t) prob * sc.slots + slot) * ACC_N;
-    const double inv = dm::pow2(-st->kexp[s]);
+    const long long* acc = sums[s];
+    const double inv     = dm::pow2(-st->kexp[s]);
+#pragma unroll
     for (int a = 0; a < D; ++a) {
+#pragma unroll
       for (int c = a; c < D; ++c) {
-        double v     = (double) (long long) acc[hidx(a, c)] * inv;
+        double v     = (double) acc[hidx(a, c)] * inv;
         H[a * D + c] = H[a * D + c] + v;
         if (c != a) H[c * D + a] = H[c * D + a] + v;
       }
-      b[a] = b[a] + (double) (long long) acc[ACC_B + a] * inv;
+      b[a] = b[a] + (double) acc[ACC_B + a] * inv;
     }
-    int n_in = (int) (long long) acc[ACC_N_IN], n_out = (int) (long long) acc[ACC_N_OUT];
-    int n_c  = (int) (long long) acc[ACC_N_CORR];
+    int n_in = (int) acc[ACC_N_IN], n_out = (int) acc[ACC_N_OUT];
+    int n_c  = (int) acc[ACC_N_CORR];
     cur.num_inliers += n_in;
     cur.num_outliers += n_out;
     cur.num_suppressed += n_c - n_in - n_out;
-    chi_in      = chi_in + (double) (long long) acc[ACC_CHI_IN] * inv;
-    chi_out     = chi_out + (double) (long long) acc[ACC_CHI_OUT] * inv;
+    chi_in      = chi_in + (double) acc[ACC_CHI_IN] * inv;
+    chi_out     = chi_out + (double) acc[ACC_CHI_OUT] * inv;
     st->ninl[s] = n_in;
   }
   cur.num_correspondences = num_correspondences(C, st);
@@ -640,7 +1011,9 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   cur.chi_outliers        = (float) chi_out;
   int bad                 = dm::solve<D>(H, b, dx);
   cur.solver_status       = bad ? 1 : 0;
+#pragma unroll
   for (int i = 0; i < D * D; ++i) st->last_H[i] = H[i];
+#pragma unroll
   for (int i = 0; i < D; ++i) {
     st->last_b[i]  = b[i];
     st->last_dx[i] = bad ? 0.0 : dx[i];
@@ -681,16 +1054,44 @@ __global__ void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs, Pr
   }
 }
 
-__global__ void k_icp_control(CtlParams C, ProblemState* __restrict__ states, srrg2_iteration_stats* __restrict__ stats,
-                              int slot) {
-  int prob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (prob >= C.K) return;
+// one 256-thread block per problem: sum the per-block partials of every cue slice (exact integer sums, any
+// order), then thread 0 runs the sequential part of the iteration
+__global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* __restrict__ states,
+                                                     srrg2_iteration_stats* __restrict__ stats) {
+  const int prob   = blockIdx.x;
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
+  __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
+  __shared__ long long part[8][ACC_N];
+  const int a = threadIdx.x & 31, c = threadIdx.x >> 5;
+  for (int s = 0; s < C.nslices; ++s) {
+    const SliceCtl& sc = C.slices[s];
+    if (sc.kind == SRRG2_SLICE_PRIOR) continue;
+    const long long* p = sc.partials + (size_t) prob * sc.nblocks * ACC_N;
+    long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int b = c;
+    for (; b + 24 < sc.nblocks; b += 32) {  // four independent loads in flight
+      v0 += p[(size_t) b * ACC_N + a];
+      v1 += p[(size_t) (b + 8) * ACC_N + a];
+      v2 += p[(size_t) (b + 16) * ACC_N + a];
+      v3 += p[(size_t) (b + 24) * ACC_N + a];
+    }
+    for (; b < sc.nblocks; b += 8) v0 += p[(size_t) b * ACC_N + a];
+    part[c][a] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (threadIdx.x < ACC_N) {
+      long long t = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+      sums[s][threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
   if (C.variable_kind == SRRG2_SE2_RIGHT)
-    control_body<3>(C, st, stats, prob, slot);
+    control_body<3>(C, st, stats, prob, sums);
   else
-    control_body<6>(C, st, stats, prob, slot);
+    control_body<6>(C, st, stats, prob, sums);
 }
 
 // after the main _runSolver: multi_aligner_impl.cpp:75-85 and the start of _postCompute (:165-171)
@@ -777,22 +1178,40 @@ void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm,
   hipLaunchKernelGGL(k_grid_scatter, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, nrm, n, cursor, out_pts, out_nrm);
 }
 
-void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int slot,
-                     int K, int max_nm, hipStream_t s) {
+void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
+                  unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
+                  float4* out_nrm, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
   int bx = (max_nm + 255) / 256;
-  if (bx > 4096) bx = 4096;
+  if (bx > 1024) bx = 1024;
+  dim3 grid(bx, K);
+  const int ncell = K << (3 * bits);
+  hipLaunchKernelGGL(k_msort_bbox, grid, dim3(256), 0, s, pts, probs, bb);
+  hipLaunchKernelGGL(k_msort_count, grid, dim3(256), 0, s, pts, probs, bb, bits, counts);
+  launch_exclusive_scan(counts, ncell, scan_sums, scan_total, s);
+  (void) hipMemcpyAsync(cursor, counts, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(k_msort_scatter, grid, dim3(256), 0, s, pts, nrm, probs, bb, bits, cursor, out_pts, out_nrm);
+}
+
+int icp_step_blocks(int max_nm) {
+  return (max_nm + 255) / 256;  // one moving point per thread
+}
+
+void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                     int max_nm, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  int bx = (max_nm + 255) / 256;  // one moving point per thread
   dim3 grid(bx, K);
   if (dim == 3) {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step<3, true>), grid, dim3(256), 0, s, S, probs, states, slot);
+      hipLaunchKernelGGL((k_icp_step<3, true>), grid, dim3(256), 0, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step<3, false>), grid, dim3(256), 0, s, S, probs, states, slot);
+      hipLaunchKernelGGL((k_icp_step<3, false>), grid, dim3(256), 0, s, S, probs, states);
   } else {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step<2, true>), grid, dim3(256), 0, s, S, probs, states, slot);
+      hipLaunchKernelGGL((k_icp_step<2, true>), grid, dim3(256), 0, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), 0, s, S, probs, states, slot);
+      hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), 0, s, S, probs, states);
   }
 }
 
@@ -800,8 +1219,8 @@ void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* 
                      hipStream_t s) {
   hipLaunchKernelGGL(k_icp_init, dim3((C.K + 63) / 64), dim3(64), 0, s, C, probs, states, guesses, tsize);
 }
-void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, int slot, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_control, dim3((C.K + 63) / 64), dim3(64), 0, s, C, states, stats, slot);
+void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_control, dim3(C.K), dim3(256), 0, s, C, states, stats);
 }
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_post, dim3((C.K + 63) / 64), dim3(64), 0, s, C, states, stats);

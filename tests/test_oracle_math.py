@@ -99,4 +99,4 @@ def test_fixed_point_exponent(oracle):
     assert f(1, 1.0) == 50  # clamped
     assert f(100000, 600.0) == 62 - 17 - 10
     assert f(1 << 20, 1.0) == 62 - 20 - 0
-    assert f(3, 2.0) == 62 - 2 - 1 if 62 - 2 - 1 <= 50 else 50
+    assert f(3, 2.0) == 49  # per-term cap: 2^k * bound <= 2^50
