@@ -411,6 +411,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   C.has_term      = a->has_term ? 1 : 0;
   C.term          = a->term;
   C.max_stats     = slots;
+  C.tune          = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {

@@ -106,5 +106,6 @@ struct CtlParams {
   int has_term;
   srrg2_termination_params term;
   int max_stats;  // capacity of the per-problem stats array
+  int tune;       // debug flags (SRRG2_AMD_TUNE); 256 = keep iterating when the association fails (timing only)
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

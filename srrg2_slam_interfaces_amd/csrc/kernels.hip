@@ -399,6 +399,12 @@ __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float q
   }
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Sum 32 per-lane values over the 64 lanes of a wave with a transposing butterfly: at every step a lane
 // hands half of its values to its partner, so the reduction costs 32 exchanges instead of 32 x 6.  The two
 // widest steps use gfx950's v_permlane32_swap / v_permlane16_swap (pure VALU, no LDS crossbar, no selects).
@@ -497,8 +503,6 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 
   // ONE moving point per thread: the 32 fixed-point terms of the point go straight into the wave
   // reduction, so no accumulator registers are live during the search.
-  __shared__ int coop_flat[4][132];
-  __shared__ int coop_first[4][128];
   const int i       = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane    = threadIdx.x & 63;
   const int wid     = threadIdx.x >> 6;
@@ -526,6 +530,13 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     cx = cell_coord(qx, g.ox, g.inv_h);
     cy = cell_coord(qy, g.oy, g.inv_h);
     cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+  }
+  // ---- phases 1 / 1b: radius-1 block, then radius-2 block for lanes that did not settle ----------------------
+  // (A variant that staged the wave's whole neighbourhood box in LDS first was measured slower on both C2 and
+  //  C4 -- 24.6 vs 19.6 us and 226 vs 160 us per launch, profiles/r1 notes -- and was removed: the search is
+  //  bound by per-wave instruction issue, not by the number of dependent global round trips.)
+  __shared__ int coop_lds[4][264];
+  if (active && !(S.tune & 16)) {
     scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
     const bool found1 = bidx != NO_MATCH && best <= g.gate2;
     if (!(found1 && best <= b2_1) && g.rmax > 1) {
@@ -535,12 +546,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
         while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
       }
     }
-  }
-  // Phase 1b: lanes that did not settle inside the 3^DIM block (sparser regions, or a misaligned first
-  // iteration) scan the radius-2 cube themselves; only what is still open afterwards goes to the
-  // cooperative scan below.
-  if (g.rmax >= 2 && !(S.tune & 2)) {
-    if (r2 > 1) {
+    if (r2 > 1 && !(S.tune & 2)) {
       scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
       const bool found2 = bidx != NO_MATCH && best <= g.gate2;
       if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
@@ -575,8 +581,8 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
         const int ny_r = y1 - y0 + 1;
         const int rows = ny_r * (z1 - z0 + 1);
-        int* flat      = coop_flat[wid];  // flattened candidate offset at which each row starts (+ total)
-        int* first     = coop_first[wid]; // sorted-array index of each row's first candidate
+        int* flat      = coop_lds[wid];        // flattened candidate offset at which each row starts (+ total)
+        int* first     = coop_lds[wid] + 132;  // sorted-array index of each row's first candidate
         for (int row0 = 0; row0 < rows; row0 += 128) {
           // (1) every lane fetches the [start, end) ranges of two rows: all row fetches of the cube in flight at once
           int sA = 0, eA = 0, sB = 0, eB = 0;
@@ -608,9 +614,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
           first[lane]      = sA;
           first[64 + lane] = sB;
           if (lane == 0) flat[128] = totA + totB;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          wave_lds_sync();
           // (3) every lane takes an equal contiguous share of the flattened candidate list
           const int total = totA + totB;
           const int share = (total + 63) >> 6;
@@ -667,10 +671,11 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   if (inrange) {
     if (active) {
       bool found = bidx != NO_MATCH && best <= g.gate2;
+      if (S.tune & 8) found = false;
       float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (found && (PLANE || S.use_normal_gate)) nf = g.nrm[bpos];
+      if (found && (PLANE || S.use_normal_gate)) nf = (S.tune & 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[bpos];
       if (found && S.use_normal_gate) {
-        const float4 nm = S.mnrm[gi];
+        const float4 nm = (S.tune & 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : S.mnrm[gi];
         float dot;
         if constexpr (DIM == 3) {
           float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
             acc[ACC_N_IN] += 1;
             acc[ACC_CHI_IN] += chi_fx;
           }
-          if (w != 0.f) {
+          if (w != 0.f && !(S.tune & 64)) {
             // (w * 2^k) is exact, (w * 2^k) * J is exact (24 x 24 bits): scaling commutes with the one
             // rounding of the final product, so these are the specified terms times 2^k exactly.
             const double ws = (double) w * scale;
@@ -947,7 +952,7 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
     st->ncorr[s] = nc;
     good |= nc > sc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
   }
-  if (!good) {
+  if (!good && !(C.tune & 256)) {
     st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;  // multi_aligner_impl.cpp:107-111
     st->done   = 1;
     return;
