@@ -81,38 +81,43 @@ def main():
     ident = syn.identity(3)
     al = make_aligner(lambda: pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=local_rank), abi, args.iterations, args.cell_size)
 
+    from srrg2_slam_interfaces_amd import distributed as D
+
     if args.workload == "c2":
         data = syn.cloud_pair_3d(n=args.points, seed=2000 + 10 * rank)
         al.set_fixed(0, data["fixed"], data["fixed_normals"])
         al.set_moving(0, data["moving"], data["moving_normals"])
-        units_per_step = args.iterations  # ICP iterations
+        K_total = world  # one alignment per rank: alignment k lives on rank k (k mod G)
+        units_per_step = args.iterations  # ICP iterations per rank per step
         alg_bytes_per_launch = 12 * args.points + 24 * args.points + 12 * args.points
 
         def step():
             al.set_moving_in_fixed(ident)
-            return al.compute()
+            st = al.compute()
+            stats = al.iteration_stats()
+            return [D.pack_record(rank, {"moving_in_fixed": al.moving_in_fixed(), "status": st,
+                                         "num_iterations": len(stats), "last": stats[-1]})]
     else:
-        probs = syn.batch_3d(K=args.batch, n=args.batch_points, seed=4000 + 1000 * rank, shared_fixed_group=8)
-        # one fixed scene per group of 8 candidates: this bench keeps ONE fixed (group 0) resident
+        # C4: K_total alignments sharded k -> k mod G; this rank's moving clouds are resident in HBM
+        K_total = args.batch * world
+        mine = D.shard(K_total, world, rank)
+        probs = syn.batch_3d(K=args.batch, n=args.batch_points, seed=4000 + 1000 * rank, shared_fixed_group=1 << 30)
         al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
-        movs = [p["moving"] for p in probs]
-        nrms = [p["moving_normals"] for p in probs]
-        guesses = [ident] * len(probs)
+        coords = torch.from_numpy(np.concatenate([p["moving"] for p in probs], axis=0)).cuda()
+        normals = torch.from_numpy(np.concatenate([p["moving_normals"] for p in probs], axis=0)).cuda()
+        offsets = np.arange(args.batch + 1, dtype=np.int32) * args.batch_points
+        guesses = np.stack([ident] * args.batch)
         units_per_step = args.iterations * args.batch
         alg_bytes_per_launch = args.batch * 48 * args.batch_points
 
         def step():
-            return al.compute_batch(movs, guesses, nrms)
-
-    gather_in = torch.zeros(16, device="cuda")
-    gather_out = [torch.zeros(16, device="cuda") for _ in range(world)] if world > 1 else None
+            res = al.compute_batch_device(coords.data_ptr(), 12, normals.data_ptr(), 12, offsets, guesses)
+            return [D.pack_record(k, r) for k, r in zip(mine, res)]
 
     def full_step():
-        step()
-        if world > 1:  # all-gather of the per-alignment result records
-            gather_in[:12] = torch.from_numpy(al.moving_in_fixed().reshape(-1)).cuda()
-            gather_in[12] = float(al.status())
-            dist.all_gather(gather_out, gather_in)
+        recs = step()
+        # the ONE collective of the path: all-gather of the per-alignment result records
+        return D.all_gather_records(recs, K_total, device="cuda")
 
     for _ in range(args.warmup):
         full_step()

@@ -254,6 +254,47 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h h, int K, const float* coords,
                                 const float* guesses /* K x 12 (or 9) */,
                                 srrg2_batch_result* results);
 
+/* ---- pose graph: the global Solver of MultiGraphSLAM_ ---------------------- */
+/* MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317): graph->bindFactors();
+ * global_solver->setGraph(graph); global_solver->compute().  The graph holds only pose variables
+ * (LocalMap2D/3D = VariableSE2RightAD / VariableSE3QuaternionRightAD, S/mapping/local_map.h:64,75) and binary
+ * SE{2,3}PosePoseGeodesicErrorFactor edges (S/registration/loop_closure.h:110-111) built at
+ * multi_graph_slam_impl.cpp:71-79 (odometry, Omega = I * info_scale) and :241-293 (closures, created disabled). */
+typedef struct srrg2_posegraph_params {
+  int32_t max_iterations;     /* Gauss-Newton iterations of one compute() */
+  int32_t pcg_max_iterations; /* linear solver: block-Jacobi preconditioned CG */
+  float   pcg_tolerance;      /* stop when |r| <= tol * |b| */
+  float   damping;            /* lambda added to the diagonal (0 = pure Gauss-Newton) */
+} srrg2_posegraph_params;
+
+typedef struct srrg2_posegraph_stats {
+  int32_t iteration;
+  int32_t num_factors;    /* enabled factors linearised */
+  int32_t pcg_iterations;
+  int32_t solver_status;  /* 0 = ok, 1 = preconditioner block not positive definite */
+  float   chi;            /* sum e^T Omega e at the linearisation point of this iteration */
+  float   pcg_residual;   /* |r| / |b| at exit */
+} srrg2_posegraph_stats;
+
+typedef struct srrg2_posegraph_s* srrg2_posegraph_h;
+
+/* variable_kind: SRRG2_SE2_RIGHT or SRRG2_SE3_QUAT_RIGHT */
+int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out);
+int srrg2_posegraph_destroy(srrg2_posegraph_h h);
+void srrg2_posegraph_default_params(srrg2_posegraph_params* p);
+/* (re)define the whole graph.  poses: V transforms (12 or 9 floats each); fixed_mask: V bytes, non-zero =
+ * VariableBase::Fixed (multi_graph_slam_impl.cpp:86), NULL = only pose 0 fixed; ij: E pairs (from, to);
+ * Z: E measurements (setMeasurement, :76); omega: E information matrices, row-major DxD float (D = 3 or 6),
+ * NULL = identity; enabled: E bytes (LoopClosure_ factors are created disabled, loop_closure.h:71), NULL = all. */
+int srrg2_posegraph_set(srrg2_posegraph_h h, int V, const float* poses, const uint8_t* fixed_mask, int E,
+                        const int32_t* ij, const float* Z, const float* omega, const uint8_t* enabled);
+/* enable / disable factors in place (multi_graph_slam_impl.cpp:285-293) */
+int srrg2_posegraph_set_enabled(srrg2_posegraph_h h, const uint8_t* enabled);
+/* global_solver->compute(): blocking; poses are updated in place.  stats: one entry per GN iteration. */
+int srrg2_posegraph_solve(srrg2_posegraph_h h, const srrg2_posegraph_params* p, srrg2_posegraph_stats* stats,
+                          int* n_inout);
+int srrg2_posegraph_get_poses(srrg2_posegraph_h h, float* poses_out);
+
 /* ---- measurement hooks (no reference counterpart: the reference profiles with
  * PROFILE_TIME scopes outside the aligner) ------------- */
 

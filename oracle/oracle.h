@@ -74,6 +74,20 @@ int oracle_aligner_compute_batch(o_aligner* h, int K, const float* coords, int c
                                  const float* normals, int normal_stride_bytes, const int32_t* offsets,
                                  int mem, const float* guesses, srrg2_batch_result* results);
 
+/* ---- pose graph (o_posegraph.c), mirrors srrg2_posegraph_* ------------------------------- */
+typedef struct o_posegraph o_posegraph;
+int oracle_posegraph_create(int variable_kind, o_posegraph** out);
+int oracle_posegraph_destroy(o_posegraph* g);
+int oracle_posegraph_set(o_posegraph* g, int V, const float* poses, const uint8_t* fixed_mask, int E, const int32_t* ij,
+                         const float* Z, const float* omega, const uint8_t* enabled);
+int oracle_posegraph_set_enabled(o_posegraph* g, const uint8_t* enabled);
+int oracle_posegraph_solve(o_posegraph* g, const srrg2_posegraph_params* p, srrg2_posegraph_stats* stats, int* n_inout);
+int oracle_posegraph_get_poses(o_posegraph* g, float* out);
+/* oracle-only: dense Cholesky instead of PCG; chi2 at the current poses; one edge's e/Ji/Jj */
+int oracle_posegraph_set_direct(o_posegraph* g, int enable);
+double oracle_posegraph_chi(o_posegraph* g);
+int oracle_posegraph_edge(o_posegraph* g, int e, double* err, double* Ji, double* Jj);
+
 /* ---- oracle-only hooks used by the tests ---------------------------------- */
 /* 1 = brute-force O(Nf*Nm) gated NN (ground truth for indices), 0 = voxel-grid finder */
 int oracle_aligner_set_bruteforce(o_aligner* h, int enable);

@@ -161,3 +161,26 @@ def solve(H, b):
     dx = np.zeros(D)
     rc = lib().o_solve(C.c_int(D), _dp(H), _dp(b), _dp(dx))
     return rc, dx
+
+
+# ---- pose graph -------------------------------------------------------------------------------
+from srrg2_slam_interfaces_amd.posegraph import PoseGraph as _PoseGraph  # noqa: E402
+
+
+class OraclePoseGraph(_PoseGraph):
+    def __init__(self, variable_kind=abi.SE3_QUAT_RIGHT):
+        l = lib()
+        l.oracle_posegraph_chi.restype = C.c_double
+        super().__init__(l, "oracle_posegraph_", l.oracle_last_error, variable_kind, device=None)
+
+    def set_direct(self, enable):
+        self._check(lib().oracle_posegraph_set_direct(self._h, C.c_int(int(enable))))
+
+    def chi(self):
+        return lib().oracle_posegraph_chi(self._h)
+
+    def edge(self, e):
+        D = self.D
+        err, Ji, Jj = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+        self._check(lib().oracle_posegraph_edge(self._h, C.c_int(e), _dp(err), _dp(Ji), _dp(Jj)))
+        return err, Ji, Jj

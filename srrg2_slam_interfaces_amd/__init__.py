@@ -8,3 +8,12 @@ def MultiAligner(variable_kind=abi.SE3_QUAT_RIGHT, device=0):
     from .aligner import MultiAligner as _MA
 
     return _MA(_capi.backend(), variable_kind, device)
+
+
+def PoseGraph(variable_kind=abi.SE3_QUAT_RIGHT, device=0):
+    """Product pose-graph solver on the HIP library (raises if the library or a HIP device is missing)."""
+    from . import _capi
+    from .posegraph import PoseGraph as _PG
+
+    l = _capi.lib()
+    return _PG(l, "srrg2_posegraph_", l.srrg2_amd_last_error, variable_kind, device=device)

@@ -188,6 +188,30 @@ class MultiAligner:
                                                     out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n2)))
         return out[:n2.value]
 
+    def compute_batch_device(self, coords_ptr, coord_stride, normals_ptr, normal_stride, offsets, guesses):
+        """compute_batch on clouds already resident in HBM (raw device pointers as ints)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        K = offsets.size - 1
+        g = _as_f32(np.asarray(guesses)).reshape(K, self.tsize)
+        res = (abi.BatchResult * max(K, 1))()
+        self._check(self._b.fn("compute_batch")(
+            self._h, C.c_int(K), C.cast(coords_ptr, C.POINTER(C.c_float)), C.c_int(coord_stride),
+            C.cast(normals_ptr, C.POINTER(C.c_float)) if normals_ptr else None, C.c_int(normal_stride),
+            offsets.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(abi.MEM_DEVICE), _fptr(g), res))
+        return self._unpack_batch(res, K)
+
+    def _unpack_batch(self, res, K):
+        out = []
+        for k in range(K):
+            T = np.array(res[k].moving_in_fixed[:self.tsize], dtype=np.float32)
+            out.append({
+                "moving_in_fixed": T.reshape(3, 3) if self.dim == 2 else T.reshape(3, 4),
+                "status": res[k].status,
+                "num_iterations": res[k].num_iterations,
+                "last": res[k].last.as_dict(),
+            })
+        return out
+
     def compute_batch(self, moving_clouds, guesses, moving_normals=None):
         """K independent alignments against the fixed scene (multi_loop_detector_brute_force_impl.cpp:63-91)."""
         K = len(moving_clouds)
@@ -206,13 +230,4 @@ class MultiAligner:
                                                 nptr, C.c_int(nstride),
                                                 offsets.ctypes.data_as(C.POINTER(C.c_int32)),
                                                 C.c_int(abi.MEM_HOST), _fptr(g), res))
-        out = []
-        for k in range(K):
-            T = np.array(res[k].moving_in_fixed[:self.tsize], dtype=np.float32)
-            out.append({
-                "moving_in_fixed": T.reshape(3, 3) if self.dim == 2 else T.reshape(3, 4),
-                "status": res[k].status,
-                "num_iterations": res[k].num_iterations,
-                "last": res[k].last.as_dict(),
-            })
-        return out
+        return self._unpack_batch(res, K)

@@ -16,44 +16,20 @@
 #include "det_math.h"
 #include "kernels.h"
 
-namespace {
+#include "host_util.h"
 
+namespace srrg2amd {
 thread_local std::string g_err;
-
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+}  // namespace srrg2amd
 
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) {                                                                        \
-      return fail(SRRG2_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
-    }                                                                                              \
-  } while (0)
+namespace {
 
-template <typename T>
-struct DevBuf {
-  T* p       = nullptr;
-  size_t cap = 0;  // elements
-  int reserve(size_t n) {
-    if (n <= cap) return 0;
-    if (p) (void) hipFree(p);
-    p   = nullptr;
-    cap = 0;
-    size_t want = n + n / 8 + 16;
-    hipError_t e = hipMalloc((void**) &p, want * sizeof(T));
-    if (e != hipSuccess) return fail(SRRG2_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-    cap = want;
-    return 0;
-  }
-  void release() {
-    if (p) (void) hipFree(p);
-    p   = nullptr;
-    cap = 0;
-  }
-};
+using srrg2amd::DevBuf;
+using srrg2amd::fail;
 
 struct Slice {
   srrg2_slice_config cfg;
@@ -543,7 +519,7 @@ int srrg2_amd_abi_version(void) {
 }
 
 const char* srrg2_amd_last_error(void) {
-  return g_err.c_str();
+  return srrg2amd::g_err.c_str();
 }
 
 int srrg2_amd_device_count(void) {

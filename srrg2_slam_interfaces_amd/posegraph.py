@@ -1,0 +1,103 @@
+"""Python mirror of the global pose-graph solve over the C ABI (srrg2_posegraph_*).
+
+Replaces the call sequence of MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317):
+``graph->bindFactors(); global_solver->setGraph(graph); global_solver->compute()``.  Thin marshalling only;
+parametrised by a backend like ``aligner.MultiAligner`` so that the oracle binding can reuse it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+
+
+class PoseGraphParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("pcg_max_iterations", C.c_int32), ("pcg_tolerance", C.c_float),
+                ("damping", C.c_float)]
+
+
+class PoseGraphStats(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("num_factors", C.c_int32), ("pcg_iterations", C.c_int32),
+                ("solver_status", C.c_int32), ("chi", C.c_float), ("pcg_residual", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def default_params():
+    return PoseGraphParams(10, 200, 1e-6, 0.0)
+
+
+class PoseGraph:
+    def __init__(self, lib, prefix, err_fn, variable_kind=abi.SE3_QUAT_RIGHT, device=None):
+        self._lib, self._prefix, self._err = lib, prefix, err_fn
+        self.variable_kind = variable_kind
+        self.tsize = abi.transform_size(variable_kind)
+        self.D = 3 if variable_kind == abi.SE2_RIGHT else 6
+        self._h = C.c_void_p()
+        if device is None:
+            rc = self._fn("create")(C.c_int(variable_kind), C.byref(self._h))
+        else:
+            rc = self._fn("create")(C.c_int(variable_kind), C.c_int(device), C.byref(self._h))
+        self._check(rc)
+        self.V = self.E = 0
+
+    def _fn(self, name):
+        return getattr(self._lib, self._prefix + name)
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._err()
+            raise RuntimeError("%s (code %d)" % (msg.decode() if msg else "", rc))
+
+    def close(self):
+        if self._h:
+            self._fn("destroy")(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_graph(self, poses, ij, Z, omega=None, fixed_mask=None, enabled=None):
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, self.tsize)
+        ij = np.ascontiguousarray(ij, np.int32).reshape(-1, 2)
+        Z = np.ascontiguousarray(Z, np.float32).reshape(-1, self.tsize)
+        self.V, self.E = poses.shape[0], ij.shape[0]
+        assert Z.shape[0] == self.E
+        fp = C.POINTER(C.c_float)
+        bp = C.POINTER(C.c_uint8)
+        om = None
+        if omega is not None:
+            omega = np.ascontiguousarray(omega, np.float32).reshape(self.E, self.D * self.D)
+            om = omega.ctypes.data_as(fp)
+        fm = None
+        if fixed_mask is not None:
+            fixed_mask = np.ascontiguousarray(fixed_mask, np.uint8)
+            fm = fixed_mask.ctypes.data_as(bp)
+        en = None
+        if enabled is not None:
+            enabled = np.ascontiguousarray(enabled, np.uint8)
+            en = enabled.ctypes.data_as(bp)
+        self._check(self._fn("set")(self._h, C.c_int(self.V), poses.ctypes.data_as(fp), fm, C.c_int(self.E),
+                                    ij.ctypes.data_as(C.POINTER(C.c_int32)), Z.ctypes.data_as(fp), om, en))
+
+    def set_enabled(self, enabled):
+        enabled = np.ascontiguousarray(enabled, np.uint8)
+        assert enabled.size == self.E
+        self._check(self._fn("set_enabled")(self._h, enabled.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def solve(self, params=None):
+        params = params or default_params()
+        n = C.c_int(max(params.max_iterations, 1))
+        buf = (PoseGraphStats * n.value)()
+        self._check(self._fn("solve")(self._h, C.byref(params), buf, C.byref(n)))
+        return [buf[i].as_dict() for i in range(min(n.value, len(buf)))]
+
+    def poses(self):
+        out = np.zeros((max(self.V, 1), self.tsize), np.float32)
+        self._check(self._fn("get_poses")(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        shape = (3, 3) if self.tsize == 9 else (3, 4)
+        return out[:self.V].reshape((self.V,) + shape)

@@ -219,3 +219,85 @@ def scan_pair_2d(beams=1000, t=(0.10, 0.05), theta_deg=3.0, sigma=0.0, seed=1000
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     return {"fixed": f32(Pf), "fixed_normals": f32(Nf), "moving": f32(Pm), "moving_normals": f32(Nm),
             "X_gt": f32(X_gt)}
+
+
+# ---- C5: pose graphs ---------------------------------------------------------------------------------
+def _quat_v2t(v):
+    x, y, z = v[3:6]
+    w = np.sqrt(max(0.0, 1.0 - x * x - y * y - z * z))
+    T = np.zeros((3, 4))
+    T[:, :3] = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    T[:, 3] = v[:3]
+    return T
+
+
+def pose_graph_3d(V=50_000, E=200_000, seed=5000, sigma_t=0.01, sigma_r=0.005, spacing=0.5, loop_radius=1.5):
+    """C5: V SE(3) poses on a 3-D lawn-mower trajectory, V-1 odometry edges + (E-V+1) loop
+    edges between poses closer than loop_radius; Z = true relative pose (+) N(0, sigma); Omega = I; initial guess =
+    odometry integration; pose 0 fixed.  Returns dict(poses_gt, poses_init, ij, Z) (float32 / int32)."""
+    row = max(2, int(round(np.sqrt(V / 4.0))))  # poses per sweep line
+    gt = np.zeros((V, 3, 4))
+    for v in range(V):
+        line, k = divmod(v, row)
+        layer, line_in_layer = divmod(line, row)
+        x = (k if line % 2 == 0 else row - 1 - k) * spacing
+        y = line_in_layer * spacing
+        z = layer * spacing * 2.0
+        yaw = 0.0 if line % 2 == 0 else np.pi
+        gt[v] = se3(np.array([x, y, z]), np.array([0.02 * np.sin(0.1 * v), 0.03 * np.cos(0.07 * v), yaw]))
+    # candidate loop pairs: neighbours on adjacent sweep lines / layers
+    pos = gt[:, :, 3]
+    n_loop = E - (V - 1)
+    cand_i = (uniform(seed + 1, 4 * n_loop) * V).astype(np.int64)
+    offs = np.array([2 * row - 1, 2 * row, 2 * row + 1, row * row, row * row + 1, 3])
+    cand_j = cand_i + offs[(uniform(seed + 2, 4 * n_loop) * len(offs)).astype(np.int64)]
+    ok = (cand_j < V) & (cand_j >= 0)
+    d = np.linalg.norm(pos[np.minimum(cand_j, V - 1)] - pos[cand_i], axis=1)
+    ok &= d < loop_radius
+    ci, cj = cand_i[ok], cand_j[ok]
+    if ci.size < n_loop:  # fall back to short-range skips to reach the requested edge count
+        extra = n_loop - ci.size
+        ei = (uniform(seed + 3, extra) * max(V - 3, 1)).astype(np.int64)
+        ci = np.concatenate([ci, ei])
+        cj = np.concatenate([cj, ei + 2])
+    ci, cj = ci[:n_loop], cj[:n_loop]
+    ij = np.concatenate([np.stack([np.arange(V - 1), np.arange(1, V)], 1), np.stack([ci, cj], 1)]).astype(np.int32)
+    Et = ij.shape[0]
+    nt = normal(seed + 10, 3 * Et, sigma_t).reshape(Et, 3)
+    nr = normal(seed + 11, 3 * Et, sigma_r).reshape(Et, 3)
+    Z = np.zeros((Et, 3, 4))
+    for e in range(Et):
+        rel = se3_mul(se3_inv(gt[ij[e, 0]]), gt[ij[e, 1]])
+        Z[e] = se3_mul(rel, _quat_v2t(np.concatenate([nt[e], 0.5 * nr[e]])))
+    init = np.zeros((V, 3, 4))
+    init[0] = gt[0]
+    for v in range(1, V):
+        init[v] = se3_mul(init[v - 1], Z[v - 1])
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"poses_gt": f32(gt), "poses_init": f32(init), "ij": ij, "Z": f32(Z)}
+
+
+def pose_graph_2d(V=400, E=900, seed=5100, sigma_t=0.01, sigma_r=0.005):
+    """small SE(2) graph: square-ish loop trajectory + random loop closures."""
+    gt = np.zeros((V, 3, 3))
+    for v in range(V):
+        a = 2 * np.pi * v / V
+        gt[v] = se2(6 * np.cos(a) + 0.5 * np.cos(5 * a), 6 * np.sin(a), a + np.pi / 2)
+    n_loop = E - (V - 1)
+    ci = (uniform(seed + 1, n_loop) * V).astype(np.int64)
+    cj = (ci + 1 + (uniform(seed + 2, n_loop) * 12).astype(np.int64)) % V
+    keep = ci != cj
+    ij = np.concatenate([np.stack([np.arange(V - 1), np.arange(1, V)], 1), np.stack([ci[keep], cj[keep]], 1)]).astype(np.int32)
+    Et = ij.shape[0]
+    n = normal(seed + 10, 3 * Et).reshape(Et, 3) * np.array([sigma_t, sigma_t, sigma_r])
+    Z = np.zeros((Et, 3, 3))
+    for e in range(Et):
+        Z[e] = np.linalg.inv(gt[ij[e, 0]]) @ gt[ij[e, 1]] @ se2(*n[e])
+    init = np.zeros((V, 3, 3))
+    init[0] = gt[0]
+    for v in range(1, V):
+        init[v] = init[v - 1] @ Z[v - 1]
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"poses_gt": f32(gt), "poses_init": f32(init), "ij": ij, "Z": f32(Z)}

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""tests/golden/posegraph_golden.npz: ONE Gauss-Newton step of a 100-pose / 300-edge SE(3) graph, assembled by an
+independent numpy implementation (numerical Jacobians of the residual, float64) and solved with
+scipy.sparse.linalg.spsolve.  SciPy exists only in the build container, hence the committed fixture.
+Run from the repo root:  python tests/golden/make_posegraph_golden.py"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from srrg2_slam_interfaces_amd import synthetic as syn  # noqa: E402
+
+
+def quat_from_R(R):
+    w = np.sqrt(max(1e-30, 1 + np.trace(R))) / 2
+    return np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (4 * w)
+
+
+def t2v(T):
+    return np.concatenate([T[:, 3], quat_from_R(T[:, :3])])
+
+
+def residual(Xi, Xj, Z):
+    return t2v(syn.se3_mul(syn.se3_inv(Z), syn.se3_mul(syn.se3_inv(Xi), Xj)))
+
+
+def main():
+    g = syn.pose_graph_3d(V=100, E=300, seed=11)
+    X = g["poses_init"].astype(np.float64)
+    V, E = X.shape[0], g["ij"].shape[0]
+    rows, cols, vals = [], [], []
+    b = np.zeros(6 * V)
+    chi = 0.0
+    eps = 1e-6
+    for e in range(E):
+        i, j = g["ij"][e]
+        Z = g["Z"][e].astype(np.float64)
+        r0 = residual(X[i], X[j], Z)
+        chi += r0 @ r0
+        J = np.zeros((6, 12))
+        for a in range(6):
+            d = np.zeros(6)
+            d[a] = eps
+            J[:, a] = (residual(syn.se3_mul(X[i], syn._quat_v2t(d)), X[j], Z) -
+                       residual(syn.se3_mul(X[i], syn._quat_v2t(-d)), X[j], Z)) / (2 * eps)
+            J[:, 6 + a] = (residual(X[i], syn.se3_mul(X[j], syn._quat_v2t(d)), Z) -
+                           residual(X[i], syn.se3_mul(X[j], syn._quat_v2t(-d)), Z)) / (2 * eps)
+        H = J.T @ J
+        idx = np.concatenate([np.arange(6 * i, 6 * i + 6), np.arange(6 * j, 6 * j + 6)])
+        for a in range(12):
+            for c in range(12):
+                rows.append(idx[a]); cols.append(idx[c]); vals.append(H[a, c])
+        b[idx] += J.T @ r0
+    H = sp.coo_matrix((vals, (rows, cols)), shape=(6 * V, 6 * V)).tolil()
+    H[:6, :] = 0
+    H[:, :6] = 0
+    for a in range(6):
+        H[a, a] = 1.0
+    b[:6] = 0
+    dx = spl.spsolve(H.tocsc(), -b)
+    after = np.zeros_like(X)
+    for v in range(V):
+        after[v] = syn.se3_mul(X[v], syn._quat_v2t(dx[6 * v:6 * v + 6]))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "posegraph_golden.npz")
+    np.savez_compressed(path, chi0=chi, dx=dx, poses_after_1=after.astype(np.float32))
+    print("wrote", path, os.path.getsize(path), "chi0", chi)
+
+
+if __name__ == "__main__":
+    main()

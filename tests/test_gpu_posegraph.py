@@ -1,0 +1,99 @@
+"""-m gpu: the HIP pose-graph solve (block-sparse GN + block-Jacobi PCG, through the C ABI) against the CPU oracle
+and against the SciPy golden fixture.  Dot-product order differs between the two PCGs, so this is a tolerance
+test: poses within 1e-5 (BASELINE.json north_star: increments within 1e-5)."""
+import os
+
+import numpy as np
+import pytest
+
+from srrg2_slam_interfaces_amd import _abi as abi
+from srrg2_slam_interfaces_amd import posegraph as pgm
+from srrg2_slam_interfaces_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _tight():
+    p = pgm.default_params()
+    p.pcg_tolerance = 1e-10
+    p.pcg_max_iterations = 3000
+    return p
+
+
+@pytest.mark.parametrize("kind", [abi.SE3_QUAT_RIGHT, abi.SE2_RIGHT])
+def test_matches_oracle(oracle, product, kind):
+    g = syn.pose_graph_3d(V=300, E=1000, seed=21) if kind == abi.SE3_QUAT_RIGHT else syn.pose_graph_2d(V=400, E=900)
+    ref = oracle.OraclePoseGraph(kind)
+    gpu = product.PoseGraph(kind)
+    for pg in (ref, gpu):
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+    sr, sg = ref.solve(_tight()), gpu.solve(_tight())
+    assert len(sr) == len(sg) == 10
+    for a, b in zip(sr, sg):
+        assert a["num_factors"] == b["num_factors"] and a["solver_status"] == b["solver_status"] == 0
+        assert abs(a["chi"] - b["chi"]) <= 1e-5 * max(a["chi"], 1e-12) + 1e-9
+    assert np.max(np.abs(ref.poses() - gpu.poses())) <= 1e-5
+    assert np.array_equal(gpu.poses()[0], g["poses_init"][0])  # Fixed variable untouched
+    assert sg[-1]["chi"] < 0.2 * sg[0]["chi"]
+
+
+def test_information_matrices_disabled_factors_fixed_mask(oracle, product):
+    kind = abi.SE3_QUAT_RIGHT
+    g = syn.pose_graph_3d(V=150, E=500, seed=22)
+    E = g["ij"].shape[0]
+    om = np.tile(np.eye(6, dtype=np.float32), (E, 1, 1))
+    om[:149] *= 0.1  # Omega = I * info_scale (0.1 when lost, multi_graph_slam_impl.cpp:188)
+    om[149:, 3:, 3:] *= 1e-3 * 1e3  # full 6x6 blocks go through
+    om[200, 0, 1] = om[200, 1, 0] = 0.2
+    en = np.ones(E, np.uint8)
+    en[::7] = 0
+    fm = np.zeros(150, np.uint8)
+    fm[[0, 75]] = 1
+    ref, gpu = oracle.OraclePoseGraph(kind), product.PoseGraph(kind)
+    for pg in (ref, gpu):
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"], omega=om, fixed_mask=fm, enabled=en)
+    sr, sg = ref.solve(_tight()), gpu.solve(_tight())
+    assert sr[0]["num_factors"] == sg[0]["num_factors"] == int(en.sum())
+    assert np.max(np.abs(ref.poses() - gpu.poses())) <= 1e-5
+    assert np.array_equal(gpu.poses()[75], g["poses_init"][75])
+    en2 = np.ones(E, np.uint8)
+    for pg in (ref, gpu):
+        pg.set_enabled(en2)
+    sr, sg = ref.solve(_tight()), gpu.solve(_tight())
+    assert sg[0]["num_factors"] == E and np.max(np.abs(ref.poses() - gpu.poses())) <= 1e-5
+
+
+def test_matches_scipy_golden(product):
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posegraph_golden.npz"))
+    g = syn.pose_graph_3d(V=100, E=300, seed=11)
+    pg = product.PoseGraph(abi.SE3_QUAT_RIGHT)
+    pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+    p = _tight()
+    p.max_iterations = 1
+    st = pg.solve(p)
+    assert abs(st[0]["chi"] - float(G["chi0"])) / float(G["chi0"]) < 1e-4
+    assert np.max(np.abs(pg.poses() - G["poses_after_1"])) < 1e-5
+
+
+def test_larger_graph_properties(product):
+    """size-independent properties at a size the oracle would need seconds for: chi decreases monotonically to the
+    noise floor, PCG converges within its budget, the optimum is near the ground truth."""
+    g = syn.pose_graph_3d(V=5000, E=20000, seed=23)
+    pg = product.PoseGraph(abi.SE3_QUAT_RIGHT)
+    pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+    st = pg.solve()
+    chis = [s["chi"] for s in st]
+    assert all(s["solver_status"] == 0 and s["pcg_iterations"] <= 200 for s in st)
+    assert chis[1] < chis[0] and chis[-1] <= chis[1] * 1.001
+    # layers of the lawn-mower trajectory are only weakly tied together, so the optimum keeps part of the drift
+    assert np.max(np.abs(pg.poses()[:, :, 3] - g["poses_gt"][:, :, 3])) < 0.6 * np.max(
+        np.abs(g["poses_init"][:, :, 3] - g["poses_gt"][:, :, 3]))
+
+
+def test_pose_graph_misuse(product):
+    with pytest.raises(RuntimeError):
+        product.PoseGraph(abi.SE3_EULER_RIGHT)
+    pg = product.PoseGraph(abi.SE2_RIGHT)
+    with pytest.raises(RuntimeError):
+        pg.set_graph(np.tile(np.eye(3, dtype=np.float32), (3, 1, 1)), np.array([[0, 5]], np.int32),
+                     np.eye(3, dtype=np.float32)[None])
