@@ -394,10 +394,15 @@ int oracle_aligner_set_termination(o_aligner* h, const srrg2_termination_params*
 int oracle_aligner_add_slice(o_aligner* h, const srrg2_slice_config* c, int* idx) {
   if (!h || !c) return fail(SRRG2_E_INVALID, "add_slice");
   if (h->nslices >= SRRG2_MAX_SLICES) return fail(SRRG2_E_INVALID, "too many slices");
-  if (c->kind == SRRG2_SLICE_REPROJECTION || c->finder == SRRG2_FINDER_PROJECTIVE)
-    return fail(SRRG2_E_UNSUPPORTED, "projective/reprojection slices: see o_projective.c");
-  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED)
+  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED && c->finder != SRRG2_FINDER_PROJECTIVE)
     return fail(SRRG2_E_INVALID, "cue slice needs a finder"); /* aligner_slice_processor_impl.cpp:13-16 */
+  if (c->finder == SRRG2_FINDER_PROJECTIVE || c->kind == SRRG2_SLICE_REPROJECTION) {
+    if (h->dim != 3) return fail(SRRG2_E_UNSUPPORTED, "projective finder / reprojection factor are SE(3) only");
+    if (c->finder != SRRG2_FINDER_PROJECTIVE) return fail(SRRG2_E_INVALID, "reprojection slice needs the projective finder");
+    if (c->image_rows <= 0 || c->image_cols <= 0 || !(c->depth_min > 0.f) || !(c->depth_max >= c->depth_min) ||
+        !(c->camera_matrix[0] > 0.f) || !(c->camera_matrix[4] > 0.f))
+      return fail(SRRG2_E_INVALID, "projective slice: bad camera / image / depth range");
+  }
   o_slice* s = &h->slices[h->nslices];
   memset(s, 0, sizeof(*s));
   s->cfg         = *c;
@@ -542,8 +547,11 @@ static inline void rot2(const float* T, const float* p, float* q) {
   q[1] = T[3] * p[0] + T[4] * p[1];
 }
 
+static int slice_compute_correspondences_projective(o_aligner* a, o_slice* s);
+
 static int slice_compute_correspondences(o_aligner* a, o_slice* s) {
   const int dim = a->dim;
+  if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) return slice_compute_correspondences_projective(a, s);
   if (!s->fixed || !s->moving) return fail(SRRG2_E_STATE, "cue slice without fixed/moving cloud");
   float gate  = s->cfg.finder_max_distance;
   float gate2 = gate * gate;
@@ -589,6 +597,83 @@ static int slice_compute_correspondences(o_aligner* a, o_slice* s) {
   return 0;
 }
 
+
+/* ---- projective finder (first principles): pinhole projection of the transformed moving
+ * points into the organised fixed cloud; z-buffer keeps, per pixel, the moving point of minimum depth, ties to the
+ * smaller moving index. ---------------------------------------------------------------------------------------- */
+#define PIX_BOUND 8.0f
+static int project_point(const srrg2_slice_config* c, const float* q, float* u_out, float* v_out) {
+  if (!isfinite(q[0]) || !isfinite(q[1]) || !isfinite(q[2])) return -1;
+  if (!(q[2] >= c->depth_min) || !(q[2] <= c->depth_max)) return -1;
+  const float* K = c->camera_matrix;
+  float u  = (K[0] * q[0]) / q[2] + K[2];
+  float v  = (K[4] * q[1]) / q[2] + K[5];
+  float uf = u + 0.5f, vf = v + 0.5f;
+  if (!(uf >= 0.f) || !(uf < (float) c->image_cols) || !(vf >= 0.f) || !(vf < (float) c->image_rows)) return -1;
+  *u_out = u;
+  *v_out = v;
+  return (int) floorf(vf) * c->image_cols + (int) floorf(uf);
+}
+
+static int slice_compute_correspondences_projective(o_aligner* a, o_slice* s) {
+  if (!s->fixed || !s->moving) return fail(SRRG2_E_STATE, "cue slice without fixed/moving cloud");
+  const int npix = s->cfg.image_rows * s->cfg.image_cols;
+  if (s->nf != npix) return fail(SRRG2_E_STATE, "projective finder: fixed cloud must be organised rows x cols");
+  float T[12];
+  finder_transform(a, s, T);
+  float* zb_depth = (float*) malloc(sizeof(float) * (size_t) npix);
+  int* zb_idx     = (int*) malloc(sizeof(int) * (size_t) npix);
+  for (int k = 0; k < npix; ++k) {
+    zb_depth[k] = INFINITY;
+    zb_idx[k]   = 0x7fffffff;
+  }
+  for (int i = 0; i < s->nm; ++i) {
+    const float* p = s->moving + (size_t) i * 3;
+    if (!point_finite(p, 3)) continue;
+    float q[3], u, v;
+    xform3(T, p, q);
+    int pix = project_point(&s->cfg, q, &u, &v);
+    if (pix < 0) continue;
+    if (q[2] < zb_depth[pix] || (q[2] == zb_depth[pix] && i < zb_idx[pix])) {
+      zb_depth[pix] = q[2];
+      zb_idx[pix]   = i;
+    }
+  }
+  const float gate = s->cfg.finder_max_distance;
+  const float lim2 = (2.f * gate) * (2.f * gate);
+  int use_ncos     = s->cfg.finder_normal_cos > -1.f && s->fixed_n && s->moving_n;
+  int nc           = 0;
+  for (int i = 0; i < s->nm; ++i) {
+    const float* p = s->moving + (size_t) i * 3;
+    if (!point_finite(p, 3)) continue;
+    float q[3], u, v;
+    xform3(T, p, q);
+    int pix = project_point(&s->cfg, q, &u, &v);
+    if (pix < 0 || zb_idx[pix] != i) continue;
+    const float* f = s->fixed + (size_t) pix * 3;
+    if (!point_finite(f, 3)) continue;
+    float dd = fabsf(f[2] - q[2]);
+    if (!(dd <= gate)) continue;
+    if (!(dist2(f, q, 3) <= lim2)) continue;
+    if (use_ncos) {
+      const float* nm = s->moving_n + (size_t) i * 3;
+      const float* nf = s->fixed_n + (size_t) pix * 3;
+      float rn[3];
+      rot3(T, nm, rn);
+      float dot = (nf[0] * rn[0] + nf[1] * rn[1]) + nf[2] * rn[2];
+      if (!(dot > s->cfg.finder_normal_cos)) continue;
+    }
+    s->corr[nc].fixed_idx  = pix;
+    s->corr[nc].moving_idx = i;
+    s->corr[nc].response   = dd;
+    ++nc;
+  }
+  s->ncorr = nc;
+  free(zb_depth);
+  free(zb_idx);
+  return 0;
+}
+
 /* ---- factor: per-correspondence linearisation + fixed-point accumulation ------------- */
 static inline float robust_weight(int kind, float thr, float chi, int* kernelized) {
   if (kind == SRRG2_ROBUST_NONE || chi < thr) {
@@ -605,12 +690,22 @@ static inline float robust_weight(int kind, float thr, float chi, int* kernelize
 
 static int slice_exponent(const o_aligner* a, const o_slice* s) {
   const int plane = s->cfg.kind == SRRG2_SLICE_P2PLANE;
+  const int repro = s->cfg.kind == SRRG2_SLICE_REPROJECTION;
+  const int proj  = s->cfg.finder == SRRG2_FINDER_PROJECTIVE;
   const double kk = a->kind == SRRG2_SE3_QUAT_RIGHT ? 2.0 : 1.0;
-  const int rows  = plane ? 1 : a->dim;
+  const int rows  = plane ? 1 : (repro ? 2 : a->dim);
   double mb       = plane ? (1.7320508075688772 * (double) s->ninf) * 1.01 : 1.01;
+  if (repro) {
+    const double K0 = (double) s->cfg.camera_matrix[0], K4 = (double) s->cfg.camera_matrix[4];
+    const double tx = (double) s->cfg.image_cols / K0, ty = (double) s->cfg.image_rows / K4;
+    const double gb = (((K0 > K4 ? K0 : K4) / (double) s->cfg.depth_min) * (1.0 + (tx > ty ? tx : ty))) * 1.01;
+    mb              = (1.7320508075688772 * gb) * 1.01;
+  }
   double pf       = (2.0 * kk) * (double) s->pinf;
   double jb       = mb * (pf > 1.0 ? pf : 1.0);
   double eb       = (mb * (double) s->cfg.finder_max_distance) * 1.01;
+  if (proj) eb = (mb * (2.0 * (double) s->cfg.finder_max_distance)) * 1.01;
+  if (repro) eb = (double) PIX_BOUND * 1.01;
   double mx       = jb > eb ? jb : eb;
   double B        = (double) rows * (mx * mx);
   return o_fixed_point_exponent(s->nm, B);
@@ -624,6 +719,7 @@ static int slice_linearize(o_aligner* a, o_slice* s) {
   const int dim   = a->dim;
   const int D     = a->dof;
   const int plane = s->cfg.kind == SRRG2_SLICE_P2PLANE;
+  const int repro = s->cfg.kind == SRRG2_SLICE_REPROJECTION;
   if (plane && !s->fixed_n) return fail(SRRG2_E_STATE, "point-to-plane slice without fixed normals");
   const float kk = a->kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
   const int k    = slice_exponent(a, s);
@@ -639,11 +735,33 @@ static int slice_linearize(o_aligner* a, o_slice* s) {
     float J[3][6];
     float e[3];
     int rows;
+    int invalid = 0;
     if (dim == 3) {
       float q[3];
       xform3(T, p, q);
       float m[3][3];
-      if (plane) {
+      if (repro) {
+        /* e = pi(q) - pi(f); rows g_r = d pi / d q, m_r = T_R^T g_r */
+        const float* K = s->cfg.camera_matrix;
+        rows           = 2;
+        if (!(f[2] > 0.f)) {
+          invalid = 1;
+          e[0] = e[1] = 0.f;
+          memset(m, 0, sizeof(m));
+        } else {
+          float uq = (K[0] * q[0]) / q[2] + K[2], vq = (K[4] * q[1]) / q[2] + K[5];
+          float uf = (K[0] * f[0]) / f[2] + K[2], vf = (K[4] * f[1]) / f[2] + K[5];
+          e[0]     = uq - uf;
+          e[1]     = vq - vf;
+          if (!(fabsf(e[0]) <= PIX_BOUND) || !(fabsf(e[1]) <= PIX_BOUND)) invalid = 1;
+          float iz   = 1.0f / q[2];
+          float g[2][3];
+          g[0][0] = K[0] * iz; g[0][1] = 0.f;       g[0][2] = -(((K[0] * q[0]) * iz) * iz);
+          g[1][0] = 0.f;       g[1][1] = K[4] * iz; g[1][2] = -(((K[4] * q[1]) * iz) * iz);
+          for (int r = 0; r < 2; ++r)
+            for (int k = 0; k < 3; ++k) m[r][k] = (T[0 * 4 + k] * g[r][0] + T[1 * 4 + k] * g[r][1]) + T[2 * 4 + k] * g[r][2];
+        }
+      } else if (plane) {
         const float* n = s->fixed_n + (size_t) j * 3;
         rows           = 1;
         e[0]           = (n[0] * (q[0] - f[0]) + n[1] * (q[1] - f[1])) + n[2] * (q[2] - f[2]);
@@ -694,7 +812,7 @@ static int slice_linearize(o_aligner* a, o_slice* s) {
     float chi = e[0] * e[0];
     for (int r = 1; r < rows; ++r) chi = chi + e[r] * e[r];
     s->acc[ACC_N_CORR] += 1;
-    if (!isfinite(chi)) {
+    if (!isfinite(chi) || invalid) {
       s->fstat[c] = SRRG2_FACTOR_SUPPRESSED;
       continue;
     }

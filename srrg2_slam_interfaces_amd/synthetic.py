@@ -301,3 +301,50 @@ def pose_graph_2d(V=400, E=900, seed=5100, sigma_t=0.01, sigma_r=0.005):
         init[v] = init[v - 1] @ Z[v - 1]
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     return {"poses_gt": f32(gt), "poses_init": f32(init), "ij": ij, "Z": f32(Z)}
+
+
+# ---- C3: RGB-D shaped organised clouds ----------------------------------------------------------------
+def default_camera(rows=480, cols=640):
+    f = 525.0 * cols / 640.0
+    return np.array([[f, 0, (cols - 1) / 2.0], [0, f, (rows - 1) / 2.0], [0, 0, 1.0]])
+
+
+def render_depth(T_w_cam, K, rows, cols, iters=30):
+    """Ray-cast the analytic surface z = 0.3 sin(1.3x) cos(0.9y) from camera pose T_w_cam (3x4, camera in world).
+    Returns (points, normals) in the CAMERA frame, each (rows*cols, 3), organised row-major."""
+    r, c = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    d = np.stack([(c - K[0, 2]) / K[0, 0], (r - K[1, 2]) / K[1, 1], np.ones_like(c, dtype=np.float64)], axis=-1).reshape(-1, 3)
+    R, p = T_w_cam[:, :3], T_w_cam[:, 3]
+    dw = d @ R.T
+    t = np.full(d.shape[0], (p[2] - 0.0) / np.maximum(-dw[:, 2], 1e-9))
+    for _ in range(iters):  # fixed-point iteration on the ray parameter (the surface is gentle)
+        x = p[0] + t * dw[:, 0]
+        y = p[1] + t * dw[:, 1]
+        t = (_surface(x, y) - p[2]) / dw[:, 2]
+    x = p[0] + t * dw[:, 0]
+    y = p[1] + t * dw[:, 1]
+    pts = d * t[:, None]
+    n_w = _surface_normal(x, y)
+    n_c = n_w @ R  # world -> camera: R^T n
+    return pts, n_c
+
+
+def rgbd_pair(rows=480, cols=640, seed=3000, t=(0.03, 0.01, -0.02), rpy_deg=(0.5, 1.0, -0.5), hole_fraction=0.02,
+              depth_min=0.4, depth_max=8.0):
+    """C3: a fixed organised cloud (+normals, invalid pixels = NaN) rendered from camera 1 and the unprojected render
+    from camera 2 as the moving cloud; X_gt maps moving (camera 2 frame) into fixed (camera 1 frame)."""
+    K = default_camera(rows, cols)
+    T_w_c1 = np.zeros((3, 4))
+    T_w_c1[:, :3] = np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]])  # looking down from 4 m
+    T_w_c1[:, 3] = [0.0, 0.0, 4.0]
+    X_gt = se3(np.array(t), np.deg2rad(np.array(rpy_deg)))
+    T_w_c2 = se3_mul(T_w_c1, X_gt)
+    Pf, Nf = render_depth(T_w_c1, K, rows, cols)
+    Pm, Nm = render_depth(T_w_c2, K, rows, cols)
+    okf = (Pf[:, 2] >= depth_min) & (Pf[:, 2] <= depth_max) & (uniform(seed + 1, rows * cols) >= hole_fraction)
+    okm = (Pm[:, 2] >= depth_min) & (Pm[:, 2] <= depth_max) & (uniform(seed + 2, rows * cols) >= hole_fraction)
+    Pf = Pf.copy()
+    Pf[~okf] = np.nan
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"fixed": f32(Pf), "fixed_normals": f32(Nf), "moving": f32(Pm[okm]), "moving_normals": f32(Nm[okm]),
+            "X_gt": f32(X_gt), "K": f32(K), "rows": rows, "cols": cols, "depth_min": depth_min, "depth_max": depth_max}

@@ -62,3 +62,18 @@ def assert_same_run(a_ref, a_gpu, slices=(0,), x_tol=1e-5):
         assert np.array_equal(c_ref["moving_idx"], c_gpu["moving_idx"])
         assert c_ref["response"].tobytes() == c_gpu["response"].tobytes()
         assert np.array_equal(a_ref.factor_status(si), a_gpu.factor_status(si))
+
+
+def projective_config(kind, slice_kind, data, gate=0.05, robust=abi.ROBUST_NONE, thr=1.0, normal_cos=-2.0):
+    c = abi.default_slice_config(kind)
+    c.kind = slice_kind
+    c.finder = abi.FINDER_PROJECTIVE
+    c.finder_max_distance = gate
+    c.robustifier = robust
+    c.robustifier_chi_threshold = thr
+    c.finder_normal_cos = normal_cos
+    for i, v in enumerate(np.asarray(data["K"], np.float32).reshape(-1)):
+        c.camera_matrix[i] = v
+    c.image_rows, c.image_cols = int(data["rows"]), int(data["cols"])
+    c.depth_min, c.depth_max = float(data["depth_min"]), float(data["depth_max"])
+    return c
