@@ -57,6 +57,7 @@ struct Slice {
   DevBuf<float> corr_resp;
   DevBuf<uint8_t> corr_stat;
   DevBuf<long long> partials;
+  DevBuf<unsigned long long> zbuf;  // projective finder: [problem][rows*cols]
   // prior
   float prior_Z[12]{};
   bool has_prior = false;
@@ -66,7 +67,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); corr_resp.release(); corr_stat.release(); partials.release();
+    corr_fixed.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release();
   }
 };
 
@@ -342,6 +343,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     if (!s->has_moving) return fail(SRRG2_E_STATE, "compute: cue slice| no moving");
     if (s->cfg.kind == SRRG2_SLICE_P2PLANE && !s->fixed_has_normals)
       return fail(SRRG2_E_STATE, "compute: point-to-plane slice needs fixed normals");
+    if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE && s->nf != s->cfg.image_rows * s->cfg.image_cols)
+      return fail(SRRG2_E_STATE, "compute: projective finder needs an organised fixed cloud of rows x cols points");
   }
   // problems: all cue slices share the problem layout of slice 0's batch; for K == 1 each slice has its own nm
   const int slots = 2 * std::max(a->params.max_iterations, 1);
@@ -404,6 +407,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     std::memcpy(sc.prior_info, s->cfg.prior_information_diag, sizeof(sc.prior_info));
     sc.partials  = nullptr;
     sc.nblocks   = 0;
+    sc.finder    = s->cfg.finder;
+    sc.K0        = s->cfg.camera_matrix[0];
+    sc.K4        = s->cfg.camera_matrix[4];
+    sc.rows      = s->cfg.image_rows;
+    sc.cols      = s->cfg.image_cols;
+    sc.depth_min = s->cfg.depth_min;
     sc.pinf_bits = nullptr;
     sc.ninf_bits = nullptr;
     if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
@@ -432,6 +441,21 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.normal_cos      = s->cfg.finder_normal_cos;
     d.use_normal_gate = (s->cfg.finder_normal_cos > -1.f && s->fixed_has_normals && s->moving_has_normals) ? 1 : 0;
     d.variable_kind   = a->kind;
+    d.finder          = s->cfg.finder;
+    d.factor          = s->cfg.kind;
+    std::memcpy(d.K, s->cfg.camera_matrix, sizeof(d.K));
+    d.rows            = s->cfg.image_rows;
+    d.cols            = s->cfg.image_cols;
+    d.depth_min       = s->cfg.depth_min;
+    d.depth_max       = s->cfg.depth_max;
+    d.gate            = s->cfg.finder_max_distance;
+    d.fixed_org       = s->fixed_raw.p;
+    d.fixed_org_nrm   = s->fixed_has_normals ? s->fixed_nrm_raw.p : nullptr;
+    d.zbuf            = nullptr;
+    if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) {
+      if ((rc = s->zbuf.reserve((size_t) K * d.rows * d.cols))) return rc;
+      d.zbuf = s->zbuf.p;
+    }
     d.tune            = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
     if (a->dim == 3)
       dm::se3_inverse(s->cfg.sensor_in_robot, d.Sinv);
@@ -467,8 +491,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           a->prof_used++;
           HIP_TRY(hipEventRecord(e0, a->stream));
         }
-        srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
-                                  a->stream);
+        if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE)
+          srrg2amd::launch_proj_step(s->cfg.kind == SRRG2_SLICE_REPROJECTION, sdev[si], a->probs.p + (size_t) si * K,
+                                     a->states.p, K, nm_max, a->stream);
+        else
+          srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
+                                    a->stream);
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }
       srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
@@ -627,10 +655,16 @@ int srrg2_aligner_set_termination(srrg2_aligner_h a, const srrg2_termination_par
 int srrg2_aligner_add_slice(srrg2_aligner_h a, const srrg2_slice_config* c, int* idx) {
   if (!a || !c) return fail(SRRG2_E_INVALID, "add_slice: bad arguments");
   if ((int) a->slices.size() >= SRRG2_MAX_SLICES) return fail(SRRG2_E_INVALID, "add_slice: too many slices");
-  if (c->kind == SRRG2_SLICE_REPROJECTION || c->finder == SRRG2_FINDER_PROJECTIVE)
-    return fail(SRRG2_E_UNSUPPORTED, "add_slice: projective finder / reprojection factor not built yet");
-  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED)
+  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED && c->finder != SRRG2_FINDER_PROJECTIVE)
     return fail(SRRG2_E_INVALID, "add_slice| no finder");  // aligner_slice_processor_impl.cpp:13-16
+  if (c->finder == SRRG2_FINDER_PROJECTIVE || c->kind == SRRG2_SLICE_REPROJECTION) {
+    if (a->dim != 3) return fail(SRRG2_E_UNSUPPORTED, "add_slice: projective finder / reprojection factor are SE(3) only");
+    if (c->finder != SRRG2_FINDER_PROJECTIVE)
+      return fail(SRRG2_E_INVALID, "add_slice: a reprojection slice needs the projective finder");
+    if (c->image_rows <= 0 || c->image_cols <= 0 || !(c->depth_min > 0.f) || !(c->depth_max >= c->depth_min) ||
+        !(c->camera_matrix[0] > 0.f) || !(c->camera_matrix[4] > 0.f))
+      return fail(SRRG2_E_INVALID, "add_slice: projective slice with bad camera / image / depth range");
+  }
   if (c->kind == SRRG2_SLICE_PRIOR && a->kind == SRRG2_SE3_EULER_RIGHT)
     return fail(SRRG2_E_UNSUPPORTED, "add_slice: SE3 prior factors exist for the quaternion variable only "
                                      "(SE3PriorErrorFactorAD, aligner_slice_odometry_prior.h:33)");
@@ -687,7 +721,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   }
   s->nf                = n;
   s->fixed_has_normals = normals != nullptr;
-  if ((rc = build_grid(a, s))) return rc;
+  if (s->cfg.finder == SRRG2_FINDER_NN_GATED && (rc = build_grid(a, s))) return rc;  // projective: organised cloud as is
   HIP_TRY(hipStreamSynchronize(a->stream));
   s->has_fixed = true;
   return 0;

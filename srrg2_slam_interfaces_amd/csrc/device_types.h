@@ -49,6 +49,16 @@ struct SliceDev {
   float normal_cos;
   int use_normal_gate;
   int variable_kind;
+  // projective finder (organised fixed cloud in ingest order + per-problem z-buffer)
+  int finder;           // srrg2_finder_kind
+  int factor;           // srrg2_slice_kind
+  float K[9];
+  int rows, cols;
+  float depth_min, depth_max;
+  float gate;           // finder_max_distance
+  const float4* fixed_org;      // rows*cols points, NaN = invalid pixel
+  const float4* fixed_org_nrm;  // or null
+  unsigned long long* zbuf;     // [problem][rows*cols] keys (depth bits << 32 | caller index)
   int tune;             // debug/tuning bit flags (env SRRG2_AMD_TUNE): 1 = skip phase 2 (WRONG results, timing only)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
 };
@@ -92,6 +102,10 @@ struct SliceCtl {
   int prior_sets_initial_guess;
   float prior_Z[12];
   float prior_info[6];
+  int finder;               // srrg2_finder_kind
+  float K0, K4;             // focal lengths (projective / reprojection bounds)
+  int rows, cols;
+  float depth_min;
   const long long* partials;  // [problem][nblocks][ACC_N] (null for priors)
   int nblocks;                // gridDim.x of the slice's step launch
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)

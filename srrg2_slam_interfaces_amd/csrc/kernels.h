@@ -20,6 +20,9 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s);
 int icp_step_blocks(int max_nm);
+// projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)
+void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,
+                      hipStream_t s);
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* states, const float* guesses, int tsize,
                      hipStream_t s);
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s);

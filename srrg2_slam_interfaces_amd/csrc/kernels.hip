@@ -465,6 +465,70 @@ __device__ __forceinline__ long long wave_transpose_reduce(long long (&v)[ACC_N]
   return v[0];
 }
 
+// per-correspondence factor arithmetic shared by every cue slice: chi, robustifier, the 27 (9 in 2D) fixed-point
+// terms of w J^T J and w J^T e, and the statistics.  Returns the srrg2_factor_status of the correspondence.
+template <int D, int ROWS>
+__device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], const float (&e)[ROWS], bool invalid,
+                                                     int rk, float thr, double scale, bool skip_terms,
+                                                     long long (&acc)[ACC_N]) {
+  float chi = e[0] * e[0];
+#pragma unroll
+  for (int r = 1; r < ROWS; ++r) chi = chi + e[r] * e[r];
+  acc[ACC_N_CORR] += 1;
+  if (!isfinite(chi) || invalid) return SRRG2_FACTOR_SUPPRESSED;
+  float w         = 1.f;
+  bool kernelized = false;
+  if (rk != SRRG2_ROBUST_NONE && !(chi < thr)) {
+    kernelized = true;
+    w = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
+  }
+  const long long chi_fx = to_fixed((double) chi * scale);
+  // (branch-free on purpose: an if/else here gets merged into a dynamically indexed acc[] access = scratch memory)
+  acc[ACC_N_OUT] += kernelized ? 1 : 0;
+  acc[ACC_CHI_OUT] += kernelized ? chi_fx : 0;
+  acc[ACC_N_IN] += kernelized ? 0 : 1;
+  acc[ACC_CHI_IN] += kernelized ? 0 : chi_fx;
+  if (w != 0.f && !skip_terms) {
+    // (w * 2^k) is exact, (w * 2^k) * J is exact (24 x 24 bits): scaling commutes with the one
+    // rounding of the final product, so these are the specified terms times 2^k exactly.
+    const double ws = (double) w * scale;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double wj[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        double t = wj[0] * (double) J[0][b];
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) J[r][b];
+        acc[hidx(a, b)] += to_fixed(t);
+      }
+      double t = wj[0] * (double) e[0];
+#pragma unroll
+      for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) e[r];
+      acc[ACC_B + a] += to_fixed(t);
+    }
+  }
+  return kernelized ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
+}
+
+// block reduction: transposing butterfly per wave, 4 waves through LDS, then ONE plain 256-byte store of the
+// block's partial sums.  (Device-scope atomics on 32 shared addresses serialise at ~10 ns each: 391 blocks x 32
+// atomics cost ~90 us at C2 -- profiles/r1a; the control kernel sums the partials instead.)
+__device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long long* __restrict__ partials, int prob) {
+  __shared__ long long red[4][ACC_N];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int my_index;
+  const long long total = wave_transpose_reduce(acc, lane, my_index);
+  if ((lane & 1) == 0) red[wid][my_index] = total;
+  __syncthreads();
+  if (threadIdx.x < ACC_N) {
+    long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    partials[((size_t) prob * gridDim.x + blockIdx.x) * ACC_N + threadIdx.x] = v;
+  }
+}
+
 }  // namespace
 
 template <int DIM, bool PLANE>
@@ -745,50 +809,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
             J[r][2] = m[r][1] * p.x - m[r][0] * p.y;
           }
         }
-        float chi = e[0] * e[0];
-#pragma unroll
-        for (int r = 1; r < ROWS; ++r) chi = chi + e[r] * e[r];
-        acc[ACC_N_CORR] += 1;
-        if (isfinite(chi)) {
-          float w = 1.f;
-          bool kernelized = false;
-          if (rk != SRRG2_ROBUST_NONE && !(chi < thr)) {
-            kernelized = true;
-            w = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
-          }
-          const long long chi_fx = to_fixed((double) chi * scale);
-          if (kernelized) {
-            fstat = SRRG2_FACTOR_KERNELIZED;
-            acc[ACC_N_OUT] += 1;
-            acc[ACC_CHI_OUT] += chi_fx;
-          } else {
-            fstat = SRRG2_FACTOR_INLIER;
-            acc[ACC_N_IN] += 1;
-            acc[ACC_CHI_IN] += chi_fx;
-          }
-          if (w != 0.f && !(S.tune & 64)) {
-            // (w * 2^k) is exact, (w * 2^k) * J is exact (24 x 24 bits): scaling commutes with the one
-            // rounding of the final product, so these are the specified terms times 2^k exactly.
-            const double ws = (double) w * scale;
-#pragma unroll
-            for (int a = 0; a < D; ++a) {
-              double wj[ROWS];
-#pragma unroll
-              for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
-#pragma unroll
-              for (int b = a; b < D; ++b) {
-                double t = wj[0] * (double) J[0][b];
-#pragma unroll
-                for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) J[r][b];
-                acc[hidx(a, b)] += to_fixed(t);
-              }
-              double t = wj[0] * (double) e[0];
-#pragma unroll
-              for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) e[r];
-              acc[ACC_B + a] += to_fixed(t);
-            }
-          }
-        }
+        fstat = factor_accumulate<D, ROWS>(J, e, false, rk, thr, scale, (S.tune & 64) != 0, acc);
       }
     }
     S.corr_fixed[oi] = match;
@@ -796,18 +817,169 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     S.corr_stat[oi]  = fstat;
   }
 
-  // block reduction: transposing butterfly per wave, 4 waves through LDS, then ONE plain 256-byte store of
-  // the block's partial sums.  (Device-scope atomics on 32 shared addresses serialise at ~10 ns each:
-  // 391 blocks x 32 atomics cost ~90 us at C2 -- profiles/r1a; the control kernel sums the partials instead.)
-  __shared__ long long red[4][ACC_N];
-  int my_index;
-  const long long total = wave_transpose_reduce(acc, lane, my_index);
-  if ((lane & 1) == 0) red[wid][my_index] = total;
-  __syncthreads();
-  if (threadIdx.x < ACC_N) {
-    long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    S.partials[((size_t) prob * gridDim.x + blockIdx.x) * ACC_N + threadIdx.x] = v;
+  block_reduce_store(acc, S.partials, prob);
+}
+
+// ============================================================================================
+// projective finder + factors on an organised fixed cloud (BASELINE config C3)
+//   k_proj_zbuf        z-buffer: per pixel the transformed moving point of minimum depth, ties -> smaller caller
+//                      index, as ONE 64-bit atomicMin on the key (depth bits << 32 | index)  (deterministic)
+//   k_icp_step_proj<R> per moving point: re-project, keep it iff it won its pixel, gates, point-to-plane (R = false)
+//                      or pinhole reprojection (R = true) rows, shared factor arithmetic + reduction
+// ============================================================================================
+namespace {
+
+#define PIX_BOUND 8.0f
+
+__device__ __forceinline__ int project_point(const SliceDev& S, float qx, float qy, float qz, float& u, float& v) {
+  if (!finite3(qx, qy, qz)) return -1;
+  if (!(qz >= S.depth_min) || !(qz <= S.depth_max)) return -1;
+  u              = (S.K[0] * qx) / qz + S.K[2];
+  v              = (S.K[4] * qy) / qz + S.K[5];
+  const float uf = u + 0.5f, vf = v + 0.5f;
+  if (!(uf >= 0.f) || !(uf < (float) S.cols) || !(vf >= 0.f) || !(vf < (float) S.rows)) return -1;
+  return (int) floorf(vf) * S.cols + (int) floorf(uf);
+}
+
+__device__ __forceinline__ void finder_transform3(const SliceDev& S, const ProblemState* st, float* T) {
+  dm::se3_compose(S.Sinv, st->X, T);  // finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                   ProblemState* __restrict__ states) {
+  const int prob   = blockIdx.y;
+  ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  const int i         = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pd.nm) return;
+  float T[12];
+  finder_transform3(S, st, T);
+  const float4 p = S.mpts[pd.moff + i];
+  if (!finite3(p.x, p.y, p.z)) return;
+  const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+  const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+  const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+  float u, v;
+  const int pix = project_point(S, qx, qy, qz, u, v);
+  if (pix < 0) return;
+  const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
+  atomicMin(&S.zbuf[(size_t) prob * S.rows * S.cols + pix], key);
+}
+
+template <bool REPRO>
+__global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                       ProblemState* __restrict__ states) {
+  constexpr int D    = 6;
+  constexpr int ROWS = REPRO ? 2 : 1;
+  const int prob     = blockIdx.y;
+  ProblemState* st   = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  float T[12];
+  finder_transform3(S, st, T);
+  const int kexp     = st->kexp[S.slice_idx];
+  const double scale = dm::pow2(kexp);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  long long acc[ACC_N];
+#pragma unroll
+  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < pd.nm) {
+    const int gi   = pd.moff + i;
+    const float4 p = S.mpts[gi];
+    const int ci   = __float_as_int(p.w);  // caller's index within the problem
+    const int oi   = pd.moff + ci;
+    int match      = -1;
+    float resp     = 0.f;
+    uint8_t fstat  = SRRG2_FACTOR_SUPPRESSED;
+    if (finite3(p.x, p.y, p.z)) {
+      const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+      const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+      const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+      float u, v;
+      const int pix = project_point(S, qx, qy, qz, u, v);
+      bool found    = false;
+      float4 f      = make_float4(0.f, 0.f, 0.f, 0.f);
+      float dd      = 0.f;
+      if (pix >= 0) {
+        const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) ci;
+        if (S.zbuf[(size_t) prob * S.rows * S.cols + pix] == key) {
+          f = S.fixed_org[pix];
+          if (finite3(f.x, f.y, f.z)) {
+            dd             = fabsf(f.z - qz);
+            const float dx = f.x - qx, dy = f.y - qy, dz = f.z - qz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const float g2 = (2.f * S.gate) * (2.f * S.gate);
+            found          = dd <= S.gate && d2 <= g2;
+          }
+        }
+      }
+      float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (found && (!REPRO || S.use_normal_gate) && S.fixed_org_nrm) nf = S.fixed_org_nrm[pix];
+      if (found && S.use_normal_gate) {
+        const float4 nm = S.mnrm[gi];
+        const float rx  = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
+        const float ry  = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
+        const float rz  = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
+        const float dot = (nf.x * rx + nf.y * ry) + nf.z * rz;
+        if (!(dot > S.normal_cos)) found = false;
+      }
+      if (found) {
+        match = pix;
+        resp  = dd;
+        float J[ROWS][D];
+        float e[ROWS];
+        float m[ROWS][3];
+        bool invalid = false;
+        if (REPRO) {
+          if (!(f.z > 0.f)) {
+            invalid = true;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+              e[r] = 0.f;
+              m[r][0] = m[r][1] = m[r][2] = 0.f;
+            }
+          } else {
+            const float uq = (S.K[0] * qx) / qz + S.K[2], vq = (S.K[4] * qy) / qz + S.K[5];
+            const float uf = (S.K[0] * f.x) / f.z + S.K[2], vf = (S.K[4] * f.y) / f.z + S.K[5];
+            e[0]           = uq - uf;
+            e[ROWS - 1]    = vq - vf;
+            if (!(fabsf(e[0]) <= PIX_BOUND) || !(fabsf(e[ROWS - 1]) <= PIX_BOUND)) invalid = true;
+            const float iz = 1.0f / qz;
+            const float g[2][3] = {{S.K[0] * iz, 0.f, -(((S.K[0] * qx) * iz) * iz)},
+                                   {0.f, S.K[4] * iz, -(((S.K[4] * qy) * iz) * iz)}};
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) m[r][k] = (T[0 * 4 + k] * g[r][0] + T[1 * 4 + k] * g[r][1]) + T[2 * 4 + k] * g[r][2];
+          }
+        } else {
+          e[0]    = (nf.x * (qx - f.x) + nf.y * (qy - f.y)) + nf.z * (qz - f.z);
+          m[0][0] = (T[0] * nf.x + T[4] * nf.y) + T[8] * nf.z;
+          m[0][1] = (T[1] * nf.x + T[5] * nf.y) + T[9] * nf.z;
+          m[0][2] = (T[2] * nf.x + T[6] * nf.y) + T[10] * nf.z;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          J[r][0] = m[r][0];
+          J[r][1] = m[r][1];
+          J[r][2] = m[r][2];
+          J[r][3] = kk * (p.y * m[r][2] - p.z * m[r][1]);
+          J[r][4] = kk * (p.z * m[r][0] - p.x * m[r][2]);
+          J[r][5] = kk * (p.x * m[r][1] - p.y * m[r][0]);
+        }
+        fstat = factor_accumulate<D, ROWS>(J, e, invalid, rk, S.robust_thr, scale, false, acc);
+      }
+    }
+    S.corr_fixed[oi] = match;
+    S.corr_resp[oi]  = resp;
+    S.corr_stat[oi]  = fstat;
   }
+  block_reduce_store(acc, S.partials, prob);
 }
 
 // ============================================================================================
@@ -817,17 +989,27 @@ namespace {
 
 __device__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, int nm) {
   const bool plane = s.kind == SRRG2_SLICE_P2PLANE;
+  const bool repro = s.kind == SRRG2_SLICE_REPROJECTION;
+  const bool proj  = s.finder == SRRG2_FINDER_PROJECTIVE;
   const double kk  = C.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.0 : 1.0;
   const int dim    = C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3;
-  const int rows   = plane ? 1 : dim;
+  const int rows   = plane ? 1 : (repro ? 2 : dim);
   const float pinf = __uint_as_float(s.pinf_bits[prob]);
   const float ninf = __uint_as_float(s.ninf_bits[0]);
   double mb        = plane ? (1.7320508075688772 * (double) ninf) * 1.01 : 1.01;
-  double pf        = (2.0 * kk) * (double) pinf;
-  double jb        = mb * (pf > 1.0 ? pf : 1.0);
-  double eb        = (mb * (double) s.gate) * 1.01;
-  double mx        = jb > eb ? jb : eb;
-  double B         = (double) rows * (mx * mx);
+  if (repro) {
+    const double K0 = (double) s.K0, K4 = (double) s.K4;
+    const double tx = (double) s.cols / K0, ty = (double) s.rows / K4;
+    const double gb = (((K0 > K4 ? K0 : K4) / (double) s.depth_min) * (1.0 + (tx > ty ? tx : ty))) * 1.01;
+    mb              = (1.7320508075688772 * gb) * 1.01;
+  }
+  double pf = (2.0 * kk) * (double) pinf;
+  double jb = mb * (pf > 1.0 ? pf : 1.0);
+  double eb = (mb * (double) s.gate) * 1.01;
+  if (proj) eb = (mb * (2.0 * (double) s.gate)) * 1.01;
+  if (repro) eb = (double) PIX_BOUND * 1.01;
+  double mx = jb > eb ? jb : eb;
+  double B  = (double) rows * (mx * mx);
   return dm::fixed_point_exponent(nm, B);
 }
 
@@ -1218,6 +1400,18 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
     else
       hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), 0, s, S, probs, states);
   }
+}
+
+void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,
+                      hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  dim3 grid(icp_step_blocks(max_nm), K);
+  (void) hipMemsetAsync(S.zbuf, 0xff, (size_t) K * S.rows * S.cols * sizeof(unsigned long long), s);
+  hipLaunchKernelGGL(k_proj_zbuf, grid, dim3(256), 0, s, S, probs, states);
+  if (repro)
+    hipLaunchKernelGGL((k_icp_step_proj<true>), grid, dim3(256), 0, s, S, probs, states);
+  else
+    hipLaunchKernelGGL((k_icp_step_proj<false>), grid, dim3(256), 0, s, S, probs, states);
 }
 
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* states, const float* guesses, int tsize,

@@ -161,3 +161,44 @@ def test_errors_are_loud(product):
         al.compute() if al.add_slice(cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2P, 0.1)) == 0 else None
     with pytest.raises(RuntimeError):
         al.set_fixed(5, np.zeros((1, 3), np.float32))
+
+
+def test_c3_projective_and_reprojection_slices(oracle, product):
+    """BASELINE config C3 (reduced resolution here, full 640x480 in test_c3_full_resolution): projective finder
+    with point-to-plane and with pinhole-reprojection factors, alone and as a 2-slice MultiAligner."""
+    from helpers import projective_config
+
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.rgbd_pair(rows=120, cols=160)
+    for sk, rob in ((abi.SLICE_P2PLANE, abi.ROBUST_CAUCHY), (abi.SLICE_REPROJECTION, abi.ROBUST_NONE)):
+        guess = syn.se3(np.array([0.01, 0.0, -0.01]), np.deg2rad([0.2, 0.4, -0.1])).astype(np.float32)
+        cfg = projective_config(kind, sk, d, gate=0.05, robust=rob, thr=1e-4, normal_cos=0.5)
+        a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, guess=guess)
+        assert a_ref.status() == abi.SUCCESS
+        assert_same_run(a_ref, a_gpu)
+    runs = []
+    for al in _pair(oracle, product, kind):
+        s0 = al.add_slice(projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05))
+        s1 = al.add_slice(projective_config(kind, abi.SLICE_REPROJECTION, d, gate=0.05))
+        for si in (s0, s1):
+            al.set_fixed(si, d["fixed"], d["fixed_normals"])
+            al.set_moving(si, d["moving"], d["moving_normals"])
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+        runs.append(al)
+    assert runs[0].status() == abi.SUCCESS
+    assert_same_run(runs[0], runs[1], slices=(0, 1))
+
+
+def test_c3_full_resolution(oracle, product):
+    """640 x 480 depth image, projective + point-to-plane: parity and convergence to the ground truth."""
+    from helpers import projective_config
+
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.rgbd_pair()
+    cfg = projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05)
+    a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg)
+    assert a_ref.status() == abi.SUCCESS
+    assert_same_run(a_ref, a_gpu)
+    assert np.max(np.abs(a_gpu.moving_in_fixed() - d["X_gt"])) < 2e-4
+    assert a_gpu.iteration_stats()[-1]["num_correspondences"] > 250000
