@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--iterations", type=int, default=10)  # aligner.h:30
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
     ap.add_argument("--batch", type=int, default=32, help="c4: alignments per GPU per step")
     ap.add_argument("--batch-points", type=int, default=50_000)
     ap.add_argument("--cell-size", type=float, default=0.0)
@@ -90,6 +90,31 @@ def main():
         K_total = world  # one alignment per rank: alignment k lives on rank k (k mod G)
         units_per_step = args.iterations  # ICP iterations per rank per step
         alg_bytes_per_launch = 12 * args.points + 24 * args.points + 12 * args.points
+
+        def step():
+            al.set_moving_in_fixed(ident)
+            st = al.compute()
+            stats = al.iteration_stats()
+            return [D.pack_record(rank, {"moving_in_fixed": al.moving_in_fixed(), "status": st,
+                                         "num_iterations": len(stats), "last": stats[-1]})]
+    elif args.workload == "c3":
+        # C3: 2-slice MultiAligner (projective + point-to-plane, projective + reprojection) on a 640x480 depth pair
+        data = syn.rgbd_pair(seed=3000 + 10 * rank)
+        al.clear_slices()
+        for sk in (abi.SLICE_P2PLANE, abi.SLICE_REPROJECTION):
+            c = abi.default_slice_config(abi.SE3_QUAT_RIGHT)
+            c.kind, c.finder, c.finder_max_distance = sk, abi.FINDER_PROJECTIVE, 0.05
+            for i, v in enumerate(data["K"].reshape(-1)):
+                c.camera_matrix[i] = v
+            c.image_rows, c.image_cols = data["rows"], data["cols"]
+            c.depth_min, c.depth_max = data["depth_min"], data["depth_max"]
+            si = al.add_slice(c)
+            al.set_fixed(si, data["fixed"], data["fixed_normals"])
+            al.set_moving(si, data["moving"], data["moving_normals"])
+        K_total = world
+        units_per_step = args.iterations
+        nm, nf = data["moving"].shape[0], data["fixed"].shape[0]
+        alg_bytes_per_launch = 12 * nm + 24 * nf + 12 * nm  # one slice's launch (18.4 MB per 2-slice iteration)
 
         def step():
             al.set_moving_in_fixed(ident)
@@ -173,6 +198,8 @@ def main():
             "workload": ("C2: SE(3) point-to-plane AlignerSlice, %d-pt synthetic cloud pair per GPU, %d ICP "
                          "iterations per compute(), gated NN 0.25 m + normal gate, Cauchy 0.05" %
                          (args.points, args.iterations)) if args.workload == "c2" else
+                        ("C3: MultiAligner with 2 slices (projective + point-to-plane, projective + reprojection), "
+                         "640x480 depth pair, %d iterations per compute()" % args.iterations) if args.workload == "c3" else
                         ("C4-shard: %d x %d-pt SE(3) point-to-plane alignments per GPU per step, %d iterations" %
                          (args.batch, args.batch_points, args.iterations)),
             "points": args.points if args.workload == "c2" else args.batch_points,
@@ -184,7 +211,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_icp_step<3,true>",
+            "kernel": "k_icp_step<3,true>" if args.workload != "c3" else "k_icp_step_proj (both slices)",
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",
