@@ -1,0 +1,29 @@
+"""The C++ host-side mirror (include/srrg2_slam_amd.hpp) and the C++ re-statement of the reference's slice tests
+(tests/cpp/test_motion_model_slice.cpp).  CPU: it compiles and links against the C-ABI library with plain g++
+(no HIP headers needed by a caller).  gpu: the binary runs the three reference scenarios on the device."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+BIN = os.path.join(CPP, "bin", "test_motion_model_slice")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", CPP, "-s"])
+
+
+def test_cpp_mirror_compiles_and_links():
+    _build()
+    assert os.path.exists(BIN)
+
+
+@pytest.mark.gpu
+def test_cpp_reference_scenarios_on_gpu():
+    if not os.path.exists(BIN):
+        _build()
+    out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASSED" in out.stdout
