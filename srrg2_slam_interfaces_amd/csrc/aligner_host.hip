@@ -58,6 +58,8 @@ struct Slice {
   DevBuf<uint8_t> corr_stat;
   DevBuf<long long> partials;
   DevBuf<unsigned long long> zbuf;  // projective finder: [problem][rows*cols]
+  DevBuf<int> queue;                // deferred searches: one 32-byte QEntry per moving point
+  DevBuf<int> qcount;               // [problem]
   // prior
   float prior_Z[12]{};
   bool has_prior = false;
@@ -67,7 +69,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release();
+    corr_fixed.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
   }
 };
 
@@ -419,9 +421,18 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     if (first_cue < 0) first_cue = si;
     int nm_max_s = 0;
     for (int k = 0; k < K; ++k) nm_max_s = std::max(nm_max_s, all[(size_t) si * K + k].nm);
-    const int nblocks = std::max(srrg2amd::icp_step_blocks(nm_max_s), 1);
+    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0;
+    const int qslots     = use_queue ? 8 : 0;
+    const int nblocks    = std::max(srrg2amd::icp_step_blocks(nm_max_s), 1) + qslots;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
-    if (nm_max_s == 0)  // no step launch will write the partials of an empty cloud
+    if (use_queue) {
+      if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 8))) return rc;  // QEntry = 8 x 4 bytes
+      if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
+      HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t) 2 * K * sizeof(int), a->stream));
+    }
+    sc.qcount = use_queue ? s->qcount.p : nullptr;
+    sc.qslots = qslots;
+    if (nm_max_s == 0 || use_queue)  // empty cloud: nothing writes the partials; queue slots start at zero
       HIP_TRY(hipMemsetAsync(s->partials.p, 0, (size_t) K * nblocks * ACC_N * sizeof(long long), a->stream));
     sc.partials  = s->partials.p;
     sc.nblocks   = nblocks;
@@ -435,6 +446,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.corr_resp       = s->corr_resp.p;
     d.corr_stat       = s->corr_stat.p;
     d.partials        = s->partials.p;
+    d.partial_blocks  = nblocks;
+    d.queue           = use_queue ? (void*) s->queue.p : nullptr;
+    d.qcount          = use_queue ? s->qcount.p : nullptr;
     d.slice_idx       = si;
     d.robust_kind     = s->cfg.robustifier;
     d.robust_thr      = s->cfg.robustifier_chi_threshold;

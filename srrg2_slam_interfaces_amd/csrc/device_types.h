@@ -42,7 +42,10 @@ struct SliceDev {
   int* corr_fixed;      // per moving point: matched fixed index or -1
   float* corr_resp;     // per moving point: response (squared distance)
   uint8_t* corr_stat;   // per moving point: srrg2_factor_status of the last linearisation
-  long long* partials;  // [problem][gridDim.x][ACC_N]: per-block fixed-point partial sums (no atomics)
+  long long* partials;  // [problem][partial_blocks][ACC_N]: per-block fixed-point partial sums (no atomics)
+  int partial_blocks;   // blocks per problem writing partials (step kernel + deferred-search kernel)
+  void* queue;          // deferred searches: QEntry[total moving points] (per problem at its moving offset), or null
+  int* qcount;          // [problem] entries in the queue
   int slice_idx;
   int robust_kind;
   float robust_thr;
@@ -106,8 +109,10 @@ struct SliceCtl {
   float K0, K4;             // focal lengths (projective / reprojection bounds)
   int rows, cols;
   float depth_min;
+  int* qcount;              // deferred-search queue counters of the slice (reset by the control kernel), or null
   const long long* partials;  // [problem][nblocks][ACC_N] (null for priors)
-  int nblocks;                // gridDim.x of the slice's step launch
+  int nblocks;                // partial blocks per problem (step kernel blocks + qslots)
+  int qslots;                 // trailing partial slots the deferred-search kernel adds into atomically
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
 };

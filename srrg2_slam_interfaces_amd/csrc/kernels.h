@@ -20,6 +20,7 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s);
 int icp_step_blocks(int max_nm);
+int icp_queue_blocks(int max_nm, int K);
 // projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)
 void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,
                       hipStream_t s);

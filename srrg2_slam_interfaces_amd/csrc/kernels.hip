@@ -516,7 +516,8 @@ __device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], 
 // block reduction: transposing butterfly per wave, 4 waves through LDS, then ONE plain 256-byte store of the
 // block's partial sums.  (Device-scope atomics on 32 shared addresses serialise at ~10 ns each: 391 blocks x 32
 // atomics cost ~90 us at C2 -- profiles/r1a; the control kernel sums the partials instead.)
-__device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long long* __restrict__ partials, int prob) {
+__device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long long* __restrict__ partials, int prob,
+                                                   int total_blocks, int block) {
   __shared__ long long red[4][ACC_N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int my_index;
@@ -525,24 +526,26 @@ __device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long
   __syncthreads();
   if (threadIdx.x < ACC_N) {
     long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    partials[((size_t) prob * gridDim.x + blockIdx.x) * ACC_N + threadIdx.x] = v;
+    partials[((size_t) prob * total_blocks + block) * ACC_N + threadIdx.x] = v;
   }
 }
 
 }  // namespace
 
-template <int DIM, bool PLANE>
-__global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                  ProblemState* __restrict__ states) {
-  constexpr int D    = DIM == 3 ? 6 : 3;
-  constexpr int ROWS = PLANE ? 1 : DIM;
-  const int prob     = blockIdx.y;
-  ProblemState* st   = &states[prob];
-  if (st->done || st->finished) return;
-  const ProblemDev pd = probs[prob];
+// ---- pieces shared by the step kernel and the deferred-search kernel --------------------------------------------
+namespace {
 
+struct QEntry {  // a moving point whose search did not settle inside the 3^DIM block (deferred to k_icp_step_queue)
+  int i;         // index in the (Morton-sorted) moving array of the problem
+  int r2;        // cube radius that still has to be scanned
+  float best;    // best so far
+  int bidx, bpos;
+  float qx, qy, qz;  // the transformed point (saves the dependent reload + transform in the queue kernel)
+};
+
+template <int DIM>
+__device__ __forceinline__ void load_finder_transform(const SliceDev& S, const ProblemState* st, float* T) {
   // finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35
-  float T[12];
   if constexpr (DIM == 3) {
     dm::se3_compose(S.Sinv, st->X, T);
   } else {
@@ -553,182 +556,132 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     T[4] = t9[3]; T[5] = t9[4]; T[6] = 0.f; T[7] = t9[5];
     T[8] = 0.f; T[9] = 0.f; T[10] = 1.f; T[11] = 0.f;
   }
-  const int kexp     = st->kexp[S.slice_idx];
-  const double scale = dm::pow2(kexp);
-  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
-  const float thr    = S.robust_thr;
-  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+}
+
+template <int DIM>
+__device__ __forceinline__ void transform_point(const float* T, const float4 p, float& qx, float& qy, float& qz) {
+  if constexpr (DIM == 3) {
+    qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+    qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+    qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+  } else {
+    qx = (T[0] * p.x + T[1] * p.y) + T[3];
+    qy = (T[4] * p.x + T[5] * p.y) + T[7];
+    qz = 0.f;
+  }
+}
+
+// Team-cooperative exact scan of a cube of radius sr cells: a team = TW consecutive lanes (TW = 64: the whole wave,
+// TW = 16: four independent queries per wave) sharing ONE query (sqx..scz, sr are team-uniform; sr < 0 = idle team).
+// The team's lanes fetch all row ranges of the cube together, prefix-sum the counts, take equal contiguous shares of
+// the flattened candidate list and reduce to the lexicographic minimum of (d2, fixed index).  Every lane of the team
+// returns the same (best, idx, pos); idx == NO_MATCH when the cube is empty.  lds: 4*TW + 8 ints per team.
+template <int DIM, int TW>
+__device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_wave, float sqx, float sqy, float sqz,
+                                          int scx, int scy, int scz, int sr, float& wbest, int& widx, int& wpos) {
+  constexpr int ROWS_PER_CHUNK = 2 * TW;
+  const int lt   = lane & (TW - 1);
+  const int team = lane / TW;
+  int* flat      = lds_wave + team * (4 * TW + 8);  // flattened candidate offset at which each row starts (+ total)
+  int* first     = flat + ROWS_PER_CHUNK + 4;       // sorted-array index of each row's first candidate
+  const int z0 = DIM == 3 ? max(scz - sr, 0) : 0, z1 = DIM == 3 ? min(scz + sr, g.nz - 1) : 0;
+  const int y0 = max(scy - sr, 0), y1 = min(scy + sr, g.ny - 1);
+  const int x0 = max(scx - sr, 0), x1 = min(scx + sr, g.nx - 1);
+  float lbest = INFINITY;
+  int lidx = NO_MATCH, lpos = 0;
+  const bool any = sr >= 0 && x0 <= x1 && y0 <= y1 && z0 <= z1;
+  const int ny_r = any ? y1 - y0 + 1 : 1;
+  const int rows = any ? ny_r * (z1 - z0 + 1) : 0;
+  // all teams of the wave iterate the same number of chunks (wave-uniform control flow for the LDS syncs)
+  int max_rows = rows;
+  if (TW < 64) {
+#pragma unroll
+    for (int off = TW; off < 64; off <<= 1) max_rows = max(max_rows, __shfl_xor(max_rows, off));
+  }
+  for (int row0 = 0; row0 < max_rows; row0 += ROWS_PER_CHUNK) {
+    // (1) every lane fetches the [start, end) ranges of two rows: all row fetches of the chunk in flight at once
+    int sA = 0, eA = 0, sB = 0, eB = 0;
+    const int rA = row0 + lt, rB = row0 + TW + lt;
+    if (rA < rows) {
+      const int row = ((z0 + rA / ny_r) * g.ny + (y0 + rA % ny_r)) * g.nx;
+      sA = g.cell_start[row + x0];
+      eA = g.cell_start[row + x1 + 1];
+    }
+    if (rB < rows) {
+      const int row = ((z0 + rB / ny_r) * g.ny + (y0 + rB % ny_r)) * g.nx;
+      sB = g.cell_start[row + x0];
+      eB = g.cell_start[row + x1 + 1];
+    }
+    // (2) team prefix sum of both counts at once (packed in 64 bits)
+    const unsigned long long pk = (unsigned long long) (unsigned) (eA - sA) | ((unsigned long long) (unsigned) (eB - sB) << 32);
+    unsigned long long inc = pk;
+#pragma unroll
+    for (int off = 1; off < TW; off <<= 1) {
+      unsigned long long t = __shfl_up(inc, off, TW);
+      if (lt >= off) inc += t;
+    }
+    const unsigned long long tot = __shfl(inc, TW - 1, TW);
+    const int totA = (int) (unsigned) tot, totB = (int) (tot >> 32);
+    const unsigned long long exc = inc - pk;
+    flat[lt]       = (int) (unsigned) exc;
+    flat[TW + lt]  = totA + (int) (exc >> 32);
+    first[lt]      = sA;
+    first[TW + lt] = sB;
+    if (lt == 0) flat[ROWS_PER_CHUNK] = totA + totB;
+    wave_lds_sync();
+    // (3) every lane takes an equal contiguous share of the flattened candidate list
+    const int total = totA + totB;
+    const int share = (total + TW - 1) / TW;
+    int t           = lt * share;
+    const int tend  = min(t + share, total);
+    if (t < tend) {
+      int lo = 0, hi = ROWS_PER_CHUNK - 1;  // last row whose start offset is <= t
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {
+        if ((1 << it) >= ROWS_PER_CHUNK) break;
+        const int mid = (lo + hi + 1) >> 1;
+        if (flat[mid] <= t) lo = mid; else hi = mid - 1;
+      }
+      int r    = lo;
+      int next = flat[r + 1];
+      while (t < tend) {
+        while (t >= next) {
+          ++r;
+          next = flat[r + 1];
+        }
+        const int j   = first[r] + (t - flat[r]);
+        const int run = min(next, tend) - t;  // candidates of this row in my share: consecutive in memory
+        scan_range<DIM>(g.pts, j, j + run, sqx, sqy, sqz, lbest, lidx, lpos);
+        t += run;
+      }
+    }
+    wave_lds_sync();
+  }
+  // team minimum of the 64-bit key (d2 bits, index): d2 >= 0 so the float bit pattern orders like the value
+  const unsigned long long key = ((unsigned long long) __float_as_uint(lbest) << 32) | (unsigned) lidx;
+  unsigned long long kmin      = key;
+#pragma unroll
+  for (int off = TW / 2; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(kmin, off);
+    kmin = o < kmin ? o : kmin;
+  }
+  // position of the winner: the first lane of the team holding the minimum key
+  unsigned long long who = __ballot(key == kmin);
+  if (TW < 64) who = (who >> (team * TW)) & ((1ull << TW) - 1ull);
+  const int wl = team * TW + __ffsll((long long) who) - 1;
+  wpos  = __shfl(lpos, wl);
+  wbest = __uint_as_float((unsigned) (kmin >> 32));
+  widx  = (int) (unsigned) kmin;
+}
+
+// gates, normals, residual rows, factor arithmetic and the per-point outputs of ONE searched moving point
+template <int DIM, bool PLANE>
+__device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, int rk, float thr, float kk, double scale,
+                                             bool inrange, bool active, int gi, int oi, const float4 p, float qx, float qy,
+                                             float qz, float best, int bidx, int bpos, long long (&acc)[ACC_N]) {
+  constexpr int D    = DIM == 3 ? 6 : 3;
+  constexpr int ROWS = PLANE ? 1 : DIM;
   const GridDev& g   = S.grid;
-  const float b2_1   = bound2_of(1, g.h);
-
-  long long acc[ACC_N];
-#pragma unroll
-  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
-
-  // ONE moving point per thread: the 32 fixed-point terms of the point go straight into the wave
-  // reduction, so no accumulator registers are live during the search.
-  const int i       = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane    = threadIdx.x & 63;
-  const int wid     = threadIdx.x >> 6;
-  const bool inrange = i < pd.nm;
-  const int gi      = pd.moff + (inrange ? i : 0);
-  float4 p          = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (inrange) p = S.mpts[gi];
-  // moving points are stored spatially sorted; p.w carries the caller's index within the problem
-  const int oi      = pd.moff + __float_as_int(p.w);
-  const bool active = inrange && finite3(p.x, p.y, p.z);
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  int cx = 0, cy = 0, cz = 0;
-  float best = INFINITY;
-  int bidx = NO_MATCH, bpos = 0;
-  int r2 = 0;  // > 1: this lane needs the second search phase with cube radius r2
-  if (active) {
-    if constexpr (DIM == 3) {
-      qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
-      qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
-      qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
-    } else {
-      qx = (T[0] * p.x + T[1] * p.y) + T[3];
-      qy = (T[4] * p.x + T[5] * p.y) + T[7];
-    }
-    cx = cell_coord(qx, g.ox, g.inv_h);
-    cy = cell_coord(qy, g.oy, g.inv_h);
-    cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
-  }
-  // ---- phases 1 / 1b: radius-1 block, then radius-2 block for lanes that did not settle ----------------------
-  // (A variant that staged the wave's whole neighbourhood box in LDS first was measured slower on both C2 and
-  //  C4 -- 24.6 vs 19.6 us and 226 vs 160 us per launch, profiles/r1 notes -- and was removed: the search is
-  //  bound by per-wave instruction issue, not by the number of dependent global round trips.)
-  __shared__ int coop_lds[4][264];
-  if (active && !(S.tune & 16)) {
-    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
-    const bool found1 = bidx != NO_MATCH && best <= g.gate2;
-    if (!(found1 && best <= b2_1) && g.rmax > 1) {
-      r2 = g.rmax;
-      if (found1) {
-        r2 = 1;
-        while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
-      }
-    }
-    if (r2 > 1 && !(S.tune & 2)) {
-      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
-      const bool found2 = bidx != NO_MATCH && best <= g.gate2;
-      if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
-        r2 = 0;
-      } else {
-        r2 = g.rmax;
-        if (found2) {
-          r2 = 2;
-          while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
-        }
-      }
-    }
-  }
-  // Second search phase, wave-cooperative: a lane whose nearest neighbour may lie outside the 3^DIM block
-  // (or that found nothing) needs a cube of radius r2 <= rmax; scanning it alone would stall its whole wave
-  // for up to (2 rmax + 1)^2 dependent row fetches.  Instead the 64 lanes split the rows of that cube, then
-  // take the lexicographic minimum of (d2, fixed index) across the wave.  Same cells, same exact result.
-  {
-    unsigned long long need = __ballot(r2 > 1);
-    if (S.tune & 1) need = 0;
-    while (need) {
-      const int src = __ffsll((long long) need) - 1;
-      need &= need - 1;
-      const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
-      const int scx = __shfl(cx, src), scy = __shfl(cy, src), scz = __shfl(cz, src);
-      const int sr = __shfl(r2, src);
-      const int z0 = DIM == 3 ? max(scz - sr, 0) : 0, z1 = DIM == 3 ? min(scz + sr, g.nz - 1) : 0;
-      const int y0 = max(scy - sr, 0), y1 = min(scy + sr, g.ny - 1);
-      const int x0 = max(scx - sr, 0), x1 = min(scx + sr, g.nx - 1);
-      float lbest = INFINITY;
-      int lidx = NO_MATCH, lpos = 0;
-      if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
-        const int ny_r = y1 - y0 + 1;
-        const int rows = ny_r * (z1 - z0 + 1);
-        int* flat      = coop_lds[wid];        // flattened candidate offset at which each row starts (+ total)
-        int* first     = coop_lds[wid] + 132;  // sorted-array index of each row's first candidate
-        for (int row0 = 0; row0 < rows; row0 += 128) {
-          // (1) every lane fetches the [start, end) ranges of two rows: all row fetches of the cube in flight at once
-          int sA = 0, eA = 0, sB = 0, eB = 0;
-          const int rA = row0 + lane, rB = row0 + 64 + lane;
-          if (rA < rows) {
-            const int row = ((z0 + rA / ny_r) * g.ny + (y0 + rA % ny_r)) * g.nx;
-            sA = g.cell_start[row + x0];
-            eA = g.cell_start[row + x1 + 1];
-          }
-          if (rB < rows) {
-            const int row = ((z0 + rB / ny_r) * g.ny + (y0 + rB % ny_r)) * g.nx;
-            sB = g.cell_start[row + x0];
-            eB = g.cell_start[row + x1 + 1];
-          }
-          // (2) wave prefix sum of both counts at once (packed in 64 bits)
-          const unsigned long long pk = (unsigned long long) (unsigned) (eA - sA) |
-                                        ((unsigned long long) (unsigned) (eB - sB) << 32);
-          unsigned long long inc = pk;
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            unsigned long long t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-          }
-          const unsigned long long tot = __shfl(inc, 63);
-          const int totA = (int) (unsigned) tot, totB = (int) (tot >> 32);
-          const unsigned long long exc = inc - pk;
-          flat[lane]       = (int) (unsigned) exc;
-          flat[64 + lane]  = totA + (int) (exc >> 32);
-          first[lane]      = sA;
-          first[64 + lane] = sB;
-          if (lane == 0) flat[128] = totA + totB;
-          wave_lds_sync();
-          // (3) every lane takes an equal contiguous share of the flattened candidate list
-          const int total = totA + totB;
-          const int share = (total + 63) >> 6;
-          int t           = lane * share;
-          const int tend  = min(t + share, total);
-          if (t < tend) {
-            int lo = 0, hi = 127;  // last row whose start offset is <= t
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-              const int mid = (lo + hi + 1) >> 1;
-              if (flat[mid] <= t) lo = mid; else hi = mid - 1;
-            }
-            int r = lo;
-            int next = flat[r + 1];
-            while (t < tend) {
-              while (t >= next) {
-                ++r;
-                next = flat[r + 1];
-              }
-              const int j = first[r] + (t - flat[r]);
-              const int run = min(next, tend) - t;  // candidates of this row in my share: consecutive in memory
-              scan_range<DIM>(g.pts, j, j + run, sqx, sqy, sqz, lbest, lidx, lpos);
-              t += run;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      // wave minimum of the 64-bit key (d2 bits, index): d2 >= 0 so the float bit pattern orders like the value
-      unsigned long long key = ((unsigned long long) __float_as_uint(lbest) << 32) | (unsigned) lidx;
-      unsigned long long kmin = key;
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        unsigned long long o = __shfl_xor(kmin, off);
-        kmin = o < kmin ? o : kmin;
-      }
-      const unsigned long long who = __ballot(key == kmin);
-      const int wl   = __ffsll((long long) who) - 1;
-      const int wpos = __shfl(lpos, wl);
-      if (lane == src) {
-        const float wbest = __uint_as_float((unsigned) (kmin >> 32));
-        const int widx    = (int) (unsigned) kmin;
-        if (wbest < best || (wbest == best && widx < bidx)) {
-          best = wbest;
-          bidx = widx;
-          bpos = wpos;
-        }
-      }
-    }
-  }
   int match     = -1;
   float resp    = 0.f;
   uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
@@ -817,7 +770,253 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     S.corr_stat[oi]  = fstat;
   }
 
-  block_reduce_store(acc, S.partials, prob);
+}
+
+}  // namespace
+
+// One moving point per thread.  Lanes whose nearest neighbour is not settled by the 3^DIM block are either pushed
+// to the per-problem queue (S.queue != null; k_icp_step_queue finishes them with all waves of the chip sharing
+// the work) or, without a queue, handled here: radius-2 scan per lane, then wave-cooperative scans.
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                  ProblemState* __restrict__ states) {
+  const int prob   = blockIdx.y;
+  ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  float T[12];
+  load_finder_transform<DIM>(S, st, T);
+  const int kexp     = st->kexp[S.slice_idx];
+  const double scale = dm::pow2(kexp);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float thr    = S.robust_thr;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  const GridDev& g   = S.grid;
+  const float b2_1   = bound2_of(1, g.h);
+
+  long long acc[ACC_N];
+#pragma unroll
+  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+
+  const int i        = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane     = threadIdx.x & 63;
+  const int wid      = threadIdx.x >> 6;
+  const bool inrange = i < pd.nm;
+  const int gi       = pd.moff + (inrange ? i : 0);
+  float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (inrange) p = S.mpts[gi];
+  // moving points are stored spatially sorted; p.w carries the caller's index within the problem
+  const int oi      = pd.moff + __float_as_int(p.w);
+  const bool active = inrange && finite3(p.x, p.y, p.z);
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  int cx = 0, cy = 0, cz = 0;
+  float best = INFINITY;
+  int bidx = NO_MATCH, bpos = 0;
+  int r2 = 0;  // > 1: this lane needs a cube of radius r2
+  __shared__ int coop_lds[4][264];
+  if (active && !(S.tune & 16)) {
+    transform_point<DIM>(T, p, qx, qy, qz);
+    cx = cell_coord(qx, g.ox, g.inv_h);
+    cy = cell_coord(qy, g.oy, g.inv_h);
+    cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
+    const bool found1 = bidx != NO_MATCH && best <= g.gate2;
+    if (!(found1 && best <= b2_1) && g.rmax > 1) {
+      r2 = g.rmax;
+      if (found1) {
+        r2 = 1;
+        while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
+      }
+    }
+  }
+  bool deferred = false;
+  if (S.queue) {
+    // push the open lanes to the problem's queues: near entries (radius 2) grow from the front of the problem's
+    // region, far entries (radius > 2) from its back; one atomic per wave and kind, entries in lane order
+    const unsigned long long need_near = __ballot(r2 == 2);
+    const unsigned long long need_far  = __ballot(r2 > 2);
+    if (need_near | need_far) {
+      int base_near = 0, base_far = 0;
+      if (lane == 0) {
+        if (need_near) base_near = atomicAdd(&S.qcount[2 * prob], __popcll(need_near));
+        if (need_far) base_far = atomicAdd(&S.qcount[2 * prob + 1], __popcll(need_far));
+      }
+      base_near = __shfl(base_near, 0);
+      base_far  = __shfl(base_far, 0);
+      if (r2 > 1) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        QEntry e;
+        e.i = i; e.r2 = r2; e.best = best; e.bidx = bidx; e.bpos = bpos;
+        e.qx = qx; e.qy = qy; e.qz = qz;
+        QEntry* qbase = reinterpret_cast<QEntry*>(S.queue) + pd.moff;
+        if (r2 == 2)
+          qbase[base_near + __popcll(need_near & below)] = e;
+        else
+          qbase[pd.nm - 1 - (base_far + __popcll(need_far & below))] = e;
+        deferred = true;
+      }
+    }
+  } else {
+    // radius-2 cube per lane, then the cooperative scan for what is still open
+    if (r2 > 1 && g.rmax >= 2 && !(S.tune & 2)) {
+      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
+      const bool found2 = bidx != NO_MATCH && best <= g.gate2;
+      if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
+        r2 = 0;
+      } else {
+        r2 = g.rmax;
+        if (found2) {
+          r2 = 2;
+          while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
+        }
+      }
+    }
+    unsigned long long need = __ballot(r2 > 1);
+    if (S.tune & 1) need = 0;
+    while (need) {
+      const int src = __ffsll((long long) need) - 1;
+      need &= need - 1;
+      float wbest;
+      int widx, wpos;
+      coop_scan<DIM, 64>(g, lane, coop_lds[wid], __shfl(qx, src), __shfl(qy, src), __shfl(qz, src), __shfl(cx, src),
+                     __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), wbest, widx, wpos);
+      if (lane == src && (wbest < best || (wbest == best && widx < bidx))) {
+        best = wbest;
+        bidx = widx;
+        bpos = wpos;
+      }
+    }
+  }
+  if (!deferred) finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, acc);
+  block_reduce_store(acc, S.partials, prob, S.partial_blocks, blockIdx.x);
+}
+
+// Deferred searches: every wave takes queue entries w, w + W, ... of its problem, runs the cooperative exact scan
+// for each (64 lanes per query), parks the result in the lane with that ordinal and, after at most 64 of them,
+// finishes all parked points in SIMT.  The partial sums go to blocks [first_block, first_block + gridDim.x).
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                        ProblemState* __restrict__ states, int first_block,
+                                                        int total_blocks) {
+  const int prob   = blockIdx.y;
+  ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  float T[12];
+  load_finder_transform<DIM>(S, st, T);
+  const int kexp     = st->kexp[S.slice_idx];
+  const double scale = dm::pow2(kexp);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float thr    = S.robust_thr;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  const GridDev& g   = S.grid;
+  __shared__ long long wave_acc[4][ACC_N];
+  if ((threadIdx.x & 63) < ACC_N) wave_acc[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+  __shared__ int coop_lds[4][4 * (4 * 16 + 8)];  // = 288 ints >= 264 needed by the 64-lane scan
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int count_near = S.qcount[2 * prob], count_far = S.qcount[2 * prob + 1];
+  const int W     = gridDim.x * 4;
+  const QEntry* queue = reinterpret_cast<const QEntry*>(S.queue) + pd.moff;
+  // Near entries (radius 2): four per pass, one per team of 16 lanes.  Far entries (radius > 2, large cubes): one
+  // per pass with all 64 lanes.  Results are parked one per lane (slot = ordinal of the entry in this wave) and
+  // finished in SIMT once 64 are parked or the queues are exhausted.
+  bool have = false;
+  int my_i = 0, my_bidx = NO_MATCH, my_bpos = 0;
+  float my_best = INFINITY;
+  int parked = 0;
+  // The 32 fixed-point accumulators live in LDS between flushes (one set per wave), not in registers: the search
+  // loop keeps its register budget (occupancy) and a flush costs one wave reduction.
+  auto flush = [&]() {
+    float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    if (have) {
+      mp = S.mpts[pd.moff + my_i];
+      transform_point<DIM>(T, mp, mx, my, mz);
+    }
+    long long acc[ACC_N];
+#pragma unroll
+    for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+    finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, have, have, pd.moff + my_i, pd.moff + __float_as_int(mp.w), mp, mx, my,
+                             mz, my_best, my_bidx, my_bpos, acc);
+    int my_index;
+    const long long total = wave_transpose_reduce(acc, lane, my_index);
+    if ((lane & 1) == 0) wave_acc[wid][my_index] += total;
+    have   = false;
+    parked = 0;
+  };
+  {
+    constexpr int TW = 16, TEAMS = 64 / TW;
+    const int team = lane / TW;
+    for (int e0 = (blockIdx.x * 4 + wid) * TEAMS; e0 < count_near; e0 += W * TEAMS) {
+      const int e     = e0 + team;
+      const bool live = e < count_near;
+      QEntry q;
+      q.i = 0; q.r2 = -1; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0; q.qx = q.qy = q.qz = 0.f;
+      if (live) q = queue[e];
+      const bool skip = (S.tune & 2048) != 0;
+      const int cx = cell_coord(q.qx, g.ox, g.inv_h);
+      const int cy = cell_coord(q.qy, g.oy, g.inv_h);
+      const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
+      float wbest;
+      int widx, wpos;
+      coop_scan<DIM, TW>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, (live && !skip) ? q.r2 : -1, wbest, widx, wpos);
+      if (wbest < q.best || (wbest == q.best && widx < q.bidx)) {
+        q.best = wbest;
+        q.bidx = widx;
+        q.bpos = wpos;
+      }
+      // park: lane (parked + t) takes the result of team t
+      const int slot_team = lane - parked;
+      const bool mine     = slot_team >= 0 && slot_team < TEAMS;
+      const int src       = mine ? slot_team * TW : 0;
+      const int pi = __shfl(q.i, src), pbi = __shfl(q.bidx, src), pbp = __shfl(q.bpos, src), plive = __shfl((int) live, src);
+      const float pb = __shfl(q.best, src);
+      if (mine && plive) {
+        have    = true;
+        my_i    = pi;
+        my_best = pb;
+        my_bidx = pbi;
+        my_bpos = pbp;
+      }
+      parked += TEAMS;
+      if (parked == 64) flush();
+    }
+  }
+  for (int e = blockIdx.x * 4 + wid; e < count_far; e += W) {
+    const QEntry q  = queue[pd.nm - 1 - e];
+    const bool skip = (S.tune & 1024) != 0;
+    const int cx = cell_coord(q.qx, g.ox, g.inv_h);
+    const int cy = cell_coord(q.qy, g.oy, g.inv_h);
+    const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
+    float wbest;
+    int widx, wpos;
+    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : q.r2, wbest, widx, wpos);
+    if (lane == parked) {
+      have    = true;
+      my_i    = q.i;
+      my_best = q.best;
+      my_bidx = q.bidx;
+      my_bpos = q.bpos;
+      if (wbest < my_best || (wbest == my_best && widx < my_bidx)) {
+        my_best = wbest;
+        my_bidx = widx;
+        my_bpos = wpos;
+      }
+    }
+    if (++parked == 64) flush();
+  }
+  if (parked > 0) flush();
+  // exact integer sums are order independent, so the blocks of this kernel may add into a few shared partial slots
+  // behind the step kernel's blocks with atomics (the control kernel zeroes the slots after reading them)
+  __syncthreads();
+  if (threadIdx.x < ACC_N) {
+    const long long v = (wave_acc[0][threadIdx.x] + wave_acc[1][threadIdx.x]) + (wave_acc[2][threadIdx.x] + wave_acc[3][threadIdx.x]);
+    if (v != 0) {
+      const int slot = first_block + (blockIdx.x % (total_blocks - first_block));
+      atomicAdd(reinterpret_cast<unsigned long long*>(S.partials) + ((size_t) prob * total_blocks + slot) * ACC_N + threadIdx.x,
+                (unsigned long long) v);
+    }
+  }
 }
 
 // ============================================================================================
@@ -979,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
     S.corr_resp[oi]  = resp;
     S.corr_stat[oi]  = fstat;
   }
-  block_reduce_store(acc, S.partials, prob);
+  block_reduce_store(acc, S.partials, prob, S.partial_blocks, blockIdx.x);
 }
 
 // ============================================================================================
@@ -1135,6 +1334,8 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
     good |= nc > sc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
   }
   if (!good && !(C.tune & 256)) {
+    for (int s = 0; s < C.nslices; ++s)
+      if (C.slices[s].qcount) C.slices[s].qcount[2 * prob] = C.slices[s].qcount[2 * prob + 1] = 0;
     st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;  // multi_aligner_impl.cpp:107-111
     st->done   = 1;
     return;
@@ -1209,6 +1410,8 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   if (st->nstats < C.max_stats) stats[(size_t) prob * C.max_stats + st->nstats] = cur;
   st->nstats++;
   if (C.has_term && has_to_stop(C, st, cur)) st->done = 1;  // :124-126
+  for (int s = 0; s < C.nslices; ++s)
+    if (C.slices[s].qcount) C.slices[s].qcount[2 * prob] = C.slices[s].qcount[2 * prob + 1] = 0;  // queues start empty next iteration
 }
 
 }  // namespace
@@ -1230,6 +1433,7 @@ __global__ void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs, Pr
     const SliceCtl& sc = C.slices[s];
     st->ncorr[s]       = 0;
     st->ninl[s]        = 0;
+    if (sc.qcount) sc.qcount[2 * prob] = sc.qcount[2 * prob + 1] = 0;
     if (sc.kind == SRRG2_SLICE_PRIOR) {
       st->kexp[s] = 0;
       if (sc.prior_sets_initial_guess) {  // aligner_slice_odometry_prior.cpp:19,34; aligner_slice_motion_model.hpp:69-70
@@ -1254,7 +1458,7 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     if (sc.kind == SRRG2_SLICE_PRIOR) continue;
-    const long long* p = sc.partials + (size_t) prob * sc.nblocks * ACC_N;
+    long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * sc.nblocks * ACC_N;
     long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     int b = c;
     for (; b + 24 < sc.nblocks; b += 32) {  // four independent loads in flight
@@ -1266,6 +1470,9 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
     for (; b < sc.nblocks; b += 8) v0 += p[(size_t) b * ACC_N + a];
     part[c][a] = (v0 + v1) + (v2 + v3);
     __syncthreads();
+    // the deferred-search kernel accumulates into the last `qslots` partial slots with atomics: reset them
+    // (after the barrier: every thread of the block has finished reading)
+    for (int q = sc.nblocks - sc.qslots + c; q < sc.nblocks; q += 8) p[(size_t) q * ACC_N + a] = 0;
     if (threadIdx.x < ACC_N) {
       long long t = 0;
 #pragma unroll
@@ -1384,6 +1591,13 @@ int icp_step_blocks(int max_nm) {
   return (max_nm + 255) / 256;  // one moving point per thread
 }
 
+int icp_queue_blocks(int max_nm, int K) {
+  // waves that share the deferred searches of one problem: up to 4096 for a single alignment, fewer per problem in a batch
+  int b = icp_step_blocks(max_nm);
+  int cap = K <= 1 ? 1024 : (K <= 8 ? 256 : 64);
+  return b < cap ? b : cap;
+}
+
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
@@ -1399,6 +1613,21 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
       hipLaunchKernelGGL((k_icp_step<2, true>), grid, dim3(256), 0, s, S, probs, states);
     else
       hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), 0, s, S, probs, states);
+  }
+  if (S.queue) {
+    const int qb = icp_queue_blocks(max_nm, K);
+    dim3 qgrid(qb, K);
+    if (dim == 3) {
+      if (plane)
+        hipLaunchKernelGGL((k_icp_step_queue<3, true>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+      else
+        hipLaunchKernelGGL((k_icp_step_queue<3, false>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+    } else {
+      if (plane)
+        hipLaunchKernelGGL((k_icp_step_queue<2, true>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+      else
+        hipLaunchKernelGGL((k_icp_step_queue<2, false>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+    }
   }
 }
 
