@@ -421,7 +421,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     if (first_cue < 0) first_cue = si;
     int nm_max_s = 0;
     for (int k = 0; k < K; ++k) nm_max_s = std::max(nm_max_s, all[(size_t) si * K + k].nm);
-    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0;
+    // deferred-search queue: a win in the latency regime (few alignments per launch: C2 0.78 -> 0.63 ms); with many
+    // alignments per launch the in-kernel path has more throughput (C4: 2.46 vs 2.74 ms per 32 x 50k batch)
+    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0 && K <= 4;
     const int qslots     = use_queue ? 8 : 0;
     const int nblocks    = std::max(srrg2amd::icp_step_blocks(nm_max_s), 1) + qslots;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;

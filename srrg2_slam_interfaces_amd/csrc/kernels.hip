@@ -78,16 +78,37 @@ __global__ void k_ingest(const float* __restrict__ src, int stride_floats, int n
 // ============================================================================================
 // grid build
 // ============================================================================================
-__global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mn, unsigned* __restrict__ mx,
+__global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
                        int* __restrict__ nvalid) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pts[i];
-  if (!finite3(p.x, p.y, p.z)) return;
-  atomicMin(&mn[0], fkey(p.x)); atomicMax(&mx[0], fkey(p.x));
-  atomicMin(&mn[1], fkey(p.y)); atomicMax(&mx[1], fkey(p.y));
-  atomicMin(&mn[2], fkey(p.z)); atomicMax(&mx[2], fkey(p.z));
-  atomicAdd(nvalid, 1);
+  unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+  int valid = 0;
+  if (i < n) {
+    float4 p = pts[i];
+    if (finite3(p.x, p.y, p.z)) {
+      valid = 1;
+      mn[0] = mx[0] = fkey(p.x);
+      mn[1] = mx[1] = fkey(p.y);
+      mn[2] = mx[2] = fkey(p.z);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = min(mn[d], (unsigned) __shfl_xor((int) mn[d], off));
+      mx[d] = max(mx[d], (unsigned) __shfl_xor((int) mx[d], off));
+    }
+    valid += __shfl_xor(valid, off);
+  }
+  if ((threadIdx.x & 63) == 0 && valid) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      atomicMin(&mn_out[d], mn[d]);
+      atomicMax(&mx_out[d], mx[d]);
+    }
+    atomicAdd(nvalid, valid);
+  }
 }
 
 __device__ __forceinline__ int grid_cell_of(const GridDev& g, float4 p) {
@@ -240,13 +261,33 @@ __device__ __forceinline__ unsigned morton_key(const float4 p, const unsigned* b
 __global__ void k_msort_bbox(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
                              unsigned* __restrict__ bb /* [K][6] */) {
   const ProblemDev pd = probs[blockIdx.y];
+  unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
     float4 p = pts[pd.moff + i];
     if (!finite3(p.x, p.y, p.z)) continue;
+    const unsigned k[3] = {fkey(p.x), fkey(p.y), fkey(p.z)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = min(mn[d], k[d]);
+      mx[d] = max(mx[d], k[d]);
+    }
+  }
+  // wave reduction first: one atomic per wave and bound instead of one per point (same-address atomics serialise)
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[d] = min(mn[d], (unsigned) __shfl_xor((int) mn[d], off));
+      mx[d] = max(mx[d], (unsigned) __shfl_xor((int) mx[d], off));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
     unsigned* b = bb + blockIdx.y * 6;
-    atomicMin(&b[0], fkey(p.x)); atomicMax(&b[3], fkey(p.x));
-    atomicMin(&b[1], fkey(p.y)); atomicMax(&b[4], fkey(p.y));
-    atomicMin(&b[2], fkey(p.z)); atomicMax(&b[5], fkey(p.z));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (mn[d] != 0xffffffffu) atomicMin(&b[d], mn[d]);
+      if (mx[d] != 0u) atomicMax(&b[3 + d], mx[d]);
+    }
   }
 }
 
@@ -835,14 +876,25 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     // region, far entries (radius > 2) from its back; one atomic per wave and kind, entries in lane order
     const unsigned long long need_near = __ballot(r2 == 2);
     const unsigned long long need_far  = __ballot(r2 > 2);
-    if (need_near | need_far) {
-      int base_near = 0, base_far = 0;
-      if (lane == 0) {
-        if (need_near) base_near = atomicAdd(&S.qcount[2 * prob], __popcll(need_near));
-        if (need_far) base_far = atomicAdd(&S.qcount[2 * prob + 1], __popcll(need_far));
+    // one atomic per BLOCK and kind (same-address device atomics serialise at ~10 ns each: per-wave atomics cost
+    // ~15 us on the misaligned first iteration of C2)
+    __shared__ int q_cnt[2][4], q_base[2];
+    if (lane == 0) {
+      q_cnt[0][wid] = __popcll(need_near);
+      q_cnt[1][wid] = __popcll(need_far);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const int tot = (q_cnt[threadIdx.x][0] + q_cnt[threadIdx.x][1]) + (q_cnt[threadIdx.x][2] + q_cnt[threadIdx.x][3]);
+      q_base[threadIdx.x] = tot ? atomicAdd(&S.qcount[2 * prob + threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+    {
+      int base_near = q_base[0], base_far = q_base[1];
+      for (int w = 0; w < wid; ++w) {
+        base_near += q_cnt[0][w];
+        base_far += q_cnt[1][w];
       }
-      base_near = __shfl(base_near, 0);
-      base_far  = __shfl(base_far, 0);
       if (r2 > 1) {
         const unsigned long long below = (1ull << lane) - 1ull;
         QEntry e;
