@@ -203,32 +203,60 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     }
   }
   const float gate = s->cfg.finder_max_distance;
-  float h          = s->cfg.finder_cell_size > 0.f ? s->cfg.finder_cell_size : gate * 0.25f;
-  if (!(h > 0.f)) h = 1.f;
-  const int dim = a->dim;
-  for (;;) {
-    double cells = 1.0;
-    bool ok      = true;
-    for (int d = 0; d < dim; ++d) {
-      double nd = std::floor(((double) mx[d] - (double) mn[d]) / (double) h) + 1.0;
-      if (nd > 1024.0) ok = false;
-      cells *= nd;
+  const int dim    = a->dim;
+  auto fit_cell = [&](float h0) {  // grow h until the dense grid fits: <= 1024 cells per axis, <= 4 Mi cells
+    float h = h0 > 0.f ? h0 : 1.f;
+    for (;;) {
+      double cells = 1.0;
+      bool ok      = true;
+      for (int d = 0; d < dim; ++d) {
+        double nd = std::floor(((double) mx[d] - (double) mn[d]) / (double) h) + 1.0;
+        if (nd > 1024.0) ok = false;
+        cells *= nd;
+      }
+      if (ok && cells <= 4194304.0) return h;
+      h *= 2.f;
     }
-    if (ok && cells <= 4194304.0) break;
-    h *= 2.f;
+  };
+  auto grid_dims = [&](float h, GridDev& g) {
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = dim == 3 ? mn[2] : 0.f;
+    g.h     = h;
+    g.inv_h = 1.0f / h;
+    auto ccoord = [&](float x, float o) {
+      float u = (x - o) * g.inv_h;
+      u       = std::fmin(std::fmax(u, -2048.f), 4096.f);
+      return (int) std::floor(u);
+    };
+    g.nx = nvalid > 0 ? ccoord(mx[0], g.ox) + 1 : 1;
+    g.ny = nvalid > 0 ? ccoord(mx[1], g.oy) + 1 : 1;
+    g.nz = (nvalid > 0 && dim == 3) ? ccoord(mx[2], g.oz) + 1 : 1;
+  };
+  float h = fit_cell(s->cfg.finder_cell_size > 0.f ? s->cfg.finder_cell_size : gate * 0.25f);
+  if (!(s->cfg.finder_cell_size > 0.f) && nvalid > 0) {
+    // Automatic cell size: probe the density with a histogram at gate/4 and rescale so that an occupied cell holds
+    // ~4 points on average (surface-like scaling: occupancy ~ h^2).  Too small a cell leaves many lanes unsettled
+    // after the 3^DIM block (sparser regions), too large a cell inflates the candidate lists; measured optimum on
+    // C2/C4 at 0.075-0.09 m for gate 0.25 m (profiles/r1c notes).  Any h gives the same exact results.
+    GridDev probe{};
+    grid_dims(h, probe);
+    const int pcell = probe.nx * probe.ny * probe.nz;
+    if ((rc = s->cell_start.reserve((size_t) pcell + 1))) return rc;
+    HIP_TRY(hipMemsetAsync(s->cell_start.p, 0, ((size_t) pcell + 1) * sizeof(int), a->stream));
+    HIP_TRY(hipMemsetAsync(s->scalars.p + 9, 0, sizeof(unsigned), a->stream));
+    srrg2amd::launch_grid_count(probe, s->fixed_raw.p, n, s->cell_start.p, a->stream);
+    srrg2amd::launch_count_nonzero(s->cell_start.p, pcell, (int*) (s->scalars.p + 9), a->stream);
+    unsigned nocc = 0;
+    HIP_TRY(hipMemcpyAsync(&nocc, s->scalars.p + 9, sizeof(unsigned), hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    if (nocc > 0) {
+      const float occupancy = (float) nvalid / (float) nocc;
+      float scale           = std::sqrt(4.0f / occupancy);
+      scale                 = std::fmin(std::fmax(scale, 0.5f), 4.0f);
+      h                     = fit_cell(std::fmin(h * scale, gate));
+    }
   }
   GridDev& g = s->grid;
-  g.ox = mn[0]; g.oy = mn[1]; g.oz = dim == 3 ? mn[2] : 0.f;
-  g.h     = h;
-  g.inv_h = 1.0f / h;
-  auto ccoord = [&](float x, float o) {
-    float u = (x - o) * g.inv_h;
-    u       = std::fmin(std::fmax(u, -2048.f), 4096.f);
-    return (int) std::floor(u);
-  };
-  g.nx = nvalid > 0 ? ccoord(mx[0], g.ox) + 1 : 1;
-  g.ny = nvalid > 0 ? ccoord(mx[1], g.oy) + 1 : 1;
-  g.nz = (nvalid > 0 && dim == 3) ? ccoord(mx[2], g.oz) + 1 : 1;
+  grid_dims(h, g);
   g.gate2 = gate * gate;
   int r   = 1;
   while (bound2_of_host(r, h) < g.gate2 && r < 4096) ++r;

@@ -129,6 +129,15 @@ __global__ void k_grid_count(GridDev g, const float4* __restrict__ pts, int n, i
   atomicAdd(&counts[grid_cell_of(g, p)], 1);
 }
 
+// number of non-empty cells (density probe for the automatic cell size)
+__global__ void k_count_nonzero(const int* __restrict__ counts, int n, int* __restrict__ out) {
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += counts[i] != 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 // exclusive scan, 3 kernels: per-block scan of SCAN_TILE elements, scan of block sums, add back
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8
@@ -327,73 +336,54 @@ __device__ __forceinline__ long long to_fixed(double v) {
   return __double_as_longlong(v + MAGIC) - __double_as_longlong(MAGIC);
 }
 
+// One candidate: squared distance in the specified float32 operation order, then ONE 64-bit unsigned compare of the
+// key (d2 bits << 32 | fixed index) -- d2 >= 0, so the bit pattern orders like the value and the low word breaks ties
+// towards the smaller index.  Written with selects only: the branchy form compiles to exec-mask juggling and dozens of
+// register moves per candidate.
 template <int DIM>
-__device__ __forceinline__ void test_candidate(const float4 f, float qx, float qy, float qz, int j, float& best,
-                                               int& bidx, int& bpos) {
-  float dx = f.x - qx, dy = f.y - qy;
-  float d2 = dx * dx + dy * dy;
+__device__ __forceinline__ void test_candidate(const float4 f, float qx, float qy, float qz, int j, bool valid,
+                                               unsigned long long& bkey, int& bpos) {
+  const float dx = f.x - qx, dy = f.y - qy;
+  float d2       = dx * dx + dy * dy;
   if (DIM == 3) {
-    float dz = f.z - qz;
-    d2       = d2 + dz * dz;
+    const float dz = f.z - qz;
+    d2             = d2 + dz * dz;
   }
-  const int idx = __float_as_int(f.w);
-  if (d2 < best || (d2 == best && idx < bidx)) {
-    best = d2;
-    bidx = idx;
-    bpos = j;
-  }
+  const unsigned long long key = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned) __float_as_int(f.w);
+  const bool better            = valid && key < bkey;
+  bkey                         = better ? key : bkey;
+  bpos                         = better ? j : bpos;
 }
 
+#define NO_KEY ((0x7f800000ull << 32) | (unsigned long long) NO_MATCH)  // (+inf, NO_MATCH)
+__device__ __forceinline__ unsigned long long make_key(float best, int bidx) {
+  return ((unsigned long long) __float_as_uint(best) << 32) | (unsigned) bidx;
+}
+__device__ __forceinline__ float key_best(unsigned long long k) { return __uint_as_float((unsigned) (k >> 32)); }
+__device__ __forceinline__ int key_idx(unsigned long long k) { return (int) (unsigned) k; }
+
 // scan the contiguous candidates [j, e) with four independent 16-byte loads in flight.  Reads up to 3 entries
-// past e (never tested): the sorted arrays are allocated with >= 4 entries of slack.
+// past e (masked out): the sorted arrays are allocated with >= 4 entries of slack.
 template <int DIM>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int j, int e, float qx, float qy, float qz,
-                                           float& best, int& bidx, int& bpos) {
+                                           unsigned long long& bkey, int& bpos) {
   for (; j < e; j += 4) {
     const float4 f0 = pts[j];
     const float4 f1 = pts[j + 1];
     const float4 f2 = pts[j + 2];
     const float4 f3 = pts[j + 3];
-    test_candidate<DIM>(f0, qx, qy, qz, j, best, bidx, bpos);
-    if (j + 1 < e) test_candidate<DIM>(f1, qx, qy, qz, j + 1, best, bidx, bpos);
-    if (j + 2 < e) test_candidate<DIM>(f2, qx, qy, qz, j + 2, best, bidx, bpos);
-    if (j + 3 < e) test_candidate<DIM>(f3, qx, qy, qz, j + 3, best, bidx, bpos);
+    test_candidate<DIM>(f0, qx, qy, qz, j, true, bkey, bpos);
+    test_candidate<DIM>(f1, qx, qy, qz, j + 1, j + 1 < e, bkey, bpos);
+    test_candidate<DIM>(f2, qx, qy, qz, j + 2, j + 2 < e, bkey, bpos);
+    test_candidate<DIM>(f3, qx, qy, qz, j + 3, j + 3 < e, bkey, bpos);
   }
-}
-
-// generic cube scan of radius r (unused fallback)
-// (arguments by value: a reference to the kernel-argument struct would force it into scratch memory)
-template <int DIM>
-__device__ __noinline__ int scan_cube(const int* __restrict__ cell_start, const float4* __restrict__ pts, int nx,
-                                       int ny, int nz, float qx, float qy, float qz, int cx, int cy, int cz, int r,
-                                       float best_in, int bidx_in, int bpos_in, float* best_out, int* bidx_out) {
-  float best = best_in;
-  int bidx = bidx_in, bpos = bpos_in;
-  int z0 = DIM == 3 ? max(cz - r, 0) : 0, z1 = DIM == 3 ? min(cz + r, nz - 1) : 0;
-  int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
-  int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
-  if (x0 > x1) {
-    *best_out = best;
-    *bidx_out = bidx;
-    return bpos;
-  }
-  for (int z = z0; z <= z1; ++z) {
-    for (int y = y0; y <= y1; ++y) {
-      int row = (z * ny + y) * nx;
-      int s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-      for (int j = s; j < e; ++j) test_candidate<DIM>(pts[j], qx, qy, qz, j, best, bidx, bpos);
-    }
-  }
-  *best_out = best;
-  *bidx_out = bidx;
-  return bpos;
 }
 
 // first search phase: the 3^DIM cells around the query.  All row ranges are fetched up front
 // (independent loads), then the candidates of each row are streamed two at a time.
 template <int DIM>
 __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             float& best, int& bidx, int& bpos) {
+                                             unsigned long long& bkey, int& bpos) {
   constexpr int NROWS = DIM == 3 ? 9 : 3;
   const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
   if (x0 > x1) return;
@@ -409,7 +399,7 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
   }
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
-    scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, best, bidx, bpos);
+    scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, bpos);
   }
 }
 
@@ -418,7 +408,7 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
 // minimum is idempotent).
 template <int DIM>
 __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             float& best, int& bidx, int& bpos) {
+                                             unsigned long long& bkey, int& bpos) {
   const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.nx - 1);
   if (x0 > x1) return;
   const int zlo = DIM == 3 ? cz - 2 : 0, zhi = DIM == 3 ? cz + 2 : 0;
@@ -435,7 +425,7 @@ __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float q
     }
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-      scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, best, bidx, bpos);
+      scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, bpos);
     }
   }
 }
@@ -628,8 +618,8 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
   const int z0 = DIM == 3 ? max(scz - sr, 0) : 0, z1 = DIM == 3 ? min(scz + sr, g.nz - 1) : 0;
   const int y0 = max(scy - sr, 0), y1 = min(scy + sr, g.ny - 1);
   const int x0 = max(scx - sr, 0), x1 = min(scx + sr, g.nx - 1);
-  float lbest = INFINITY;
-  int lidx = NO_MATCH, lpos = 0;
+  unsigned long long key = NO_KEY;
+  int lpos               = 0;
   const bool any = sr >= 0 && x0 <= x1 && y0 <= y1 && z0 <= z1;
   const int ny_r = any ? y1 - y0 + 1 : 1;
   const int rows = any ? ny_r * (z1 - z0 + 1) : 0;
@@ -692,15 +682,14 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
         }
         const int j   = first[r] + (t - flat[r]);
         const int run = min(next, tend) - t;  // candidates of this row in my share: consecutive in memory
-        scan_range<DIM>(g.pts, j, j + run, sqx, sqy, sqz, lbest, lidx, lpos);
+        scan_range<DIM>(g.pts, j, j + run, sqx, sqy, sqz, key, lpos);
         t += run;
       }
     }
     wave_lds_sync();
   }
   // team minimum of the 64-bit key (d2 bits, index): d2 >= 0 so the float bit pattern orders like the value
-  const unsigned long long key = ((unsigned long long) __float_as_uint(lbest) << 32) | (unsigned) lidx;
-  unsigned long long kmin      = key;
+  unsigned long long kmin = key;
 #pragma unroll
   for (int off = TW / 2; off >= 1; off >>= 1) {
     const unsigned long long o = __shfl_xor(kmin, off);
@@ -860,7 +849,10 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     cx = cell_coord(qx, g.ox, g.inv_h);
     cy = cell_coord(qy, g.oy, g.inv_h);
     cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
-    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
+    unsigned long long bkey = NO_KEY;
+    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, bkey, bpos);
+    best = key_best(bkey);
+    bidx = key_idx(bkey);
     const bool found1 = bidx != NO_MATCH && best <= g.gate2;
     if (!(found1 && best <= b2_1) && g.rmax > 1) {
       r2 = g.rmax;
@@ -911,7 +903,10 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   } else {
     // radius-2 cube per lane, then the cooperative scan for what is still open
     if (r2 > 1 && g.rmax >= 2 && !(S.tune & 2)) {
-      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, best, bidx, bpos);
+      unsigned long long bkey = make_key(best, bidx);
+      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, bkey, bpos);
+      best = key_best(bkey);
+      bidx = key_idx(bkey);
       const bool found2 = bidx != NO_MATCH && best <= g.gate2;
       if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
         r2 = 0;
@@ -1605,6 +1600,13 @@ void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nval
 void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, n, counts);
+}
+
+void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s) {
+  if (n <= 0) return;
+  int nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_count_nonzero, dim3(nb), dim3(256), 0, s, counts, n, out);
 }
 
 int scan_num_blocks(int n) {
