@@ -452,8 +452,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // deferred-search queue: a win in the latency regime (few alignments per launch: C2 0.78 -> 0.63 ms); with many
     // alignments per launch the in-kernel path has more throughput (C4: 2.46 vs 2.74 ms per 32 x 50k batch)
     const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0 && K <= 4;
-    const int qslots     = use_queue ? 8 : 0;
-    const int nblocks    = std::max(srrg2amd::icp_step_blocks(nm_max_s), 1) + qslots;
+    const int qslots     = 0;
+    const int nblocks    = PARTIAL_SLOTS;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
     if (use_queue) {
       if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 8))) return rc;  // QEntry = 8 x 4 bytes
@@ -462,8 +462,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     sc.qcount = use_queue ? s->qcount.p : nullptr;
     sc.qslots = qslots;
-    if (nm_max_s == 0 || use_queue)  // empty cloud: nothing writes the partials; queue slots start at zero
-      HIP_TRY(hipMemsetAsync(s->partials.p, 0, (size_t) K * nblocks * ACC_N * sizeof(long long), a->stream));
+    // slot sets start at zero; afterwards the control kernel resets them each iteration
+    HIP_TRY(hipMemsetAsync(s->partials.p, 0, (size_t) K * nblocks * ACC_N * sizeof(long long), a->stream));
     sc.partials  = s->partials.p;
     sc.nblocks   = nblocks;
     sc.pinf_bits = s->pinf.p;

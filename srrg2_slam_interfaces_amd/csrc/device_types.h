@@ -5,7 +5,8 @@
 
 #include "../../include/srrg2_slam_amd.h"
 
-#define ACC_N 32          // int64 accumulators per (problem, slice, iteration slot)
+#define ACC_N 32          // int64 accumulators per (problem, slice)
+#define PARTIAL_SLOTS 32  // slot sets per problem that the step kernels add into (atomics), summed by the control kernel
 #define ACC_B 21          // b starts after the 21 upper-triangular entries of H
 #define ACC_CHI_IN 27
 #define ACC_CHI_OUT 28

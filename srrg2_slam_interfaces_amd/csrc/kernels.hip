@@ -544,11 +544,14 @@ __device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], 
   return kernelized ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
 }
 
-// block reduction: transposing butterfly per wave, 4 waves through LDS, then ONE plain 256-byte store of the
-// block's partial sums.  (Device-scope atomics on 32 shared addresses serialise at ~10 ns each: 391 blocks x 32
-// atomics cost ~90 us at C2 -- profiles/r1a; the control kernel sums the partials instead.)
+// block reduction: transposing butterfly per wave, 4 waves through LDS, then the block adds its 32 totals into one of
+// PARTIAL_SLOTS slot sets of its problem with 64-bit atomics.  Integer addition is exact, so the order of the atomic
+// adds cannot change a bit; spreading the blocks over 32 slot sets keeps same-address contention (~10 ns per atomic)
+// at <= ceil(blocks/32) per address, and the control kernel has 32 x 32 values to sum instead of blocks x 32.
+// (History: one atomic target per entry serialised 391 blocks -> ~90 us; plain per-block partials made the control
+// kernel read 100 KB -> ~10 us.  profiles/r1a, r1b.)
 __device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long long* __restrict__ partials, int prob,
-                                                   int total_blocks, int block) {
+                                                   int block) {
   __shared__ long long red[4][ACC_N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int my_index;
@@ -556,8 +559,11 @@ __device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long
   if ((lane & 1) == 0) red[wid][my_index] = total;
   __syncthreads();
   if (threadIdx.x < ACC_N) {
-    long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    partials[((size_t) prob * total_blocks + block) * ACC_N + threadIdx.x] = v;
+    const long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (v != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(partials) +
+                  ((size_t) prob * PARTIAL_SLOTS + (block & (PARTIAL_SLOTS - 1))) * ACC_N + threadIdx.x,
+                (unsigned long long) v);
   }
 }
 
@@ -935,16 +941,15 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     }
   }
   if (!deferred) finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, acc);
-  block_reduce_store(acc, S.partials, prob, S.partial_blocks, blockIdx.x);
+  block_reduce_store(acc, S.partials, prob, blockIdx.x);
 }
 
 // Deferred searches: every wave takes queue entries w, w + W, ... of its problem, runs the cooperative exact scan
 // for each (64 lanes per query), parks the result in the lane with that ordinal and, after at most 64 of them,
-// finishes all parked points in SIMT.  The partial sums go to blocks [first_block, first_block + gridDim.x).
+// finishes all parked points in SIMT.
 template <int DIM, bool PLANE>
 __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                        ProblemState* __restrict__ states, int first_block,
-                                                        int total_blocks) {
+                                                        ProblemState* __restrict__ states) {
   const int prob   = blockIdx.y;
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
@@ -1053,16 +1058,13 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
     if (++parked == 64) flush();
   }
   if (parked > 0) flush();
-  // exact integer sums are order independent, so the blocks of this kernel may add into a few shared partial slots
-  // behind the step kernel's blocks with atomics (the control kernel zeroes the slots after reading them)
   __syncthreads();
   if (threadIdx.x < ACC_N) {
     const long long v = (wave_acc[0][threadIdx.x] + wave_acc[1][threadIdx.x]) + (wave_acc[2][threadIdx.x] + wave_acc[3][threadIdx.x]);
-    if (v != 0) {
-      const int slot = first_block + (blockIdx.x % (total_blocks - first_block));
-      atomicAdd(reinterpret_cast<unsigned long long*>(S.partials) + ((size_t) prob * total_blocks + slot) * ACC_N + threadIdx.x,
+    if (v != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(S.partials) +
+                  ((size_t) prob * PARTIAL_SLOTS + (blockIdx.x & (PARTIAL_SLOTS - 1))) * ACC_N + threadIdx.x,
                 (unsigned long long) v);
-    }
   }
 }
 
@@ -1225,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
     S.corr_resp[oi]  = resp;
     S.corr_stat[oi]  = fstat;
   }
-  block_reduce_store(acc, S.partials, prob, S.partial_blocks, blockIdx.x);
+  block_reduce_store(acc, S.partials, prob, blockIdx.x);
 }
 
 // ============================================================================================
@@ -1505,21 +1507,16 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     if (sc.kind == SRRG2_SLICE_PRIOR) continue;
-    long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * sc.nblocks * ACC_N;
-    long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-    int b = c;
-    for (; b + 24 < sc.nblocks; b += 32) {  // four independent loads in flight
-      v0 += p[(size_t) b * ACC_N + a];
-      v1 += p[(size_t) (b + 8) * ACC_N + a];
-      v2 += p[(size_t) (b + 16) * ACC_N + a];
-      v3 += p[(size_t) (b + 24) * ACC_N + a];
-    }
-    for (; b < sc.nblocks; b += 8) v0 += p[(size_t) b * ACC_N + a];
-    part[c][a] = (v0 + v1) + (v2 + v3);
+    long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+    long long v  = 0;
+#pragma unroll
+    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) v += p[(size_t) (c + 8 * q) * ACC_N + a];
+    part[c][a] = v;
     __syncthreads();
-    // the deferred-search kernel accumulates into the last `qslots` partial slots with atomics: reset them
+    // the slot sets are accumulated with atomics by the step kernels: reset them for the next iteration
     // (after the barrier: every thread of the block has finished reading)
-    for (int q = sc.nblocks - sc.qslots + c; q < sc.nblocks; q += 8) p[(size_t) q * ACC_N + a] = 0;
+#pragma unroll
+    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) p[(size_t) (c + 8 * q) * ACC_N + a] = 0;
     if (threadIdx.x < ACC_N) {
       long long t = 0;
 #pragma unroll
@@ -1673,14 +1670,14 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
     dim3 qgrid(qb, K);
     if (dim == 3) {
       if (plane)
-        hipLaunchKernelGGL((k_icp_step_queue<3, true>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+        hipLaunchKernelGGL((k_icp_step_queue<3, true>), qgrid, dim3(256), 0, s, S, probs, states);
       else
-        hipLaunchKernelGGL((k_icp_step_queue<3, false>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+        hipLaunchKernelGGL((k_icp_step_queue<3, false>), qgrid, dim3(256), 0, s, S, probs, states);
     } else {
       if (plane)
-        hipLaunchKernelGGL((k_icp_step_queue<2, true>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+        hipLaunchKernelGGL((k_icp_step_queue<2, true>), qgrid, dim3(256), 0, s, S, probs, states);
       else
-        hipLaunchKernelGGL((k_icp_step_queue<2, false>), qgrid, dim3(256), 0, s, S, probs, states, bx, S.partial_blocks);
+        hipLaunchKernelGGL((k_icp_step_queue<2, false>), qgrid, dim3(256), 0, s, S, probs, states);
     }
   }
 }
