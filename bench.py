@@ -202,16 +202,17 @@ def main():
                          "640x480 depth pair, %d iterations per compute()" % args.iterations) if args.workload == "c3" else
                         ("C4-shard: %d x %d-pt SE(3) point-to-plane alignments per GPU per step, %d iterations" %
                          (args.batch, args.batch_points, args.iterations)),
-            "points": args.points if args.workload == "c2" else args.batch_points,
+            "points": args.points if args.workload == "c2" else (int(data["moving"].shape[0]) if args.workload == "c3" else args.batch_points),
             "iterations_per_step": args.iterations,
-            "alignments_per_step_per_gpu": 1 if args.workload == "c2" else args.batch,
+            "alignments_per_step_per_gpu": args.batch if args.workload == "c4" else 1,
             "last_status": status,
             "last_num_inliers": stats[-1]["num_inliers"] if stats else None,
             "parallelism": "1 alignment stream per GPU, results all-gathered" if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_icp_step<3,true>" if args.workload != "c3" else "k_icp_step_proj (both slices)",
+            "kernel": ("k_icp_step<3,true> + k_icp_step_queue<3,true> (one finder+factor pass of the slice)" if args.workload == "c2" else
+                       "k_icp_step<3,true>" if args.workload == "c4" else "k_proj_zbuf + k_icp_step_proj (per slice)"),
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",
