@@ -54,6 +54,7 @@ struct Slice {
   bool moving_has_normals = false;
   // outputs
   DevBuf<int> corr_fixed;
+  DevBuf<int> prev_pos;             // previous nearest neighbour per moving point (search bound of the next iteration)
   DevBuf<float> corr_resp;
   DevBuf<uint8_t> corr_stat;
   DevBuf<long long> partials;
@@ -69,7 +70,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
+    corr_fixed.release(); prev_pos.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
   }
 };
 
@@ -258,6 +259,7 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   GridDev& g = s->grid;
   grid_dims(h, g);
   g.gate2 = gate * gate;
+  g.n     = n;
   int r   = 1;
   while (bound2_of_host(r, h) < g.gate2 && r < 4096) ++r;
   g.rmax          = r;
@@ -296,6 +298,7 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   if (normals && (rc = s->moving_nrm.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->pinf.reserve((size_t) K))) return rc;
   if ((rc = s->corr_fixed.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->prev_pos.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->corr_resp.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->corr_stat.reserve((size_t) std::max(n, 1)))) return rc;
   const size_t bytes_c = (size_t) n * a->dim * 4;
@@ -475,6 +478,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.corr_fixed      = s->corr_fixed.p;
     d.corr_resp       = s->corr_resp.p;
     d.corr_stat       = s->corr_stat.p;
+    d.prev_pos        = s->prev_pos.p;
     d.partials        = s->partials.p;
     d.partial_blocks  = nblocks;
     d.queue           = use_queue ? (void*) s->queue.p : nullptr;

@@ -30,6 +30,7 @@ struct GridDev {
   int nx, ny, nz;
   int rmax;        // cube radius that covers the gate
   float gate2;     // max_distance^2
+  int n;           // number of fixed points (entries of pts)
   const int* cell_start;  // ncell + 1
   const float4* pts;
   const float4* nrm;      // sorted like pts (w unused); null when the cloud has no normals
@@ -43,6 +44,8 @@ struct SliceDev {
   int* corr_fixed;      // per moving point: matched fixed index or -1
   float* corr_resp;     // per moving point: response (squared distance)
   uint8_t* corr_stat;   // per moving point: srrg2_factor_status of the last linearisation
+  int* prev_pos;        // per moving point (sorted order): position in grid.pts of the nearest neighbour found by the
+                        // previous iteration of this compute() (-1: none); an upper bound for the next search
   long long* partials;  // [problem][partial_blocks][ACC_N]: per-block fixed-point partial sums (no atomics)
   int partial_blocks;   // blocks per problem writing partials (step kernel + deferred-search kernel)
   void* queue;          // deferred searches: QEntry[total moving points] (per problem at its moving offset), or null

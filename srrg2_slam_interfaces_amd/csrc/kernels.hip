@@ -379,20 +379,38 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int j
   }
 }
 
-// first search phase: the 3^DIM cells around the query.  All row ranges are fetched up front
-// (independent loads), then the candidates of each row are streamed two at a time.
+// Cells that can hold a fixed point f with d2(f, q) <= r2 (d2 as computed by test_candidate), per axis:
+// [cell(q - s), cell(q + s)] with s = r inflated by 1e-5 relative + 4.8e-7 of the coordinate magnitude.  The cell of a
+// point is a monotone function of its coordinate (fl(x - o), fl(. * inv_h), floor: all monotone), and the float32
+// roundings of d2 and of q -+ s are far inside the inflation, so the range is conservative: trimming a scan to it
+// can never drop the exact nearest neighbour.  r2 = +inf gives the unbounded range.
+__device__ __forceinline__ float ball_radius(float r2) { return sqrtf(r2) * 1.00001f; }
+__device__ __forceinline__ void axis_range(float q, float rr, float o, float inv_h, int clo, int chi, int n, int& lo,
+                                           int& hi) {
+  const float s = rr + (fabsf(q) + rr) * 4.8e-7f;
+  lo            = max(max(cell_coord(q - s, o, inv_h), clo), 0);
+  hi            = min(min(cell_coord(q + s, o, inv_h), chi), n - 1);
+}
+
+// first search phase: the 3^DIM cells around the query, trimmed to the ball of squared radius r2box (an upper bound
+// of the nearest-neighbour distance known beforehand, +inf if none).  All row ranges are fetched up front
+// (independent loads), then the candidates of each row are streamed four at a time.
 template <int DIM>
 __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             unsigned long long& bkey, int& bpos) {
+                                             float r2box, unsigned long long& bkey, int& bpos) {
   constexpr int NROWS = DIM == 3 ? 9 : 3;
-  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+  const float rr = ball_radius(r2box);
+  int x0, x1, y0, y1, z0 = 0, z1 = 0;
+  axis_range(qx, rr, g.ox, g.inv_h, cx - 1, cx + 1, g.nx, x0, x1);
+  axis_range(qy, rr, g.oy, g.inv_h, cy - 1, cy + 1, g.ny, y0, y1);
+  if (DIM == 3) axis_range(qz, rr, g.oz, g.inv_h, cz - 1, cz + 1, g.nz, z0, z1);
   if (x0 > x1) return;
   int rs[NROWS], re[NROWS];
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
     const int y = cy + (r % 3) - 1;
     const int z = DIM == 3 ? cz + (r / 3) - 1 : 0;
-    const bool ok = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+    const bool ok = y >= y0 && y <= y1 && z >= z0 && z <= z1;
     const int row = ok ? (z * g.ny + y) * g.nx : 0;
     rs[r] = ok ? g.cell_start[row + x0] : 0;
     re[r] = ok ? g.cell_start[row + x1 + 1] : 0;
@@ -403,22 +421,24 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
   }
 }
 
-// radius-2 cube, one z-layer (5 rows) at a time: the 10 range fetches of a layer are independent, so a lane
-// pays one fetch latency per layer instead of one per row.  Re-visits the radius-1 block (harmless: the
-// minimum is idempotent).
+// radius-2 cube (trimmed to the ball of the best candidate so far), one z-layer (5 rows) at a time: the 10 range
+// fetches of a layer are independent, so a lane pays one fetch latency per layer instead of one per row.  Re-visits
+// the radius-1 block (harmless: the minimum is idempotent).
 template <int DIM>
 __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             unsigned long long& bkey, int& bpos) {
-  const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.nx - 1);
+                                             float r2box, unsigned long long& bkey, int& bpos) {
+  const float rr = ball_radius(r2box);
+  int x0, x1, y0, y1, z0 = 0, z1 = 0;
+  axis_range(qx, rr, g.ox, g.inv_h, cx - 2, cx + 2, g.nx, x0, x1);
+  axis_range(qy, rr, g.oy, g.inv_h, cy - 2, cy + 2, g.ny, y0, y1);
+  if (DIM == 3) axis_range(qz, rr, g.oz, g.inv_h, cz - 2, cz + 2, g.nz, z0, z1);
   if (x0 > x1) return;
-  const int zlo = DIM == 3 ? cz - 2 : 0, zhi = DIM == 3 ? cz + 2 : 0;
-  for (int z = zlo; z <= zhi; ++z) {
-    if (z < 0 || z >= g.nz) continue;
+  for (int z = z0; z <= z1; ++z) {
     int rs[5], re[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       const int y   = cy + r - 2;
-      const bool ok = y >= 0 && y < g.ny;
+      const bool ok = y >= y0 && y <= y1;
       const int row = ok ? (z * g.ny + y) * g.nx : 0;
       rs[r] = ok ? g.cell_start[row + x0] : 0;
       re[r] = ok ? g.cell_start[row + x1 + 1] : 0;
@@ -615,15 +635,45 @@ __device__ __forceinline__ void transform_point(const float* T, const float4 p, 
 // returns the same (best, idx, pos); idx == NO_MATCH when the cube is empty.  lds: 4*TW + 8 ints per team.
 template <int DIM, int TW>
 __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_wave, float sqx, float sqy, float sqz,
-                                          int scx, int scy, int scz, int sr, float& wbest, int& widx, int& wpos) {
+                                          int scx, int scy, int scz, int sr, float sr2, float& wbest, int& widx,
+                                          int& wpos) {
   constexpr int ROWS_PER_CHUNK = 2 * TW;
   const int lt   = lane & (TW - 1);
   const int team = lane / TW;
   int* flat      = lds_wave + team * (4 * TW + 8);  // flattened candidate offset at which each row starts (+ total)
   int* first     = flat + ROWS_PER_CHUNK + 4;       // sorted-array index of each row's first candidate
-  const int z0 = DIM == 3 ? max(scz - sr, 0) : 0, z1 = DIM == 3 ? min(scz + sr, g.nz - 1) : 0;
-  const int y0 = max(scy - sr, 0), y1 = min(scy + sr, g.ny - 1);
-  const int x0 = max(scx - sr, 0), x1 = min(scx + sr, g.nx - 1);
+  // the cube of radius sr cells, trimmed to the ball of squared radius sr2 (the team's best candidate so far or the
+  // gate): first to the ball's bounding box, then row by row to the chord of the ball through that row of cells
+  const float rr = ball_radius(sr2);
+  int x0, x1, y0, y1, z0 = 0, z1 = 0;
+  axis_range(sqx, rr, g.ox, g.inv_h, scx - sr, scx + sr, g.nx, x0, x1);
+  axis_range(sqy, rr, g.oy, g.inv_h, scy - sr, scy + sr, g.ny, y0, y1);
+  if (DIM == 3) axis_range(sqz, rr, g.oz, g.inv_h, scz - sr, scz + sr, g.nz, z0, z1);
+  // distance of the query to a row of cells, shrunk by 1% of a cell + 2e-6 of the coordinate magnitude: covers the
+  // float32 rounding of the cell boundaries (a point's cell is floor(fl(fl(x - o) * inv_h)))
+  auto row_range = [&](int rrow, int ny_r, int& rs, int& re) {
+    const int y = y0 + rrow % ny_r, z = z0 + rrow / ny_r;
+    const float ylo = g.oy + (float) y * g.h;
+    float dy        = fmaxf(fmaxf(ylo - sqy, sqy - (ylo + g.h)), 0.f);
+    dy              = fmaxf(dy - (0.01f * g.h + (fabsf(sqy) + rr) * 2e-6f), 0.f);
+    float rem       = rr * rr - dy * dy;
+    if (DIM == 3) {
+      const float zlo = g.oz + (float) z * g.h;
+      float dz        = fmaxf(fmaxf(zlo - sqz, sqz - (zlo + g.h)), 0.f);
+      dz              = fmaxf(dz - (0.01f * g.h + (fabsf(sqz) + rr) * 2e-6f), 0.f);
+      rem             = rem - dz * dz;
+    }
+    rs = re = 0;
+    if (!(rem < 0.f)) {  // (+inf radius: rem = +inf or NaN -> full row)
+      int xa = x0, xb = x1;
+      if (rem < 3.0e38f) axis_range(sqx, ball_radius(rem), g.ox, g.inv_h, x0, x1, g.nx, xa, xb);
+      if (xa <= xb) {
+        const int row = (z * g.ny + y) * g.nx;
+        rs = g.cell_start[row + xa];
+        re = g.cell_start[row + xb + 1];
+      }
+    }
+  };
   unsigned long long key = NO_KEY;
   int lpos               = 0;
   const bool any = sr >= 0 && x0 <= x1 && y0 <= y1 && z0 <= z1;
@@ -639,16 +689,8 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
     // (1) every lane fetches the [start, end) ranges of two rows: all row fetches of the chunk in flight at once
     int sA = 0, eA = 0, sB = 0, eB = 0;
     const int rA = row0 + lt, rB = row0 + TW + lt;
-    if (rA < rows) {
-      const int row = ((z0 + rA / ny_r) * g.ny + (y0 + rA % ny_r)) * g.nx;
-      sA = g.cell_start[row + x0];
-      eA = g.cell_start[row + x1 + 1];
-    }
-    if (rB < rows) {
-      const int row = ((z0 + rB / ny_r) * g.ny + (y0 + rB % ny_r)) * g.nx;
-      sB = g.cell_start[row + x0];
-      eB = g.cell_start[row + x1 + 1];
-    }
+    if (rA < rows) row_range(rA, ny_r, sA, eA);
+    if (rB < rows) row_range(rB, ny_r, sB, eB);
     // (2) team prefix sum of both counts at once (packed in 64 bits)
     const unsigned long long pk = (unsigned long long) (unsigned) (eA - sA) | ((unsigned long long) (unsigned) (eB - sB) << 32);
     unsigned long long inc = pk;
@@ -801,6 +843,7 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
         fstat = factor_accumulate<D, ROWS>(J, e, false, rk, thr, scale, (S.tune & 64) != 0, acc);
       }
     }
+    S.prev_pos[gi]   = (active && bidx != NO_MATCH) ? bpos : -1;
     S.corr_fixed[oi] = match;
     S.corr_resp[oi]  = resp;
     S.corr_stat[oi]  = fstat;
@@ -829,6 +872,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
   const GridDev& g   = S.grid;
   const float b2_1   = bound2_of(1, g.h);
+  const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
 
   long long acc[ACC_N];
 #pragma unroll
@@ -856,7 +900,18 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     cy = cell_coord(qy, g.oy, g.inv_h);
     cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
     unsigned long long bkey = NO_KEY;
-    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, bkey, bpos);
+    // Temporal coherence: the nearest neighbour found by the previous iteration of this compute() is a candidate
+    // like any other, and its distance bounds the search ball; the result is the same exact minimum of
+    // (d2, fixed index), reached through fewer cells.  Any fixed point would be a valid bound.
+    float r2box = INFINITY;
+    if (use_prior) {
+      const int ppos = S.prev_pos[gi];
+      if (ppos >= 0 && ppos < g.n) {
+        test_candidate<DIM>(g.pts[ppos], qx, qy, qz, ppos, true, bkey, bpos);
+        r2box = fminf(key_best(bkey), g.gate2);
+      }
+    }
+    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos);
     best = key_best(bkey);
     bidx = key_idx(bkey);
     const bool found1 = bidx != NO_MATCH && best <= g.gate2;
@@ -910,7 +965,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     // radius-2 cube per lane, then the cooperative scan for what is still open
     if (r2 > 1 && g.rmax >= 2 && !(S.tune & 2)) {
       unsigned long long bkey = make_key(best, bidx);
-      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, bkey, bpos);
+      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, fminf(best, g.gate2), bkey, bpos);
       best = key_best(bkey);
       bidx = key_idx(bkey);
       const bool found2 = bidx != NO_MATCH && best <= g.gate2;
@@ -932,7 +987,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       float wbest;
       int widx, wpos;
       coop_scan<DIM, 64>(g, lane, coop_lds[wid], __shfl(qx, src), __shfl(qy, src), __shfl(qz, src), __shfl(cx, src),
-                     __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), wbest, widx, wpos);
+                     __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), fminf(__shfl(best, src), g.gate2), wbest, widx, wpos);
       if (lane == src && (wbest < best || (wbest == best && widx < bidx))) {
         best = wbest;
         bidx = widx;
@@ -1011,7 +1066,8 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
       const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
       float wbest;
       int widx, wpos;
-      coop_scan<DIM, TW>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, (live && !skip) ? q.r2 : -1, wbest, widx, wpos);
+      coop_scan<DIM, TW>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, (live && !skip) ? q.r2 : -1, fminf(q.best, g.gate2), wbest,
+                         widx, wpos);
       if (wbest < q.best || (wbest == q.best && widx < q.bidx)) {
         q.best = wbest;
         q.bidx = widx;
@@ -1042,7 +1098,8 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
     const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
     float wbest;
     int widx, wpos;
-    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : q.r2, wbest, widx, wpos);
+    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : q.r2, fminf(q.best, g.gate2), wbest, widx,
+                       wpos);
     if (lane == parked) {
       have    = true;
       my_i    = q.i;

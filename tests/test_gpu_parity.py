@@ -202,3 +202,29 @@ def test_c3_full_resolution(oracle, product):
     assert_same_run(a_ref, a_gpu)
     assert np.max(np.abs(a_gpu.moving_in_fixed() - d["X_gt"])) < 2e-4
     assert a_gpu.iteration_stats()[-1]["num_correspondences"] > 250000
+
+
+@pytest.mark.parametrize("offset", [0.0, 900.0, -7000.0])
+@pytest.mark.parametrize("cell", [0.0, 0.05, 0.4])
+def test_ball_trimmed_search_is_exact(oracle, product, offset, cell):
+    """The finder trims its scans to the ball of the best candidate known so far (previous iteration's neighbour,
+    first-phase candidate).  Large coordinate offsets (coarse float32 spacing), cells much smaller / larger than the
+    gate and a mixed-density cloud stress the conservative margins: the result must stay the exact (d2, index) minimum."""
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=12000, seed=2500, t=(0.12, -0.08, 0.05), rpy_deg=(2.0, -2.5, 3.0))
+    d = {k: v.copy() for k, v in d.items()}
+    d["fixed"] = np.ascontiguousarray(d["fixed"][::1])
+    # thin out half of the fixed cloud: neighbours at several cell radii
+    keep = np.ones(len(d["fixed"]), bool)
+    keep[: len(keep) // 2][1::2] = False
+    keep[: len(keep) // 4][::3] = False
+    d["fixed"], d["fixed_normals"] = d["fixed"][keep], d["fixed_normals"][keep]
+    # both clouds far from the origin: same relative geometry, coarse float32 spacing (4.9e-4 m at 7000 m)
+    d["fixed"] = d["fixed"] + np.float32(offset)
+    d["moving"] = d["moving"] + np.float32(offset)
+    guess = syn.identity(3)
+    cfg = cue_config(kind, abi.SLICE_P2P, 0.45, abi.ROBUST_CAUCHY, 0.05)
+    cfg.finder_cell_size = cell
+    a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, params=dict(max_iterations=6), guess=guess)
+    assert_same_run(a_ref, a_gpu)
+    assert a_ref.iteration_stats()[0]["num_correspondences"] > 1000
