@@ -54,6 +54,9 @@ struct Slice {
   bool moving_has_normals = false;
   // outputs
   DevBuf<int> corr_fixed;
+  DevBuf<float4> prev_f;
+  DevBuf<float> prev_m;
+  DevBuf<unsigned long long> dbg;   // SRRG2_AMD_TIMELINE (debug builds): per-wave stamps of the step kernel
   DevBuf<int> prev_pos;             // previous nearest neighbour per moving point (search bound of the next iteration)
   DevBuf<float> corr_resp;
   DevBuf<uint8_t> corr_stat;
@@ -70,7 +73,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); prev_pos.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
+    corr_fixed.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
   }
 };
 
@@ -299,6 +302,8 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   if ((rc = s->pinf.reserve((size_t) K))) return rc;
   if ((rc = s->corr_fixed.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->prev_pos.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->prev_f.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->prev_m.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->corr_resp.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->corr_stat.reserve((size_t) std::max(n, 1)))) return rc;
   const size_t bytes_c = (size_t) n * a->dim * 4;
@@ -459,7 +464,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     const int nblocks    = PARTIAL_SLOTS;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
     if (use_queue) {
-      if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 8))) return rc;  // QEntry = 8 x 4 bytes
+      if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 10))) return rc;  // QEntry = 10 x 4 bytes
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
       HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t) 2 * K * sizeof(int), a->stream));
     }
@@ -479,6 +484,15 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.corr_resp       = s->corr_resp.p;
     d.corr_stat       = s->corr_stat.p;
     d.prev_pos        = s->prev_pos.p;
+    d.prev_f          = s->prev_f.p;
+    d.prev_m          = s->prev_m.p;
+    d.dbg             = nullptr;
+    if (std::getenv("SRRG2_AMD_TIMELINE")) {
+      const size_t nw = (size_t) K * ((nm_max_s + 255) / 256) * 4;
+      if ((rc = s->dbg.reserve(32 * nw * 16))) return rc;
+      HIP_TRY(hipMemsetAsync(s->dbg.p, 0, 32 * nw * 16 * sizeof(unsigned long long), a->stream));
+      d.dbg = s->dbg.p;
+    }
     d.partials        = s->partials.p;
     d.partial_blocks  = nblocks;
     d.queue           = use_queue ? (void*) s->queue.p : nullptr;
@@ -562,6 +576,22 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   HIP_TRY(hipMemcpyAsync(a->stats_host, a->stats.p, (size_t) K * slots * sizeof(srrg2_iteration_stats),
                          hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
+  if (const char* tl_path = std::getenv("SRRG2_AMD_TIMELINE")) {  // dump of the last compute(): u64 nwaves, then stamps
+    for (int si = 0; si < nslices; ++si) {
+      Slice* s = a->slices[si];
+      if (!sdev[si].dbg) continue;
+      int nm_max = 0;
+      for (int k = 0; k < K; ++k) nm_max = std::max(nm_max, all[(size_t) si * K + k].nm);
+      const unsigned long long nw = (unsigned long long) K * ((nm_max + 255) / 256) * 4;
+      std::vector<unsigned long long> host(32 * nw * 16);
+      HIP_TRY(hipMemcpy(host.data(), s->dbg.p, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE* f = std::fopen(tl_path, "wb")) {
+        std::fwrite(&nw, sizeof(nw), 1, f);
+        std::fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+        std::fclose(f);
+      }
+    }
+  }
   if (a->profile) {
     for (size_t i = 0; i < a->prof_used; ++i) {
       float ms = 0.f;

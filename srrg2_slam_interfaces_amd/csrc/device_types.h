@@ -46,6 +46,8 @@ struct SliceDev {
   uint8_t* corr_stat;   // per moving point: srrg2_factor_status of the last linearisation
   int* prev_pos;        // per moving point (sorted order): position in grid.pts of the nearest neighbour found by the
                         // previous iteration of this compute() (-1: none); an upper bound for the next search
+  float4* prev_f;       // ... and that fixed point {x, y, z, bits(index)} (saves the dependent load)
+  float* prev_m;        // ... and its exclusion radius: no other fixed point within prev_m of the previous query
   long long* partials;  // [problem][partial_blocks][ACC_N]: per-block fixed-point partial sums (no atomics)
   int partial_blocks;   // blocks per problem writing partials (step kernel + deferred-search kernel)
   void* queue;          // deferred searches: QEntry[total moving points] (per problem at its moving offset), or null
@@ -66,6 +68,7 @@ struct SliceDev {
   const float4* fixed_org;      // rows*cols points, NaN = invalid pixel
   const float4* fixed_org_nrm;  // or null
   unsigned long long* zbuf;     // [problem][rows*cols] keys (depth bits << 32 | caller index)
+  unsigned long long* dbg;  // -DSRRG2_TIMELINE builds only: [iteration < 32][wave][16] shader-clock stamps, or null
   int tune;             // debug/tuning bit flags (env SRRG2_AMD_TUNE): 1 = skip phase 2 (WRONG results, timing only)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
 };
@@ -78,6 +81,7 @@ struct ProblemDev {
 // device-resident state of one alignment (one MultiAlignerBase_::compute())
 struct ProblemState {
   float X[12];      // moving_in_fixed; equals the `moving_in_fixed` backup of _runSolver (:102)
+  float Xprev[12];  // X of the previous iteration's finder passes (temporal coherence of the search)
   int status;       // srrg2_status
   int done;         // current _runSolver loop left (break at :110 or :125)
   int finished;     // compute() returned early (:75-78, :81-85)

@@ -355,6 +355,40 @@ __device__ __forceinline__ void test_candidate(const float4 f, float qx, float q
   bpos                         = better ? j : bpos;
 }
 
+// ... and the squared distance of the runner-up (b2 = second smallest d2 over the candidates seen): the loser of every
+// comparison is a runner-up candidate.  Used by the first search phase to leave an exclusion radius behind.
+template <int DIM>
+__device__ __forceinline__ void test_candidate2(const float4 f, float qx, float qy, float qz, int j, bool valid,
+                                                unsigned long long& bkey, int& bpos, float& b2) {
+  const float dx = f.x - qx, dy = f.y - qy;
+  float d2       = dx * dx + dy * dy;
+  if (DIM == 3) {
+    const float dz = f.z - qz;
+    d2             = d2 + dz * dz;
+  }
+  const unsigned long long key = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned) __float_as_int(f.w);
+  const bool better            = valid && key < bkey;
+  const float loser            = better ? __uint_as_float((unsigned) (bkey >> 32)) : d2;
+  b2                           = valid ? fminf(b2, loser) : b2;
+  bkey                         = better ? key : bkey;
+  bpos                         = better ? j : bpos;
+}
+
+// -DSRRG2_TIMELINE: per-wave timeline of the step kernel (tools/timeline.py); compiled out of the product build
+#ifdef SRRG2_TIMELINE
+#define STAMP(slot, k)                                                       \
+  do {                                                                       \
+    if (slot) {                                                              \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
+      if ((threadIdx.x & 63) == 0) (slot)[k] = (unsigned long long) wall_clock64(); \
+    }                                                                        \
+  } while (0)
+#else
+#define STAMP(slot, k) do { } while (0)
+#endif
+#ifndef SCAN_W0
+#define SCAN_W0 1
+#endif
 #define NO_KEY ((0x7f800000ull << 32) | (unsigned long long) NO_MATCH)  // (+inf, NO_MATCH)
 __device__ __forceinline__ unsigned long long make_key(float best, int bidx) {
   return ((unsigned long long) __float_as_uint(best) << 32) | (unsigned) bidx;
@@ -364,6 +398,21 @@ __device__ __forceinline__ int key_idx(unsigned long long k) { return (int) (uns
 
 // scan the contiguous candidates [j, e) with four independent 16-byte loads in flight.  Reads up to 3 entries
 // past e (masked out): the sorted arrays are allocated with >= 4 entries of slack.
+template <int DIM>
+__device__ __forceinline__ void scan_range2(const float4* __restrict__ pts, int j, int e, float qx, float qy, float qz,
+                                            unsigned long long& bkey, int& bpos, float& b2) {
+  for (; j < e; j += 4) {
+    const float4 f0 = pts[j];
+    const float4 f1 = pts[j + 1];
+    const float4 f2 = pts[j + 2];
+    const float4 f3 = pts[j + 3];
+    test_candidate2<DIM>(f0, qx, qy, qz, j, true, bkey, bpos, b2);
+    test_candidate2<DIM>(f1, qx, qy, qz, j + 1, j + 1 < e, bkey, bpos, b2);
+    test_candidate2<DIM>(f2, qx, qy, qz, j + 2, j + 2 < e, bkey, bpos, b2);
+    test_candidate2<DIM>(f3, qx, qy, qz, j + 3, j + 3 < e, bkey, bpos, b2);
+  }
+}
+
 template <int DIM>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int j, int e, float qx, float qy, float qz,
                                            unsigned long long& bkey, int& bpos) {
@@ -397,7 +446,8 @@ __device__ __forceinline__ void axis_range(float q, float rr, float o, float inv
 // (independent loads), then the candidates of each row are streamed four at a time.
 template <int DIM>
 __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             float r2box, unsigned long long& bkey, int& bpos) {
+                                             float r2box, unsigned long long& bkey, int& bpos, float& b2,
+                                             unsigned long long* tl = nullptr) {
   constexpr int NROWS = DIM == 3 ? 9 : 3;
   const float rr = ball_radius(r2box);
   int x0, x1, y0, y1, z0 = 0, z1 = 0;
@@ -405,19 +455,46 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
   axis_range(qy, rr, g.oy, g.inv_h, cy - 1, cy + 1, g.ny, y0, y1);
   if (DIM == 3) axis_range(qz, rr, g.oz, g.inv_h, cz - 1, cz + 1, g.nz, z0, z1);
   if (x0 > x1) return;
+  // The step kernel is bound by the rate at which a CU's texture path accepts scattered per-lane requests (one per
+  // lane per load instruction; measured with the per-wave timeline, tools/timeline.py) -- so every load below is
+  // predicated per lane: rows outside the ball and empty rows issue no request at all.
   int rs[NROWS], re[NROWS];
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
     const int y = cy + (r % 3) - 1;
     const int z = DIM == 3 ? cz + (r / 3) - 1 : 0;
-    const bool ok = y >= y0 && y <= y1 && z >= z0 && z <= z1;
-    const int row = ok ? (z * g.ny + y) * g.nx : 0;
-    rs[r] = ok ? g.cell_start[row + x0] : 0;
-    re[r] = ok ? g.cell_start[row + x1 + 1] : 0;
+    rs[r] = re[r] = 0;
+    if (y >= y0 && y <= y1 && z >= z0 && z <= z1) {
+      const int row = (z * g.ny + y) * g.nx;
+      rs[r] = g.cell_start[row + x0];
+      re[r] = g.cell_start[row + x1 + 1];
+    }
+  }
+  STAMP(tl, 2);  // row ranges arrived
+  // first W0 candidates of ALL rows in flight together (one round trip instead of one per row), then the rows
+  // that hold more
+  constexpr int W0 = SCAN_W0;
+  float4 c[NROWS][W0];
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+#pragma unroll
+    for (int k = 0; k < W0; ++k) {
+      c[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rs[r] + k < re[r]) c[r][k] = g.pts[rs[r] + k];
+    }
   }
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
-    scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, bpos);
+    if (__any(rs[r] < re[r])) {
+#pragma unroll
+      for (int k = 0; k < W0; ++k)
+        test_candidate2<DIM>(c[r][k], qx, qy, qz, rs[r] + k, rs[r] + k < re[r], bkey, bpos, b2);
+    }
+  }
+  STAMP(tl, 3);  // first W0 candidates of every row tested
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+    scan_range2<DIM>(g.pts, rs[r] + W0, re[r], qx, qy, qz, bkey, bpos, b2);
   }
 }
 
@@ -426,7 +503,7 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
 // the radius-1 block (harmless: the minimum is idempotent).
 template <int DIM>
 __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             float r2box, unsigned long long& bkey, int& bpos) {
+                                             float r2box, unsigned long long& bkey, int& bpos, float& b2) {
   const float rr = ball_radius(r2box);
   int x0, x1, y0, y1, z0 = 0, z1 = 0;
   axis_range(qx, rr, g.ox, g.inv_h, cx - 2, cx + 2, g.nx, x0, x1);
@@ -445,7 +522,7 @@ __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float q
     }
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-      scan_range<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, bpos);
+      scan_range2<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, bpos, b2);
     }
   }
 }
@@ -598,16 +675,19 @@ struct QEntry {  // a moving point whose search did not settle inside the 3^DIM 
   float best;    // best so far
   int bidx, bpos;
   float qx, qy, qz;  // the transformed point (saves the dependent reload + transform in the queue kernel)
+  float ball2;       // squared radius of the ball the scan can be trimmed to (best so far, prior bound or the gate)
+  int pad_;
 };
+static_assert(sizeof(QEntry) == 40, "host reserves 10 words per entry");
 
 template <int DIM>
-__device__ __forceinline__ void load_finder_transform(const SliceDev& S, const ProblemState* st, float* T) {
+__device__ __forceinline__ void load_finder_transform(const SliceDev& S, const float* X, float* T) {
   // finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35
   if constexpr (DIM == 3) {
-    dm::se3_compose(S.Sinv, st->X, T);
+    dm::se3_compose(S.Sinv, X, T);
   } else {
     float t9[9];
-    dm::se2_compose(S.Sinv, st->X, t9);
+    dm::se2_compose(S.Sinv, X, t9);
     // spread the 3x3 into the 3x4 slots used below: rows [r0 r1 . t]
     T[0] = t9[0]; T[1] = t9[1]; T[2] = 0.f; T[3] = t9[2];
     T[4] = t9[3]; T[5] = t9[4]; T[6] = 0.f; T[7] = t9[5];
@@ -636,7 +716,7 @@ __device__ __forceinline__ void transform_point(const float* T, const float4 p, 
 template <int DIM, int TW>
 __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_wave, float sqx, float sqy, float sqz,
                                           int scx, int scy, int scz, int sr, float sr2, float& wbest, int& widx,
-                                          int& wpos) {
+                                          int& wpos, float& wexcl2) {
   constexpr int ROWS_PER_CHUNK = 2 * TW;
   const int lt   = lane & (TW - 1);
   const int team = lane / TW;
@@ -676,6 +756,7 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
   };
   unsigned long long key = NO_KEY;
   int lpos               = 0;
+  float lb2              = INFINITY;
   const bool any = sr >= 0 && x0 <= x1 && y0 <= y1 && z0 <= z1;
   const int ny_r = any ? y1 - y0 + 1 : 1;
   const int rows = any ? ny_r * (z1 - z0 + 1) : 0;
@@ -730,7 +811,7 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
         }
         const int j   = first[r] + (t - flat[r]);
         const int run = min(next, tend) - t;  // candidates of this row in my share: consecutive in memory
-        scan_range<DIM>(g.pts, j, j + run, sqx, sqy, sqz, key, lpos);
+        scan_range2<DIM>(g.pts, j, j + run, sqx, sqy, sqz, key, lpos, lb2);
         t += run;
       }
     }
@@ -750,25 +831,34 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
   wpos  = __shfl(lpos, wl);
   wbest = __uint_as_float((unsigned) (kmin >> 32));
   widx  = (int) (unsigned) kmin;
+  // squared exclusion radius: the runner-up of the team (a lane that does not hold the winner contributes its own
+  // best), capped by the region the scan was complete in: the ball and the cube
+  float v = key == kmin ? lb2 : fminf(lb2, __uint_as_float((unsigned) (key >> 32)));
+#pragma unroll
+  for (int off = TW / 2; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  wexcl2 = fminf(v, fminf(sr2, bound2_of(max(sr, 0), g.h)));
 }
 
 // gates, normals, residual rows, factor arithmetic and the per-point outputs of ONE searched moving point
 template <int DIM, bool PLANE>
 __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, int rk, float thr, float kk, double scale,
                                              bool inrange, bool active, int gi, int oi, const float4 p, float qx, float qy,
-                                             float qz, float best, int bidx, int bpos, long long (&acc)[ACC_N]) {
+                                             float qz, float best, int bidx, int bpos, float excl,
+                                             long long (&acc)[ACC_N]) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   const GridDev& g   = S.grid;
   int match     = -1;
   float resp    = 0.f;
   uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
+  float4 fm     = make_float4(0.f, 0.f, 0.f, 0.f);  // the nearest fixed point {x, y, z, index}
   if (inrange) {
     if (active) {
       bool found = bidx != NO_MATCH && best <= g.gate2;
       if (S.tune & 8) found = false;
       float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
       if (found && (PLANE || S.use_normal_gate)) nf = (S.tune & 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[bpos];
+      if (bidx != NO_MATCH) fm = g.pts[bpos];  // (with nf: one round trip, not one after the normal gate)
       if (found && S.use_normal_gate) {
         const float4 nm = (S.tune & 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : S.mnrm[gi];
         float dot;
@@ -787,7 +877,7 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       if (found) {
         match          = bidx;
         resp           = best;
-        const float4 f = g.pts[bpos];
+        const float4 f = fm;
         float J[ROWS][D];
         float e[ROWS];
         if constexpr (DIM == 3) {
@@ -844,6 +934,8 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       }
     }
     S.prev_pos[gi]   = (active && bidx != NO_MATCH) ? bpos : -1;
+    S.prev_f[gi]     = fm;
+    S.prev_m[gi]     = excl;
     S.corr_fixed[oi] = match;
     S.corr_resp[oi]  = resp;
     S.corr_stat[oi]  = fstat;
@@ -864,7 +956,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   float T[12];
-  load_finder_transform<DIM>(S, st, T);
+  load_finder_transform<DIM>(S, st->X, T);
   const int kexp     = st->kexp[S.slice_idx];
   const double scale = dm::pow2(kexp);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
@@ -873,10 +965,20 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   const GridDev& g   = S.grid;
   const float b2_1   = bound2_of(1, g.h);
   const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
+  float Tprev[12];  // the finder transform of the previous iteration (its queries: q' = Tprev * p)
+  load_finder_transform<DIM>(S, st->Xprev, Tprev);
 
   long long acc[ACC_N];
 #pragma unroll
   for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+#ifdef SRRG2_TIMELINE
+  unsigned long long* tl = (S.dbg && st->nstats < 32 && st->phase == 0)
+                             ? S.dbg + (((size_t) st->nstats * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)) * 16
+                             : nullptr;
+#else
+  unsigned long long* tl = nullptr;
+#endif
+  STAMP(tl, 0);  // state + transform loaded
 
   const int i        = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane     = threadIdx.x & 63;
@@ -884,7 +986,17 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   const bool inrange = i < pd.nm;
   const int gi       = pd.moff + (inrange ? i : 0);
   float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (inrange) p = S.mpts[gi];
+  int ppos           = -1;
+  float4 pf          = make_float4(0.f, 0.f, 0.f, 0.f);
+  float pm           = 0.f;
+  if (inrange) {
+    p = S.mpts[gi];
+    if (use_prior) {  // previous nearest neighbour: position in grid.pts, its {x, y, z, index}, exclusion radius
+      ppos = S.prev_pos[gi];
+      pf   = S.prev_f[gi];
+      pm   = S.prev_m[gi];
+    }
+  }
   // moving points are stored spatially sorted; p.w carries the caller's index within the problem
   const int oi      = pd.moff + __float_as_int(p.w);
   const bool active = inrange && finite3(p.x, p.y, p.z);
@@ -893,36 +1005,87 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   float best = INFINITY;
   int bidx = NO_MATCH, bpos = 0;
   int r2 = 0;  // > 1: this lane needs a cube of radius r2
+  float excl = 0.f;  // exclusion radius left behind for the next iteration (0: none)
+  float r2box  = INFINITY;  // squared radius of the ball the first search phase can be trimmed to
+  float ball2  = INFINITY;  // ... and the wider scans
+  bool skipped = false;     // the previous nearest neighbour is provably still the nearest
+  float excl_wide = 0.f;
+  float pad       = 0.02f * g.h;  // margin of the scans beyond the nearest neighbour (grows with the motion)
   __shared__ int coop_lds[4][264];
+  STAMP(tl, 1);  // moving point + prior loaded
   if (active && !(S.tune & 16)) {
     transform_point<DIM>(T, p, qx, qy, qz);
-    cx = cell_coord(qx, g.ox, g.inv_h);
-    cy = cell_coord(qy, g.oy, g.inv_h);
-    cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
-    unsigned long long bkey = NO_KEY;
-    // Temporal coherence: the nearest neighbour found by the previous iteration of this compute() is a candidate
-    // like any other, and its distance bounds the search ball; the result is the same exact minimum of
-    // (d2, fixed index), reached through fewer cells.  Any fixed point would be a valid bound.
-    float r2box = INFINITY;
-    if (use_prior) {
-      const int ppos = S.prev_pos[gi];
-      if (ppos >= 0 && ppos < g.n) {
-        test_candidate<DIM>(g.pts[ppos], qx, qy, qz, ppos, true, bkey, bpos);
-        r2box = fminf(key_best(bkey), g.gate2);
-      }
-    }
-    scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos);
-    best = key_best(bkey);
-    bidx = key_idx(bkey);
-    const bool found1 = bidx != NO_MATCH && best <= g.gate2;
-    if (!(found1 && best <= b2_1) && g.rmax > 1) {
-      r2 = g.rmax;
-      if (found1) {
-        r2 = 1;
-        while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
+    // Temporal coherence, exactly.  The previous iteration of this compute() left, per moving point, its nearest
+    // neighbour f* and an exclusion radius m: no OTHER fixed point lies within m of the previous query q'.
+    //  (a) d(q, f*) + |q - q'| < m  =>  every other point is farther than f* (triangle inequality): f* is still the
+    //      unique nearest neighbour and the search is skipped; the exclusion radius shrinks by |q - q'|.
+    //  (b) otherwise the search is trimmed to the ball of radius d(q, f*) + pad around q: it contains f*, finds the
+    //      exact (d2, index) minimum, and the runner-up distance / the ball / the 3^DIM block leave a new m behind.
+    // All float32 roundings here are relative (~1e-6: differences and squares of exact float coordinates); the
+    // factors 1.00001 / 0.99999 keep every inequality on the safe side.  The oracle searches from scratch.
+    if (use_prior && ppos >= 0 && ppos < g.n) {
+      unsigned long long k1 = NO_KEY;
+      int pos1              = 0;
+      test_candidate<DIM>(pf, qx, qy, qz, ppos, true, k1, pos1);
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p, px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      const float d1 = sqrtf(key_best(k1));
+      if (d1 * 1.00001f + dl * 1.00001f < pm * 0.99999f && !(S.tune & 4096)) {
+        skipped = true;
+        best    = key_best(k1);
+        bidx    = key_idx(k1);
+        bpos    = ppos;
+        excl    = pm * 0.99999f - dl * 1.00001f;
+      } else {
+        pad            = 2.f * dl + 0.02f * g.h;
+        const float rr = (d1 + pad) * 1.00001f;
+        r2box          = fminf(rr * rr, g.gate2);
       }
     }
   }
+  // Converged iterations: a handful of lanes per wave still need a search (near-ties, lost exclusion radius) and would
+  // make the whole wave pay the search latency.  Hand them to the deferred-search kernel, which is launched anyway.
+  bool straggler = false;
+  if (S.queue && use_prior && g.rmax > 1 && !(S.tune & (16 | 8192))) {
+    const bool need  = active && !skipped;
+    const int n_need = __popcll(__ballot(need));
+    if (need && n_need <= 8) {
+      straggler = true;
+      ball2     = fminf(r2box, g.gate2);
+      r2        = ball2 <= bound2_of(2, g.h) ? 2 : g.rmax;
+    }
+  }
+  if (active && !(S.tune & 16)) {
+    if (!skipped && !straggler) {
+      cx = cell_coord(qx, g.ox, g.inv_h);
+      cy = cell_coord(qy, g.oy, g.inv_h);
+      cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+      unsigned long long bkey = NO_KEY;
+      float b2                = INFINITY;
+      scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos, b2, tl);
+      best = key_best(bkey);
+      bidx = key_idx(bkey);
+      const bool found1 = bidx != NO_MATCH && best <= g.gate2;
+      ball2             = g.gate2;
+      if (!(found1 && best <= b2_1) && g.rmax > 1) {
+        r2 = g.rmax;
+        if (found1) {
+          // the wider scan covers the ball of the candidate plus a pad, so that it leaves an exclusion radius
+          // larger than the neighbour's distance behind (otherwise these points would be searched every iteration)
+          const float rr = (sqrtf(best) + pad) * 1.00001f;
+          ball2          = fminf(rr * rr, g.gate2);
+          r2             = 1;
+          while (r2 < g.rmax && bound2_of(r2, g.h) < ball2) ++r2;
+        }
+      } else {
+        // settled: the scan was complete inside min(ball, block); nothing but the winner is closer than this
+        excl = sqrtf(fminf(fminf(b2, r2box), b2_1)) * 0.99999f;
+      }
+    }
+  }
+  STAMP(tl, 4);  // first search phase done
   bool deferred = false;
   if (S.queue) {
     // push the open lanes to the problem's queues: near entries (radius 2) grow from the front of the problem's
@@ -953,6 +1116,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
         QEntry e;
         e.i = i; e.r2 = r2; e.best = best; e.bidx = bidx; e.bpos = bpos;
         e.qx = qx; e.qy = qy; e.qz = qz;
+        e.ball2 = ball2; e.pad_ = 0;
         QEntry* qbase = reinterpret_cast<QEntry*>(S.queue) + pd.moff;
         if (r2 == 2)
           qbase[base_near + __popcll(need_near & below)] = e;
@@ -964,18 +1128,25 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   } else {
     // radius-2 cube per lane, then the cooperative scan for what is still open
     if (r2 > 1 && g.rmax >= 2 && !(S.tune & 2)) {
-      unsigned long long bkey = make_key(best, bidx);
-      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, fminf(best, g.gate2), bkey, bpos);
+      // (starts from scratch: the cube contains the 3^DIM block again, and the runner-up tracking must meet every
+      // fixed point exactly once)
+      unsigned long long bkey = NO_KEY;
+      float b2                = INFINITY;
+      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, ball2, bkey, bpos, b2);
       best = key_best(bkey);
       bidx = key_idx(bkey);
       const bool found2 = bidx != NO_MATCH && best <= g.gate2;
       if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
-        r2 = 0;
+        r2        = 0;
+        excl_wide = sqrtf(fminf(fminf(b2, ball2), bound2_of(2, g.h))) * 0.99999f;
       } else {
-        r2 = g.rmax;
+        r2    = g.rmax;
+        ball2 = g.gate2;
         if (found2) {
-          r2 = 2;
-          while (r2 < g.rmax && bound2_of(r2, g.h) < best) ++r2;
+          const float rr = (sqrtf(best) + pad) * 1.00001f;
+          ball2          = fminf(rr * rr, g.gate2);
+          r2             = 2;
+          while (r2 < g.rmax && bound2_of(r2, g.h) < ball2) ++r2;
         }
       }
     }
@@ -984,10 +1155,12 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     while (need) {
       const int src = __ffsll((long long) need) - 1;
       need &= need - 1;
-      float wbest;
+      float wbest, wexcl2;
       int widx, wpos;
       coop_scan<DIM, 64>(g, lane, coop_lds[wid], __shfl(qx, src), __shfl(qy, src), __shfl(qz, src), __shfl(cx, src),
-                     __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), fminf(__shfl(best, src), g.gate2), wbest, widx, wpos);
+                     __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), __shfl(ball2, src), wbest, widx, wpos,
+                     wexcl2);
+      if (lane == src) excl_wide = sqrtf(wexcl2) * 0.99999f;
       if (lane == src && (wbest < best || (wbest == best && widx < bidx))) {
         best = wbest;
         bidx = widx;
@@ -995,8 +1168,13 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       }
     }
   }
-  if (!deferred) finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, acc);
+  STAMP(tl, 5);  // open lanes pushed / searched
+  if (excl_wide != 0.f || r2 != 0) excl = excl_wide;  // finished by the wider scans above
+  if (!deferred)
+    finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, excl, acc);
+  STAMP(tl, 6);  // gates, rows, factor arithmetic, per-point outputs
   block_reduce_store(acc, S.partials, prob, blockIdx.x);
+  STAMP(tl, 7);  // reduction + atomics issued
 }
 
 // Deferred searches: every wave takes queue entries w, w + W, ... of its problem, runs the cooperative exact scan
@@ -1010,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   float T[12];
-  load_finder_transform<DIM>(S, st, T);
+  load_finder_transform<DIM>(S, st->X, T);
   const int kexp     = st->kexp[S.slice_idx];
   const double scale = dm::pow2(kexp);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
@@ -1029,7 +1207,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
   // finished in SIMT once 64 are parked or the queues are exhausted.
   bool have = false;
   int my_i = 0, my_bidx = NO_MATCH, my_bpos = 0;
-  float my_best = INFINITY;
+  float my_best = INFINITY, my_excl = 0.f;
   int parked = 0;
   // The 32 fixed-point accumulators live in LDS between flushes (one set per wave), not in registers: the search
   // loop keeps its register budget (occupancy) and a flush costs one wave reduction.
@@ -1044,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
 #pragma unroll
     for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
     finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, have, have, pd.moff + my_i, pd.moff + __float_as_int(mp.w), mp, mx, my,
-                             mz, my_best, my_bidx, my_bpos, acc);
+                             mz, my_best, my_bidx, my_bpos, my_excl, acc);
     int my_index;
     const long long total = wave_transpose_reduce(acc, lane, my_index);
     if ((lane & 1) == 0) wave_acc[wid][my_index] += total;
@@ -1059,15 +1237,17 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
       const bool live = e < count_near;
       QEntry q;
       q.i = 0; q.r2 = -1; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0; q.qx = q.qy = q.qz = 0.f;
+      q.ball2 = 0.f; q.pad_ = 0;
       if (live) q = queue[e];
       const bool skip = (S.tune & 2048) != 0;
       const int cx = cell_coord(q.qx, g.ox, g.inv_h);
       const int cy = cell_coord(q.qy, g.oy, g.inv_h);
       const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
-      float wbest;
+      float wbest, wexcl2;
       int widx, wpos;
-      coop_scan<DIM, TW>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, (live && !skip) ? q.r2 : -1, fminf(q.best, g.gate2), wbest,
-                         widx, wpos);
+      coop_scan<DIM, TW>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, (live && !skip) ? q.r2 : -1, q.ball2, wbest,
+                         widx, wpos, wexcl2);
+      const float qexcl = skip ? 0.f : sqrtf(wexcl2) * 0.99999f;
       if (wbest < q.best || (wbest == q.best && widx < q.bidx)) {
         q.best = wbest;
         q.bidx = widx;
@@ -1078,13 +1258,14 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
       const bool mine     = slot_team >= 0 && slot_team < TEAMS;
       const int src       = mine ? slot_team * TW : 0;
       const int pi = __shfl(q.i, src), pbi = __shfl(q.bidx, src), pbp = __shfl(q.bpos, src), plive = __shfl((int) live, src);
-      const float pb = __shfl(q.best, src);
+      const float pb = __shfl(q.best, src), pex = __shfl(qexcl, src);
       if (mine && plive) {
         have    = true;
         my_i    = pi;
         my_best = pb;
         my_bidx = pbi;
         my_bpos = pbp;
+        my_excl = pex;
       }
       parked += TEAMS;
       if (parked == 64) flush();
@@ -1096,12 +1277,13 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
     const int cx = cell_coord(q.qx, g.ox, g.inv_h);
     const int cy = cell_coord(q.qy, g.oy, g.inv_h);
     const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
-    float wbest;
+    float wbest, wexcl2;
     int widx, wpos;
-    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : q.r2, fminf(q.best, g.gate2), wbest, widx,
-                       wpos);
+    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : q.r2, q.ball2, wbest, widx,
+                       wpos, wexcl2);
     if (lane == parked) {
       have    = true;
+      my_excl = skip ? 0.f : sqrtf(wexcl2) * 0.99999f;
       my_i    = q.i;
       my_best = q.best;
       my_bidx = q.bidx;
@@ -1512,6 +1694,7 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
     st->last_b[i]  = b[i];
     st->last_dx[i] = bad ? 0.0 : dx[i];
   }
+  for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];  // the estimate this iteration's finder passes ran with
   if (!bad) dm::box_plus(C.variable_kind, st->X, dx);  // solver Success: multi_aligner_impl.cpp:118-121
   if (st->nstats < C.max_stats) stats[(size_t) prob * C.max_stats + st->nstats] = cur;
   st->nstats++;
