@@ -90,7 +90,6 @@ struct srrg2_aligner_s {
   int status = SRRG2_FAIL;
   // problems of the current batch (K = 1 for compute())
   int K = 1;
-  std::vector<ProblemDev> probs_host;
   DevBuf<ProblemDev> probs;
   DevBuf<ProblemState> states;
   DevBuf<ProblemOut> outs;
@@ -101,6 +100,7 @@ struct srrg2_aligner_s {
   ProblemOut* outs_host = nullptr; size_t outs_host_cap = 0;
   srrg2_iteration_stats* stats_host = nullptr; size_t stats_host_cap = 0;
   float* guesses_host = nullptr; size_t guesses_host_cap = 0;
+  ProblemDev* probs_host = nullptr; size_t probs_host_cap = 0;
   int max_stats = 0;
   std::vector<srrg2_iteration_stats> last_stats;  // of problem K-1 (== the only one for compute())
   int last_ncorr[SRRG2_MAX_SLICES]{};
@@ -395,9 +395,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   if ((rc = ensure_pinned(a->outs_host, a->outs_host_cap, (size_t) K))) return rc;
   if ((rc = ensure_pinned(a->stats_host, a->stats_host_cap, (size_t) K * slots))) return rc;
   if ((rc = ensure_pinned(a->guesses_host, a->guesses_host_cap, (size_t) K * a->tsize))) return rc;
+  // guesses and problem tables go through pinned host memory that k_icp_init reads directly (no copies on the stream;
+  // the previous compute() has been waited for, so the buffers are free)
   std::memcpy(a->guesses_host, guesses, (size_t) K * a->tsize * sizeof(float));
-  HIP_TRY(hipMemcpyAsync(a->guesses.p, a->guesses_host, (size_t) K * a->tsize * sizeof(float), hipMemcpyHostToDevice,
-                         a->stream));
+  if ((rc = ensure_pinned(a->probs_host, a->probs_host_cap, (size_t) K * std::max(nslices, 1)))) return rc;
   // per-slice problem tables live back to back in a->probs: [slice][K]
   std::vector<ProblemDev> all((size_t) K * std::max(nslices, 1));
   for (int si = 0; si < nslices; ++si) {
@@ -417,8 +418,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       all[(size_t) si * K + k] = pd;
     }
   }
-  if (nslices > 0)
-    HIP_TRY(hipMemcpyAsync(a->probs.p, all.data(), all.size() * sizeof(ProblemDev), hipMemcpyHostToDevice, a->stream));
+  std::memcpy(a->probs_host, all.data(), all.size() * sizeof(ProblemDev));
 
   CtlParams C{};
   C.variable_kind = a->kind;
@@ -466,12 +466,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     if (use_queue) {
       if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 10))) return rc;  // QEntry = 10 x 4 bytes
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
-      HIP_TRY(hipMemsetAsync(s->qcount.p, 0, (size_t) 2 * K * sizeof(int), a->stream));
     }
     sc.qcount = use_queue ? s->qcount.p : nullptr;
     sc.qslots = qslots;
-    // slot sets start at zero; afterwards the control kernel resets them each iteration
-    HIP_TRY(hipMemsetAsync(s->partials.p, 0, (size_t) K * nblocks * ACC_N * sizeof(long long), a->stream));
+    // (k_icp_init zeroes the slot sets and the queue counters; afterwards the control kernel resets them each iteration)
     sc.partials  = s->partials.p;
     sc.nblocks   = nblocks;
     sc.pinf_bits = s->pinf.p;
@@ -530,7 +528,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         return fail(SRRG2_E_UNSUPPORTED, "compute_batch supports one cue slice (plus prior slices)");
   }
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
-  srrg2amd::launch_icp_init(C, a->probs.p, a->states.p, a->guesses.p, a->tsize, a->stream);
+  srrg2amd::launch_icp_init(C, a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, a->stream);
 
   auto run_phase = [&](int slot0) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
@@ -570,11 +568,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   if (a->params.enable_inlier_only_runs) {
     if ((rc = run_phase(a->params.max_iterations))) return rc;
   }
-  srrg2amd::launch_icp_finalize(C, a->states.p, a->outs.p, a->stream);
+  // results land in pinned host memory (written by k_icp_finalize): the only host-device interaction of compute() after
+  // the launches is this wait
+  srrg2amd::launch_icp_finalize(C, a->states.p, a->stats.p, a->outs_host, a->stats_host, a->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(a->outs_host, a->outs.p, (size_t) K * sizeof(ProblemOut), hipMemcpyDeviceToHost, a->stream));
-  HIP_TRY(hipMemcpyAsync(a->stats_host, a->stats.p, (size_t) K * slots * sizeof(srrg2_iteration_stats),
-                         hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
   if (const char* tl_path = std::getenv("SRRG2_AMD_TIMELINE")) {  // dump of the last compute(): u64 nwaves, then stamps
     for (int si = 0; si < nslices; ++si) {
@@ -703,6 +700,7 @@ int srrg2_aligner_destroy(srrg2_aligner_h a) {
   if (a->outs_host) (void) hipHostFree(a->outs_host);
   if (a->stats_host) (void) hipHostFree(a->stats_host);
   if (a->guesses_host) (void) hipHostFree(a->guesses_host);
+  if (a->probs_host) (void) hipHostFree(a->probs_host);
   for (auto& ev : a->prof_events) {
     (void) hipEventDestroy(ev.first);
     (void) hipEventDestroy(ev.second);

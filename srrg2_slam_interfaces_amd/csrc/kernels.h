@@ -25,10 +25,11 @@ int icp_queue_blocks(int max_nm, int K);
 // projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)
 void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,
                       hipStream_t s);
-void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* states, const float* guesses, int tsize,
-                     hipStream_t s);
+void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
+                     const float* guesses_host, int tsize, hipStream_t s);
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s);
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s);
-void launch_icp_finalize(const CtlParams& C, ProblemState* states, ProblemOut* outs, hipStream_t s);
+void launch_icp_finalize(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats,
+                         ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s);
 
 }  // namespace srrg2amd

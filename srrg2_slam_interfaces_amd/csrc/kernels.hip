@@ -1705,13 +1705,23 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
 
 }  // namespace
 
-// compute() prologue: term_crit->init, stats clear, _preCompute (prior init overrides the guess)
-__global__ void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs, ProblemState* __restrict__ states,
-                           const float* __restrict__ guesses, int tsize) {
-  int prob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (prob >= C.K) return;
+// compute() prologue: term_crit->init, stats clear, _preCompute (prior init overrides the guess).  One block per
+// problem.  The initial guesses and the problem tables are read straight from pinned host memory (no staging copies on
+// the stream), the partial-sum slots and queue counters are zeroed here (no memsets on the stream).
+__global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs_host,
+                                                 ProblemDev* __restrict__ probs, ProblemState* __restrict__ states,
+                                                 const float* __restrict__ guesses_host, int tsize) {
+  const int prob = blockIdx.x;
+  for (int s = 0; s < C.nslices; ++s) {
+    const SliceCtl& sc = C.slices[s];
+    if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
+    long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+    for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += blockDim.x) p[k] = 0;
+  }
+  if (threadIdx.x != 0) return;
   ProblemState* st = &states[prob];
-  for (int i = 0; i < 12; ++i) st->X[i] = i < tsize ? guesses[(size_t) prob * tsize + i] : 0.f;
+  for (int i = 0; i < 12; ++i) st->X[i] = i < tsize ? guesses_host[(size_t) prob * tsize + i] : 0.f;
+  for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];
   st->status   = SRRG2_FAIL;
   st->done     = 0;
   st->finished = 0;
@@ -1720,6 +1730,8 @@ __global__ void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs, Pr
   st->w_count  = 0;
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
+    const ProblemDev pd = probs_host[(size_t) s * C.K + prob];
+    probs[(size_t) s * C.K + prob] = pd;
     st->ncorr[s]       = 0;
     st->ninl[s]        = 0;
     if (sc.qcount) sc.qcount[2 * prob] = sc.qcount[2 * prob + 1] = 0;
@@ -1729,7 +1741,7 @@ __global__ void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs, Pr
         for (int i = 0; i < tsize; ++i) st->X[i] = sc.prior_Z[i];
       }
     } else {
-      st->kexp[s] = slice_exponent(C, sc, prob, probs[(size_t) s * C.K + prob].nm);
+      st->kexp[s] = slice_exponent(C, sc, prob, pd.nm);
     }
   }
 }
@@ -1794,11 +1806,22 @@ __global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const
   }
 }
 
-// end of compute(): _pruneCorrespondences bookkeeping, fixTransform, Success (:88-94); fills ProblemOut
-__global__ void k_icp_finalize(CtlParams C, ProblemState* __restrict__ states, ProblemOut* __restrict__ outs) {
-  int prob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (prob >= C.K) return;
+// end of compute(): _pruneCorrespondences bookkeeping, fixTransform, Success (:88-94).  One block per problem; the
+// results (ProblemOut + the IterationStats appended by this compute()) are written straight into pinned host memory:
+// the host only waits for the stream, there are no device-to-host copies.
+__global__ __launch_bounds__(64) void k_icp_finalize(CtlParams C, ProblemState* __restrict__ states,
+                                                     const srrg2_iteration_stats* __restrict__ stats,
+                                                     ProblemOut* __restrict__ outs_host,
+                                                     srrg2_iteration_stats* __restrict__ stats_host) {
+  const int prob   = blockIdx.x;
   ProblemState* st = &states[prob];
+  {  // the iteration statistics, 8 words each
+    const int n       = min(st->nstats, C.max_stats) * (int) (sizeof(srrg2_iteration_stats) / sizeof(int));
+    const int* src    = reinterpret_cast<const int*>(stats + (size_t) prob * C.max_stats);
+    int* dst          = reinterpret_cast<int*>(stats_host + (size_t) prob * C.max_stats);
+    for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = src[k];
+  }
+  if (threadIdx.x != 0) return;
   if (!st->finished) {
     if (C.params.keep_only_inlier_correspondences) {
       for (int s = 0; s < C.nslices; ++s)
@@ -1810,7 +1833,7 @@ __global__ void k_icp_finalize(CtlParams C, ProblemState* __restrict__ states, P
       dm::se3_fix_transform(st->X);
     st->status = SRRG2_SUCCESS;
   }
-  ProblemOut* o = &outs[prob];
+  ProblemOut* o = &outs_host[prob];
   for (int i = 0; i < 12; ++i) o->X[i] = st->X[i];
   o->status = st->status;
   o->nstats = st->nstats;
@@ -1934,9 +1957,9 @@ void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, Pr
     hipLaunchKernelGGL((k_icp_step_proj<false>), grid, dim3(256), 0, s, S, probs, states);
 }
 
-void launch_icp_init(const CtlParams& C, const ProblemDev* probs, ProblemState* states, const float* guesses, int tsize,
-                     hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_init, dim3((C.K + 63) / 64), dim3(64), 0, s, C, probs, states, guesses, tsize);
+void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
+                     const float* guesses_host, int tsize, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_init, dim3(C.K), dim3(64), 0, s, C, probs_host, probs, states, guesses_host, tsize);
 }
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_control, dim3(C.K), dim3(256), 0, s, C, states, stats);
@@ -1944,8 +1967,9 @@ void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteratio
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_post, dim3((C.K + 63) / 64), dim3(64), 0, s, C, states, stats);
 }
-void launch_icp_finalize(const CtlParams& C, ProblemState* states, ProblemOut* outs, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_finalize, dim3((C.K + 63) / 64), dim3(64), 0, s, C, states, outs);
+void launch_icp_finalize(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats,
+                         ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_finalize, dim3(C.K), dim3(64), 0, s, C, states, stats, outs_host, stats_host);
 }
 
 }  // namespace srrg2amd
