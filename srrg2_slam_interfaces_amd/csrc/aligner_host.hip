@@ -238,9 +238,10 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   float h = fit_cell(s->cfg.finder_cell_size > 0.f ? s->cfg.finder_cell_size : gate * 0.25f);
   if (!(s->cfg.finder_cell_size > 0.f) && nvalid > 0) {
     // Automatic cell size: probe the density with a histogram at gate/4 and rescale so that an occupied cell holds
-    // ~4 points on average (surface-like scaling: occupancy ~ h^2).  Too small a cell leaves many lanes unsettled
-    // after the 3^DIM block (sparser regions), too large a cell inflates the candidate lists; measured optimum on
-    // C2/C4 at 0.075-0.09 m for gate 0.25 m (profiles/r1c notes).  Any h gives the same exact results.
+    // ~8 points on average (surface-like scaling: occupancy ~ h^2).  Too small a cell leaves many lanes unsettled
+    // after the 3^DIM block (misaligned first iterations, sparser regions), too large a cell inflates the candidate
+    // lists.  Measured on C2/C4: optimum at 8 (4: -5% / -17%, 16: -5% / -8%); it was 4 before converged iterations
+    // learnt to skip their searches.  Any h gives the same exact results.
     GridDev probe{};
     grid_dims(h, probe);
     const int pcell = probe.nx * probe.ny * probe.nz;
@@ -254,7 +255,8 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     HIP_TRY(hipStreamSynchronize(a->stream));
     if (nocc > 0) {
       const float occupancy = (float) nvalid / (float) nocc;
-      float scale           = std::sqrt(4.0f / occupancy);
+      const float target    = std::getenv("SRRG2_AMD_CELL_TARGET") ? (float) std::atof(std::getenv("SRRG2_AMD_CELL_TARGET")) : 8.0f;
+      float scale           = std::sqrt(target / occupancy);
       scale                 = std::fmin(std::fmax(scale, 0.5f), 4.0f);
       h                     = fit_cell(std::fmin(h * scale, gate));
     }
