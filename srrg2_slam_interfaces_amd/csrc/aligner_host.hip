@@ -894,9 +894,23 @@ static int fetch_dense(srrg2_aligner* a, int si, std::vector<int>& cf, std::vect
   }
   cf.resize((size_t) nm); cr.resize((size_t) nm); cst.resize((size_t) nm);
   if (nm > 0) {
-    HIP_TRY(hipMemcpy(cf.data(), s->corr_fixed.p + moff, sizeof(int) * (size_t) nm, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cr.data(), s->corr_resp.p + moff, sizeof(float) * (size_t) nm, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cst.data(), s->corr_stat.p + moff, (size_t) nm, hipMemcpyDeviceToHost));
+    // the kernels write these arrays in the (Morton) sorted order of the moving cloud; moving[g].w = caller's index
+    std::vector<int> sf((size_t) nm);
+    std::vector<float> sr((size_t) nm);
+    std::vector<uint8_t> sst((size_t) nm);
+    std::vector<float4> mp((size_t) nm);
+    HIP_TRY(hipMemcpy(sf.data(), s->corr_fixed.p + moff, sizeof(int) * (size_t) nm, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sr.data(), s->corr_resp.p + moff, sizeof(float) * (size_t) nm, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sst.data(), s->corr_stat.p + moff, (size_t) nm, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mp.data(), s->moving.p + moff, sizeof(float4) * (size_t) nm, hipMemcpyDeviceToHost));
+    for (int g = 0; g < nm; ++g) {
+      int ci;
+      std::memcpy(&ci, &mp[(size_t) g].w, sizeof(int));
+      if (ci < 0 || ci >= nm) return fail(SRRG2_E_STATE, "correspondences: corrupt moving index");
+      cf[(size_t) ci]  = sf[(size_t) g];
+      cr[(size_t) ci]  = sr[(size_t) g];
+      cst[(size_t) ci] = sst[(size_t) g];
+    }
   }
   *moff_out = moff;
   return 0;

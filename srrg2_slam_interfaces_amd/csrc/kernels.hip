@@ -843,8 +843,8 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
 template <int DIM, bool PLANE>
 __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, int rk, float thr, float kk, double scale,
                                              bool inrange, bool active, int gi, int oi, const float4 p, float qx, float qy,
-                                             float qz, float best, int bidx, int bpos, float excl,
-                                             long long (&acc)[ACC_N]) {
+                                             float qz, float best, int bidx, int bpos, float excl, bool kept,
+                                             const float4 kept_f, long long (&acc)[ACC_N]) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   const GridDev& g   = S.grid;
@@ -858,7 +858,8 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       if (S.tune & 8) found = false;
       float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
       if (found && (PLANE || S.use_normal_gate)) nf = (S.tune & 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[bpos];
-      if (bidx != NO_MATCH) fm = g.pts[bpos];  // (with nf: one round trip, not one after the normal gate)
+      // (with nf: one round trip, not one after the normal gate; a kept neighbour comes with its coordinates)
+      if (bidx != NO_MATCH) fm = kept ? kept_f : g.pts[bpos];
       if (found && S.use_normal_gate) {
         const float4 nm = (S.tune & 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : S.mnrm[gi];
         float dot;
@@ -933,12 +934,15 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
         fstat = factor_accumulate<D, ROWS>(J, e, false, rk, thr, scale, (S.tune & 64) != 0, acc);
       }
     }
-    S.prev_pos[gi]   = (active && bidx != NO_MATCH) ? bpos : -1;
-    S.prev_f[gi]     = fm;
+    if (!kept) {  // (a skipped search keeps its neighbour: only the exclusion radius changes)
+      S.prev_pos[gi] = (active && bidx != NO_MATCH) ? bpos : -1;
+      S.prev_f[gi]   = fm;
+    }
     S.prev_m[gi]     = excl;
-    S.corr_fixed[oi] = match;
-    S.corr_resp[oi]  = resp;
-    S.corr_stat[oi]  = fstat;
+    // (stored in the sorted order of the moving cloud: coalesced; the host API maps back to the caller's order)
+    S.corr_fixed[gi] = match;
+    S.corr_resp[gi]  = resp;
+    S.corr_stat[gi]  = fstat;
   }
 
 }
@@ -1171,7 +1175,8 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   STAMP(tl, 5);  // open lanes pushed / searched
   if (excl_wide != 0.f || r2 != 0) excl = excl_wide;  // finished by the wider scans above
   if (!deferred)
-    finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, excl, acc);
+    finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, excl, skipped,
+                             pf, acc);
   STAMP(tl, 6);  // gates, rows, factor arithmetic, per-point outputs
   block_reduce_store(acc, S.partials, prob, blockIdx.x);
   STAMP(tl, 7);  // reduction + atomics issued
@@ -1222,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
 #pragma unroll
     for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
     finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, have, have, pd.moff + my_i, pd.moff + __float_as_int(mp.w), mp, mx, my,
-                             mz, my_best, my_bidx, my_bpos, my_excl, acc);
+                             mz, my_best, my_bidx, my_bpos, my_excl, false, make_float4(0.f, 0.f, 0.f, 0.f), acc);
     int my_index;
     const long long total = wave_transpose_reduce(acc, lane, my_index);
     if ((lane & 1) == 0) wave_acc[wid][my_index] += total;
@@ -1379,7 +1384,6 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
     const int gi   = pd.moff + i;
     const float4 p = S.mpts[gi];
     const int ci   = __float_as_int(p.w);  // caller's index within the problem
-    const int oi   = pd.moff + ci;
     int match      = -1;
     float resp     = 0.f;
     uint8_t fstat  = SRRG2_FACTOR_SUPPRESSED;
@@ -1462,9 +1466,10 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
         fstat = factor_accumulate<D, ROWS>(J, e, invalid, rk, S.robust_thr, scale, false, acc);
       }
     }
-    S.corr_fixed[oi] = match;
-    S.corr_resp[oi]  = resp;
-    S.corr_stat[oi]  = fstat;
+    // (stored in the sorted order of the moving cloud: coalesced; the host API maps back to the caller's order)
+    S.corr_fixed[gi] = match;
+    S.corr_resp[gi]  = resp;
+    S.corr_stat[gi]  = fstat;
   }
   block_reduce_store(acc, S.partials, prob, blockIdx.x);
 }
