@@ -329,10 +329,6 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     const int off = offsets[k] - offsets[0], cnt = offsets[k + 1] - offsets[k];
     pd[k]  = ProblemDev{off, cnt};
     max_nm = std::max(max_nm, cnt);
-    srrg2amd::launch_ingest(dsrc + (size_t) off * sf, sf, cnt, a->dim, s->moving_raw.p + off, s->pinf.p + k, 1, a->stream);
-    if (normals)
-      srrg2amd::launch_ingest(nsrc + (size_t) off * nsf, nsf, cnt, a->dim, s->moving_nrm_raw.p + off, nullptr, 0,
-                              a->stream);
   }
   // Morton sort per problem: 64^3 cells for one cloud, fewer per problem for big batches
   const int bits = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
@@ -354,6 +350,10 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     HIP_TRY(hipMemsetAsync(s->ms_counts.p, 0, (ncell + 1) * sizeof(int), a->stream));
     HIP_TRY(hipStreamSynchronize(a->stream));  // bb / pd are stack-lifetime host buffers
   }
+  // all clouds of the batch in one launch each (points, normals)
+  srrg2amd::launch_ingest_batch(dsrc, sf, s->ms_probs.p, K, max_nm, a->dim, s->moving_raw.p, s->pinf.p, 1, a->stream);
+  if (normals)
+    srrg2amd::launch_ingest_batch(nsrc, nsf, s->ms_probs.p, K, max_nm, a->dim, s->moving_nrm_raw.p, nullptr, 0, a->stream);
   srrg2amd::launch_msort(s->moving_raw.p, normals ? s->moving_nrm_raw.p : nullptr, s->ms_probs.p, K, max_nm, bits,
                          s->ms_bb.p, s->ms_counts.p, s->ms_cursor.p, s->ms_sums.p, s->ms_sums.p + s->ms_sums.cap - 1,
                          s->moving.p, normals ? s->moving_nrm.p : nullptr, a->stream);

@@ -6,6 +6,8 @@ namespace srrg2amd {
 
 void launch_ingest(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits,
                    int finite_per_point, hipStream_t s);
+void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* probs, int K, int max_nm, int dim,
+                         float4* dst, unsigned* maxabs_bits, int finite_per_point, hipStream_t s);
 void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s);
 void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s);
 void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s);

@@ -75,21 +75,54 @@ __global__ void k_ingest(const float* __restrict__ src, int stride_floats, int n
   if ((threadIdx.x & 63) == 0 && maxabs_bits && amax > 0.f) atomicMax(maxabs_bits, __float_as_uint(amax));
 }
 
+// the clouds of a batch in ONE launch: blockIdx.y = problem (its points are [moff, moff + nm) of src and dst)
+__global__ void k_ingest_batch(const float* __restrict__ src, int stride_floats, const ProblemDev* __restrict__ probs,
+                               int dim, float4* __restrict__ dst, unsigned* __restrict__ maxabs_bits /* [K] or null */,
+                               int finite_per_point) {
+  const ProblemDev pd = probs[blockIdx.y];
+  float amax          = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
+    const float* p = src + (size_t) (pd.moff + i) * stride_floats;
+    float x = p[0], y = p[1], z = dim == 3 ? p[2] : 0.f;
+    dst[pd.moff + i] = make_float4(x, y, z, 0.f);
+    if (finite_per_point) {
+      if (finite3(x, y, z)) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)));
+    } else {
+      if (isfinite(x)) amax = fmaxf(amax, fabsf(x));
+      if (isfinite(y)) amax = fmaxf(amax, fabsf(y));
+      if (isfinite(z)) amax = fmaxf(amax, fabsf(z));
+    }
+  }
+  if (!maxabs_bits) return;
+  // block maximum, then one atomic per block (same-address atomics serialise at tens of ns each)
+  __shared__ float red[4];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (amax > 0.f) atomicMax(maxabs_bits + blockIdx.y, __float_as_uint(amax));
+  }
+}
+
 // ============================================================================================
 // grid build
 // ============================================================================================
 __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
                        int* __restrict__ nvalid) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
   int valid = 0;
-  if (i < n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 p = pts[i];
     if (finite3(p.x, p.y, p.z)) {
-      valid = 1;
-      mn[0] = mx[0] = fkey(p.x);
-      mn[1] = mx[1] = fkey(p.y);
-      mn[2] = mx[2] = fkey(p.z);
+      valid += 1;
+      const unsigned k[3] = {fkey(p.x), fkey(p.y), fkey(p.z)};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = min(mn[d], k[d]);
+        mx[d] = max(mx[d], k[d]);
+      }
     }
   }
 #pragma unroll
@@ -101,13 +134,29 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
     }
     valid += __shfl_xor(valid, off);
   }
-  if ((threadIdx.x & 63) == 0 && valid) {
+  // one atomic per block and value (a few grid-striding blocks): same-address atomics serialise at tens of ns each
+  __shared__ unsigned red[4][7];
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      atomicMin(&mn_out[d], mn[d]);
-      atomicMax(&mx_out[d], mx[d]);
+      red[threadIdx.x >> 6][d]     = mn[d];
+      red[threadIdx.x >> 6][3 + d] = mx[d];
     }
-    atomicAdd(nvalid, valid);
+    red[threadIdx.x >> 6][6] = (unsigned) valid;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    const int d = threadIdx.x;
+    if (d < 3) {
+      const unsigned v = min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]));
+      if (v != 0xffffffffu) atomicMin(&mn_out[d], v);
+    } else if (d < 6) {
+      const unsigned v = max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
+      if (v != 0u) atomicMax(&mx_out[d - 3], v);
+    } else {
+      const int v = (int) (red[0][6] + red[1][6] + red[2][6] + red[3][6]);
+      if (v) atomicAdd(nvalid, v);
+    }
   }
 }
 
@@ -290,12 +339,26 @@ __global__ void k_msort_bbox(const float4* __restrict__ pts, const ProblemDev* _
       mx[d] = max(mx[d], (unsigned) __shfl_xor((int) mx[d], off));
     }
   }
+  // ... then the 4 waves of the block through LDS: one atomic per block and bound (measured: per-wave atomics on the
+  // 6 addresses of a problem cost 109 us at C2 and 541 us for a 32 x 50k batch)
+  __shared__ unsigned red[4][6];
   if ((threadIdx.x & 63) == 0) {
-    unsigned* b = bb + blockIdx.y * 6;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      if (mn[d] != 0xffffffffu) atomicMin(&b[d], mn[d]);
-      if (mx[d] != 0u) atomicMax(&b[3 + d], mx[d]);
+      red[threadIdx.x >> 6][d]     = mn[d];
+      red[threadIdx.x >> 6][3 + d] = mx[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    unsigned* b = bb + blockIdx.y * 6;
+    if (d < 3) {
+      const unsigned v = min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]));
+      if (v != 0xffffffffu) atomicMin(&b[d], v);
+    } else {
+      const unsigned v = max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
+      if (v != 0u) atomicMax(&b[d], v);
     }
   }
 }
@@ -1857,9 +1920,19 @@ void launch_ingest(const float* src, int stride_floats, int n, int dim, float4* 
                      finite_per_point);
 }
 
+void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* probs, int K, int max_nm, int dim,
+                         float4* dst, unsigned* maxabs_bits, int finite_per_point, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  int bx = (max_nm + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(k_ingest_batch, dim3(bx, K), dim3(256), 0, s, src, stride_floats, probs, dim, dst, maxabs_bits,
+                     finite_per_point);
+}
+
 void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_bbox, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, mn, mx, nvalid);
+  const int bx = (n + 255) / 256;
+  hipLaunchKernelGGL(k_bbox, dim3(bx < 64 ? bx : 64), dim3(256), 0, s, pts, n, mn, mx, nvalid);
 }
 
 void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s) {
@@ -1899,7 +1972,8 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
   if (bx > 1024) bx = 1024;
   dim3 grid(bx, K);
   const int ncell = K << (3 * bits);
-  hipLaunchKernelGGL(k_msort_bbox, grid, dim3(256), 0, s, pts, probs, bb);
+  // (few, grid-striding blocks per problem for the bounding box: its cost is the atomics, not the reads)
+  hipLaunchKernelGGL(k_msort_bbox, dim3(bx < 32 ? bx : 32, K), dim3(256), 0, s, pts, probs, bb);
   hipLaunchKernelGGL(k_msort_count, grid, dim3(256), 0, s, pts, probs, bb, bits, counts);
   launch_exclusive_scan(counts, ncell, scan_sums, scan_total, s);
   (void) hipMemcpyAsync(cursor, counts, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, s);
