@@ -295,6 +295,81 @@ int srrg2_posegraph_solve(srrg2_posegraph_h h, const srrg2_posegraph_params* p, 
                           int* n_inout);
 int srrg2_posegraph_get_poses(srrg2_posegraph_h h, float* poses_out);
 
+/* ---- scene slices kept in HBM between frames: clipping and correspondence-based merging ------
+ * the tracker-side steps either side of align()
+ * (S/trackers/tracker_slice_processor_impl.cpp:111-205: merge(), clip()).  A scene is a point
+ * cloud with optional normals (PointNormal2f / PointNormal3f clouds, S/mapping/
+ * merger_correspondence_homo.h:38-47); a point is Valid iff its coordinates are finite.  Scenes
+ * live in device memory with spare capacity, so adapt -> clip -> align -> merge runs without
+ * moving clouds across PCIe. */
+
+typedef struct srrg2_scene* srrg2_scene_h;
+
+/* MergerBase::Status, S/mapping/merger.h:19-23 (values identical) */
+enum srrg2_merger_status { SRRG2_MERGER_ERROR = 0, SRRG2_MERGER_INITIALIZING = 1, SRRG2_MERGER_SUCCESS = 2 };
+/* SceneClipper_::Status, S/mapping/scene_clipper.h:24-28 (values identical) */
+enum srrg2_clipper_status { SRRG2_CLIPPER_ERROR = 0, SRRG2_CLIPPER_SUCCESSFUL = 1, SRRG2_CLIPPER_READY = 2 };
+
+/* PARAMs of MergerCorrespondence_ / MergerCorrespondenceHomo_ (S/mapping/merger.h:126-131,
+ * S/mapping/merger_correspondence_homo.h:22-31), same defaults: 50, 0.25, 200 */
+typedef struct srrg2_merger_params {
+  float maximum_response;
+  float maximum_distance_geometry_squared;
+  int32_t target_number_of_merges;
+} srrg2_merger_params;
+
+typedef struct srrg2_merge_result {
+  int32_t status;            /* srrg2_merger_status */
+  int32_t num_correspondences;
+  int32_t num_merged;        /* distinct measurement points merged into the scene (merged_points_moving.size()) */
+  int32_t num_added;         /* measurement points appended to the scene */
+  int32_t scene_size;        /* after the merge */
+} srrg2_merge_result;
+
+int srrg2_merger_default_params(srrg2_merger_params* p);
+
+/* dim = 2 | 3.  An empty scene. */
+int srrg2_scene_create(int dim, int device, srrg2_scene_h* out);
+int srrg2_scene_destroy(srrg2_scene_h h);
+/* replace the content (strides in bytes; normals may be null; mem = srrg2_mem) */
+int srrg2_scene_set(srrg2_scene_h h, const float* coords, int coord_stride_bytes, const float* normals,
+                    int normal_stride_bytes, int n, int mem);
+int srrg2_scene_size(srrg2_scene_h h, int* n);
+/* copy out up to `capacity` points as packed dim-float records (normals_out may be null) */
+int srrg2_scene_get(srrg2_scene_h h, float* coords_out, float* normals_out, int capacity, int* n);
+/* borrow the device arrays (float4 records: stride 16 bytes) -- e.g. to feed
+ * srrg2_aligner_set_fixed/set_moving with SRRG2_MEM_DEVICE without touching the host.  Valid
+ * until the scene is next modified. */
+int srrg2_scene_device_arrays(srrg2_scene_h h, const float** coords, const float** normals, int* n);
+
+/* SceneClipper_::compute() (S/mapping/scene_clipper.h:17-122; the reference ships the interface
+ * only, concrete clippers live in the SLAM pipelines): ball policy -- keeps the Valid points of
+ * `full` within `range` of the robot, in scene order, expressed in the robot frame
+ * (local_map_in_robot * p, normals rotated: "the clipped scene will be compared directly with
+ * the measurement", :106-107).  `clipped` receives the points and the local -> global index map
+ * (globalIndices(), :98-101).  status: Ready when `full` is empty, else Successful. */
+int srrg2_scene_clip_ball(srrg2_scene_h full, const float* robot_in_local_map, float range, srrg2_scene_h clipped,
+                          int* status);
+int srrg2_scene_global_indices(srrg2_scene_h clipped, int32_t* buf, int* n_inout);
+
+/* MergerCorrespondenceHomo_::compute() (S/mapping/merger_correspondence_homo_impl.cpp:11-125).
+ * correspondences: fixed_idx = scene point, moving_idx = measurement point, processed in order
+ * (a scene point hit twice sees the first update, :55-73); n_correspondences < 0 = "no
+ * correspondences set" (:30-41: every Valid measurement point is appended).  Merged points take
+ * all fields of the measurement point, coordinates = mean of both (:66-70); if fewer than
+ * target_number_of_merges were merged, the unmerged Valid measurement points are appended
+ * (:92-115). */
+int srrg2_scene_merge(srrg2_scene_h scene, srrg2_scene_h measurement, const float* measurement_in_scene,
+                      const srrg2_correspondence* correspondences, int n_correspondences, const srrg2_merger_params* p,
+                      srrg2_merge_result* out);
+/* the same, with the correspondences taken on the device from slice `slice_idx` of an aligner
+ * whose moving cloud was `clipped` and whose fixed cloud was `measurement`: flipped and mapped
+ * to the global scene as TrackerSliceProcessor_::merge() does (S/trackers/
+ * tracker_slice_processor_impl.cpp:160-186). */
+int srrg2_scene_merge_from_aligner(srrg2_scene_h scene, srrg2_scene_h measurement, const float* measurement_in_scene,
+                                   srrg2_aligner_h aligner, int slice_idx, srrg2_scene_h clipped,
+                                   const srrg2_merger_params* p, srrg2_merge_result* out);
+
 /* ---- measurement hooks (no reference counterpart: the reference profiles with
  * PROFILE_TIME scopes outside the aligner) ------------- */
 

@@ -42,6 +42,9 @@ static int fail(int code, const char* msg) {
 const char* oracle_last_error(void) {
   return g_err;
 }
+void oracle_set_error(const char* msg) { /* shared error slot (o_scene.c) */
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+}
 int oracle_abi_version(void) {
   return SRRG2_AMD_ABI_VERSION;
 }

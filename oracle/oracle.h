@@ -26,6 +26,21 @@ extern "C" {
 
 typedef struct o_aligner o_aligner;
 
+typedef struct o_scene o_scene;
+
+/* ---- scene clipping / merging (o_scene.c; same surface as srrg2_scene_* without devices) ---- */
+int oracle_scene_create(int dim, o_scene** out);
+int oracle_scene_destroy(o_scene* s);
+int oracle_scene_set(o_scene* s, const float* coords, int coord_stride_bytes, const float* normals, int normal_stride_bytes,
+                     int n);
+int oracle_scene_size(o_scene* s, int* n);
+int oracle_scene_get(o_scene* s, float* coords_out, float* normals_out, int capacity, int* n);
+int oracle_scene_clip_ball(o_scene* full, const float* robot_in_local_map, float range, o_scene* clipped, int* status);
+int oracle_scene_global_indices(o_scene* clipped, int32_t* buf, int* n_inout);
+int oracle_scene_merge(o_scene* scene, o_scene* measurement, const float* measurement_in_scene,
+                       const srrg2_correspondence* correspondences, int n_correspondences, const srrg2_merger_params* p,
+                       srrg2_merge_result* out);
+
 /* ---- deterministic math (o_math.c) --------------------------------------- */
 void   o_sincos(double x, double* s, double* c);
 double o_atan2(double y, double x);

@@ -184,3 +184,12 @@ class OraclePoseGraph(_PoseGraph):
         err, Ji, Jj = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
         self._check(lib().oracle_posegraph_edge(self._h, C.c_int(e), _dp(err), _dp(Ji), _dp(Jj)))
         return err, Ji, Jj
+
+
+# ---- scene clipping / merging --------------------------------------------------------------------
+from srrg2_slam_interfaces_amd.mapping import _Binding as _SceneBinding  # noqa: E402
+
+
+def scene_binding():
+    l = lib()
+    return _SceneBinding(l, "oracle_scene_", l.oracle_last_error, None)

@@ -17,3 +17,12 @@ def PoseGraph(variable_kind=abi.SE3_QUAT_RIGHT, device=0):
 
     l = _capi.lib()
     return _PG(l, "srrg2_posegraph_", l.srrg2_amd_last_error, variable_kind, device=device)
+
+
+def scene_binding(device=0):
+    """Binding of the scene/clipper/merger classes of ``mapping`` to the HIP library."""
+    from . import _capi
+    from .mapping import _Binding
+
+    l = _capi.lib()
+    return _Binding(l, "srrg2_scene_", l.srrg2_amd_last_error, device)

@@ -916,6 +916,27 @@ static int fetch_dense(srrg2_aligner* a, int si, std::vector<int>& cf, std::vect
   return 0;
 }
 
+}  // extern "C" (reopened below)
+namespace srrg2amd {
+int aligner_slice_view(srrg2_aligner_s* a, int si, AlignerSliceView* v) {
+  int rc = check_slice(a, si, "aligner_slice_view");
+  if (rc) return rc;
+  Slice* s = a->slices[si];
+  if (!a->computed || a->K != 1 || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving || !s->has_fixed)
+    return fail(SRRG2_E_STATE, "aligner_slice_view: needs a cue slice after a single-problem compute()");
+  v->moving_sorted = s->moving.p;
+  v->corr_fixed    = s->corr_fixed.p;
+  v->corr_resp     = s->corr_resp.p;
+  v->corr_stat     = s->corr_stat.p;
+  v->nm            = s->nm_total;
+  v->nf            = s->nf;
+  v->prune         = a->params.keep_only_inlier_correspondences && a->status == SRRG2_SUCCESS;
+  v->device        = a->device;
+  return 0;
+}
+}  // namespace srrg2amd
+extern "C" {
+
 int srrg2_aligner_get_correspondences(srrg2_aligner_h a, int si, srrg2_correspondence* buf, int* n) {
   int rc = check_slice(a, si, "get_correspondences");
   if (rc) return rc;

@@ -33,6 +33,18 @@ struct DevBuf {
   }
 };
 
+// what scene.hip needs to see of an aligner slice after compute() (device pointers into the aligner's buffers)
+struct AlignerSliceView {
+  const float4* moving_sorted;  // .w = caller's index (= index in the cloud given to set_moving)
+  const int* corr_fixed;        // per sorted moving point: matched fixed index or -1
+  const float* corr_resp;
+  const unsigned char* corr_stat;
+  int nm, nf;
+  bool prune;  // keep_only_inlier_correspondences && Success: only inlier correspondences count
+  int device;
+};
+int aligner_slice_view(srrg2_aligner_s* a, int slice_idx, AlignerSliceView* v);
+
 }  // namespace srrg2amd
 
 #define HIP_TRY(expr)                                                                              \

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | tail -5
-echo "c2"; python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
-echo "c3"; python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
-echo "c4"; python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"
+timeout 900 python -m pytest tests/test_gpu_scene.py -x -q 2>&1 | tail -30
