@@ -15,6 +15,7 @@
 //   - appends keep measurement order (stable compaction by exclusive scan).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -120,6 +121,19 @@ __global__ void k_clip_scatter(int dim, Xf L, float range2, const float4* __rest
   }
 }
 
+// block sum -> ONE atomic per block (same-address atomics serialise at tens of ns each; blockDim = 256)
+__device__ __forceinline__ void block_add(int v, int* target) {
+  __shared__ int red[4];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t) atomicAdd(target, t);
+  }
+}
+
 // ---- merge --------------------------------------------------------------------------------------------------
 // one correspondence: merger_correspondence_homo_impl.cpp:55-76.  Returns true if merged.
 __device__ __forceinline__ bool merge_one(int dim, const Xf& M, float max_response, float max_d2, float4* scene_pts,
@@ -210,17 +224,13 @@ __global__ void k_merge_from_aligner(int dim, Xf M, float max_response, float ma
     ++ncorr;
     if (merge_one(dim, M, max_response, max_d2, scene_pts, scene_nrm, meas_pts, meas_nrm, s, m, corr_resp[g])) merged[m] = 1;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) ncorr += __shfl_xor(ncorr, off);
-  if ((threadIdx.x & 63) == 0 && ncorr) atomicAdd(&scalars[4], ncorr);
+  block_add(ncorr, &scalars[4]);
 }
 
 __global__ void k_count_merged(const unsigned char* __restrict__ merged, int n, int* __restrict__ scalars) {
   int c = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += merged[i] ? 1 : 0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&scalars[1], c);
+  block_add(c, &scalars[1]);
 }
 
 // append: flags (unmerged && Valid) -> exclusive scan -> scatter in measurement order (:100-114, :33-40)
@@ -302,7 +312,7 @@ int finish_merge(srrg2_scene* scene, srrg2_scene* meas, const Xf& M, bool have_c
   const int n_meas = meas->n;
   int num_merged   = 0;
   if (have_corr && n_meas > 0) {
-    hipLaunchKernelGGL(k_count_merged, dim3(blocks_for(n_meas)), dim3(256), 0, scene->stream, scene->merged.p, n_meas,
+    hipLaunchKernelGGL(k_count_merged, dim3(std::min(blocks_for(n_meas), 64)), dim3(256), 0, scene->stream, scene->merged.p, n_meas,
                        scene->dscalars.p);
     if ((rc = read_scalars(scene))) return rc;
     num_merged = scene->scalars[1];
@@ -576,7 +586,7 @@ int srrg2_scene_merge_from_aligner(srrg2_scene_h scene, srrg2_scene_h meas, cons
   HIP_TRY(hipMemsetAsync(scene->merged.p, 0, (size_t) n_meas + 1, st));
   HIP_TRY(hipMemsetAsync(scene->dscalars.p, 0, 16 * sizeof(int), st));
   if (v.nm > 0) {
-    hipLaunchKernelGGL(k_merge_from_aligner, dim3(blocks_for(v.nm)), dim3(256), 0, st, scene->dim, M, p->maximum_response,
+    hipLaunchKernelGGL(k_merge_from_aligner, dim3(std::min(blocks_for(v.nm), 256)), dim3(256), 0, st, scene->dim, M, p->maximum_response,
                        p->maximum_distance_geometry_squared, v.moving_sorted, v.corr_fixed, v.corr_resp, v.corr_stat,
                        v.prune ? 1 : 0, v.nm, clipped->gidx.p, n_scene, n_meas, scene->pts.p,
                        scene->nrm.p, meas->pts.p, meas->has_normals ? meas->nrm.p : nullptr,
