@@ -219,6 +219,30 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
   for (int k = 0; k < D; ++k) b[(size_t) v * D + k] = bv[k];
 }
 
+// Vertex-major copy of the off-diagonal blocks for the PCG loop: incidence q of a variable gets the D x D block that
+// multiplies p[other] (H_ij, or its transpose for the `to` end), so k_pg_spmv streams contiguous memory instead of
+// gathering 288-byte blocks by factor index and reading columns with a 48-byte stride.  Written once per
+// linearisation, read once per PCG iteration.  other = -1: the term is skipped (disabled factor, fixed neighbour).
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_pg_build_csr(int n_inc, const int2* __restrict__ ij,
+                                                             const int* __restrict__ inc_edge,
+                                                             const uint8_t* __restrict__ enabled,
+                                                             const uint8_t* __restrict__ fixed,
+                                                             const double* __restrict__ Ho, double* __restrict__ Hcsr,
+                                                             int* __restrict__ inc_other) {
+  const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t) n_inc * D * D) return;
+  const int q = (int) (idx / (D * D)), k = (int) (idx - (size_t) q * D * D);
+  const int code = inc_edge[q];
+  const int e    = code >> 1;
+  const int2 vv  = ij[e];
+  const int other = (code & 1) ? vv.x : vv.y;
+  const bool skip = !enabled[e] || fixed[other];
+  const int r = k / D, c = k - r * D;
+  Hcsr[idx] = skip ? 0.0 : ((code & 1) ? Ho[(size_t) e * D * D + c * D + r] : Ho[(size_t) e * D * D + k]);
+  if (k == 0) inc_other[q] = skip ? -1 : other;
+}
+
 // ---- deterministic block reduction of one double per thread -> partial[blockIdx.x] ------------------------------
 __device__ double block_sum(double v) {
   __shared__ double sh[PG_THREADS / 64];
@@ -308,10 +332,9 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_pcg_init(int n, const double*
 // Ap = A p; partial p.Ap.  First launch of an iteration also folds the scalars of the init / previous update.
 template <int D>
 __global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(int n, const uint8_t* __restrict__ fixed,
-                                                        const int2* __restrict__ ij, const int* __restrict__ inc_start,
-                                                        const int* __restrict__ inc_edge,
-                                                        const uint8_t* __restrict__ enabled,
-                                                        const double* __restrict__ Hd, const double* __restrict__ Ho,
+                                                        const int* __restrict__ inc_start,
+                                                        const int* __restrict__ inc_other,
+                                                        const double* __restrict__ Hd, const double* __restrict__ Hcsr,
                                                         const double* __restrict__ p, double* __restrict__ Ap,
                                                         double* __restrict__ part_pAp, const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
@@ -323,22 +346,14 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(int n, const uint8_t* __
 #pragma unroll
     for (int c = 0; c < D; ++c) y = y + Hd[((size_t) v * D + row) * D + c] * p[(size_t) v * D + c];
     if (!fixed[v]) {
+      // the D row-threads of a variable read consecutive rows of consecutive blocks: one contiguous stream per block
       for (int q = inc_start[v]; q < inc_start[v + 1]; ++q) {
-        const int code = inc_edge[q];
-        const int e    = code >> 1;
-        if (!enabled[e]) continue;
-        const int2 vv   = ij[e];
-        const int other = (code & 1) ? vv.x : vv.y;
-        if (fixed[other]) continue;
-        const double* B = Ho + (size_t) e * D * D;
+        const int other = inc_other[q];
+        if (other < 0) continue;
+        const double* B = Hcsr + ((size_t) q * D + row) * D;
         double s        = 0.0;
-        if (code & 1) {  // v is the `to` vertex: H_ji = H_ij^T
 #pragma unroll
-          for (int c = 0; c < D; ++c) s = s + B[c * D + row] * p[(size_t) other * D + c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < D; ++c) s = s + B[row * D + c] * p[(size_t) other * D + c];
-        }
+        for (int c = 0; c < D; ++c) s = s + B[c] * p[(size_t) other * D + c];
         y = y + s;
       }
     }
@@ -435,9 +450,9 @@ struct srrg2_posegraph_s {
   DevBuf<float> poses, Z;
   DevBuf<uint8_t> fixed, enabled;
   DevBuf<int2> ij;
-  DevBuf<double> omega, Hd, Ho, b, Minv, x, r, z, p, Ap, contrib;
+  DevBuf<double> omega, Hd, Ho, Hcsr, b, Minv, x, r, z, p, Ap, contrib;
   DevBuf<double> part_rz, part_rz_new, part_pAp, part_rr, part_bb, part_chi;
-  DevBuf<int> part_n, inc_start, inc_edge;
+  DevBuf<int> part_n, inc_start, inc_edge, inc_other;
   DevBuf<PgScalars> sc;
 };
 
@@ -456,6 +471,8 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   if ((rc = g->Hd.reserve((size_t) std::max(V, 1) * D * D))) return rc;
   if ((rc = g->Minv.reserve((size_t) std::max(V, 1) * D * D))) return rc;
   if ((rc = g->Ho.reserve((size_t) std::max(E, 1) * D * D))) return rc;
+  if ((rc = g->Hcsr.reserve((size_t) std::max(2 * E, 1) * D * D))) return rc;
+  if ((rc = g->inc_other.reserve((size_t) std::max(2 * E, 1)))) return rc;
   if ((rc = g->contrib.reserve((size_t) std::max(E, 1) * (sizeof(EdgeContrib<D>) / sizeof(double))))) return rc;
   for (DevBuf<double>* v : {&g->b, &g->x, &g->r, &g->z, &g->p, &g->Ap})
     if ((rc = v->reserve((size_t) std::max(n, 1)))) return rc;
@@ -473,6 +490,12 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     if (E > 0)
       hipLaunchKernelGGL(k_pg_edges<D>, dim3(nbe), dim3(PG_THREADS), 0, g->stream, E, T, g->poses.p, g->ij.p, g->Z.p,
                          g->omega.p, g->enabled.p, g->Ho.p, contrib);
+    if (E > 0) {
+      const size_t nel = (size_t) 2 * E * D * D;
+      hipLaunchKernelGGL(k_pg_build_csr<D>, dim3((unsigned) ((nel + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0,
+                         g->stream, 2 * E, g->ij.p, g->inc_edge.p, g->enabled.p, g->fixed.p, g->Ho.p, g->Hcsr.p,
+                         g->inc_other.p);
+    }
     hipLaunchKernelGGL(k_pg_chi, dim3(nchi), dim3(PG_THREADS), 0, g->stream, E, g->enabled.p, (const void*) contrib,
                        cstride, chi_off, g->part_chi.p, g->part_n.p);
     hipLaunchKernelGGL(k_pg_vertices<D>, dim3(nbv), dim3(PG_THREADS), 0, g->stream, V, g->fixed.p, g->inc_start.p,
@@ -486,8 +509,8 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       for (int k = 0; k < chunk; ++k) {
         double* rz_cur = ((launched + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
         double* rz_nxt = ((launched + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
-        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->fixed.p, g->ij.p, g->inc_start.p,
-                           g->inc_edge.p, g->enabled.p, g->Hd.p, g->Ho.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
+        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->fixed.p, g->inc_start.p,
+                           g->inc_other.p, g->Hd.p, g->Hcsr.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_update_xr<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, g->Minv.p, g->p.p, g->Ap.p,
                            g->x.p, g->r.p, g->z.p, rz_cur, g->part_pAp.p, g->part_rr.p, rz_nxt, g->sc.p);
         hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance,
@@ -558,7 +581,7 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   (void) hipSetDevice(g->device);
   if (g->stream) (void) hipStreamSynchronize(g->stream);
   g->poses.release(); g->Z.release(); g->fixed.release(); g->enabled.release(); g->ij.release(); g->omega.release();
-  g->Hd.release(); g->Ho.release(); g->b.release(); g->Minv.release(); g->x.release(); g->r.release(); g->z.release();
+  g->Hd.release(); g->Ho.release(); g->Hcsr.release(); g->inc_other.release(); g->b.release(); g->Minv.release(); g->x.release(); g->r.release(); g->z.release();
   g->p.release(); g->Ap.release(); g->contrib.release(); g->part_rz.release(); g->part_rz_new.release();
   g->part_pAp.release(); g->part_rr.release(); g->part_bb.release(); g->part_chi.release(); g->part_n.release();
   g->inc_start.release(); g->inc_edge.release(); g->sc.release();
