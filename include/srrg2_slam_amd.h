@@ -295,6 +295,22 @@ int srrg2_posegraph_solve(srrg2_posegraph_h h, const srrg2_posegraph_params* p, 
                           int* n_inout);
 int srrg2_posegraph_get_poses(srrg2_posegraph_h h, float* poses_out);
 
+/* Incremental interface = the pose-graph lifecycle of MultiGraphSLAM_.  The graph
+ * stays in device memory between solves; graph ids are indices in insertion order.
+ *   add_variable          _graph->addVariable(local map)  (S/system/multi_graph_slam_impl.cpp:70; the first one is
+ *                         Fixed, :86: pass fixed = 1)
+ *   add_factor            _graph->addFactor(odometry factor / closure)  (:71-79, :238-241); information = D x D
+ *                         row-major or null for identity; closures enter with enabled = 0
+ *   set_factor_enabled    closure->setEnabled(true) after validation  (:247-249, :283-286)
+ *   remove_factor         _graph->removeFactor(rejected closure)  (:279-281); the other ids do not change
+ *   size                  variables, factors still in the graph, enabled factors */
+int srrg2_posegraph_add_variable(srrg2_posegraph_h h, const float* pose, int fixed, int* id_out);
+int srrg2_posegraph_add_factor(srrg2_posegraph_h h, int i, int j, const float* Z, const float* information, int enabled,
+                               int* id_out);
+int srrg2_posegraph_set_factor_enabled(srrg2_posegraph_h h, int factor_id, int enabled);
+int srrg2_posegraph_remove_factor(srrg2_posegraph_h h, int factor_id);
+int srrg2_posegraph_size(srrg2_posegraph_h h, int* num_variables, int* num_factors, int* num_enabled_factors);
+
 /* ---- scene slices kept in HBM between frames: clipping and correspondence-based merging ------
  * the tracker-side steps either side of align()
  * (S/trackers/tracker_slice_processor_impl.cpp:111-205: merge(), clip()).  A scene is a point

@@ -454,6 +454,10 @@ struct srrg2_posegraph_s {
   DevBuf<double> part_rz, part_rz_new, part_pAp, part_rr, part_bb, part_chi;
   DevBuf<int> part_n, inc_start, inc_edge, inc_other;
   DevBuf<PgScalars> sc;
+  // host mirrors for the incremental interface (incidence lists are rebuilt lazily from these)
+  std::vector<int> h_ij;
+  std::vector<uint8_t> h_enabled, h_removed;
+  bool inc_dirty = false;
 };
 
 namespace {
@@ -556,6 +560,49 @@ void srrg2_posegraph_default_params(srrg2_posegraph_params* p) {
   p->damping            = 0.f;
 }
 
+}  // extern "C" (reopened below)
+namespace {
+// grow a device array keeping its first `keep` elements (DevBuf::reserve drops the content)
+template <typename T>
+int grow_keep(DevBuf<T>& b, size_t keep, size_t want) {
+  if (want <= b.cap) return 0;
+  DevBuf<T> nb;
+  int rc;
+  if ((rc = nb.reserve(want + want / 2 + 64))) return rc;
+  if (keep > 0) HIP_TRY(hipMemcpy(nb.p, b.p, sizeof(T) * keep, hipMemcpyDeviceToDevice));
+  b.release();
+  b = nb;
+  return 0;
+}
+
+// incidence lists in (vertex, edge id) order: fixed summation order of the diagonal blocks
+int upload_incidence(srrg2_posegraph_s* g) {
+  const int V = g->V, E = g->E;
+  int rc;
+  if ((rc = g->inc_start.reserve((size_t) V + 1))) return rc;
+  if ((rc = g->inc_edge.reserve((size_t) std::max(2 * E, 1)))) return rc;
+  std::vector<int> start((size_t) V + 1, 0), inc((size_t) std::max(2 * E, 1), 0);
+  const int* ij = g->h_ij.data();
+  for (int e = 0; e < E; ++e) {
+    start[ij[2 * e] + 1]++;
+    start[ij[2 * e + 1] + 1]++;
+  }
+  for (int v = 0; v < V; ++v) start[v + 1] += start[v];
+  {
+    std::vector<int> cur(start.begin(), start.end() - 1);
+    for (int e = 0; e < E; ++e) {
+      inc[cur[ij[2 * e]]++]     = 2 * e;
+      inc[cur[ij[2 * e + 1]]++] = 2 * e + 1;
+    }
+  }
+  HIP_TRY(hipMemcpy(g->inc_start.p, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->inc_edge.p, inc.data(), sizeof(int) * inc.size(), hipMemcpyHostToDevice));
+  g->inc_dirty = false;
+  return 0;
+}
+}  // namespace
+extern "C" {
+
 int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out) {
   if (!out || (variable_kind != SRRG2_SE2_RIGHT && variable_kind != SRRG2_SE3_QUAT_RIGHT))
     return fail(SRRG2_E_INVALID, "posegraph_create: variable kind must be SE2_RIGHT or SE3_QUAT_RIGHT");
@@ -621,30 +668,105 @@ int srrg2_posegraph_set(srrg2_posegraph_h g, int V, const float* poses, const ui
     for (int a = 0; a < D; ++a)
       for (int b = 0; b < D; ++b)
         om[((size_t) e * D + a) * D + b] = omega ? (double) omega[((size_t) e * D + a) * D + b] : (a == b ? 1.0 : 0.0);
-  // incidence lists in (vertex, edge id) order: fixed summation order of the diagonal blocks
-  std::vector<int> start((size_t) V + 1, 0), inc((size_t) std::max(2 * E, 1), 0);
-  for (int e = 0; e < E; ++e) {
-    start[ij[2 * e] + 1]++;
-    start[ij[2 * e + 1] + 1]++;
-  }
-  for (int v = 0; v < V; ++v) start[v + 1] += start[v];
-  {
-    std::vector<int> cur(start.begin(), start.end() - 1);
-    for (int e = 0; e < E; ++e) {
-      inc[cur[ij[2 * e]]++]     = 2 * e;
-      inc[cur[ij[2 * e + 1]]++] = 2 * e + 1;
-    }
-  }
   HIP_TRY(hipMemcpy(g->poses.p, poses, sizeof(float) * (size_t) V * T, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->fixed.p, fx.data(), (size_t) std::max(V, 1), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->ij.p, ij, sizeof(int32_t) * 2 * (size_t) E, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->Z.p, Z, sizeof(float) * (size_t) E * T, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->omega.p, om.data(), sizeof(double) * om.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->enabled.p, en.data(), (size_t) std::max(E, 1), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(g->inc_start.p, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(g->inc_edge.p, inc.data(), sizeof(int) * inc.size(), hipMemcpyHostToDevice));
   g->V = V;
   g->E = E;
+  g->h_ij.assign(ij, ij + 2 * (size_t) E);
+  g->h_enabled.assign(en.begin(), en.begin() + E);
+  g->h_removed.assign((size_t) E, 0);
+  return upload_incidence(g);
+}
+
+/* ---- incremental interface: the pose-graph lifecycle of MultiGraphSLAM_ (S/system/multi_graph_slam_impl.cpp:52-90
+ * makeNewMap, :227-297 loopValidate, :300-317 optimize).  The arrays stay on the device between solves; appends grow
+ * them in place, the incidence lists are rebuilt at the next solve. */
+int srrg2_posegraph_add_variable(srrg2_posegraph_h g, const float* pose, int fixed, int* id_out) {
+  if (!g || !pose) return fail(SRRG2_E_INVALID, "posegraph_add_variable: bad arguments");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  const int V = g->V, T = g->T;
+  int rc;
+  if ((rc = grow_keep(g->poses, (size_t) V * T, (size_t) (V + 1) * T))) return rc;
+  if ((rc = grow_keep(g->fixed, (size_t) V, (size_t) V + 1))) return rc;
+  const uint8_t fx = fixed ? 1 : 0;
+  HIP_TRY(hipMemcpy(g->poses.p + (size_t) V * T, pose, sizeof(float) * (size_t) T, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->fixed.p + V, &fx, 1, hipMemcpyHostToDevice));
+  if (id_out) *id_out = V;  // graph ids are indices
+  g->V         = V + 1;
+  g->inc_dirty = true;
+  return 0;
+}
+
+int srrg2_posegraph_add_factor(srrg2_posegraph_h g, int i, int j, const float* Z, const float* information, int enabled,
+                               int* id_out) {
+  if (!g || !Z) return fail(SRRG2_E_INVALID, "posegraph_add_factor: bad arguments");
+  if (i < 0 || i >= g->V || j < 0 || j >= g->V || i == j) return fail(SRRG2_E_INVALID, "posegraph_add_factor: bad endpoints");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  const int E = g->E, T = g->T, D = g->D;
+  int rc;
+  if ((rc = grow_keep(g->ij, (size_t) E, (size_t) E + 1))) return rc;
+  if ((rc = grow_keep(g->Z, (size_t) E * T, (size_t) (E + 1) * T))) return rc;
+  if ((rc = grow_keep(g->omega, (size_t) E * D * D, (size_t) (E + 1) * D * D))) return rc;
+  if ((rc = grow_keep(g->enabled, (size_t) E, (size_t) E + 1))) return rc;
+  double om[36];
+  for (int a = 0; a < D; ++a)
+    for (int b = 0; b < D; ++b) om[a * D + b] = information ? (double) information[a * D + b] : (a == b ? 1.0 : 0.0);
+  const int2 e2    = make_int2(i, j);
+  const uint8_t en = enabled ? 1 : 0;
+  HIP_TRY(hipMemcpy(g->ij.p + E, &e2, sizeof(int2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->Z.p + (size_t) E * T, Z, sizeof(float) * (size_t) T, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->omega.p + (size_t) E * D * D, om, sizeof(double) * (size_t) D * D, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->enabled.p + E, &en, 1, hipMemcpyHostToDevice));
+  g->h_ij.push_back(i);
+  g->h_ij.push_back(j);
+  g->h_enabled.push_back(en);
+  g->h_removed.push_back(0);
+  if (id_out) *id_out = E;
+  g->E         = E + 1;
+  g->inc_dirty = true;
+  return 0;
+}
+
+/* FactorBase::setEnabled (closures are added disabled and promoted by the validator, :238-241, :283-286) */
+int srrg2_posegraph_set_factor_enabled(srrg2_posegraph_h g, int factor_id, int enabled) {
+  if (!g || factor_id < 0 || factor_id >= g->E) return fail(SRRG2_E_INVALID, "posegraph_set_factor_enabled: bad factor id");
+  if (g->h_removed[(size_t) factor_id]) return fail(SRRG2_E_STATE, "posegraph_set_factor_enabled: factor was removed");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  const uint8_t en = enabled ? 1 : 0;
+  g->h_enabled[(size_t) factor_id] = en;
+  HIP_TRY(hipMemcpy(g->enabled.p + factor_id, &en, 1, hipMemcpyHostToDevice));
+  return 0;
+}
+
+/* FactorGraph::removeFactor (rejected closures, :279-281): the ids of the other factors do not change */
+int srrg2_posegraph_remove_factor(srrg2_posegraph_h g, int factor_id) {
+  if (!g || factor_id < 0 || factor_id >= g->E) return fail(SRRG2_E_INVALID, "posegraph_remove_factor: bad factor id");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  const uint8_t en = 0;
+  g->h_enabled[(size_t) factor_id] = 0;
+  g->h_removed[(size_t) factor_id] = 1;
+  HIP_TRY(hipMemcpy(g->enabled.p + factor_id, &en, 1, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int srrg2_posegraph_size(srrg2_posegraph_h g, int* num_variables, int* num_factors, int* num_enabled_factors) {
+  if (!g) return fail(SRRG2_E_INVALID, "posegraph_size: null handle");
+  int nf = 0, ne = 0;
+  for (int e = 0; e < g->E; ++e) {
+    nf += g->h_removed[(size_t) e] ? 0 : 1;
+    ne += g->h_enabled[(size_t) e] ? 1 : 0;
+  }
+  if (num_variables) *num_variables = g->V;
+  if (num_factors) *num_factors = nf;
+  if (num_enabled_factors) *num_enabled_factors = ne;
   return 0;
 }
 
@@ -652,7 +774,8 @@ int srrg2_posegraph_set_enabled(srrg2_posegraph_h g, const uint8_t* enabled) {
   if (!g || !enabled) return fail(SRRG2_E_INVALID, "posegraph_set_enabled: bad arguments");
   HIP_TRY(hipSetDevice(g->device));
   std::vector<uint8_t> en((size_t) std::max(g->E, 1), 1);
-  for (int e = 0; e < g->E; ++e) en[e] = enabled[e] ? 1 : 0;
+  for (int e = 0; e < g->E; ++e) en[e] = (enabled[e] && !g->h_removed[(size_t) e]) ? 1 : 0;
+  g->h_enabled.assign(en.begin(), en.begin() + g->E);
   HIP_TRY(hipMemcpy(g->enabled.p, en.data(), (size_t) std::max(g->E, 1), hipMemcpyHostToDevice));
   return 0;
 }
@@ -665,6 +788,10 @@ int srrg2_posegraph_solve(srrg2_posegraph_h g, const srrg2_posegraph_params* p, 
   if (g->V == 0) {
     if (n_inout) *n_inout = 0;
     return 0;
+  }
+  if (g->inc_dirty) {
+    int rc = upload_incidence(g);
+    if (rc) return rc;
   }
   return g->D == 6 ? pg_solve_t<6>(g, p, stats, n_inout) : pg_solve_t<3>(g, p, stats, n_inout);
 }

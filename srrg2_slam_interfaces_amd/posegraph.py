@@ -89,6 +89,41 @@ class PoseGraph:
         assert enabled.size == self.E
         self._check(self._fn("set_enabled")(self._h, enabled.ctypes.data_as(C.POINTER(C.c_uint8))))
 
+    # -- incremental interface (product backend): the lifecycle of MultiGraphSLAM_, multi_graph_slam_impl.cpp:52-90,227-297
+    def add_variable(self, pose, fixed=False):
+        pose = np.ascontiguousarray(pose, np.float32).reshape(-1)
+        assert pose.size == self.tsize
+        vid = C.c_int(-1)
+        self._check(self._fn("add_variable")(self._h, pose.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(int(fixed)),
+                                             C.byref(vid)))
+        self.V += 1
+        return vid.value
+
+    def add_factor(self, i, j, Z, information=None, enabled=True):
+        Z = np.ascontiguousarray(Z, np.float32).reshape(-1)
+        assert Z.size == self.tsize
+        info = None
+        if information is not None:
+            information = np.ascontiguousarray(information, np.float32).reshape(self.D * self.D)
+            info = information.ctypes.data_as(C.POINTER(C.c_float))
+        fid = C.c_int(-1)
+        self._check(self._fn("add_factor")(self._h, C.c_int(i), C.c_int(j), Z.ctypes.data_as(C.POINTER(C.c_float)), info,
+                                           C.c_int(int(enabled)), C.byref(fid)))
+        self.E += 1
+        return fid.value
+
+    def set_factor_enabled(self, factor_id, enabled):
+        self._check(self._fn("set_factor_enabled")(self._h, C.c_int(factor_id), C.c_int(int(enabled))))
+
+    def remove_factor(self, factor_id):
+        self._check(self._fn("remove_factor")(self._h, C.c_int(factor_id)))
+
+    def size(self):
+        """(variables, factors still in the graph, enabled factors)"""
+        v, f, e = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._fn("size")(self._h, C.byref(v), C.byref(f), C.byref(e)))
+        return v.value, f.value, e.value
+
     def solve(self, params=None):
         params = params or default_params()
         n = C.c_int(max(params.max_iterations, 1))

@@ -1,0 +1,79 @@
+"""-m gpu: the incremental pose-graph interface (srrg2_posegraph_add_variable / add_factor / set_factor_enabled /
+remove_factor) against the one-shot interface and the CPU oracle, driven through the MultiGraphSLAM_ lifecycle mirror
+(S/system/multi_graph_slam_impl.cpp:52-90, :227-297, :300-317)."""
+import numpy as np
+import pytest
+
+from srrg2_slam_interfaces_amd import _abi as abi
+from srrg2_slam_interfaces_amd import graph_slam
+from srrg2_slam_interfaces_amd import posegraph as pgm
+from srrg2_slam_interfaces_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(Xi, Xj):
+    A = np.vstack([Xi, [0, 0, 0, 1]]).astype(np.float64)
+    B = np.vstack([Xj, [0, 0, 0, 1]]).astype(np.float64)
+    return (np.linalg.inv(A) @ B)[:3].astype(np.float32)
+
+
+def test_lifecycle_matches_one_shot_graph_and_oracle(oracle, product):
+    kind = abi.SE3_QUAT_RIGHT
+    g = syn.pose_graph_3d(V=400, E=1200, seed=77)  # ground truth, noisy initial poses, odometry chain + closures
+    poses0, ij, Z = g["poses_init"], g["ij"], g["Z"]
+    V = poses0.shape[0]
+    chain = [e for e in range(len(ij)) if ij[e][1] == ij[e][0] + 1]
+    closures = [e for e in range(len(ij)) if e not in set(chain)]
+    assert len(chain) == V - 1 and len(closures) > 100
+    inc = product.PoseGraph(kind, 0)
+    life = graph_slam.GraphSLAMLifecycle(inc)
+    by_pair = {tuple(ij[e]): e for e in chain}
+    # local maps arrive one by one; every 100 maps a batch of closures is detected, validated, optimised
+    params = pgm.PoseGraphParams(5, 100, 1e-8, 0.0)
+    rejected, accepted_edges, order = set(), [], []
+    pending = sorted(closures, key=lambda e: max(ij[e]))
+    for v in range(V):
+        Zodo = Z[by_pair[(v - 1, v)]] if v > 0 else syn.identity(3)
+        life.make_new_map(poses0[v], Zodo)
+        if v > 0:
+            order.append(by_pair[(v - 1, v)])
+        if v % 100 == 99 or v == V - 1:
+            batch = [e for e in pending if max(ij[e]) <= v]
+            pending = [e for e in pending if max(ij[e]) > v]
+            verdict = lambda ids: [graph_slam.REJECTED if k % 5 == 0 else graph_slam.ACCEPTED for k in range(len(ids))]
+            before = inc.size()
+            acc = life.loop_validate([(int(ij[e][0]), int(ij[e][1]), Z[e], None) for e in batch], verdict)
+            order.extend(batch)
+            rejected.update(e for k, e in enumerate(batch) if k % 5 == 0)
+            assert len(acc) == len(batch) - len([k for k in range(len(batch)) if k % 5 == 0])
+            after = inc.size()
+            assert after[1] - before[1] == len(acc) and after[0] == v + 1
+            assert life.num_valid_closures == len(acc)
+    stats_inc = life.optimize(params)
+    assert len(stats_inc) == 5
+    # the same graph in one shot (same factor order), rejected closures disabled: product and oracle
+    ij1 = np.array([ij[e] for e in order], np.int32)
+    Z1 = np.array([Z[e] for e in order], np.float32)
+    en1 = np.array([0 if e in rejected else 1 for e in order], np.uint8)
+    fixed = np.zeros(V, np.uint8); fixed[0] = 1
+    one = product.PoseGraph(kind, 0)
+    one.set_graph(poses0, ij1, Z1, fixed_mask=fixed, enabled=en1)
+    stats_one = one.solve(params)
+    assert [s["chi"] for s in stats_inc] == [s["chi"] for s in stats_one]
+    assert inc.poses().tobytes() == one.poses().tobytes()
+    ref = oracle.OraclePoseGraph(kind)
+    ref.set_graph(poses0, ij1, Z1, fixed_mask=fixed, enabled=en1)
+    stats_ref = ref.solve(params)
+    assert np.max(np.abs(ref.poses() - inc.poses())) < 1e-4
+    assert abs(stats_ref[-1]["chi"] - stats_inc[-1]["chi"]) <= 1e-3 * max(1.0, stats_ref[-1]["chi"])
+    assert stats_inc[-1]["chi"] < 0.05 * stats_inc[0]["chi"]
+    # misuse
+    with pytest.raises(RuntimeError):
+        inc.add_factor(0, V, Z[0])
+    removed = order.index(next(iter(rejected)))
+    with pytest.raises(RuntimeError):
+        inc.set_factor_enabled(removed, True)
+    # no valid closure -> optimize() is a no-op (multi_graph_slam_impl.cpp:302-304)
+    life.loop_validate([])
+    assert life.optimize(params) == []
