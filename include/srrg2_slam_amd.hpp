@@ -10,6 +10,7 @@
 //   MotionModelConstantVelocity     MotionModelConstantVelocity<Estimate>  motion_models/motion_model_constant_velocity.hpp
 //   AlignerSliceMotionModel         AlignerSliceMotionModel_               aligner_slice_motion_model.hpp:13-92
 //   AlignerSliceOdomPrior           AlignerSliceOdom{2,3}DPrior            aligner_slice_odometry_prior.{h,cpp}
+//   Scene / SceneClipperBall / MergerCorrespondenceHomo                    mapping/scene_clipper.h, merger_correspondence_homo.h
 #pragma once
 #include <array>
 #include <cstring>
@@ -263,6 +264,125 @@ private:
   int _count                        = 0;
   const EstimateType* _fixed_slice  = nullptr;
   const EstimateType* _moving_slice = nullptr;
+};
+
+// ---- scene slices in device memory: SceneClipper_ / MergerCorrespondenceHomo_ ------
+//   Scene                       a PointNormal{2,3}f cloud living in HBM (LocalMap scene slice / measurement)
+//   SceneClipperBall            SceneClipper_<Estimate, Scene>              S/mapping/scene_clipper.h:17-122
+//   MergerCorrespondenceHomo    MergerCorrespondenceHomo_<Estimate, Scene>  S/mapping/merger_correspondence_homo.h
+template <int DIM>
+class Scene {
+public:
+  explicit Scene(int device = 0) { check(srrg2_scene_create(DIM, device, &_h)); }
+  ~Scene() { srrg2_scene_destroy(_h); }
+  Scene(const Scene&)            = delete;
+  Scene& operator=(const Scene&) = delete;
+  void set(const float* coords, int stride_bytes, const float* normals, int normal_stride_bytes, int n,
+           int mem = SRRG2_MEM_HOST) {
+    check(srrg2_scene_set(_h, coords, stride_bytes, normals, normal_stride_bytes, n, mem));
+  }
+  int size() const {
+    int n = 0;
+    check(srrg2_scene_size(_h, &n));
+    return n;
+  }
+  // packed DIM-float records
+  void get(std::vector<float>& coords, std::vector<float>& normals) const {
+    int n = size();
+    coords.assign((size_t) n * DIM, 0.f);
+    normals.assign((size_t) n * DIM, 0.f);
+    check(srrg2_scene_get(_h, coords.data(), normals.data(), n, &n));
+  }
+  // device float4 arrays (stride 16 bytes), e.g. for MultiAligner_::setMoving(..., SRRG2_MEM_DEVICE)
+  void deviceArrays(const float*& coords, const float*& normals, int& n) const {
+    check(srrg2_scene_device_arrays(_h, &coords, &normals, &n));
+  }
+  srrg2_scene_h handle() const { return _h; }
+
+private:
+  srrg2_scene_h _h = nullptr;
+};
+
+template <int DIM>
+class SceneClipperBall {
+public:
+  enum Status { Error = 0, Successful = 1, Ready = 2 };  // scene_clipper.h:24-28
+  using EstimateType = Isometry<DIM>;
+  using SceneType    = Scene<DIM>;
+  float param_range  = 10.f;
+  void setFullScene(SceneType* s) { _full = s; }
+  void setClippedSceneInRobot(SceneType* s) { _clipped = s; }
+  void setRobotInLocalMap(const EstimateType& T) { _robot_in_local_map = T; }
+  void compute() {
+    if (!_full || !_clipped) throw std::runtime_error("SceneClipperBall::compute|scene not set");
+    int st = Error;
+    check(srrg2_scene_clip_ball(_full->handle(), _robot_in_local_map.data(), param_range, _clipped->handle(), &st));
+    _status = static_cast<Status>(st);
+  }
+  Status status() const { return _status; }
+  std::vector<int> globalIndices() const {  // :98-101
+    int n = 0;
+    check(srrg2_scene_global_indices(_clipped->handle(), nullptr, &n));
+    std::vector<int> v((size_t) n);
+    if (n) check(srrg2_scene_global_indices(_clipped->handle(), v.data(), &n));
+    return v;
+  }
+
+private:
+  SceneType* _full    = nullptr;
+  SceneType* _clipped = nullptr;
+  EstimateType _robot_in_local_map = EstimateType::Identity();
+  Status _status = Error;
+};
+
+template <int DIM>
+class MergerCorrespondenceHomo {
+public:
+  enum Status { Error = 0, Initializing = 1, Success = 2 };  // merger.h:19-23
+  using EstimateType = Isometry<DIM>;
+  using SceneType    = Scene<DIM>;
+  // PARAMs: merger_correspondence_homo.h:22-31, merger.h:126-131
+  float param_maximum_response                  = 50.f;
+  float param_maximum_distance_geometry_squared = 0.25f;
+  unsigned param_target_number_of_merges        = 200;
+  void setScene(SceneType* s) { _scene = s; }
+  void setMeasurement(const SceneType* m) { _meas = m; }
+  void setMeasurementInScene(const EstimateType& T) { _T = T; }
+  void setCorrespondences(const CorrespondenceVector* c) { _corr = c; }  // nullptr: none set (impl.cpp:30)
+  void compute() {
+    ready();
+    srrg2_merger_params p = params();
+    check(srrg2_scene_merge(_scene->handle(), _meas->handle(), _T.data(), _corr ? _corr->data() : nullptr,
+                            _corr ? (int) _corr->size() : -1, &p, &_last));
+    _status = static_cast<Status>(_last.status);
+  }
+  // correspondences taken on the device from the aligner run that matched `clipped` (moving) against the measurement
+  // (fixed): TrackerSliceProcessor_::merge(), tracker_slice_processor_impl.cpp:160-186
+  template <typename AlignerType>
+  void computeFromAligner(AlignerType& aligner, int slice, const SceneType& clipped) {
+    ready();
+    srrg2_merger_params p = params();
+    check(srrg2_scene_merge_from_aligner(_scene->handle(), _meas->handle(), _T.data(), aligner.handle(), slice,
+                                         clipped.handle(), &p, &_last));
+    _status = static_cast<Status>(_last.status);
+  }
+  Status status() const { return _status; }
+  const srrg2_merge_result& last() const { return _last; }
+
+private:
+  void ready() const {
+    if (!_scene || !_meas) throw std::runtime_error("MergerCorrespondenceHomo::compute|scene or measurement not set");
+  }
+  srrg2_merger_params params() const {
+    return srrg2_merger_params{param_maximum_response, param_maximum_distance_geometry_squared,
+                               (int32_t) param_target_number_of_merges};
+  }
+  SceneType* _scene       = nullptr;
+  const SceneType* _meas  = nullptr;
+  const CorrespondenceVector* _corr = nullptr;
+  EstimateType _T = EstimateType::Identity();
+  srrg2_merge_result _last{};
+  Status _status = Error;
 };
 
 }  // namespace srrg2_slam_amd

@@ -9,6 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(CPP, "bin", "test_motion_model_slice")
+BIN_CYCLE = os.path.join(CPP, "bin", "test_tracker_cycle")
 
 
 def _build():
@@ -17,7 +18,7 @@ def _build():
 
 def test_cpp_mirror_compiles_and_links():
     _build()
-    assert os.path.exists(BIN)
+    assert os.path.exists(BIN) and os.path.exists(BIN_CYCLE)
 
 
 @pytest.mark.gpu
@@ -25,5 +26,15 @@ def test_cpp_reference_scenarios_on_gpu():
     if not os.path.exists(BIN):
         _build()
     out = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASSED" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_tracker_cycle_on_gpu():
+    """clip -> align -> merge through SceneClipperBall / MultiAligner3DQR / MergerCorrespondenceHomo (C++ mirror)."""
+    if not os.path.exists(BIN_CYCLE):
+        _build()
+    out = subprocess.run([BIN_CYCLE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASSED" in out.stdout

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_graph_lifecycle.py tests/test_gpu_posegraph.py -x -q 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_cpp_mirror.py -x -q -m gpu 2>&1 | tail -15
