@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="c4: alignments per GPU per step")
     ap.add_argument("--batch-points", type=int, default=50_000)
     ap.add_argument("--cell-size", type=float, default=0.0)
+    ap.add_argument("--overlap", type=float, default=1.0, help="c2 experiment: keep this x-quantile of the fixed cloud")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -85,6 +86,10 @@ def main():
 
     if args.workload == "c2":
         data = syn.cloud_pair_3d(n=args.points, seed=2000 + 10 * rank)
+        if args.overlap < 1.0:  # (experiment, not the benchmark configuration) drop the fixed points beyond an x quantile:
+            import numpy as _np  # a share of the moving cloud then has no neighbour within the gate
+            keep = data["fixed"][:, 0] <= _np.quantile(data["fixed"][:, 0], args.overlap)
+            data["fixed"], data["fixed_normals"] = data["fixed"][keep], data["fixed_normals"][keep]
         al.set_fixed(0, data["fixed"], data["fixed_normals"])
         al.set_moving(0, data["moving"], data["moving_normals"])
         K_total = world  # one alignment per rank: alignment k lives on rank k (k mod G)

@@ -263,10 +263,11 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   }
   GridDev& g = s->grid;
   grid_dims(h, g);
-  g.gate2 = gate * gate;
-  g.n     = n;
-  int r   = 1;
-  while (bound2_of_host(r, h) < g.gate2 && r < 4096) ++r;
+  g.gate2     = gate * gate;
+  g.gate2_ext = (gate * 1.25f) * (gate * 1.25f);
+  g.n         = n;
+  int r       = 1;
+  while (bound2_of_host(r, h) < g.gate2_ext && r < 4096) ++r;
   g.rmax          = r;
   const int ncell = g.nx * g.ny * g.nz;
   if ((rc = s->cell_start.reserve((size_t) ncell + 1))) return rc;

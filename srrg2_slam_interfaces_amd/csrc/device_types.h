@@ -30,6 +30,7 @@ struct GridDev {
   int nx, ny, nz;
   int rmax;        // cube radius that covers the gate
   float gate2;     // max_distance^2
+  float gate2_ext; // (1.25 max_distance)^2: how far scans of unmatched points reach (rmax covers it)
   int n;           // number of fixed points (entries of pts)
   const int* cell_start;  // ncell + 1
   const float4* pts;

@@ -1032,6 +1032,11 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   const GridDev& g   = S.grid;
   const float b2_1   = bound2_of(1, g.h);
   const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
+  // Scans of points without a neighbour inside the gate reach 25% beyond it once a prior exists: what they find (a
+  // point just outside the gate, or nothing) then certifies "no match" for the following iterations without a search.
+  const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
+  int rfar         = 1;  // cube radius that covers the ball of radius sqrt(gfar) (g.rmax covers the extended gate)
+  while (rfar < g.rmax && bound2_of(rfar, g.h) < gfar) ++rfar;
   float Tprev[12];  // the finder transform of the previous iteration (its queries: q' = Tprev * p)
   load_finder_transform<DIM>(S, st->Xprev, Tprev);
 
@@ -1108,20 +1113,31 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       } else {
         pad            = 2.f * dl + 0.02f * g.h;
         const float rr = (d1 + pad) * 1.00001f;
-        r2box          = fminf(rr * rr, g.gate2);
+        r2box          = fminf(rr * rr, gfar);
+      }
+    } else if (use_prior && ppos < 0 && pm > 0.f && !(S.tune & (4096 | 65536))) {
+      // (c) no fixed point at all within m of q' (an empty scan left m behind): if gate + |q - q'| < m there is still
+      //     none within the gate of q: no match, no search
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p, px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      if (sqrtf(g.gate2) * 1.00001f + dl * 1.00001f < pm * 0.99999f) {
+        skipped = true;
+        excl    = pm * 0.99999f - dl * 1.00001f;  // (best = inf, bidx = NO_MATCH: stays "none")
       }
     }
   }
   // Converged iterations: a handful of lanes per wave still need a search (near-ties, lost exclusion radius) and would
   // make the whole wave pay the search latency.  Hand them to the deferred-search kernel, which is launched anyway.
   bool straggler = false;
-  if (S.queue && use_prior && g.rmax > 1 && !(S.tune & (16 | 8192))) {
+  if (S.queue && use_prior && rfar > 1 && !(S.tune & (16 | 8192))) {
     const bool need  = active && !skipped;
     const int n_need = __popcll(__ballot(need));
     if (need && n_need <= 8) {
       straggler = true;
-      ball2     = fminf(r2box, g.gate2);
-      r2        = ball2 <= bound2_of(2, g.h) ? 2 : g.rmax;
+      ball2     = fminf(r2box, gfar);
+      r2        = ball2 <= bound2_of(2, g.h) ? 2 : rfar;
     }
   }
   if (active && !(S.tune & 16)) {
@@ -1134,17 +1150,17 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos, b2, tl);
       best = key_best(bkey);
       bidx = key_idx(bkey);
-      const bool found1 = bidx != NO_MATCH && best <= g.gate2;
-      ball2             = g.gate2;
-      if (!(found1 && best <= b2_1) && g.rmax > 1) {
-        r2 = g.rmax;
+      const bool found1 = bidx != NO_MATCH && best <= gfar;  // a candidate that can bound the wider scan
+      ball2             = gfar;
+      if (!(found1 && best <= b2_1) && rfar > 1) {
+        r2 = rfar;
         if (found1) {
           // the wider scan covers the ball of the candidate plus a pad, so that it leaves an exclusion radius
           // larger than the neighbour's distance behind (otherwise these points would be searched every iteration)
           const float rr = (sqrtf(best) + pad) * 1.00001f;
-          ball2          = fminf(rr * rr, g.gate2);
+          ball2          = fminf(rr * rr, gfar);
           r2             = 1;
-          while (r2 < g.rmax && bound2_of(r2, g.h) < ball2) ++r2;
+          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
         }
       } else {
         // settled: the scan was complete inside min(ball, block); nothing but the winner is closer than this
@@ -1194,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     }
   } else {
     // radius-2 cube per lane, then the cooperative scan for what is still open
-    if (r2 > 1 && g.rmax >= 2 && !(S.tune & 2)) {
+    if (r2 > 1 && rfar >= 2 && !(S.tune & 2)) {
       // (starts from scratch: the cube contains the 3^DIM block again, and the runner-up tracking must meet every
       // fixed point exactly once)
       unsigned long long bkey = NO_KEY;
@@ -1202,18 +1218,18 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, ball2, bkey, bpos, b2);
       best = key_best(bkey);
       bidx = key_idx(bkey);
-      const bool found2 = bidx != NO_MATCH && best <= g.gate2;
-      if ((found2 && best <= bound2_of(2, g.h)) || g.rmax == 2) {
+      const bool found2 = bidx != NO_MATCH && best <= gfar;
+      if ((found2 && best <= bound2_of(2, g.h)) || rfar == 2) {
         r2        = 0;
         excl_wide = sqrtf(fminf(fminf(b2, ball2), bound2_of(2, g.h))) * 0.99999f;
       } else {
-        r2    = g.rmax;
-        ball2 = g.gate2;
+        r2    = rfar;
+        ball2 = gfar;
         if (found2) {
           const float rr = (sqrtf(best) + pad) * 1.00001f;
-          ball2          = fminf(rr * rr, g.gate2);
+          ball2          = fminf(rr * rr, gfar);
           r2             = 2;
-          while (r2 < g.rmax && bound2_of(r2, g.h) < ball2) ++r2;
+          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
         }
       }
     }

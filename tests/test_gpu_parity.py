@@ -228,3 +228,22 @@ def test_ball_trimmed_search_is_exact(oracle, product, offset, cell):
     a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, params=dict(max_iterations=6), guess=guess)
     assert_same_run(a_ref, a_gpu)
     assert a_ref.iteration_stats()[0]["num_correspondences"] > 1000
+
+
+@pytest.mark.parametrize("slice_kind", [abi.SLICE_P2PLANE, abi.SLICE_P2P])
+def test_partial_overlap_parity(oracle, product, slice_kind):
+    """40 % of the moving cloud has no neighbour within the gate (the fixed cloud is cropped): those points are
+    certified 'no match' by an empty scan reaching beyond the gate and then skip their searches; points just outside
+    the gate become (unmatched) nearest neighbours.  Results must stay those of the from-scratch search."""
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=30000, seed=2600, t=(0.08, -0.05, 0.03), rpy_deg=(1.5, -2.0, 2.5))
+    d = {k: v.copy() for k, v in d.items()}
+    keep = d["fixed"][:, 0] <= np.quantile(d["fixed"][:, 0], 0.6)
+    d["fixed"], d["fixed_normals"] = d["fixed"][keep], d["fixed_normals"][keep]
+    cfg = cue_config(kind, slice_kind, 0.25, abi.ROBUST_CAUCHY, 0.05)
+    a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg,
+                             params=dict(max_iterations=12, enable_inlier_only_runs=True))
+    assert a_ref.status() == abi.SUCCESS
+    assert_same_run(a_ref, a_gpu)
+    n_corr = a_ref.iteration_stats()[-1]["num_correspondences"]
+    assert 0.4 * 30000 < n_corr < 0.8 * 30000

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_cpp_mirror.py -x -q -m gpu 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "partial or trimmed" 2>&1 | tail -5
