@@ -449,6 +449,12 @@ __device__ __forceinline__ void test_candidate2(const float4 f, float qx, float 
 #else
 #define STAMP(slot, k) do { } while (0)
 #endif
+// margin of a trimmed scan beyond the previous neighbour's distance: 2 |q - q'| capped at PAD_CAP cells + 2% of a
+// cell.  A margin that turns out too small only means one more (trimmed) scan next iteration; measured on C2 / C4:
+// no cap 27.4k / 196k, 0.25: 28.1k / 199k, 0.1: 28.7k / 202k it/s.
+#ifndef PAD_CAP
+#define PAD_CAP 0.1f
+#endif
 #ifndef SCAN_W0
 #define SCAN_W0 1
 #endif
@@ -1111,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
         bpos    = ppos;
         excl    = pm * 0.99999f - dl * 1.00001f;
       } else {
-        pad            = 2.f * dl + 0.02f * g.h;
+        pad            = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
         const float rr = (d1 + pad) * 1.00001f;
         r2box          = fminf(rr * rr, gfar);
       }
