@@ -28,8 +28,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--iterations", type=int, default=10)  # aligner.h:30
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
