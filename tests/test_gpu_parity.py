@@ -247,3 +247,43 @@ def test_partial_overlap_parity(oracle, product, slice_kind):
     assert_same_run(a_ref, a_gpu)
     n_corr = a_ref.iteration_stats()[-1]["num_correspondences"]
     assert 0.4 * 30000 < n_corr < 0.8 * 30000
+
+
+@pytest.mark.parametrize("seed", list(range(64)))
+def test_randomised_configurations(oracle, product, seed):
+    """Random clouds, gates, cell sizes, overlaps, noise levels, robustifiers, iteration counts and flavours: the
+    finder's shortcuts (ball-trimmed scans, exclusion radii, certificates for unmatched points, deferred searches)
+    must never change a bit of the from-scratch result."""
+    rng = np.random.default_rng(1000 + seed)
+    dim3 = bool(rng.integers(0, 4))  # mostly 3-D
+    gate = float(rng.choice([0.1, 0.25, 0.6, 1.5]))
+    cell = float(rng.choice([0.0, 0.0, gate / 6, gate / 2, gate * 1.5]))
+    iters = int(rng.integers(2, 15))
+    rob = int(rng.choice([abi.ROBUST_NONE, abi.ROBUST_CAUCHY, abi.ROBUST_SATURATED, abi.ROBUST_CLAMP]))
+    inlier_runs = bool(rng.integers(0, 2))
+    if dim3:
+        kind = int(rng.choice([abi.SE3_QUAT_RIGHT, abi.SE3_EULER_RIGHT]))
+        n = int(rng.integers(500, 20000))
+        t = rng.uniform(-0.5, 0.5, 3) * gate
+        rpy = rng.uniform(-3.0, 3.0, 3)
+        d = syn.cloud_pair_3d(n=n, seed=3000 + seed, t=tuple(t), rpy_deg=tuple(rpy),
+                              noise_sigma=float(rng.choice([0.0, 0.01])))
+        d = {k: v.copy() for k, v in d.items()}
+        keep = d["fixed"][:, 1] <= np.quantile(d["fixed"][:, 1], float(rng.choice([1.0, 0.8, 0.5])))
+        d["fixed"], d["fixed_normals"] = d["fixed"][keep], d["fixed_normals"][keep]
+        if rng.integers(0, 2):  # thin out a part of the fixed cloud: neighbours at several cell radii
+            m = np.ones(len(d["fixed"]), bool)
+            m[: len(m) // 3][::2] = False
+            d["fixed"], d["fixed_normals"] = d["fixed"][m], d["fixed_normals"][m]
+    else:
+        kind = abi.SE2_RIGHT
+        d = syn.scan_pair_2d(beams=int(rng.integers(200, 3000)), sigma=float(rng.choice([0.0, 0.01])))
+    slice_kind = int(rng.choice([abi.SLICE_P2PLANE, abi.SLICE_P2P]))
+    cfg = cue_config(kind, slice_kind, gate, rob, float(rng.choice([0.01, 0.05, 0.5])),
+                     float(rng.choice([-1.0, 0.5, 0.8])))
+    cfg.finder_cell_size = cell
+    a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg,
+                             params=dict(max_iterations=iters, enable_inlier_only_runs=inlier_runs,
+                                         keep_only_inlier_correspondences=bool(rng.integers(0, 2))),
+                             moving_normals=bool(rng.integers(0, 4)))
+    assert_same_run(a_ref, a_gpu)

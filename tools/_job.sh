@@ -1,17 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -3
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py > gpurun_out/bench_r1_h.json 2> gpurun_out/bench_r1_h.err; tail -1 gpurun_out/bench_r1_h.json | cut -c1-200
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT/gpurun_out
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/r1e_c2_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2>&1; echo trace rc=$?
-for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $R/r1e_c2_pmc_$set -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "$set rc=$?"
-done
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/r1e_c4_trace -- python $GRAFT_REPO_ROOT/bench.py --workload c4 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; echo c4 rc=$?
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/r1e_c4_pmc_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; echo c4f rc=$?
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/r1e_c4_pmc_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --workload c4 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; echo c4w rc=$?
-cd $GRAFT_REPO_ROOT
-python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_r1_h_c3.json
-python bench.py --workload c4 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_r1_h_c4.json
-python tools/bench_posegraph.py 2>&1 | tail -1 > gpurun_out/bench_r1_h_c5.json
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "randomised" 2>&1 | tail -30
