@@ -287,3 +287,34 @@ def test_randomised_configurations(oracle, product, seed):
                                          keep_only_inlier_correspondences=bool(rng.integers(0, 2))),
                              moving_normals=bool(rng.integers(0, 4)))
     assert_same_run(a_ref, a_gpu)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_batches(oracle, product, seed):
+    """compute_batch (more than 4 alignments per launch: searches finish inside the step kernel, no deferred-search
+    kernel) on random batches against the oracle."""
+    rng = np.random.default_rng(5000 + seed)
+    kind = int(rng.choice([abi.SE3_QUAT_RIGHT, abi.SE3_EULER_RIGHT]))
+    K = int(rng.integers(5, 13))
+    gate = float(rng.choice([0.2, 0.35, 0.8]))
+    probs = syn.batch_3d(K=K, n=int(rng.integers(1000, 8000)), seed=6000 + 17 * seed, shared_fixed_group=64,
+                         t_max=float(rng.uniform(0.05, 0.6)) * gate, rpy_max_deg=float(rng.uniform(0.5, 4.0)))
+    fixed, fixed_n = probs[0]["fixed"].copy(), probs[0]["fixed_normals"].copy()
+    keep = fixed[:, 0] <= np.quantile(fixed[:, 0], float(rng.choice([1.0, 0.7])))
+    fixed, fixed_n = fixed[keep], fixed_n[keep]
+    cfg = cue_config(kind, int(rng.choice([abi.SLICE_P2PLANE, abi.SLICE_P2P])), gate,
+                     int(rng.choice([abi.ROBUST_NONE, abi.ROBUST_CAUCHY])), 0.05, float(rng.choice([-1.0, 0.7])))
+    cfg.finder_cell_size = float(rng.choice([0.0, gate / 5, gate]))
+    movs = [p["moving"][: int(rng.integers(len(p["moving"]) // 2, len(p["moving"]) + 1))] for p in probs]  # ragged
+    nrms = [p["moving_normals"][: len(m)] for p, m in zip(probs, movs)]
+    res = []
+    for al in _pair(oracle, product, kind):
+        al.set_params(max_iterations=int(4 + seed % 9), enable_inlier_only_runs=bool(seed % 2))
+        si = al.add_slice(cfg)
+        al.set_fixed(si, fixed, fixed_n)
+        res.append(al.compute_batch(movs, [syn.identity(3)] * K, nrms))
+    for r, g in zip(*res):
+        assert r["status"] == g["status"]
+        assert r["num_iterations"] == g["num_iterations"]
+        assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes()
+        assert r["last"] == g["last"]

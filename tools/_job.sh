@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "randomised" 2>&1 | tail -30
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "randomised_batches" 2>&1 | tail -30
