@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "randomised_batches" 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_graph_lifecycle.py tests/test_gpu_posegraph.py -x -q 2>&1 | tail -5
+python tools/bench_posegraph.py 2>&1 | tail -1
