@@ -516,8 +516,9 @@ __device__ __forceinline__ void axis_range(float q, float rr, float o, float inv
 template <int DIM>
 __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
                                              float r2box, unsigned long long& bkey, int& bpos, float& b2,
-                                             unsigned long long* tl = nullptr) {
+                                             float& complete2, unsigned long long* tl = nullptr) {
   constexpr int NROWS = DIM == 3 ? 9 : 3;
+  complete2 = r2box;
   const float rr = ball_radius(r2box);
   int x0, x1, y0, y1, z0 = 0, z1 = 0;
   axis_range(qx, rr, g.ox, g.inv_h, cx - 1, cx + 1, g.nx, x0, x1);
@@ -540,8 +541,39 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
     }
   }
   STAMP(tl, 2);  // row ranges arrived
-  // first W0 candidates of ALL rows in flight together (one round trip instead of one per row), then the rows
-  // that hold more
+  // The row through the query's own cell first: once the estimate is roughly right the nearest neighbour is there, and
+  // its distance (+ a pad, so that the scan still proves an exclusion margin) prunes the other rows by their distance
+  // to the query.  complete2 = squared radius inside which this scan has seen every fixed point of the block.
+  constexpr int RC = DIM == 3 ? 4 : 1;
+  scan_range2<DIM>(g.pts, rs[RC], re[RC], qx, qy, qz, bkey, bpos, b2);
+  rs[RC] = re[RC] = 0;
+  complete2 = r2box;
+  if (key_idx(bkey) != NO_MATCH) {
+    const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+    complete2      = fminf(complete2, rb * rb);
+  }
+  if (complete2 < 3.0e38f) {
+    const float rb = sqrtf(complete2);
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {
+      if (r == RC) continue;
+      const int y     = cy + (r % 3) - 1;
+      const float ylo = g.oy + (float) y * g.h;
+      float dy        = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)), 0.f);
+      dy              = fmaxf(dy - (0.01f * g.h + (fabsf(qy) + rb) * 2e-6f), 0.f);
+      float rem       = complete2 * 1.00002f - dy * dy;
+      if (DIM == 3) {
+        const int z     = cz + (r / 3) - 1;
+        const float zlo = g.oz + (float) z * g.h;
+        float dz        = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)), 0.f);
+        dz              = fmaxf(dz - (0.01f * g.h + (fabsf(qz) + rb) * 2e-6f), 0.f);
+        rem             = rem - dz * dz;
+      }
+      if (rem < 0.f) rs[r] = re[r] = 0;  // every point of this row is farther than the pruning radius
+    }
+  }
+  // first W0 candidates of ALL remaining rows in flight together (one round trip instead of one per row), then the
+  // rows that hold more
   constexpr int W0 = SCAN_W0;
   float4 c[NROWS][W0];
 #pragma unroll
@@ -1153,7 +1185,8 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
       unsigned long long bkey = NO_KEY;
       float b2                = INFINITY;
-      scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos, b2, tl);
+      float complete2         = INFINITY;
+      scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos, b2, complete2, tl);
       best = key_best(bkey);
       bidx = key_idx(bkey);
       const bool found1 = bidx != NO_MATCH && best <= gfar;  // a candidate that can bound the wider scan
@@ -1170,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
         }
       } else {
         // settled: the scan was complete inside min(ball, block); nothing but the winner is closer than this
-        excl = sqrtf(fminf(fminf(b2, r2box), b2_1)) * 0.99999f;
+        excl = sqrtf(fminf(fminf(b2, complete2), b2_1)) * 0.99999f;
       }
     }
   }
