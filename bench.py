@@ -186,6 +186,17 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM-side bytes per launch of the timed kernels: PMC counters cannot be read from inside this process, so the
+    # number comes from the committed rocprofv3 --pmc passes of this same command (tools/traffic_from_pmc.py: separate
+    # FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes); only
+    # reported when the passes were taken at the default problem size of the workload
+    traffic, traffic_source = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_%s.json" % args.workload)
+    default_size = (args.points == 100_000 and args.overlap == 1.0) if args.workload == "c2" else True
+    if os.path.exists(tpath) and default_size:
+        with open(tpath) as fh:
+            traffic = json.load(fh)["bytes_per_slice_pass"]
+        traffic_source = "profiles/traffic_%s.json" % args.workload
     out = {
         "metric": "icp_iterations_per_sec",
         "value": units_per_step * args.steps * world / dt,
@@ -222,7 +233,8 @@ def main():
             "peak": 8000.0,
             "unit": "GB/s",
             "frac": achieved / 8000.0,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "avg_launch_ms": kern_ms,
             "launches_timed": launches.value,
