@@ -67,7 +67,10 @@ enum srrg2_slice_kind {
 enum srrg2_finder_kind {
   SRRG2_FINDER_NONE       = 0, /* prior slices                                        */
   SRRG2_FINDER_NN_GATED   = 1, /* exact nearest neighbour within max_distance         */
-  SRRG2_FINDER_PROJECTIVE = 2  /* pinhole projection into the organised fixed cloud   */
+  SRRG2_FINDER_PROJECTIVE = 2, /* pinhole projection into the organised fixed cloud   */
+  SRRG2_FINDER_CORRESPONDENCES = 3 /* no search: the correspondences are given and stay locked during the
+                                      optimisation (MultiLoopDetectorHBST_::_computeAlignments,
+                                      S/registration/loop_detector/multi_loop_detector_hbst_impl.cpp:320-352) */
 };
 
 /* robustifier bound per slice (S/registration/aligners/aligner_slice_processor_base.h:34-38,
@@ -253,6 +256,22 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h h, int K, const float* coords,
                                 int normal_stride_bytes, const int32_t* offsets, int mem,
                                 const float* guesses /* K x 12 (or 9) */,
                                 srrg2_batch_result* results);
+
+/* Slices with SRRG2_FINDER_CORRESPONDENCES: factor->setCorrespondences(corrs)
+ * (multi_loop_detector_hbst_impl.cpp:330) -- fixed_idx / moving_idx index the clouds given to
+ * set_fixed / set_moving; every compute() linearises exactly these pairs (a pair with a
+ * non-finite point is Suppressed).  No gate applies: the fixed-point scale of the sums follows
+ * the estimate. */
+int srrg2_aligner_set_correspondences(srrg2_aligner_h h, int slice_idx, const srrg2_correspondence* correspondences,
+                                      int n);
+/* K such alignments against the fixed cloud already set (the loop over _correspondences_per_reference,
+ * :296-374): moving clouds concatenated with offsets[K+1], correspondences concatenated with
+ * corr_offsets[K+1] (moving_idx relative to its own cloud).  Host pointers for the correspondences. */
+int srrg2_aligner_compute_batch_correspondences(srrg2_aligner_h h, int K, const float* coords, int coord_stride_bytes,
+                                                const float* normals, int normal_stride_bytes, const int32_t* offsets,
+                                                int mem, const srrg2_correspondence* correspondences,
+                                                const int32_t* corr_offsets, const float* guesses,
+                                                srrg2_batch_result* results);
 
 /* ---- pose graph: the global Solver of MultiGraphSLAM_ ---------------------- */
 /* MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317): graph->bindFactors();

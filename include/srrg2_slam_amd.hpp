@@ -127,6 +127,11 @@ public:
                  int mem = SRRG2_MEM_HOST) {
     check(srrg2_aligner_set_moving(_h, slice, coords, stride_bytes, normals, normal_stride_bytes, n, mem));
   }
+  // factor->setCorrespondences(corrs) of a SRRG2_FINDER_CORRESPONDENCES slice: locked during compute()
+  // (MultiLoopDetectorHBST_::_computeAlignments, multi_loop_detector_hbst_impl.cpp:330,343)
+  void setCorrespondences(int slice, const std::vector<srrg2_correspondence>& c) {
+    check(srrg2_aligner_set_correspondences(_h, slice, c.data(), (int) c.size()));
+  }
   void setPriorMeasurement(int slice, const EstimateType& Z) { check(srrg2_aligner_set_prior_measurement(_h, slice, Z.data())); }
 
   void setMovingInFixed(const EstimateType& X) { check(srrg2_aligner_set_moving_in_fixed(_h, X.data())); }

@@ -282,6 +282,9 @@ typedef struct {
   float* moving_n;
   int nm;
   float pinf; /* max |coordinate| of the finite moving points */
+  float finf; /* max |coordinate| of the finite fixed points (given-correspondences slices) */
+  srrg2_correspondence* given; /* SRRG2_FINDER_CORRESPONDENCES: the locked correspondences */
+  int ngiven;
   float ninf; /* max |component| of the fixed normals */
   o_grid grid;
   int grid_valid;
@@ -364,6 +367,7 @@ static void slice_free(o_slice* s) {
   free(s->moving_n);
   free(s->corr);
   free(s->fstat);
+  free(s->given);
   grid_free(&s->grid);
   memset(s, 0, sizeof(*s));
 }
@@ -397,8 +401,11 @@ int oracle_aligner_set_termination(o_aligner* h, const srrg2_termination_params*
 int oracle_aligner_add_slice(o_aligner* h, const srrg2_slice_config* c, int* idx) {
   if (!h || !c) return fail(SRRG2_E_INVALID, "add_slice");
   if (h->nslices >= SRRG2_MAX_SLICES) return fail(SRRG2_E_INVALID, "too many slices");
-  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED && c->finder != SRRG2_FINDER_PROJECTIVE)
+  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED && c->finder != SRRG2_FINDER_PROJECTIVE &&
+      c->finder != SRRG2_FINDER_CORRESPONDENCES)
     return fail(SRRG2_E_INVALID, "cue slice needs a finder"); /* aligner_slice_processor_impl.cpp:13-16 */
+  if (c->finder == SRRG2_FINDER_CORRESPONDENCES && c->kind != SRRG2_SLICE_P2P && c->kind != SRRG2_SLICE_P2PLANE)
+    return fail(SRRG2_E_INVALID, "given correspondences drive point-to-point / point-to-plane factors");
   if (c->finder == SRRG2_FINDER_PROJECTIVE || c->kind == SRRG2_SLICE_REPROJECTION) {
     if (h->dim != 3) return fail(SRRG2_E_UNSUPPORTED, "projective finder / reprojection factor are SE(3) only");
     if (c->finder != SRRG2_FINDER_PROJECTIVE) return fail(SRRG2_E_INVALID, "reprojection slice needs the projective finder");
@@ -464,6 +471,7 @@ int oracle_aligner_set_fixed(o_aligner* h, int si, const float* coords, int cs, 
   s->fixed_n = normals ? gather(normals, ns, n, h->dim) : NULL;
   s->nf      = n;
   s->ninf    = s->fixed_n ? max_abs_finite(s->fixed_n, n, h->dim, 0) : 0.f;
+  s->finf    = max_abs_finite(s->fixed, n, h->dim, 1);
   s->grid_valid = 0; /* _fixed_changed_flag, correspondence_finder.h:80-83 */
   return 0;
 }
@@ -556,6 +564,25 @@ static int slice_compute_correspondences(o_aligner* a, o_slice* s) {
   const int dim = a->dim;
   if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) return slice_compute_correspondences_projective(a, s);
   if (!s->fixed || !s->moving) return fail(SRRG2_E_STATE, "cue slice without fixed/moving cloud");
+  if (s->cfg.finder == SRRG2_FINDER_CORRESPONDENCES) {
+    /* "we keep the correspondences locked during optimization", multi_loop_detector_hbst_impl.cpp:343 */
+    if (!s->given) return fail(SRRG2_E_STATE, "given-correspondences slice without correspondences");
+    if (s->ngiven > s->corr_cap) {
+      free(s->corr);
+      free(s->fstat);
+      s->corr     = (srrg2_correspondence*) malloc(sizeof(srrg2_correspondence) * (size_t) s->ngiven);
+      s->fstat    = (uint8_t*) malloc((size_t) s->ngiven);
+      s->corr_cap = s->ngiven;
+    }
+    for (int c = 0; c < s->ngiven; ++c) {
+      if (s->given[c].fixed_idx < 0 || s->given[c].fixed_idx >= s->nf || s->given[c].moving_idx < 0 ||
+          s->given[c].moving_idx >= s->nm)
+        return fail(SRRG2_E_INVALID, "correspondence index out of range");
+      s->corr[c] = s->given[c];
+    }
+    s->ncorr = s->ngiven;
+    return 0;
+  }
   float gate  = s->cfg.finder_max_distance;
   float gate2 = gate * gate;
   if (!a->bruteforce && !s->grid_valid) {
@@ -709,9 +736,22 @@ static int slice_exponent(const o_aligner* a, const o_slice* s) {
   double eb       = (mb * (double) s->cfg.finder_max_distance) * 1.01;
   if (proj) eb = (mb * (2.0 * (double) s->cfg.finder_max_distance)) * 1.01;
   if (repro) eb = (double) PIX_BOUND * 1.01;
+  int n_terms = s->nm;
+  if (s->cfg.finder == SRRG2_FINDER_CORRESPONDENCES) {
+    /* no gate bounds the residual: |e_r| <= sqrt3 (sqrt3 |p|inf + |t|inf + |f|inf) with the CURRENT estimate */
+    const float* X = a->X;
+    double tmax    = 0.0;
+    if (a->dim == 3) {
+      for (int r = 0; r < 3; ++r) tmax = fabs((double) X[r * 4 + 3]) > tmax ? fabs((double) X[r * 4 + 3]) : tmax;
+    } else {
+      for (int r = 0; r < 2; ++r) tmax = fabs((double) X[r * 3 + 2]) > tmax ? fabs((double) X[r * 3 + 2]) : tmax;
+    }
+    eb      = ((mb * 1.7320508075688772) * ((1.7320508075688772 * (double) s->pinf + tmax) + (double) s->finf)) * 1.01;
+    n_terms = s->ngiven > 1 ? s->ngiven : 1;
+  }
   double mx       = jb > eb ? jb : eb;
   double B        = (double) rows * (mx * mx);
-  return o_fixed_point_exponent(s->nm, B);
+  return o_fixed_point_exponent(n_terms, B);
 }
 
 static inline int64_t to_fixed(double v, int k) {
@@ -1205,6 +1245,44 @@ int oracle_aligner_get_last_system(o_aligner* h, double* H, double* b, double* d
   if (H) memcpy(H, h->last_H, sizeof(double) * h->dof * h->dof);
   if (b) memcpy(b, h->last_b, sizeof(double) * h->dof);
   if (dx) memcpy(dx, h->last_dx, sizeof(double) * h->dof);
+  return 0;
+}
+
+int oracle_aligner_set_correspondences(o_aligner* h, int si, const srrg2_correspondence* corr, int n) {
+  if (!h || si < 0 || si >= h->nslices || n < 0 || (n > 0 && !corr)) return fail(SRRG2_E_INVALID, "set_correspondences");
+  o_slice* s = &h->slices[si];
+  if (s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES) return fail(SRRG2_E_INVALID, "set_correspondences: wrong finder kind");
+  free(s->given);
+  s->given = (srrg2_correspondence*) malloc(sizeof(srrg2_correspondence) * (size_t) (n > 0 ? n : 1));
+  if (n > 0) memcpy(s->given, corr, sizeof(srrg2_correspondence) * (size_t) n);
+  s->ngiven = n;
+  return 0;
+}
+
+int oracle_aligner_compute_batch_correspondences(o_aligner* h, int K, const float* coords, int cs, const float* normals,
+                                                 int ns, const int32_t* offsets, int mem,
+                                                 const srrg2_correspondence* corr, const int32_t* corr_offsets,
+                                                 const float* guesses, srrg2_batch_result* results) {
+  /* loop body of multi_loop_detector_hbst_impl.cpp:296-374, one candidate after the other */
+  if (!h || K < 0 || !offsets || !corr_offsets || !guesses || !results) return fail(SRRG2_E_INVALID, "compute_batch_correspondences");
+  for (int k = 0; k < K; ++k) {
+    const float* c = (const float*) ((const char*) coords + (size_t) offsets[k] * cs);
+    const float* n = normals ? (const float*) ((const char*) normals + (size_t) offsets[k] * ns) : NULL;
+    int rc         = oracle_aligner_set_moving(h, 0, c, cs, n, ns, offsets[k + 1] - offsets[k], mem);
+    if (rc) return rc;
+    rc = oracle_aligner_set_correspondences(h, 0, corr + corr_offsets[k], corr_offsets[k + 1] - corr_offsets[k]);
+    if (rc) return rc;
+    rc = oracle_aligner_set_moving_in_fixed(h, guesses + (size_t) k * h->tsize);
+    if (rc) return rc;
+    int st;
+    rc = oracle_aligner_compute(h, &st);
+    if (rc) return rc;
+    memset(&results[k], 0, sizeof(results[k]));
+    memcpy(results[k].moving_in_fixed, h->X, sizeof(float) * h->tsize);
+    results[k].status         = st;
+    results[k].num_iterations = h->nstats;
+    if (h->nstats) results[k].last = h->stats[h->nstats - 1];
+  }
   return 0;
 }
 

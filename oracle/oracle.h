@@ -85,6 +85,12 @@ int oracle_aligner_get_iteration_stats(o_aligner* h, srrg2_iteration_stats* buf,
 int oracle_aligner_num_correspondences(o_aligner* h, int* n_out);
 int oracle_aligner_get_correspondences(o_aligner* h, int slice_idx, srrg2_correspondence* buf, int* n_inout);
 int oracle_aligner_get_factor_status(o_aligner* h, int slice_idx, uint8_t* buf, int* n_inout);
+int oracle_aligner_set_correspondences(o_aligner* h, int slice_idx, const srrg2_correspondence* correspondences, int n);
+int oracle_aligner_compute_batch_correspondences(o_aligner* h, int K, const float* coords, int coord_stride_bytes,
+                                                 const float* normals, int normal_stride_bytes, const int32_t* offsets,
+                                                 int mem, const srrg2_correspondence* correspondences,
+                                                 const int32_t* corr_offsets, const float* guesses,
+                                                 srrg2_batch_result* results);
 int oracle_aligner_compute_batch(o_aligner* h, int K, const float* coords, int coord_stride_bytes,
                                  const float* normals, int normal_stride_bytes, const int32_t* offsets,
                                  int mem, const float* guesses, srrg2_batch_result* results);

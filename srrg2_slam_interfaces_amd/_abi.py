@@ -15,7 +15,7 @@ SUCCESS, NOT_ENOUGH_CORRESPONDENCES, NOT_ENOUGH_INLIERS, FAIL = 0, 1, 2, 3
 # enum srrg2_slice_kind
 SLICE_P2P, SLICE_P2PLANE, SLICE_REPROJECTION, SLICE_PRIOR = 0, 1, 2, 3
 # enum srrg2_finder_kind
-FINDER_NONE, FINDER_NN_GATED, FINDER_PROJECTIVE = 0, 1, 2
+FINDER_NONE, FINDER_NN_GATED, FINDER_PROJECTIVE, FINDER_CORRESPONDENCES = 0, 1, 2, 3
 # enum srrg2_robustifier_kind
 ROBUST_NONE, ROBUST_CLAMP, ROBUST_SATURATED, ROBUST_CAUCHY = 0, 1, 2, 3
 # enum srrg2_factor_status

@@ -188,6 +188,40 @@ class MultiAligner:
                                                     out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n2)))
         return out[:n2.value]
 
+    @staticmethod
+    def _corr_array(corr):
+        arr = (abi.Correspondence * max(len(corr), 1))()
+        for k, c in enumerate(corr):
+            arr[k].fixed_idx, arr[k].moving_idx, arr[k].response = int(c["fixed_idx"]), int(c["moving_idx"]), float(c["response"])
+        return arr
+
+    def set_correspondences(self, slice_idx, corr):
+        """factor->setCorrespondences(corrs) for a FINDER_CORRESPONDENCES slice: the pairs stay locked during
+        compute() (multi_loop_detector_hbst_impl.cpp:330,343).  corr: structured array / list of dicts."""
+        self._check(self._b.fn("set_correspondences")(self._h, C.c_int(slice_idx), self._corr_array(corr), C.c_int(len(corr))))
+
+    def compute_batch_correspondences(self, moving_clouds, correspondences, guesses, moving_normals=None):
+        """K alignments with given correspondences against the fixed cloud (the loop of
+        MultiLoopDetectorHBST_::_computeAlignments, multi_loop_detector_hbst_impl.cpp:296-374)."""
+        K = len(moving_clouds)
+        offsets = np.zeros(K + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum([int(np.asarray(m).shape[0]) for m in moving_clouds])
+        coffsets = np.zeros(K + 1, dtype=np.int32)
+        coffsets[1:] = np.cumsum([len(c) for c in correspondences])
+        coords = _as_f32(np.concatenate([_as_f32(m) for m in moving_clouds], axis=0)) if K else np.zeros((0, self.dim), np.float32)
+        nptr, nstride = None, 0
+        if moving_normals is not None:
+            normals = _as_f32(np.concatenate([_as_f32(m) for m in moving_normals], axis=0))
+            nptr, nstride = _fptr(normals), normals.strides[0]
+        flat = [c for cs in correspondences for c in cs]
+        g = _as_f32(np.asarray(guesses)).reshape(K, self.tsize)
+        res = (abi.BatchResult * max(K, 1))()
+        self._check(self._b.fn("compute_batch_correspondences")(
+            self._h, C.c_int(K), _fptr(coords), C.c_int(coords.strides[0]), nptr, C.c_int(nstride),
+            offsets.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(abi.MEM_HOST), self._corr_array(flat),
+            coffsets.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(g), res))
+        return self._unpack_batch(res, K)
+
     def compute_batch_device(self, coords_ptr, coord_stride, normals_ptr, normal_stride, offsets, guesses):
         """compute_batch on clouds already resident in HBM (raw device pointers as ints)."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)

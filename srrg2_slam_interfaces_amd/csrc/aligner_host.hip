@@ -54,6 +54,12 @@ struct Slice {
   bool moving_has_normals = false;
   // outputs
   DevBuf<int> corr_fixed;
+  // given correspondences (SRRG2_FINDER_CORRESPONDENCES)
+  DevBuf<srrg2_correspondence> gcorr;
+  DevBuf<int> gcorr_off;
+  DevBuf<uint8_t> gcorr_stat;
+  std::vector<srrg2_correspondence> h_gcorr;
+  std::vector<int> h_gcorr_off;  // [K + 1]; empty: none set
   DevBuf<float4> prev_f;
   DevBuf<float> prev_m;
   DevBuf<unsigned long long> dbg;   // SRRG2_AMD_TIMELINE (debug builds): per-wave stamps of the step kernel
@@ -73,7 +79,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
+    corr_fixed.release(); gcorr.release(); gcorr_off.release(); gcorr_stat.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
   }
 };
 
@@ -477,6 +483,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     sc.nblocks   = nblocks;
     sc.pinf_bits = s->pinf.p;
     sc.ninf_bits = s->scalars.p + 7;
+    sc.finf_bits = s->scalars.p + 10;
+    sc.gcorr_off = nullptr;
     SliceDev& d       = sdev[si];
     d.grid            = s->grid;
     d.mpts            = s->moving.p;
@@ -515,6 +523,35 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.fixed_org       = s->fixed_raw.p;
     d.fixed_org_nrm   = s->fixed_has_normals ? s->fixed_nrm_raw.p : nullptr;
     d.zbuf            = nullptr;
+    d.gcorr = nullptr; d.gcorr_off = nullptr; d.gcorr_stat = nullptr;
+    d.moving_raw      = s->moving_raw.p;
+    if (s->cfg.finder == SRRG2_FINDER_CORRESPONDENCES) {
+      if ((int) s->h_gcorr_off.size() != K + 1)
+        return fail(SRRG2_E_STATE, "compute: given-correspondences slice without correspondences for every alignment");
+      if (s->cfg.kind == SRRG2_SLICE_P2PLANE && !s->fixed_has_normals)
+        return fail(SRRG2_E_STATE, "compute: point-to-plane slice without fixed normals");
+      const int total = s->h_gcorr_off[(size_t) K];
+      for (int k = 0; k < K; ++k) {
+        const int nmk = all[(size_t) si * K + k].nm;
+        for (int c = s->h_gcorr_off[(size_t) k]; c < s->h_gcorr_off[(size_t) k + 1]; ++c)
+          if (s->h_gcorr[(size_t) c].fixed_idx < 0 || s->h_gcorr[(size_t) c].fixed_idx >= s->nf ||
+              s->h_gcorr[(size_t) c].moving_idx < 0 || s->h_gcorr[(size_t) c].moving_idx >= nmk)
+            return fail(SRRG2_E_INVALID, "compute: correspondence index out of range");
+      }
+      if ((rc = s->gcorr.reserve((size_t) std::max(total, 1)))) return rc;
+      if ((rc = s->gcorr_off.reserve((size_t) K + 1))) return rc;
+      if ((rc = s->gcorr_stat.reserve((size_t) std::max(total, 1)))) return rc;
+      if (total > 0)
+        HIP_TRY(hipMemcpyAsync(s->gcorr.p, s->h_gcorr.data(), sizeof(srrg2_correspondence) * (size_t) total,
+                               hipMemcpyHostToDevice, a->stream));
+      HIP_TRY(hipMemcpyAsync(s->gcorr_off.p, s->h_gcorr_off.data(), sizeof(int) * ((size_t) K + 1), hipMemcpyHostToDevice,
+                             a->stream));
+      HIP_TRY(hipStreamSynchronize(a->stream));  // (pageable host vectors)
+      d.gcorr      = s->gcorr.p;
+      d.gcorr_off  = s->gcorr_off.p;
+      d.gcorr_stat = s->gcorr_stat.p;
+      sc.gcorr_off = s->gcorr_off.p;
+    }
     if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) {
       if ((rc = s->zbuf.reserve((size_t) K * d.rows * d.cols))) return rc;
       d.zbuf = s->zbuf.p;
@@ -554,7 +591,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           a->prof_used++;
           HIP_TRY(hipEventRecord(e0, a->stream));
         }
-        if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE)
+        if (s->cfg.finder == SRRG2_FINDER_CORRESPONDENCES) {
+          int max_nc = 0;
+          for (int k = 0; k < K; ++k) max_nc = std::max(max_nc, s->h_gcorr_off[(size_t) k + 1] - s->h_gcorr_off[(size_t) k]);
+          srrg2amd::launch_corr_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, max_nc, a->stream);
+        } else if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE)
           srrg2amd::launch_proj_step(s->cfg.kind == SRRG2_SLICE_REPROJECTION, sdev[si], a->probs.p + (size_t) si * K,
                                      a->states.p, K, nm_max, a->stream);
         else
@@ -734,8 +775,11 @@ int srrg2_aligner_set_termination(srrg2_aligner_h a, const srrg2_termination_par
 int srrg2_aligner_add_slice(srrg2_aligner_h a, const srrg2_slice_config* c, int* idx) {
   if (!a || !c) return fail(SRRG2_E_INVALID, "add_slice: bad arguments");
   if ((int) a->slices.size() >= SRRG2_MAX_SLICES) return fail(SRRG2_E_INVALID, "add_slice: too many slices");
-  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED && c->finder != SRRG2_FINDER_PROJECTIVE)
+  if (c->kind != SRRG2_SLICE_PRIOR && c->finder != SRRG2_FINDER_NN_GATED && c->finder != SRRG2_FINDER_PROJECTIVE &&
+      c->finder != SRRG2_FINDER_CORRESPONDENCES)
     return fail(SRRG2_E_INVALID, "add_slice| no finder");  // aligner_slice_processor_impl.cpp:13-16
+  if (c->finder == SRRG2_FINDER_CORRESPONDENCES && c->kind != SRRG2_SLICE_P2P && c->kind != SRRG2_SLICE_P2PLANE)
+    return fail(SRRG2_E_INVALID, "add_slice: given correspondences drive point-to-point / point-to-plane factors");
   if (c->finder == SRRG2_FINDER_PROJECTIVE || c->kind == SRRG2_SLICE_REPROJECTION) {
     if (a->dim != 3) return fail(SRRG2_E_UNSUPPORTED, "add_slice: projective finder / reprojection factor are SE(3) only");
     if (c->finder != SRRG2_FINDER_PROJECTIVE)
@@ -791,7 +835,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   const float* dsrc;
   int sf;
   if ((rc = stage_input(a, coords, cs, n, a->dim, mem, &dsrc, &sf, 0))) return rc;
-  srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, nullptr, 1, a->stream);
+  srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, 1, a->stream);  // [10] = |fixed|inf
   if (normals) {
     const float* nsrc;
     int nsf;
@@ -938,10 +982,39 @@ int aligner_slice_view(srrg2_aligner_s* a, int si, AlignerSliceView* v) {
 }  // namespace srrg2amd
 extern "C" {
 
+// given-correspondences slices: the pairs of the LAST problem and their factor status
+static int fetch_given(srrg2_aligner* a, int si, std::vector<srrg2_correspondence>& pairs, std::vector<uint8_t>& st) {
+  Slice* s = a->slices[si];
+  pairs.clear();
+  st.clear();
+  int rc;
+  if ((rc = set_device(a))) return rc;
+  if (!a->computed || (int) s->h_gcorr_off.size() != a->K + 1) return 0;
+  const int c0 = s->h_gcorr_off[(size_t) a->K - 1], c1 = s->h_gcorr_off[(size_t) a->K];
+  pairs.assign(s->h_gcorr.begin() + c0, s->h_gcorr.begin() + c1);
+  st.resize((size_t) (c1 - c0));
+  if (c1 > c0) HIP_TRY(hipMemcpy(st.data(), s->gcorr_stat.p + c0, (size_t) (c1 - c0), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int srrg2_aligner_get_correspondences(srrg2_aligner_h a, int si, srrg2_correspondence* buf, int* n) {
   int rc = check_slice(a, si, "get_correspondences");
   if (rc) return rc;
   if (!n) return fail(SRRG2_E_INVALID, "get_correspondences: null count");
+  if (a->slices[si]->cfg.finder == SRRG2_FINDER_CORRESPONDENCES && a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR) {
+    std::vector<srrg2_correspondence> pairs;
+    std::vector<uint8_t> st;
+    if ((rc = fetch_given(a, si, pairs, st))) return rc;
+    const bool prune = a->params.keep_only_inlier_correspondences && a->status == SRRG2_SUCCESS;
+    int cnt = 0;
+    for (size_t i = 0; i < pairs.size(); ++i) {
+      if (prune && st[i] != SRRG2_FACTOR_INLIER) continue;
+      if (buf && cnt < *n) buf[cnt] = pairs[i];
+      ++cnt;
+    }
+    *n = cnt;
+    return 0;
+  }
   std::vector<int> cf;
   std::vector<float> cr;
   std::vector<uint8_t> cst;
@@ -967,6 +1040,20 @@ int srrg2_aligner_get_factor_status(srrg2_aligner_h a, int si, uint8_t* buf, int
   int rc = check_slice(a, si, "get_factor_status");
   if (rc) return rc;
   if (!n) return fail(SRRG2_E_INVALID, "get_factor_status: null count");
+  if (a->slices[si]->cfg.finder == SRRG2_FINDER_CORRESPONDENCES && a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR) {
+    std::vector<srrg2_correspondence> pairs;
+    std::vector<uint8_t> st;
+    if ((rc = fetch_given(a, si, pairs, st))) return rc;
+    const bool prune = a->params.keep_only_inlier_correspondences && a->status == SRRG2_SUCCESS;
+    int cnt = 0;
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (prune && st[i] != SRRG2_FACTOR_INLIER) continue;
+      if (buf && cnt < *n) buf[cnt] = st[i];
+      ++cnt;
+    }
+    *n = cnt;
+    return 0;
+  }
   std::vector<int> cf;
   std::vector<float> cr;
   std::vector<uint8_t> cst;
@@ -1010,6 +1097,37 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
     if (o.nstats > 0) results[k].last = a->stats_host[(size_t) k * slots + std::min(o.nstats, slots) - 1];
   }
   return 0;
+}
+
+int srrg2_aligner_set_correspondences(srrg2_aligner_h a, int si, const srrg2_correspondence* corr, int n) {
+  int rc = check_slice(a, si, "set_correspondences");
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && !corr)) return fail(SRRG2_E_INVALID, "set_correspondences: bad arguments");
+  Slice* s = a->slices[si];
+  if (s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES)
+    return fail(SRRG2_E_INVALID, "set_correspondences: the slice's finder kind is not SRRG2_FINDER_CORRESPONDENCES");
+  s->h_gcorr.assign(corr, corr + n);
+  s->h_gcorr_off = {0, n};
+  return 0;
+}
+
+int srrg2_aligner_compute_batch_correspondences(srrg2_aligner_h a, int K, const float* coords, int cs, const float* normals,
+                                                int ns, const int32_t* offsets, int mem, const srrg2_correspondence* corr,
+                                                const int32_t* corr_offsets, const float* guesses,
+                                                srrg2_batch_result* results) {
+  if (!a || K < 0 || !offsets || !corr_offsets || !guesses || !results)
+    return fail(SRRG2_E_INVALID, "compute_batch_correspondences: bad arguments");
+  if (K == 0) return 0;
+  if (a->slices.empty() || a->slices[0]->cfg.finder != SRRG2_FINDER_CORRESPONDENCES)
+    return fail(SRRG2_E_STATE, "compute_batch_correspondences: slice 0 must be a given-correspondences slice");
+  for (int k = 0; k < K; ++k)
+    if (corr_offsets[k + 1] < corr_offsets[k]) return fail(SRRG2_E_INVALID, "compute_batch_correspondences: bad offsets");
+  if (corr_offsets[K] > corr_offsets[0] && !corr) return fail(SRRG2_E_INVALID, "compute_batch_correspondences: null pairs");
+  Slice* s = a->slices[0];
+  s->h_gcorr.assign(corr + corr_offsets[0], corr + corr_offsets[K]);
+  s->h_gcorr_off.resize((size_t) K + 1);
+  for (int k = 0; k <= K; ++k) s->h_gcorr_off[(size_t) k] = corr_offsets[k] - corr_offsets[0];
+  return srrg2_aligner_compute_batch(a, K, coords, cs, normals, ns, offsets, mem, guesses, results);
 }
 
 int srrg2_aligner_profile_enable(srrg2_aligner_h a, int enable) {

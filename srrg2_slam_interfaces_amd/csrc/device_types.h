@@ -69,6 +69,11 @@ struct SliceDev {
   const float4* fixed_org;      // rows*cols points, NaN = invalid pixel
   const float4* fixed_org_nrm;  // or null
   unsigned long long* zbuf;     // [problem][rows*cols] keys (depth bits << 32 | caller index)
+  // given correspondences (SRRG2_FINDER_CORRESPONDENCES): pairs of all problems, per-problem offsets, factor status
+  const srrg2_correspondence* gcorr;
+  const int* gcorr_off;         // [K + 1]
+  uint8_t* gcorr_stat;
+  const float4* moving_raw;     // moving clouds in ingest order (moving_idx is the caller's index)
   unsigned long long* dbg;  // -DSRRG2_TIMELINE builds only: [iteration < 32][wave][16] shader-clock stamps, or null
   int tune;             // debug/tuning bit flags (env SRRG2_AMD_TUNE): 1 = skip phase 2 (WRONG results, timing only)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
@@ -124,6 +129,8 @@ struct SliceCtl {
   int qslots;                 // trailing partial slots the deferred-search kernel adds into atomically
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
+  const unsigned* finf_bits;      // [1] max |coordinate| of the fixed cloud (given-correspondences slices)
+  const int* gcorr_off;           // [K + 1] offsets of the given correspondences (or null)
 };
 
 struct CtlParams {

@@ -1431,6 +1431,96 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
 }
 
 // ============================================================================================
+// given correspondences (SRRG2_FINDER_CORRESPONDENCES): no search, one thread per correspondence of the problem;
+// clouds in ingest order (the indices are the caller's).  MultiLoopDetectorHBST_::_computeAlignments,
+// multi_loop_detector_hbst_impl.cpp:320-352.
+// ============================================================================================
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step_corr(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                       ProblemState* __restrict__ states) {
+  constexpr int D    = DIM == 3 ? 6 : 3;
+  constexpr int ROWS = PLANE ? 1 : DIM;
+  const int prob     = blockIdx.y;
+  ProblemState* st   = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  float T[12];
+  load_finder_transform<DIM>(S, st->X, T);
+  const double scale = dm::pow2(st->kexp[S.slice_idx]);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  long long acc[ACC_N];
+#pragma unroll
+  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+  const int c0 = S.gcorr_off[prob], c1 = S.gcorr_off[prob + 1];
+  const int c  = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < c1) {
+    const srrg2_correspondence k = S.gcorr[c];
+    const float4 p  = S.moving_raw[pd.moff + k.moving_idx];
+    const float4 f  = S.fixed_org[k.fixed_idx];
+    float qx, qy, qz;
+    transform_point<DIM>(T, p, qx, qy, qz);
+    float J[ROWS][D];
+    float e[ROWS];
+    if constexpr (DIM == 3) {
+      float m[ROWS][3];
+      if (PLANE) {
+        const float4 nf = S.fixed_org_nrm[k.fixed_idx];
+        e[0]    = (nf.x * (qx - f.x) + nf.y * (qy - f.y)) + nf.z * (qz - f.z);
+        m[0][0] = (T[0] * nf.x + T[4] * nf.y) + T[8] * nf.z;
+        m[0][1] = (T[1] * nf.x + T[5] * nf.y) + T[9] * nf.z;
+        m[0][2] = (T[2] * nf.x + T[6] * nf.y) + T[10] * nf.z;
+      } else {
+        const float q[3]  = {qx, qy, qz};
+        const float ff[3] = {f.x, f.y, f.z};
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          e[r]    = q[r] - ff[r];
+          m[r][0] = T[r * 4 + 0];
+          m[r][1] = T[r * 4 + 1];
+          m[r][2] = T[r * 4 + 2];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        J[r][0]     = m[r][0];
+        J[r][1]     = m[r][1];
+        J[r][2]     = m[r][2];
+        J[r][D - 3] = kk * (p.y * m[r][2] - p.z * m[r][1]);
+        J[r][D - 2] = kk * (p.z * m[r][0] - p.x * m[r][2]);
+        J[r][D - 1] = kk * (p.x * m[r][1] - p.y * m[r][0]);
+      }
+    } else {
+      float m[ROWS][2];
+      if (PLANE) {
+        const float4 nf = S.fixed_org_nrm[k.fixed_idx];
+        e[0]    = nf.x * (qx - f.x) + nf.y * (qy - f.y);
+        m[0][0] = T[0] * nf.x + T[4] * nf.y;
+        m[0][1] = T[1] * nf.x + T[5] * nf.y;
+      } else {
+        const float q[2]  = {qx, qy};
+        const float ff[2] = {f.x, f.y};
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          e[r]    = q[r] - ff[r];
+          m[r][0] = T[r * 4 + 0];
+          m[r][1] = T[r * 4 + 1];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        J[r][0] = m[r][0];
+        J[r][1] = m[r][1];
+        J[r][2] = m[r][1] * p.x - m[r][0] * p.y;
+      }
+    }
+    // (a pair with a non-finite point gives a non-finite chi: Suppressed)
+    S.gcorr_stat[c] = factor_accumulate<D, ROWS>(J, e, false, rk, S.robust_thr, scale, false, acc);
+  }
+  block_reduce_store(acc, S.partials, prob, blockIdx.x);
+}
+
+// ============================================================================================
 // projective finder + factors on an organised fixed cloud (BASELINE config C3)
 //   k_proj_zbuf        z-buffer: per pixel the transformed moving point of minimum depth, ties -> smaller caller
 //                      index, as ONE 64-bit atomicMin on the key (depth bits << 32 | index)  (deterministic)
@@ -1597,7 +1687,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
 // ============================================================================================
 namespace {
 
-__device__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, int nm) {
+__device__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, int nm, const float* X) {
   const bool plane = s.kind == SRRG2_SLICE_P2PLANE;
   const bool repro = s.kind == SRRG2_SLICE_REPROJECTION;
   const bool proj  = s.finder == SRRG2_FINDER_PROJECTIVE;
@@ -1618,9 +1708,23 @@ __device__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, i
   double eb = (mb * (double) s.gate) * 1.01;
   if (proj) eb = (mb * (2.0 * (double) s.gate)) * 1.01;
   if (repro) eb = (double) PIX_BOUND * 1.01;
+  int n_terms = nm;
+  if (s.finder == SRRG2_FINDER_CORRESPONDENCES) {
+    // no gate bounds the residual: |e_r| <= sqrt3 (sqrt3 |p|inf + |t|inf + |f|inf) with the CURRENT estimate
+    double tmax = 0.0;
+    if (dim == 3) {
+      for (int r = 0; r < 3; ++r) tmax = fabs((double) X[r * 4 + 3]) > tmax ? fabs((double) X[r * 4 + 3]) : tmax;
+    } else {
+      for (int r = 0; r < 2; ++r) tmax = fabs((double) X[r * 3 + 2]) > tmax ? fabs((double) X[r * 3 + 2]) : tmax;
+    }
+    const float finf = __uint_as_float(s.finf_bits[0]);
+    eb          = ((mb * 1.7320508075688772) * ((1.7320508075688772 * (double) pinf + tmax) + (double) finf)) * 1.01;
+    const int ng = s.gcorr_off[prob + 1] - s.gcorr_off[prob];
+    n_terms     = ng > 1 ? ng : 1;
+  }
   double mx = jb > eb ? jb : eb;
   double B  = (double) rows * (mx * mx);
-  return dm::fixed_point_exponent(nm, B);
+  return dm::fixed_point_exponent(n_terms, B);
 }
 
 __device__ float robust_weight(int kind, float thr, float chi, bool& kernelized) {
@@ -1819,6 +1923,9 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   }
   for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];  // the estimate this iteration's finder passes ran with
   if (!bad) dm::box_plus(C.variable_kind, st->X, dx);  // solver Success: multi_aligner_impl.cpp:118-121
+  for (int s = 0; s < C.nslices; ++s)  // the fixed-point scale of given-correspondences slices follows the estimate
+    if (C.slices[s].finder == SRRG2_FINDER_CORRESPONDENCES && C.slices[s].kind != SRRG2_SLICE_PRIOR)
+      st->kexp[s] = slice_exponent(C, C.slices[s], prob, 0, st->X);
   if (st->nstats < C.max_stats) stats[(size_t) prob * C.max_stats + st->nstats] = cur;
   st->nstats++;
   if (C.has_term && has_to_stop(C, st, cur)) st->done = 1;  // :124-126
@@ -1851,8 +1958,10 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   st->nstats   = 0;
   st->phase    = 0;
   st->w_count  = 0;
+  int nm_of[SRRG2_MAX_SLICES];
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
+    nm_of[s]           = 0;
     const ProblemDev pd = probs_host[(size_t) s * C.K + prob];
     probs[(size_t) s * C.K + prob] = pd;
     st->ncorr[s]       = 0;
@@ -1864,9 +1973,11 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
         for (int i = 0; i < tsize; ++i) st->X[i] = sc.prior_Z[i];
       }
     } else {
-      st->kexp[s] = slice_exponent(C, sc, prob, pd.nm);
+      nm_of[s] = pd.nm;
     }
   }
+  for (int s = 0; s < C.nslices; ++s)  // (after the loop: a prior slice may have replaced the initial guess)
+    if (C.slices[s].kind != SRRG2_SLICE_PRIOR) st->kexp[s] = slice_exponent(C, C.slices[s], prob, nm_of[s], st->X);
 }
 
 // one 256-thread block per problem: sum the per-block partials of every cue slice (exact integer sums, any
@@ -2076,6 +2187,23 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
       else
         hipLaunchKernelGGL((k_icp_step_queue<2, false>), qgrid, dim3(256), 0, s, S, probs, states);
     }
+  }
+}
+
+void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                      int max_ncorr, hipStream_t s) {
+  if (K <= 0 || max_ncorr <= 0) return;
+  dim3 grid((max_ncorr + 255) / 256, K);
+  if (dim == 3) {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_corr<3, true>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_corr<3, false>), grid, dim3(256), 0, s, S, probs, states);
+  } else {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_corr<2, true>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_corr<2, false>), grid, dim3(256), 0, s, S, probs, states);
   }
 }
 

@@ -236,3 +236,71 @@ class MultiRelocalizer:
                 best_chi_average = chi_inliers
                 self.relocalized_closure = c
         return self.relocalization_map
+
+
+class MultiLoopDetectorHBST:
+    """The alignment half of MultiLoopDetectorHBST_ (S/registration/loop_detector/multi_loop_detector_hbst_impl.cpp):
+    ``_computeAlignments`` (:257-377) -- per reference local map with enough descriptor matches, a one-variable
+    Gauss-Newton solve with the matches kept locked, starting from the identity -- and the accept gates and closure
+    record of ``_addLoopClosure`` (:379-447).  Here all candidates go through ONE compute_batch_correspondences().
+    The descriptor tree that produces the matches (srrg_hbst) is out of scope: matches are an input.
+    PARAMs: loop_detector.h (relocalize_min_inliers / max_chi_inliers / min_inliers_ratio)."""
+
+    def __init__(self, relocalize_aligner, relocalize_min_inliers=500, relocalize_max_chi_inliers=0.005,
+                 relocalize_min_inliers_ratio=0.7):
+        if relocalize_aligner is None:
+            raise RuntimeError("MultiLoopDetectorHBST::computeAlignments|ERROR: aligner not set")  # :264-268
+        self.relocalize_aligner = relocalize_aligner
+        self.relocalize_min_inliers = relocalize_min_inliers
+        self.relocalize_max_chi_inliers = relocalize_max_chi_inliers
+        self.relocalize_min_inliers_ratio = relocalize_min_inliers_ratio
+        self.detected_closures = []
+        self.drops = []
+
+    def compute_alignments(self, query_id, fixed, fixed_normals, candidates, pose_in_query=None):
+        """candidates: list of dicts {reference, moving, moving_normals or None, correspondences (fixed_idx = query
+        point, moving_idx = reference point)}"""
+        al = self.relocalize_aligner
+        dim = al.dim
+        pose_in_query = sl.identity(dim) if pose_in_query is None else np.asarray(pose_in_query, np.float32)
+        self.detected_closures, self.drops = [], []
+        todo = []
+        for c in candidates:
+            if len(c["correspondences"]) < self.relocalize_min_inliers:  # :309-314
+                self.drops.append((c["reference"], "ALIGNER DROP [code: %d]" % abi.NOT_ENOUGH_CORRESPONDENCES))
+                continue
+            todo.append(c)
+        if not todo:
+            return self.detected_closures
+        al.set_fixed(0, fixed, fixed_normals)
+        normals = [c.get("moving_normals") for c in todo]
+        results = al.compute_batch_correspondences(
+            [c["moving"] for c in todo], [c["correspondences"] for c in todo], [sl.identity(dim)] * len(todo),  # :335
+            normals if all(n is not None for n in normals) else None)
+        for c, r in zip(todo, results):
+            if r["status"] != abi.SUCCESS:  # :346-356
+                self.drops.append((c["reference"], "ALIGNER DROP [code: %d]" % r["status"]))
+                continue
+            last = r["last"]
+            num_inliers = last["num_inliers"]
+            num_correspondences = num_inliers + last["num_outliers"] + last["num_suppressed"]  # :388-389
+            chi_inliers = np.float32(last["chi_inliers"]) / np.float32(num_inliers)
+            if num_inliers < self.relocalize_min_inliers:  # :394-398
+                self.drops.append((c["reference"], "NUM_INLIERS DROP"))
+                continue
+            if chi_inliers > np.float32(self.relocalize_max_chi_inliers):  # :400-404
+                self.drops.append((c["reference"], "MAX_CHI_INLIERS DROP"))
+                continue
+            if np.float32(num_inliers) / np.float32(num_correspondences) < np.float32(self.relocalize_min_inliers_ratio):
+                self.drops.append((c["reference"], "MIN_INLIERS_RATIO DROP"))  # :406-413
+                continue
+            reference_in_query = r["moving_in_fixed"]
+            D = 3 if dim == 2 else 6
+            info = np.eye(D, dtype=np.float32)
+            info[dim - 1, dim - 1] = 1e-3  # :429-430 (reduced weight along the last translation axis)
+            self.detected_closures.append({
+                "source": query_id, "target": c["reference"], "measurement": reference_in_query, "information": info,
+                "pose_in_target": sl.compose(sl.inverse(reference_in_query), pose_in_query),  # :420
+                "chi_inliers": float(chi_inliers), "num_inliers": int(num_inliers),
+                "num_correspondences": int(num_correspondences), "correspondences": c["correspondences"]})
+        return self.detected_closures

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_loop_detector.py -x -q -m gpu 2>&1 | tail -5
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -3
