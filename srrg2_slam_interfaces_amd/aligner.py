@@ -188,17 +188,26 @@ class MultiAligner:
                                                     out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n2)))
         return out[:n2.value]
 
-    @staticmethod
-    def _corr_array(corr):
-        arr = (abi.Correspondence * max(len(corr), 1))()
-        for k, c in enumerate(corr):
-            arr[k].fixed_idx, arr[k].moving_idx, arr[k].response = int(c["fixed_idx"]), int(c["moving_idx"]), float(c["response"])
-        return arr
+    _CORR_DTYPE = np.dtype([("fixed_idx", np.int32), ("moving_idx", np.int32), ("response", np.float32)])
+
+    @classmethod
+    def _corr_array(cls, corr):
+        """(pointer, keep-alive array): srrg2_correspondence records from a structured array or a list of dicts"""
+        if isinstance(corr, np.ndarray) and corr.dtype.names:
+            a = np.empty(len(corr), cls._CORR_DTYPE)
+            for f in cls._CORR_DTYPE.names:
+                a[f] = corr[f]
+        else:
+            a = np.array([(int(c["fixed_idx"]), int(c["moving_idx"]), float(c["response"])) for c in corr], cls._CORR_DTYPE)
+        if a.size == 0:
+            a = np.zeros(1, cls._CORR_DTYPE)
+        return a.ctypes.data_as(C.POINTER(abi.Correspondence)), a
 
     def set_correspondences(self, slice_idx, corr):
         """factor->setCorrespondences(corrs) for a FINDER_CORRESPONDENCES slice: the pairs stay locked during
         compute() (multi_loop_detector_hbst_impl.cpp:330,343).  corr: structured array / list of dicts."""
-        self._check(self._b.fn("set_correspondences")(self._h, C.c_int(slice_idx), self._corr_array(corr), C.c_int(len(corr))))
+        ptr, keep = self._corr_array(corr)
+        self._check(self._b.fn("set_correspondences")(self._h, C.c_int(slice_idx), ptr, C.c_int(len(corr))))
 
     def compute_batch_correspondences(self, moving_clouds, correspondences, guesses, moving_normals=None):
         """K alignments with given correspondences against the fixed cloud (the loop of
@@ -213,12 +222,13 @@ class MultiAligner:
         if moving_normals is not None:
             normals = _as_f32(np.concatenate([_as_f32(m) for m in moving_normals], axis=0))
             nptr, nstride = _fptr(normals), normals.strides[0]
-        flat = [c for cs in correspondences for c in cs]
+        parts = [self._corr_array(cs)[1][: len(cs)] for cs in correspondences]
+        cptr, keep = self._corr_array(np.concatenate(parts) if parts else np.zeros(0, self._CORR_DTYPE))
         g = _as_f32(np.asarray(guesses)).reshape(K, self.tsize)
         res = (abi.BatchResult * max(K, 1))()
         self._check(self._b.fn("compute_batch_correspondences")(
             self._h, C.c_int(K), _fptr(coords), C.c_int(coords.strides[0]), nptr, C.c_int(nstride),
-            offsets.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(abi.MEM_HOST), self._corr_array(flat),
+            offsets.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int(abi.MEM_HOST), cptr,
             coffsets.ctypes.data_as(C.POINTER(C.c_int32)), _fptr(g), res))
         return self._unpack_batch(res, K)
 
