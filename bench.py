@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--overlap", type=float, default=1.0, help="c2 experiment: keep this x-quantile of the fixed cloud")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -277,6 +278,21 @@ def main():
             "parity_indices_bit_exact_and_X_within_1e-5": bool(parity),
         }
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if not args.no_cpu_all_cores:
+            # secondary number: the same single-threaded oracle on every host CPU at once, one independent
+            # alignment stream per process; run in a helper process (no HIP state is forked)
+            import subprocess
+
+            try:
+                helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "cpu_all_cores.py")
+                r = subprocess.run([sys.executable, helper, "--points", str(args.points), "--iterations", str(args.iterations),
+                                    "--seconds", "6"], capture_output=True, text=True, timeout=180)
+                allc = json.loads(r.stdout.strip().splitlines()[-1])
+                out["cpu_baseline"]["all_cores"] = allc
+                out["cpu_baseline"]["cpu_model"] = allc.get("cpu_model", "")
+                out["speedup_vs_cpu_all_cores"] = out["value"] / allc["value"]
+            except Exception as e:  # the all-core figure is informative: never fail the bench line for it
+                out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
