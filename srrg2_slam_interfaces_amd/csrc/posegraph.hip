@@ -27,6 +27,7 @@
 #define PG_THREADS 256
 #define PG_ROWS 252  // scalar rows per block in the PCG kernels: a multiple of 6 and 3, so a variable never straddles blocks
 #define PG_MAX_PARTIALS 4096
+#define PG_TILES 4  // tiles of PG_ROWS rows per block in the element-wise PCG kernels: 4x fewer partial sums to re-add
 
 namespace {
 
@@ -292,19 +293,21 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_pcg_init(int n, const double*
                                                             PgScalars* __restrict__ sc,
                                                             const double* __restrict__ partial_chi,
                                                             const int* __restrict__ partial_n, int n_chi_partials) {
-  const int t = blockIdx.x * PG_ROWS + threadIdx.x;
   double rz = 0.0, bb = 0.0;
-  if (threadIdx.x < PG_ROWS && t < n) {
-    const int v = t / D, row = t - v * D;
-    double z = 0.0;
+  for (int tile = 0; tile < PG_TILES; ++tile) {
+    const int t = (blockIdx.x * PG_TILES + tile) * PG_ROWS + threadIdx.x;
+    if (threadIdx.x < PG_ROWS && t < n) {
+      const int v = t / D, row = t - v * D;
+      double z = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) z = z + Minv[((size_t) v * D + row) * D + c] * (-b[(size_t) v * D + c]);
-    const double ri = -b[t];
-    x[t] = 0.0;
-    r[t] = ri;
-    p[t] = z;
-    rz   = ri * z;
-    bb   = ri * ri;
+      for (int c = 0; c < D; ++c) z = z + Minv[((size_t) v * D + row) * D + c] * (-b[(size_t) v * D + c]);
+      const double ri = -b[t];
+      x[t] = 0.0;
+      r[t] = ri;
+      p[t] = z;
+      rz   = rz + ri * z;
+      bb   = bb + ri * ri;
+    }
   }
   rz = block_sum(rz);
   bb = block_sum(bb);
@@ -372,27 +375,29 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_update_xr(int n, int nblocks,
                                                              double* __restrict__ z, const double* __restrict__ part_rz,
                                                              const double* __restrict__ part_pAp,
                                                              double* __restrict__ part_rr, double* __restrict__ part_rz_new,
-                                                             const PgScalars* __restrict__ sc) {
+                                                             const PgScalars* __restrict__ sc, int nblocks_spmv) {
   if (sc->done || sc->bad) return;
   const double rz  = sum_partials(part_rz, nblocks);
-  const double pap = sum_partials(part_pAp, nblocks);
+  const double pap = sum_partials(part_pAp, nblocks_spmv);
   const double alpha = pap > 0.0 ? rz / pap : 0.0;
-  const int t       = blockIdx.x * PG_ROWS + threadIdx.x;
-  const bool active = threadIdx.x < PG_ROWS && t < n;
-  if (active) {
-    x[t] = x[t] + alpha * p[t];
-    r[t] = r[t] - alpha * Ap[t];
-  }
-  __syncthreads();  // all D rows of a variable live in this block (PG_ROWS is a multiple of D)
   double rr = 0.0, rzn = 0.0;
-  if (active) {
-    const int v = t / D, row = t - v * D;
-    double zi = 0.0;
+  for (int tile = 0; tile < PG_TILES; ++tile) {
+    const int t       = (blockIdx.x * PG_TILES + tile) * PG_ROWS + threadIdx.x;
+    const bool active = threadIdx.x < PG_ROWS && t < n;
+    if (active) {
+      x[t] = x[t] + alpha * p[t];
+      r[t] = r[t] - alpha * Ap[t];
+    }
+    __syncthreads();  // all D rows of a variable live in this tile (PG_ROWS is a multiple of D)
+    if (active) {
+      const int v = t / D, row = t - v * D;
+      double zi = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) zi = zi + Minv[((size_t) v * D + row) * D + c] * r[(size_t) v * D + c];
-    z[t] = zi;
-    rr   = r[t] * r[t];
-    rzn  = r[t] * zi;
+      for (int c = 0; c < D; ++c) zi = zi + Minv[((size_t) v * D + row) * D + c] * r[(size_t) v * D + c];
+      z[t] = zi;
+      rr   = rr + r[t] * r[t];
+      rzn  = rzn + r[t] * zi;
+    }
   }
   rr  = block_sum(rr);
   rzn = block_sum(rzn);
@@ -414,8 +419,10 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_update_p(int n, int nblocks, 
   const double rr     = sum_partials(part_rr, nblocks);
   const double bb     = sum_partials(part_bb, nblocks);
   const double beta   = rz != 0.0 ? rz_new / rz : 0.0;
-  const int t = blockIdx.x * PG_ROWS + threadIdx.x;
-  if (threadIdx.x < PG_ROWS && t < n) p[t] = z[t] + beta * p[t];
+  for (int tile = 0; tile < PG_TILES; ++tile) {
+    const int t = (blockIdx.x * PG_TILES + tile) * PG_ROWS + threadIdx.x;
+    if (threadIdx.x < PG_ROWS && t < n) p[t] = z[t] + beta * p[t];
+  }
   // (the host swaps the rz / rz_new partial buffers for the next iteration: no in-kernel copy, no race)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sc->rz = rz_new;
@@ -467,7 +474,8 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   const int V = g->V, E = g->E, T = g->T;
   const int n = V * D;
   int rc;
-  const int nb  = std::max((n + PG_ROWS - 1) / PG_ROWS, 1);
+  const int nb  = std::max((n + PG_ROWS - 1) / PG_ROWS, 1);          // SpMV blocks (one tile each)
+  const int nbt = std::max((nb + PG_TILES - 1) / PG_TILES, 1);        // element-wise kernels: PG_TILES tiles per block
   const int nbv = std::max((V + PG_THREADS - 1) / PG_THREADS, 1);
   const int nbe = std::max((E + PG_THREADS - 1) / PG_THREADS, 1);
   const int nchi = std::min(nbe, 1024);
@@ -504,7 +512,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
                        cstride, chi_off, g->part_chi.p, g->part_n.p);
     hipLaunchKernelGGL(k_pg_vertices<D>, dim3(nbv), dim3(PG_THREADS), 0, g->stream, V, g->fixed.p, g->inc_start.p,
                        g->inc_edge.p, g->enabled.p, contrib, (double) p->damping, g->Hd.p, g->b.p, g->Minv.p, g->sc.p);
-    hipLaunchKernelGGL(k_pg_pcg_init<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->b.p, g->Minv.p, g->x.p, g->r.p,
+    hipLaunchKernelGGL(k_pg_pcg_init<D>, dim3(nbt), dim3(PG_THREADS), 0, g->stream, n, g->b.p, g->Minv.p, g->x.p, g->r.p,
                        g->p.p, g->part_rz.p, g->part_bb.p, g->sc.p, g->part_chi.p, g->part_n.p, nchi);
     PgScalars h{};
     int launched = 0;
@@ -515,9 +523,9 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         double* rz_nxt = ((launched + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
         hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->fixed.p, g->inc_start.p,
                            g->inc_other.p, g->Hd.p, g->Hcsr.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
-        hipLaunchKernelGGL(k_pg_update_xr<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, g->Minv.p, g->p.p, g->Ap.p,
-                           g->x.p, g->r.p, g->z.p, rz_cur, g->part_pAp.p, g->part_rr.p, rz_nxt, g->sc.p);
-        hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance,
+        hipLaunchKernelGGL(k_pg_update_xr<D>, dim3(nbt), dim3(PG_THREADS), 0, g->stream, n, nbt, g->Minv.p, g->p.p, g->Ap.p,
+                           g->x.p, g->r.p, g->z.p, rz_cur, g->part_pAp.p, g->part_rr.p, rz_nxt, g->sc.p, nb);
+        hipLaunchKernelGGL(k_pg_update_p, dim3(nbt), dim3(PG_THREADS), 0, g->stream, n, nbt, (double) p->pcg_tolerance,
                            g->z.p, g->p.p, rz_cur, rz_nxt, g->part_rr.p, g->part_bb.p, g->sc.p);
       }
       launched += chunk;
