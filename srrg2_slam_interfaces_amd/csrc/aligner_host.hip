@@ -453,7 +453,6 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     std::memcpy(sc.prior_Z, s->prior_Z, sizeof(sc.prior_Z));
     std::memcpy(sc.prior_info, s->cfg.prior_information_diag, sizeof(sc.prior_info));
     sc.partials  = nullptr;
-    sc.nblocks   = 0;
     sc.finder    = s->cfg.finder;
     sc.K0        = s->cfg.camera_matrix[0];
     sc.K4        = s->cfg.camera_matrix[4];
@@ -469,7 +468,6 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // deferred-search queue: a win in the latency regime (few alignments per launch: C2 0.78 -> 0.63 ms); with many
     // alignments per launch the in-kernel path has more throughput (C4: 2.46 vs 2.74 ms per 32 x 50k batch)
     const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0 && K <= 4;
-    const int qslots     = 0;
     const int nblocks    = PARTIAL_SLOTS;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
     if (use_queue) {
@@ -477,10 +475,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
     }
     sc.qcount = use_queue ? s->qcount.p : nullptr;
-    sc.qslots = qslots;
     // (k_icp_init zeroes the slot sets and the queue counters; afterwards the control kernel resets them each iteration)
     sc.partials  = s->partials.p;
-    sc.nblocks   = nblocks;
     sc.pinf_bits = s->pinf.p;
     sc.ninf_bits = s->scalars.p + 7;
     sc.finf_bits = s->scalars.p + 10;
@@ -503,7 +499,6 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       d.dbg = s->dbg.p;
     }
     d.partials        = s->partials.p;
-    d.partial_blocks  = nblocks;
     d.queue           = use_queue ? (void*) s->queue.p : nullptr;
     d.qcount          = use_queue ? s->qcount.p : nullptr;
     d.slice_idx       = si;

@@ -49,8 +49,7 @@ struct SliceDev {
                         // previous iteration of this compute() (-1: none); an upper bound for the next search
   float4* prev_f;       // ... and that fixed point {x, y, z, bits(index)} (saves the dependent load)
   float* prev_m;        // ... and its exclusion radius: no other fixed point within prev_m of the previous query
-  long long* partials;  // [problem][partial_blocks][ACC_N]: per-block fixed-point partial sums (no atomics)
-  int partial_blocks;   // blocks per problem writing partials (step kernel + deferred-search kernel)
+  long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N]: fixed-point partial sums, added with 64-bit atomics
   void* queue;          // deferred searches: QEntry[total moving points] (per problem at its moving offset), or null
   int* qcount;          // [problem] entries in the queue
   int slice_idx;
@@ -124,9 +123,7 @@ struct SliceCtl {
   int rows, cols;
   float depth_min;
   int* qcount;              // deferred-search queue counters of the slice (reset by the control kernel), or null
-  const long long* partials;  // [problem][nblocks][ACC_N] (null for priors)
-  int nblocks;                // partial blocks per problem (step kernel blocks + qslots)
-  int qslots;                 // trailing partial slots the deferred-search kernel adds into atomically
+  const long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N] (null for priors)
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
   const unsigned* finf_bits;      // [1] max |coordinate| of the fixed cloud (given-correspondences slices)
