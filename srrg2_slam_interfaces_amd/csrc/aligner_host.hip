@@ -518,6 +518,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.fixed_org       = s->fixed_raw.p;
     d.fixed_org_nrm   = s->fixed_has_normals ? s->fixed_nrm_raw.p : nullptr;
     d.zbuf            = nullptr;
+    d.zbuf_parity     = 0;
     d.gcorr = nullptr; d.gcorr_off = nullptr; d.gcorr_stat = nullptr;
     d.moving_raw      = s->moving_raw.p;
     if (s->cfg.finder == SRRG2_FINDER_CORRESPONDENCES) {
@@ -548,8 +549,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       sc.gcorr_off = s->gcorr_off.p;
     }
     if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) {
-      if ((rc = s->zbuf.reserve((size_t) K * d.rows * d.cols))) return rc;
+      if ((rc = s->zbuf.reserve((size_t) 2 * K * d.rows * d.cols))) return rc;
       d.zbuf = s->zbuf.p;
+      // both z-buffers start clean; afterwards every pass resets the buffer of the next one
+      HIP_TRY(hipMemsetAsync(s->zbuf.p, 0xff, (size_t) 2 * K * d.rows * d.cols * sizeof(unsigned long long), a->stream));
     }
     d.tune            = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
     if (a->dim == 3)
@@ -590,10 +593,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           int max_nc = 0;
           for (int k = 0; k < K; ++k) max_nc = std::max(max_nc, s->h_gcorr_off[(size_t) k + 1] - s->h_gcorr_off[(size_t) k]);
           srrg2amd::launch_corr_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, max_nc, a->stream);
-        } else if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE)
+        } else if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) {
           srrg2amd::launch_proj_step(s->cfg.kind == SRRG2_SLICE_REPROJECTION, sdev[si], a->probs.p + (size_t) si * K,
                                      a->states.p, K, nm_max, a->stream);
-        else
+          sdev[si].zbuf_parity ^= 1;  // the pass just launched reset the other buffer
+        } else
           srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
                                     a->stream);
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));

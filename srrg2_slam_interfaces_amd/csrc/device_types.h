@@ -67,7 +67,8 @@ struct SliceDev {
   float gate;           // finder_max_distance
   const float4* fixed_org;      // rows*cols points, NaN = invalid pixel
   const float4* fixed_org_nrm;  // or null
-  unsigned long long* zbuf;     // [problem][rows*cols] keys (depth bits << 32 | caller index)
+  unsigned long long* zbuf;     // [2][problem][rows*cols] keys (depth bits << 32 | caller index), ping-pong
+  int zbuf_parity;              // which of the two this pass uses
   // given correspondences (SRRG2_FINDER_CORRESPONDENCES): pairs of all problems, per-problem offsets, factor status
   const srrg2_correspondence* gcorr;
   const int* gcorr_off;         // [K + 1]

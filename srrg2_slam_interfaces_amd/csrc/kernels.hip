@@ -1566,7 +1566,7 @@ __global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev*
   const int pix = project_point(S, qx, qy, qz, u, v);
   if (pix < 0) return;
   const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
-  atomicMin(&S.zbuf[(size_t) prob * S.rows * S.cols + pix], key);
+  atomicMin(&S.zbuf[((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols + pix], key);
 }
 
 template <bool REPRO>
@@ -1576,10 +1576,18 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
   constexpr int ROWS = REPRO ? 2 : 1;
   const int prob     = blockIdx.y;
   ProblemState* st   = &states[prob];
+  {  // the z-buffers ping-pong: this pass reads buffer `zbuf_parity` and resets the other one for the next pass (no
+     // memset launch per iteration); done before the early exit so that a later phase finds a clean buffer
+    const size_t npix        = (size_t) S.rows * S.cols;
+    unsigned long long* next = S.zbuf + ((size_t) (1 - S.zbuf_parity) * gridDim.y + prob) * npix;
+    for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < npix; k += (size_t) gridDim.x * blockDim.x)
+      next[k] = ~0ull;
+  }
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   float T[12];
   finder_transform3(S, st, T);
+  const unsigned long long* zcur = S.zbuf + ((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols;
   const int kexp     = st->kexp[S.slice_idx];
   const double scale = dm::pow2(kexp);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
@@ -1606,7 +1614,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
       float dd      = 0.f;
       if (pix >= 0) {
         const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) ci;
-        if (S.zbuf[(size_t) prob * S.rows * S.cols + pix] == key) {
+        if (zcur[pix] == key) {
           f = S.fixed_org[pix];
           if (finite3(f.x, f.y, f.z)) {
             dd             = fabsf(f.z - qz);
@@ -2211,7 +2219,7 @@ void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, Pr
                       hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
   dim3 grid(icp_step_blocks(max_nm), K);
-  (void) hipMemsetAsync(S.zbuf, 0xff, (size_t) K * S.rows * S.cols * sizeof(unsigned long long), s);
+  // (no memset: the z-buffers ping-pong, k_icp_step_proj resets the one the next pass will use)
   hipLaunchKernelGGL(k_proj_zbuf, grid, dim3(256), 0, s, S, probs, states);
   if (repro)
     hipLaunchKernelGGL((k_icp_step_proj<true>), grid, dim3(256), 0, s, S, probs, states);

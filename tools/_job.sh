@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -2
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+echo "c3"; python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])"
