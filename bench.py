@@ -120,7 +120,7 @@ def main():
         K_total = world
         units_per_step = args.iterations
         nm, nf = data["moving"].shape[0], data["fixed"].shape[0]
-        alg_bytes_per_launch = 12 * nm + 24 * nf + 12 * nm  # one slice's launch (18.4 MB per 2-slice iteration)
+        alg_bytes_per_launch = 12 * nm + 24 * nf + 2 * 12 * nm  # both slices in one launch pair (clouds once, C1 + C2)
 
         def step():
             al.set_moving_in_fixed(ident)
@@ -229,7 +229,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("k_icp_step<3,true> + k_icp_step_queue<3,true> (one finder+factor pass of the slice)" if args.workload == "c2" else
-                       "k_icp_step<3,true>" if args.workload == "c4" else "k_proj_zbuf + k_icp_step_proj (per slice)"),
+                       "k_icp_step<3,true>" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",

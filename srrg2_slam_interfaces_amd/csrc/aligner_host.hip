@@ -568,8 +568,48 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
   srrg2amd::launch_icp_init(C, a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, a->stream);
 
+  // all cue slices projective (RGB-D: point-to-plane + reprojection): one launch pair per iteration for all of them
+  std::vector<int> proj_group;
+  {
+    bool all_proj = true;
+    for (int si = 0; si < nslices; ++si) {
+      if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+      if (a->slices[si]->cfg.finder != SRRG2_FINDER_PROJECTIVE) all_proj = false;
+      proj_group.push_back(si);
+    }
+    if (!all_proj || proj_group.size() < 2 || proj_group.size() > 4 || (C.tune & 131072)) proj_group.clear();
+  }
   auto run_phase = [&](int slot0) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
+      if (!proj_group.empty()) {
+        SliceDev pack[4];
+        const ProblemDev* pp[4];
+        int nm_max = 0;
+        for (size_t z = 0; z < proj_group.size(); ++z) {
+          const int si = proj_group[z];
+          pack[z]      = sdev[si];
+          pp[z]        = a->probs.p + (size_t) si * K;
+          for (int k = 0; k < K; ++k) nm_max = std::max(nm_max, all[(size_t) si * K + k].nm);
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (a->profile) {
+          if (a->prof_used == a->prof_events.size()) {
+            hipEvent_t x, y;
+            HIP_TRY(hipEventCreate(&x));
+            HIP_TRY(hipEventCreate(&y));
+            a->prof_events.emplace_back(x, y);
+          }
+          e0 = a->prof_events[a->prof_used].first;
+          e1 = a->prof_events[a->prof_used].second;
+          a->prof_used++;
+          HIP_TRY(hipEventRecord(e0, a->stream));
+        }
+        srrg2amd::launch_proj_step_pack(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
+        for (int si : proj_group) sdev[si].zbuf_parity ^= 1;
+        if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
+        srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
+        continue;
+      }
       for (int si = 0; si < nslices; ++si) {
         Slice* s = a->slices[si];
         if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;

@@ -25,6 +25,8 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
 int icp_step_blocks(int max_nm);
 int icp_queue_blocks(int max_nm, int K);
 // projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)
+void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
+                           int max_nm, hipStream_t s);
 void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                       int max_ncorr, hipStream_t s);
 void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,

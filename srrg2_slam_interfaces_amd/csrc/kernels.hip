@@ -1547,8 +1547,15 @@ __device__ __forceinline__ void finder_transform3(const SliceDev& S, const Probl
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                   ProblemState* __restrict__ states) {
+// the projective slices of one aligner in ONE launch (blockIdx.z = slice): their passes are independent until the
+// control step, and at ~5 us of launch floor per kernel two slices cost two launches less per iteration
+struct SlicePack {
+  SliceDev s[4];
+  const ProblemDev* probs[4];
+};
+
+__device__ __forceinline__ void proj_zbuf_body(const SliceDev& S, const ProblemDev* __restrict__ probs,
+                                               ProblemState* __restrict__ states) {
   const int prob   = blockIdx.y;
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
@@ -1569,9 +1576,17 @@ __global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev*
   atomicMin(&S.zbuf[((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols + pix], key);
 }
 
+__global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                   ProblemState* __restrict__ states) {
+  proj_zbuf_body(S, probs, states);
+}
+__global__ __launch_bounds__(256) void k_proj_zbuf_pack(SlicePack P, ProblemState* __restrict__ states) {
+  proj_zbuf_body(P.s[blockIdx.z], P.probs[blockIdx.z], states);
+}
+
 template <bool REPRO>
-__global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                       ProblemState* __restrict__ states) {
+__device__ __forceinline__ void step_proj_body(const SliceDev& S, const ProblemDev* __restrict__ probs,
+                                               ProblemState* __restrict__ states) {
   constexpr int D    = 6;
   constexpr int ROWS = REPRO ? 2 : 1;
   const int prob     = blockIdx.y;
@@ -1688,6 +1703,19 @@ __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const Problem
     S.corr_stat[gi]  = fstat;
   }
   block_reduce_store(acc, S.partials, prob, blockIdx.x);
+}
+
+template <bool REPRO>
+__global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                       ProblemState* __restrict__ states) {
+  step_proj_body<REPRO>(S, probs, states);
+}
+__global__ __launch_bounds__(256) void k_icp_step_proj_pack(SlicePack P, ProblemState* __restrict__ states) {
+  const SliceDev& S = P.s[blockIdx.z];
+  if (S.factor == SRRG2_SLICE_REPROJECTION)
+    step_proj_body<true>(S, P.probs[blockIdx.z], states);
+  else
+    step_proj_body<false>(S, P.probs[blockIdx.z], states);
 }
 
 // ============================================================================================
@@ -2225,6 +2253,23 @@ void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, Pr
     hipLaunchKernelGGL((k_icp_step_proj<true>), grid, dim3(256), 0, s, S, probs, states);
   else
     hipLaunchKernelGGL((k_icp_step_proj<false>), grid, dim3(256), 0, s, S, probs, states);
+}
+
+void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
+                           int max_nm, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0 || nslices <= 0 || nslices > 4) return;
+  SlicePack P;
+  for (int z = 0; z < nslices; ++z) {
+    P.s[z]     = slices[z];
+    P.probs[z] = probs[z];
+  }
+  for (int z = nslices; z < 4; ++z) {
+    P.s[z]     = slices[0];
+    P.probs[z] = probs[0];
+  }
+  dim3 grid(icp_step_blocks(max_nm), K, nslices);
+  hipLaunchKernelGGL(k_proj_zbuf_pack, grid, dim3(256), 0, s, P, states);
+  hipLaunchKernelGGL(k_icp_step_proj_pack, grid, dim3(256), 0, s, P, states);
 }
 
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
