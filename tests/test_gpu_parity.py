@@ -318,3 +318,31 @@ def test_randomised_batches(oracle, product, seed):
         assert r["num_iterations"] == g["num_iterations"]
         assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes()
         assert r["last"] == g["last"]
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_ties_and_duplicates(oracle, product, dim):
+    """Fixed points on a lattice (every moving point at a cell centre is equidistant to 2^dim of them), exact duplicates
+    in both clouds: ties resolve to the smallest fixed index in every search mode, and exclusion radii that equal the
+    neighbour's distance never certify a skip."""
+    kind = abi.SE3_QUAT_RIGHT if dim == 3 else abi.SE2_RIGHT
+    g = np.arange(-6, 7, dtype=np.float32) * np.float32(0.25)
+    mesh = np.stack(np.meshgrid(*([g] * dim), indexing="ij"), -1).reshape(-1, dim).astype(np.float32)
+    fixed = np.concatenate([mesh, mesh[::3]])                       # duplicates with larger indices
+    centres = (mesh + np.float32(0.125))[: len(mesh) // 2]           # equidistant to the lattice corners
+    moving = np.concatenate([centres, centres[::5], mesh[1::7]]).astype(np.float32)  # duplicates, exact hits
+    fn = np.zeros_like(fixed); fn[:, -1] = 1
+    mn = np.zeros_like(moving); mn[:, -1] = 1
+    d = dict(fixed=fixed, fixed_normals=fn, moving=moving, moving_normals=mn)
+    for gate, cell in ((0.3, 0.0), (0.3, 0.1), (0.6, 0.25)):
+        cfg = cue_config(kind, abi.SLICE_P2P, gate, abi.ROBUST_CAUCHY, 0.05)
+        cfg.finder_cell_size = cell
+        guess = (syn.se3(np.array([0.01, -0.02, 0.015]), np.deg2rad(np.array([0.5, -0.3, 0.8]))) if dim == 3
+                 else syn.se2(0.01, -0.02, 0.01)).astype(np.float32)
+        a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, params=dict(max_iterations=8), guess=guess)
+        assert_same_run(a_ref, a_gpu)
+        assert a_ref.iteration_stats()[0]["num_correspondences"] > len(moving) // 2
+    # exactly at the lattice: identity guess, every centre ties 2^dim ways
+    cfg = cue_config(kind, abi.SLICE_P2P, 0.3)
+    a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, params=dict(max_iterations=3))
+    assert_same_run(a_ref, a_gpu)
