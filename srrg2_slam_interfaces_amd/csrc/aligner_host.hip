@@ -214,18 +214,21 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   }
   const float gate = s->cfg.finder_max_distance;
   const int dim    = a->dim;
-  auto fit_cell = [&](float h0) {  // grow h until the dense grid fits: <= 1024 cells per axis, <= 4 Mi cells
+  // grow h until the dense grid fits: <= 2048 cells per axis and <= max(4 Mi, min(16 n, 128 Mi)) cells (big clouds get
+  // big grids: a 5 M-point cloud at 4 Mi cells had ~50 points per cell and ran 30x slower than at 80 Mi cells)
+  const double cell_cap = std::max(4194304.0, std::min(16.0 * (double) n, 134217728.0));
+  auto fit_cell = [&](float h0) {
     float h = h0 > 0.f ? h0 : 1.f;
     for (;;) {
       double cells = 1.0;
       bool ok      = true;
       for (int d = 0; d < dim; ++d) {
         double nd = std::floor(((double) mx[d] - (double) mn[d]) / (double) h) + 1.0;
-        if (nd > 1024.0) ok = false;
+        if (nd > 2048.0) ok = false;
         cells *= nd;
       }
-      if (ok && cells <= 4194304.0) return h;
-      h *= 2.f;
+      if (ok && cells <= cell_cap) return h;
+      h *= 1.25f;
     }
   };
   auto grid_dims = [&](float h, GridDev& g) {

@@ -1402,8 +1402,27 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
     const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
     float wbest, wexcl2;
     int widx, wpos;
-    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : q.r2, q.ball2, wbest, widx,
-                       wpos, wexcl2);
+    int sr      = q.r2;
+    float ball2 = q.ball2;
+    if (q.bidx == NO_MATCH && q.r2 >= 5 && !skip && !(S.tune & 262144)) {  // (small cubes: one pass is cheaper)
+      // Nothing is known about this point's neighbourhood and the ball is the whole gate: in a dense cloud that is
+      // thousands of candidates.  Grow the cube instead (radius 2, 4, 8, ...) until something turns up, then scan once
+      // more with the ball of that candidate (+ pad, for the exclusion radius).  Every pass is exact inside
+      // min(ball, cube), so the final result is the same minimum; the passes are wave-uniform.
+      for (int r = 2; r < q.r2; r *= 2) {
+        const float b2 = fminf(bound2_of(r, g.h), q.ball2);
+        coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, r, b2, wbest, widx, wpos, wexcl2);
+        if (widx != NO_MATCH) {  // (wave-uniform: every lane gets the same result)
+          const float rr = (sqrtf(wbest) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+          ball2          = fminf(rr * rr, q.ball2);
+          sr             = 1;
+          while (sr < q.r2 && bound2_of(sr, g.h) < ball2) ++sr;
+          break;
+        }
+      }
+    }
+    coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, skip ? -1 : sr, ball2, wbest, widx, wpos,
+                       wexcl2);
     if (lane == parked) {
       have    = true;
       my_excl = skip ? 0.f : sqrtf(wexcl2) * 0.99999f;
