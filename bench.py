@@ -67,13 +67,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # SRRG2_BENCH_SHARE_GPU=1 (test hook: exercise the multi-rank control flow on a one-GPU box): every rank uses
+    # device 0 and the process group runs on gloo with host tensors -- RCCL refuses two ranks on one GPU
+    share = os.environ.get("SRRG2_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    coll_device = "cpu" if share else "cuda"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import srrg2_slam_interfaces_amd as pkg
     from srrg2_slam_interfaces_amd import _abi as abi
@@ -148,7 +157,7 @@ def main():
     def full_step():
         recs = step()
         # the ONE collective of the path: all-gather of the per-alignment result records
-        return D.all_gather_records(recs, K_total, device="cuda")
+        return D.all_gather_records(recs, K_total, device=coll_device)
 
     for _ in range(args.warmup):
         full_step()
@@ -163,7 +172,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     status = al.status()

@@ -78,3 +78,27 @@ def test_two_ranks_gloo_equal_single_process(tmp_path):
     for k in range(K):
         r = D.unpack_record(t0[k])
         assert r["k"] == k and r["status"] == 0 and r["num_iterations"] == 10
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """bench.py under torch.distributed.run with 2 ranks (barriers, max-over-ranks timing, the all-gather of the result
+    records, rank 0 prints the one JSON line).  A one-GPU box cannot run two RCCL ranks, so the test hook
+    SRRG2_BENCH_SHARE_GPU=1 puts both ranks on device 0 and the process group on gloo; the 8-GPU run is the driver's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRRG2_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--points", "20000"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and rec["config"]["last_status"] == 0
+    assert "cpu_baseline" not in rec  # rank 0 at N = 1 only

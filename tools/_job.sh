@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_lifetime.py -x -q -m gpu 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_multi_gpu_gloo.py -x -q -m gpu 2>&1 | tail -5
