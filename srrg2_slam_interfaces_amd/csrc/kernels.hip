@@ -184,7 +184,13 @@ __global__ void k_count_nonzero(const int* __restrict__ counts, int n, int* __re
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += counts[i] != 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+  __shared__ int red[4];  // one atomic per block (same-address atomics serialise: per-wave ones cost 47 us here)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t) atomicAdd(out, t);
+  }
 }
 
 // exclusive scan, 3 kernels: per-block scan of SCAN_TILE elements, scan of block sums, add back
@@ -2164,7 +2170,7 @@ void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, 
 void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s) {
   if (n <= 0) return;
   int nb = (n + 255) / 256;
-  if (nb > 1024) nb = 1024;
+  if (nb > 256) nb = 256;
   hipLaunchKernelGGL(k_count_nonzero, dim3(nb), dim3(256), 0, s, counts, n, out);
 }
 

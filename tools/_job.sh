@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_multi_gpu_gloo.py -x -q -m gpu 2>&1 | tail -5
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+python tools/bench_tracker.py 2>&1 | tail -1 | tee gpurun_out/bench_tracker.json
