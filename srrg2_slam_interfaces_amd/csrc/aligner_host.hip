@@ -40,6 +40,8 @@ struct Slice {
   DevBuf<unsigned> scalars;  // [0..2] bbox min keys, [3..5] bbox max keys, [6] nvalid, [7] ninf bits, [8] scan total
   GridDev grid{};
   int nf          = 0;
+  float probe_h = 0.f, probe_ext = 0.f, probe_gate = 0.f;  // last automatic cell size and the cloud it was probed on
+  int probe_n   = 0;
   bool has_fixed  = false;
   bool fixed_has_normals = false;
   // moving cloud(s)
@@ -251,6 +253,15 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     // after the 3^DIM block (misaligned first iterations, sparser regions), too large a cell inflates the candidate
     // lists.  Measured on C2/C4: optimum at 8 (4: -5% / -17%, 16: -5% / -8%); it was 4 before converged iterations
     // learnt to skip their searches.  Any h gives the same exact results.
+    // (a tracker sets a similar cloud every frame: when the point count, the extent and the gate are within 10% of
+    // the last probed cloud, its cell size is reused and the probe with its host round trip is skipped)
+    float ext = 0.f;
+    for (int d = 0; d < dim; ++d) ext = std::fmax(ext, mx[d] - mn[d]);
+    const bool similar = s->probe_h > 0.f && s->probe_gate == gate && std::fabs((float) nvalid - (float) s->probe_n) <= 0.1f * (float) s->probe_n &&
+                         std::fabs(ext - s->probe_ext) <= 0.1f * s->probe_ext && !std::getenv("SRRG2_AMD_CELL_TARGET");
+    if (similar) {
+      h = fit_cell(s->probe_h);
+    } else {
     GridDev probe{};
     grid_dims(h, probe);
     const int pcell = probe.nx * probe.ny * probe.nz;
@@ -268,6 +279,8 @@ int build_grid(srrg2_aligner* a, Slice* s) {
       float scale           = std::sqrt(target / occupancy);
       scale                 = std::fmin(std::fmax(scale, 0.5f), 4.0f);
       h                     = fit_cell(std::fmin(h * scale, gate));
+      s->probe_h = h; s->probe_n = nvalid; s->probe_ext = ext; s->probe_gate = gate;
+    }
     }
   }
   GridDev& g = s->grid;
