@@ -71,3 +71,34 @@ def test_handles_side_by_side(oracle, product):
     setup_pair(r1, d1, cfg)
     r1.compute()
     assert r1.moving_in_fixed().tobytes() == X1.tobytes()
+
+
+def test_distinct_handles_from_distinct_threads(product):
+    """one handle = one non-thread-safe object; distinct handles are usable from distinct threads:
+    four threads align concurrently (ctypes releases the GIL), results equal the sequential ones bit for bit."""
+    import threading
+
+    cfg = cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.05)
+    data = [syn.cloud_pair_3d(n=20000 + 3000 * k, seed=60 + k) for k in range(4)]
+
+    def run(k, out, reps):
+        al = product.MultiAligner(abi.SE3_QUAT_RIGHT)
+        setup_pair(al, data[k], cfg)
+        for _ in range(reps):
+            al.set_moving_in_fixed(syn.identity(3))
+            al.compute()
+        out[k] = (al.moving_in_fixed().copy(), al.correspondences(0).copy(), al.status())
+        al.close()
+
+    seq, par = {}, {}
+    for k in range(4):
+        run(k, seq, 1)
+    threads = [threading.Thread(target=run, args=(k, par, 20)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(4):
+        assert par[k][2] == seq[k][2] == abi.SUCCESS
+        assert par[k][0].tobytes() == seq[k][0].tobytes()
+        assert np.array_equal(par[k][1], seq[k][1])
