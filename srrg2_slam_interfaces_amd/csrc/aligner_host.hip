@@ -62,6 +62,7 @@ struct Slice {
   DevBuf<uint8_t> gcorr_stat;
   std::vector<srrg2_correspondence> h_gcorr;
   std::vector<int> h_gcorr_off;  // [K + 1]; empty: none set
+  int* qprobe_host = nullptr; size_t qprobe_cap = 0;  // pinned: deferred counts of the last finished iteration
   DevBuf<float4> prev_f;
   DevBuf<float> prev_m;
   DevBuf<unsigned long long> dbg;   // SRRG2_AMD_TIMELINE (debug builds): per-wave stamps of the step kernel
@@ -76,6 +77,9 @@ struct Slice {
   float prior_Z[12]{};
   bool has_prior = false;
   void release() {
+    if (qprobe_host) (void) hipHostFree(qprobe_host);
+    qprobe_host = nullptr;
+    qprobe_cap  = 0;
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
     cell_start.release(); cursor.release(); scan_sums.release(); scalars.release();
     moving.release(); moving_nrm.release(); pinf.release();
@@ -491,6 +495,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
     }
     sc.qcount = use_queue ? s->qcount.p : nullptr;
+    sc.qprobe_host = nullptr;
+    if (use_queue) {
+      if ((rc = ensure_pinned(s->qprobe_host, s->qprobe_cap, (size_t) 2 * K))) return rc;
+      std::memset(s->qprobe_host, 0x7f, sizeof(int) * (size_t) 2 * K);  // "large" until the device reports
+      sc.qprobe_host = s->qprobe_host;
+    }
     // (k_icp_init zeroes the slot sets and the queue counters; afterwards the control kernel resets them each iteration)
     sc.partials  = s->partials.p;
     sc.pinf_bits = s->pinf.p;
@@ -595,8 +605,34 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     if (!all_proj || proj_group.size() < 2 || proj_group.size() > 4 || (C.tune & 131072)) proj_group.clear();
   }
+  // Adaptive use of the deferred-search kernel: after iteration `probe_it` the host waits once for the control kernel
+  // and reads how much that iteration deferred (pinned counters).  Few entries, none of them far (a far entry is a
+  // whole-wave scan: expensive when a wave has to do several in a row) => the remaining iterations finish their open
+  // points inside the step kernel and skip the extra launch (C2: 8 us per iteration).  Partial overlaps keep hundreds
+  // of far entries per iteration (near-ties along the border of the fixed cloud) and keep the queue.
+  const int probe_it = std::getenv("SRRG2_AMD_QPROBE") ? std::atoi(std::getenv("SRRG2_AMD_QPROBE")) : 1;
+  std::vector<char> queue_on((size_t) std::max(nslices, 1), 1);
+  bool probed = false;
   auto run_phase = [&](int slot0) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
+      if (!probed && slot0 == 0 && it == probe_it + 1 && probe_it >= 0 && a->params.max_iterations > probe_it + 2) {
+        probed       = true;
+        bool any_q   = false;
+        for (int si = 0; si < nslices; ++si) any_q = any_q || sdev[si].queue != nullptr;
+        if (any_q) {
+          HIP_TRY(hipStreamSynchronize(a->stream));
+          for (int si = 0; si < nslices; ++si) {
+            if (!sdev[si].queue) continue;
+            bool small = true;
+            for (int k = 0; k < K; ++k) {
+              const int near = a->slices[si]->qprobe_host[2 * k], far = a->slices[si]->qprobe_host[2 * k + 1];
+              const int nmk  = all[(size_t) si * K + k].nm;
+              if (far > 32 || near > std::max(1024, nmk / 64)) small = false;
+            }
+            queue_on[(size_t) si] = small ? 0 : 1;
+          }
+        }
+      }
       if (!proj_group.empty()) {
         SliceDev pack[4];
         const ProblemDev* pp[4];
@@ -653,9 +689,16 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           srrg2amd::launch_proj_step(s->cfg.kind == SRRG2_SLICE_REPROJECTION, sdev[si], a->probs.p + (size_t) si * K,
                                      a->states.p, K, nm_max, a->stream);
           sdev[si].zbuf_parity ^= 1;  // the pass just launched reset the other buffer
-        } else
-          srrg2amd::launch_icp_step(a->dim, plane, sdev[si], a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
-                                    a->stream);
+        } else {
+          // The deferred-search kernel pays off while many points are open; once the searches are mostly skipped
+          // its launch costs more than finishing a few near points inside the step kernel (queue_on, decided below).
+          SliceDev sd = sdev[si];
+          if (!queue_on[si]) {
+            sd.queue  = nullptr;
+            sd.qcount = nullptr;
+          }
+          srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
+        }
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }
       srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);

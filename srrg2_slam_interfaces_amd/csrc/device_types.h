@@ -124,6 +124,7 @@ struct SliceCtl {
   int rows, cols;
   float depth_min;
   int* qcount;              // deferred-search queue counters of the slice (reset by the control kernel), or null
+  int* qprobe_host;         // pinned host copy of the counters of the last finished iteration ([problem][near, far]), or null
   const long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N] (null for priors)
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals

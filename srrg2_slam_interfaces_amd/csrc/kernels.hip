@@ -1213,6 +1213,17 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       }
     }
   }
+#ifdef SRRG2_TIMELINE
+  if (tl) {  // per-wave census of this iteration (tools/timeline.py prints the sums)
+    const unsigned long long b_skip_a = __ballot(skipped && bidx != NO_MATCH), b_skip_c = __ballot(skipped && bidx == NO_MATCH);
+    const unsigned long long b_strag = __ballot(straggler), b_near = __ballot(!straggler && r2 == 2), b_far = __ballot(!straggler && r2 > 2);
+    const unsigned long long b_act = __ballot(active);
+    if ((threadIdx.x & 63) == 0) {
+      tl[8] = __popcll(b_act); tl[9] = __popcll(b_skip_a); tl[10] = __popcll(b_skip_c); tl[11] = __popcll(b_strag);
+      tl[12] = __popcll(b_near); tl[13] = __popcll(b_far);
+    }
+  }
+#endif
   STAMP(tl, 4);  // first search phase done
   bool deferred = false;
   if (S.queue) {
@@ -1991,7 +2002,15 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   st->nstats++;
   if (C.has_term && has_to_stop(C, st, cur)) st->done = 1;  // :124-126
   for (int s = 0; s < C.nslices; ++s)
-    if (C.slices[s].qcount) C.slices[s].qcount[2 * prob] = C.slices[s].qcount[2 * prob + 1] = 0;  // queues start empty next iteration
+    if (C.slices[s].qcount) {
+      // how much was deferred this iteration, for the host (pinned memory): it decides after a few iterations whether
+      // the deferred-search kernel is still worth its launch
+      if (C.slices[s].qprobe_host) {
+        C.slices[s].qprobe_host[2 * prob]     = C.slices[s].qcount[2 * prob];
+        C.slices[s].qprobe_host[2 * prob + 1] = C.slices[s].qcount[2 * prob + 1];
+      }
+      C.slices[s].qcount[2 * prob] = C.slices[s].qcount[2 * prob + 1] = 0;  // queues start empty next iteration
+    }
 }
 
 }  // namespace

@@ -28,6 +28,8 @@ def main():
             t[:, k] = np.where(t[:, k] > 0, t[:, k], t[:, k - 1])
         rel = (t - t0) / 100.0
         print("iteration %d: %d waves, launch span %.2f us" % (it, len(t), rel[:, 7].max()))
+        cen = st[it][ok][:, 8:14].sum(axis=0)
+        print("  census: active %d | skipped with neighbour %d, certified unmatched %d | stragglers %d | open near %d far %d" % tuple(cen))
         prev = np.zeros(len(t))
         for k in range(8):
             d = rel[:, k] - (rel[:, k - 1] if k else 0)
