@@ -458,6 +458,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   C.term          = a->term;
   C.max_stats     = slots;
   C.tune          = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
+  C.probe_it      = std::getenv("SRRG2_AMD_QPROBE") ? std::atoi(std::getenv("SRRG2_AMD_QPROBE")) : 1;
+  if (a->params.max_iterations <= C.probe_it + 3 || K > 4) C.probe_it = -1;
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {
@@ -496,10 +498,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     sc.qcount = use_queue ? s->qcount.p : nullptr;
     sc.qprobe_host = nullptr;
+    sc.probs       = nullptr;
     if (use_queue) {
       if ((rc = ensure_pinned(s->qprobe_host, s->qprobe_cap, (size_t) 2 * K))) return rc;
       std::memset(s->qprobe_host, 0x7f, sizeof(int) * (size_t) 2 * K);  // "large" until the device reports
       sc.qprobe_host = s->qprobe_host;
+      sc.probs       = a->probs.p + (size_t) si * K;
     }
     // (k_icp_init zeroes the slot sets and the queue counters; afterwards the control kernel resets them each iteration)
     sc.partials  = s->partials.p;
@@ -605,32 +609,35 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     if (!all_proj || proj_group.size() < 2 || proj_group.size() > 4 || (C.tune & 131072)) proj_group.clear();
   }
-  // Adaptive use of the deferred-search kernel: after iteration `probe_it` the host waits once for the control kernel
-  // and reads how much that iteration deferred (pinned counters).  Few entries, none of them far (a far entry is a
-  // whole-wave scan: expensive when a wave has to do several in a row) => the remaining iterations finish their open
-  // points inside the step kernel and skip the extra launch (C2: 8 us per iteration).  Partial overlaps keep hundreds
-  // of far entries per iteration (near-ties along the border of the fixed cloud) and keep the queue.
-  const int probe_it = std::getenv("SRRG2_AMD_QPROBE") ? std::atoi(std::getenv("SRRG2_AMD_QPROBE")) : 1;
+  // Adaptive use of the deferred-search kernel.  After iteration `probe_it` the control kernel looks at what that
+  // iteration deferred: few entries, none of them far (a far entry is a whole-wave scan: expensive when a wave has to do
+  // several in a row) => it clears st->qmode and the step kernels finish their open points themselves from then on; it
+  // also mirrors the counters into pinned memory.  The host enqueues one more full iteration, then reads the mirror
+  // (it has arrived by then: no idle GPU) and applies the same rule to drop the deferred-search launch for the
+  // remaining iterations (C2: 8 us each).  Partial overlaps keep hundreds of far entries per iteration (near-ties along
+  // the border of the fixed cloud) and keep the queue.
+  const int probe_it = C.probe_it;
   std::vector<char> queue_on((size_t) std::max(nslices, 1), 1);
   bool probed = false;
   auto run_phase = [&](int slot0) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
-      if (!probed && slot0 == 0 && it == probe_it + 1 && probe_it >= 0 && a->params.max_iterations > probe_it + 2) {
-        probed       = true;
-        bool any_q   = false;
-        for (int si = 0; si < nslices; ++si) any_q = any_q || sdev[si].queue != nullptr;
-        if (any_q) {
-          HIP_TRY(hipStreamSynchronize(a->stream));
-          for (int si = 0; si < nslices; ++si) {
-            if (!sdev[si].queue) continue;
-            bool small = true;
-            for (int k = 0; k < K; ++k) {
-              const int near = a->slices[si]->qprobe_host[2 * k], far = a->slices[si]->qprobe_host[2 * k + 1];
-              const int nmk  = all[(size_t) si * K + k].nm;
-              if (far > 32 || near > std::max(1024, nmk / 64)) small = false;
+      if (!probed && slot0 == 0 && probe_it >= 0 && it == probe_it + 2) {
+        probed = true;
+        for (int si = 0; si < nslices; ++si) {
+          if (!sdev[si].queue) continue;
+          volatile int* mirror = a->slices[si]->qprobe_host;
+          bool small           = true;
+          for (int k = 0; k < K; ++k) {
+            int spins = 0;
+            while (mirror[2 * k] == 0x7f7f7f7f || mirror[2 * k + 1] == 0x7f7f7f7f) {  // not reported yet
+              // (a problem that stopped before the probe iteration never reports: once the stream has drained, give up
+              // and keep the queue)
+              if ((++spins & 1023) == 0 && hipStreamQuery(a->stream) == hipSuccess) break;
             }
-            queue_on[(size_t) si] = small ? 0 : 1;
+            const int near = mirror[2 * k], far = mirror[2 * k + 1];
+            if (near == 0x7f7f7f7f || far > 32 || near > std::max(1024, all[(size_t) si * K + k].nm / 64)) small = false;
           }
+          queue_on[(size_t) si] = small ? 0 : 1;
         }
       }
       if (!proj_group.empty()) {

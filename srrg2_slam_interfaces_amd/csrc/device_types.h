@@ -96,6 +96,7 @@ struct ProblemState {
   int kexp[SRRG2_MAX_SLICES];   // fixed-point exponent per slice
   int ncorr[SRRG2_MAX_SLICES];  // correspondences of the last finder pass per slice
   int ninl[SRRG2_MAX_SLICES];   // inliers of the last linearisation per slice
+  int qmode[SRRG2_MAX_SLICES];  // 1: open points are deferred to the queue; 0: finished inside the step kernel
   int w_count;
   double w_corr[TERM_WINDOW_MAX], w_inl[TERM_WINDOW_MAX], w_out[TERM_WINDOW_MAX], w_chi[TERM_WINDOW_MAX];
   double last_H[36], last_b[6], last_dx[6];
@@ -124,7 +125,8 @@ struct SliceCtl {
   int rows, cols;
   float depth_min;
   int* qcount;              // deferred-search queue counters of the slice (reset by the control kernel), or null
-  int* qprobe_host;         // pinned host copy of the counters of the last finished iteration ([problem][near, far]), or null
+  int* qprobe_host;         // pinned host copy of the counters of iteration probe_it ([problem][near, far]), or null
+  const ProblemDev* probs;  // [problem] table of the slice (device): point counts for the decision threshold
   const long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N] (null for priors)
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
@@ -141,5 +143,6 @@ struct CtlParams {
   srrg2_termination_params term;
   int max_stats;  // capacity of the per-problem stats array
   int tune;       // debug flags (SRRG2_AMD_TUNE); 256 = keep iterating when the association fails (timing only)
+  int probe_it;   // iteration after which the use of the deferred-search queue is decided (-1: never)
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

@@ -1076,6 +1076,9 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   const GridDev& g   = S.grid;
   const float b2_1   = bound2_of(1, g.h);
   const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
+  // open points go to the deferred-search queue, or are finished here (no queue; or the control kernel saw that the
+  // queue stays nearly empty: st->qmode, mirrored by the host which then drops the deferred-search launch)
+  const bool use_q = S.queue != nullptr && st->qmode[S.slice_idx] != 0;
   // Scans of points without a neighbour inside the gate reach 25% beyond it once a prior exists: what they find (a
   // point just outside the gate, or nothing) then certifies "no match" for the following iterations without a search.
   const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   // Converged iterations: a handful of lanes per wave still need a search (near-ties, lost exclusion radius) and would
   // make the whole wave pay the search latency.  Hand them to the deferred-search kernel, which is launched anyway.
   bool straggler = false;
-  if (S.queue && use_prior && rfar > 1 && !(S.tune & (16 | 8192))) {
+  if (use_q && use_prior && rfar > 1 && !(S.tune & (16 | 8192))) {
     const bool need  = active && !skipped;
     const int n_need = __popcll(__ballot(need));
     if (need && n_need <= 8) {
@@ -1226,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 #endif
   STAMP(tl, 4);  // first search phase done
   bool deferred = false;
-  if (S.queue) {
+  if (use_q) {
     // push the open lanes to the problem's queues: near entries (radius 2) grow from the front of the problem's
     // region, far entries (radius > 2) from its back; one atomic per wave and kind, entries in lane order
     const unsigned long long need_near = __ballot(r2 == 2);
@@ -2005,9 +2008,12 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
     if (C.slices[s].qcount) {
       // how much was deferred this iteration, for the host (pinned memory): it decides after a few iterations whether
       // the deferred-search kernel is still worth its launch
-      if (C.slices[s].qprobe_host) {
-        C.slices[s].qprobe_host[2 * prob]     = C.slices[s].qcount[2 * prob];
-        C.slices[s].qprobe_host[2 * prob + 1] = C.slices[s].qcount[2 * prob + 1];
+      if (C.slices[s].qprobe_host && st->phase == 0 && st->nstats == C.probe_it + 1) {
+        const int near = C.slices[s].qcount[2 * prob], far = C.slices[s].qcount[2 * prob + 1];
+        // (the host applies the same rule to the mirrored counters: srrg2amd::queue_stays_small)
+        if (far <= 32 && near <= max(1024, C.slices[s].probs[prob].nm / 64)) st->qmode[s] = 0;
+        C.slices[s].qprobe_host[2 * prob]     = near;
+        C.slices[s].qprobe_host[2 * prob + 1] = far;
       }
       C.slices[s].qcount[2 * prob] = C.slices[s].qcount[2 * prob + 1] = 0;  // queues start empty next iteration
     }
@@ -2038,6 +2044,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   st->nstats   = 0;
   st->phase    = 0;
   st->w_count  = 0;
+  for (int s = 0; s < SRRG2_MAX_SLICES; ++s) st->qmode[s] = 1;
   int nm_of[SRRG2_MAX_SLICES];
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
