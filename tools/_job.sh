@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-for q in -1 1; do
-echo "QPROBE $q: full / ov0.7 / 10k"
-for extra in "" "--overlap 0.7" "--points 10000"; do
-SRRG2_AMD_QPROBE=$q python bench.py $extra --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('   ', round(d['value']), d['ms_per_step'])"
+python bench.py > gpurun_out/bench_r1_j.json 2> gpurun_out/bench_r1_j.err; tail -1 gpurun_out/bench_r1_j.json | cut -c1-160
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT/gpurun_out
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/r1g_c2_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2>&1; echo trace rc=$?
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $R/r1g_c2_pmc_$set -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "$set rc=$?"
 done
-done
-python tools/bench_tracker.py 2>&1 | tail -1 | cut -c60-330
+cd $GRAFT_REPO_ROOT
+python tools/bench_tracker.py 2>&1 | tail -1 > gpurun_out/bench_r1_j_tracker.json

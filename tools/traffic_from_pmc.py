@@ -27,12 +27,17 @@ def main():
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     kernels = {}
     total = 0.0
+    passes = 0
     for k in sorted(set(f) | set(w)):
         fb = 2.0 * 1024.0 * f.get(k, (0.0, 0))[0]
         wb = 1024.0 * w.get(k, (0.0, 0))[0]
-        kernels[k] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "dispatches": f.get(k, (0, 0))[1]}
-        total += fb + wb
-    json.dump({"workload": workload, "bytes_per_slice_pass": total, "kernels": kernels,
+        n = f.get(k, (0, 0))[1]
+        kernels[k] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "dispatches": n}
+        total += (fb + wb) * n
+        if "queue" not in k and "zbuf" not in k:
+            passes = max(passes, n)  # one step-kernel dispatch per slice pass; the deferred-search kernel runs in some
+    total = total / max(passes, 1)
+    json.dump({"workload": workload, "bytes_per_slice_pass": total, "slice_passes": passes, "kernels": kernels,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, averaged per dispatch; KiB -> bytes; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes); includes Infinity-Cache hits"},
               open(out, "w"), indent=1)
