@@ -1,10 +1,15 @@
-cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_r1_j.json 2> gpurun_out/bench_r1_j.err; tail -1 gpurun_out/bench_r1_j.json | cut -c1-160
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT/gpurun_out
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/r1g_c2_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2>&1; echo trace rc=$?
-for set in "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $R/r1g_c2_pmc_$set -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "$set rc=$?"
-done
-cd $GRAFT_REPO_ROOT
-python tools/bench_tracker.py 2>&1 | tail -1 > gpurun_out/bench_r1_j_tracker.json
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 120 > gpurun_out/p_parity.log 2>&1
+tail -3 gpurun_out/p_parity.log
+SRRG2_AMD_TUNE=2097152 SRRG2_AMD_PERSIST_DBG=gpurun_out/p_stamps.bin timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/p_bench_dbg.json 2> gpurun_out/p_bench_dbg.err
+python tools/persist_stamps.py gpurun_out/p_stamps.bin
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/p_bench_c2.json 2> gpurun_out/p_bench_c2.err
+python - <<'PY'
+import json
+for f in ("p_bench_c2",):
+    try:
+        d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["config"])
+    except Exception as e: print(f, "ERR", e)
+PY
