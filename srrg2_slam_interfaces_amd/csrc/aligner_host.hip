@@ -377,6 +377,19 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     HIP_TRY(hipMemsetAsync(s->ms_counts.p, 0, (ncell + 1) * sizeof(int), a->stream));
     HIP_TRY(hipStreamSynchronize(a->stream));  // bb / pd are stack-lifetime host buffers
   }
+  // small key spaces: one workgroup per problem sorts straight from the caller's (staged) layout; the ingest-order copy
+  // is only read by given-correspondences slices
+  static const bool local_sort = !(std::getenv("SRRG2_AMD_TUNE") && (std::atoi(std::getenv("SRRG2_AMD_TUNE")) & (1 << 22)));
+  if (local_sort && s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES &&
+      srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs.p, K, a->dim, bits, s->moving.p,
+                                   normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
+    HIP_TRY(hipGetLastError());
+    if (mem == SRRG2_MEM_HOST) HIP_TRY(hipStreamSynchronize(a->stream));
+    s->nm_total           = n;
+    s->has_moving         = true;
+    s->moving_has_normals = normals != nullptr;
+    return 0;
+  }
   // all clouds of the batch in one launch each (points, normals)
   srrg2amd::launch_ingest_batch(dsrc, sf, s->ms_probs.p, K, max_nm, a->dim, s->moving_raw.p, s->pinf.p, 1, a->stream);
   if (normals)

@@ -17,6 +17,8 @@ void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm,
                          float4* out_nrm, hipStream_t s);
 // Morton sort of K moving clouds (counts/cursor: (K << 3*bits) + 1 ints; bb: K*6 keys initialised to
 // {0xffffffff x3, 0 x3}; counts zeroed)
+bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int bits,
+                        float4* out_pts, float4* out_nrm, unsigned* maxabs_bits, hipStream_t s);
 void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
                   unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
                   float4* out_nrm, hipStream_t s);

@@ -1,15 +1,16 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 120 > gpurun_out/p_parity.log 2>&1
-tail -3 gpurun_out/p_parity.log
-SRRG2_AMD_TUNE=2097152 SRRG2_AMD_PERSIST_DBG=gpurun_out/p_stamps.bin timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/p_bench_dbg.json 2> gpurun_out/p_bench_dbg.err
-python tools/persist_stamps.py gpurun_out/p_stamps.bin
-timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/p_bench_c2.json 2> gpurun_out/p_bench_c2.err
+timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/t_gpu.log 2>&1
+tail -3 gpurun_out/t_gpu.log
+timeout 300 python bench.py --workload c4 --steps 100 --warmup 10 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/q_bench_c4.json 2> gpurun_out/q_bench_c4.err
+SRRG2_AMD_TUNE=4194304 timeout 300 python bench.py --workload c4 --steps 100 --warmup 10 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/q_bench_c4old.json 2>/dev/null
+timeout 300 python bench.py --workload c4 --batch 256 --steps 20 --warmup 3 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/q_bench_c4_256.json 2> gpurun_out/q_bench_c4_256.err
+SRRG2_AMD_TUNE=4194304 timeout 300 python bench.py --workload c4 --batch 256 --steps 20 --warmup 3 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/q_bench_c4_256old.json 2>/dev/null
 python - <<'PY'
 import json
-for f in ("p_bench_c2",):
+for f in ("q_bench_c4","q_bench_c4old","q_bench_c4_256","q_bench_c4_256old"):
     try:
-        d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["config"])
+        d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"])
     except Exception as e: print(f, "ERR", e)
 PY
