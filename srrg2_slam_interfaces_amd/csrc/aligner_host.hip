@@ -63,6 +63,8 @@ struct Slice {
   std::vector<srrg2_correspondence> h_gcorr;
   std::vector<int> h_gcorr_off;  // [K + 1]; empty: none set
   int* qprobe_host = nullptr; size_t qprobe_cap = 0;  // pinned: deferred counts of the last finished iteration
+  ProblemDev* ms_probs_host = nullptr; size_t ms_probs_host_cap = 0;  // pinned: problem table of the last moving batch
+  bool ms_pending = false;  // a sort that reads ms_probs_host may still be in flight
   DevBuf<float4> prev_f;
   DevBuf<float> prev_m;
   DevBuf<unsigned long long> dbg;   // SRRG2_AMD_TIMELINE (debug builds): per-wave stamps of the step kernel
@@ -80,6 +82,9 @@ struct Slice {
     if (qprobe_host) (void) hipHostFree(qprobe_host);
     qprobe_host = nullptr;
     qprobe_cap  = 0;
+    if (ms_probs_host) (void) hipHostFree(ms_probs_host);
+    ms_probs_host     = nullptr;
+    ms_probs_host_cap = 0;
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
     cell_start.release(); cursor.release(); scan_sums.release(); scalars.release();
     moving.release(); moving_nrm.release(); pinf.release();
@@ -337,7 +342,6 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   if ((rc = s->corr_stat.reserve((size_t) std::max(n, 1)))) return rc;
   const size_t bytes_c = (size_t) n * a->dim * 4;
   if (mem == SRRG2_MEM_HOST && (rc = a->staging.reserve(2 * bytes_c + 64))) return rc;
-  HIP_TRY(hipMemsetAsync(s->pinf.p, 0, (size_t) K * sizeof(unsigned), a->stream));
   const float* base_c = (const float*) ((const char*) coords + (size_t) offsets[0] * cs);
   const float* dsrc;
   int sf;
@@ -359,6 +363,29 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   }
   // Morton sort per problem: 64^3 cells for one cloud, fewer per problem for big batches
   const int bits = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
+  // small key spaces: one workgroup per problem sorts straight from the caller's (staged) layout, with the problem
+  // table read from pinned host memory (no copies, memsets or waits on the stream); the ingest-order copy of the
+  // clouds, which this path does not produce, is only read by given-correspondences slices
+  static const bool local_sort = !(std::getenv("SRRG2_AMD_TUNE") && (std::atoi(std::getenv("SRRG2_AMD_TUNE")) & (1 << 22)));
+  if (local_sort && bits <= 5 && s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES) {
+    if ((rc = ensure_pinned(s->ms_probs_host, s->ms_probs_host_cap, (size_t) K))) return rc;
+    if (s->ms_pending) HIP_TRY(hipStreamSynchronize(a->stream));  // (set_moving twice without a compute() in between)
+    s->ms_pending = false;
+    std::memcpy(s->ms_probs_host, pd.data(), (size_t) K * sizeof(ProblemDev));
+    if (srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, bits, s->moving.p,
+                                     normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
+      HIP_TRY(hipGetLastError());
+      if (mem == SRRG2_MEM_HOST)
+        HIP_TRY(hipStreamSynchronize(a->stream));  // caller may reuse its buffer on return
+      else
+        s->ms_pending = true;
+      s->nm_total           = n;
+      s->has_moving         = true;
+      s->moving_has_normals = normals != nullptr;
+      return 0;
+    }
+  }
+  HIP_TRY(hipMemsetAsync(s->pinf.p, 0, (size_t) K * sizeof(unsigned), a->stream));
   const size_t ncell = (size_t) K << (3 * bits);
   if ((rc = s->ms_counts.reserve(ncell + 1))) return rc;
   if ((rc = s->ms_cursor.reserve(ncell + 1))) return rc;
@@ -376,19 +403,6 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     HIP_TRY(hipMemcpyAsync(s->ms_probs.p, pd.data(), pd.size() * sizeof(ProblemDev), hipMemcpyHostToDevice, a->stream));
     HIP_TRY(hipMemsetAsync(s->ms_counts.p, 0, (ncell + 1) * sizeof(int), a->stream));
     HIP_TRY(hipStreamSynchronize(a->stream));  // bb / pd are stack-lifetime host buffers
-  }
-  // small key spaces: one workgroup per problem sorts straight from the caller's (staged) layout; the ingest-order copy
-  // is only read by given-correspondences slices
-  static const bool local_sort = !(std::getenv("SRRG2_AMD_TUNE") && (std::atoi(std::getenv("SRRG2_AMD_TUNE")) & (1 << 22)));
-  if (local_sort && s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES &&
-      srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs.p, K, a->dim, bits, s->moving.p,
-                                   normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
-    HIP_TRY(hipGetLastError());
-    if (mem == SRRG2_MEM_HOST) HIP_TRY(hipStreamSynchronize(a->stream));
-    s->nm_total           = n;
-    s->has_moving         = true;
-    s->moving_has_normals = normals != nullptr;
-    return 0;
   }
   // all clouds of the batch in one launch each (points, normals)
   srrg2amd::launch_ingest_batch(dsrc, sf, s->ms_probs.p, K, max_nm, a->dim, s->moving_raw.p, s->pinf.p, 1, a->stream);
@@ -760,6 +774,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     a->prof_used = 0;
   }
+  for (Slice* sl : a->slices) sl->ms_pending = false;  // (the stream has drained)
   a->K = K;
   // the handle's observable state is that of the last alignment (sequential semantics)
   const ProblemOut& o = a->outs_host[K - 1];

@@ -396,14 +396,16 @@ __global__ void k_msort_scatter(const float4* __restrict__ pts, const float4* __
 // problem does everything -- bounding box and max |coordinate| of the raw strided input, histogram with LDS atomics,
 // exclusive scan in place, scatter of the widened points (and normals) through LDS cursors.  Replaces two ingest
 // kernels, the bounding-box / count / scan x 3 / copy / scatter kernels and their 2 x nm global atomics per problem
-// (a 32 x 50k batch: 68 + 188 us -> one kernel).  Each thread keeps four points in flight per round.
+// (a 32 x 50k batch: 68 + 188 us -> one kernel).  Each thread keeps eight points in flight per round.
 __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ src, int sf, const float* __restrict__ nsrc,
                                                       int nsf, const ProblemDev* __restrict__ probs, int dim, int bits,
                                                       float4* __restrict__ out_pts, float4* __restrict__ out_nrm,
                                                       unsigned* __restrict__ maxabs_bits /* [K] */) {
+  constexpr int NPT = 8;  // points in flight per thread and round
   extern __shared__ int hist[];  // 1 << (3 * bits) counters, then cursors
   __shared__ unsigned red[16][6];
   __shared__ unsigned bbs[6];
+  __shared__ float kmn[3], kscale[3];  // cell coordinate = (v - kmn) * kscale (one reciprocal per axis, not a division per point)
   __shared__ int wsum[16];
   const ProblemDev pd = probs[blockIdx.x];
   const int ncell     = 1 << (3 * bits);
@@ -416,12 +418,12 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
   for (int c = tid; c < ncell; c += 1024) hist[c] = 0;
   // ---- pass 1: bounding box of the finite points (order-preserving unsigned keys, like k_msort_bbox)
   unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-  for (int i0 = tid; i0 < pd.nm; i0 += 4096) {
-    float4 q[4];
+  for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
+    float4 q[NPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = (i0 + j * 1024 < pd.nm) ? load(i0 + j * 1024) : make_float4(NAN, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NPT; ++j) q[j] = (i0 + j * 1024 < pd.nm) ? load(i0 + j * 1024) : make_float4(NAN, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPT; ++j) {
       if (!finite3(q[j].x, q[j].y, q[j].z)) continue;
       const unsigned k[3] = {fkey(q[j].x), fkey(q[j].y), fkey(q[j].z)};
 #pragma unroll
@@ -465,45 +467,65 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
     }
     maxabs_bits[blockIdx.x] = __float_as_uint(amax);
   }
-  // ---- pass 2: histogram
-  for (int i0 = tid; i0 < pd.nm; i0 += 4096) {
-    float4 q[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) q[j] = (i0 + j * 1024 < pd.nm) ? load(i0 + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i0 + j * 1024 < pd.nm) atomicAdd(&hist[morton_key(q[j], bbs, bits)], 1);
+  if (tid < 3) {
+    const unsigned a = bbs[tid], z = bbs[3 + tid];
+    const float mnf  = __uint_as_float((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
+    const float mxf  = __uint_as_float((z & 0x80000000u) ? (z & 0x7fffffffu) : ~z);
+    const float ext  = mxf - mnf;
+    kmn[tid]         = mnf;
+    kscale[tid]      = (bbs[0] != 0xffffffffu && ext > 0.f) ? (float) (1 << bits) / ext : 0.f;
   }
   __syncthreads();
-  // ---- exclusive scan in place: every thread owns `per` consecutive cells
-  {
-    const int per = (ncell + 1023) / 1024;
-    const int c0  = tid * per;
-    int sum = 0;
-    for (int c = c0; c < c0 + per && c < ncell; ++c) sum += hist[c];
-    int incl = sum;
+  // (any monotone cell assignment gives a valid sort: the keys only order the points)
+  auto key_of = [&](const float4 p) -> unsigned {
+    if (!finite3(p.x, p.y, p.z)) return (unsigned) ncell - 1u;
+    const int hi = (1 << bits) - 1;
+    const int cx = min(max((int) ((p.x - kmn[0]) * kscale[0]), 0), hi);
+    const int cy = min(max((int) ((p.y - kmn[1]) * kscale[1]), 0), hi);
+    const int cz = min(max((int) ((p.z - kmn[2]) * kscale[2]), 0), hi);
+    return spread3((unsigned) cx) | (spread3((unsigned) cy) << 1) | (spread3((unsigned) cz) << 2);
+  };
+  // ---- pass 2: histogram
+  for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
+    float4 q[NPT];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
+    for (int j = 0; j < NPT; ++j) q[j] = (i0 + j * 1024 < pd.nm) ? load(i0 + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+      if (i0 + j * 1024 < pd.nm) atomicAdd(&hist[key_of(q[j])], 1);
+  }
+  __syncthreads();
+  // ---- exclusive scan in place.  Wave w owns the cells [w * seg, (w + 1) * seg) and walks them 64 at a time (lane =
+  // consecutive cell: no bank conflicts; a thread owning consecutive cells would put all 64 lanes on one bank), carrying
+  // the running total; then every cell gets the total of the waves before its own.
+  {
+    const int seg = (ncell + 15) / 16;
+    int carry     = 0;
+    for (int c = wid * seg + lane; c - lane < min((wid + 1) * seg, ncell); c += 64) {
+      const bool in = c < min((wid + 1) * seg, ncell);
+      const int v   = in ? hist[c] : 0;
+      int incl      = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (in) hist[c] = carry + incl - v;
+      carry += __shfl(incl, 63);
     }
-    if (lane == 63) wsum[wid] = incl;
+    if (lane == 0) wsum[wid] = carry;
     __syncthreads();
-    int before = incl - sum;
+    int before = 0;
     for (int w = 0; w < wid; ++w) before += wsum[w];
-    for (int c = c0; c < c0 + per && c < ncell; ++c) {
-      const int v = hist[c];
-      hist[c]     = before;
-      before += v;
-    }
+    for (int c = wid * seg + lane; c < min((wid + 1) * seg, ncell); c += 64) hist[c] += before;
   }
   __syncthreads();
   // ---- pass 3: scatter (the caller's index travels in .w; the order inside a cell does not matter: see above)
   const float* nbase = nsrc ? nsrc + (size_t) pd.moff * nsf : nullptr;
-  for (int i0 = tid; i0 < pd.nm; i0 += 4096) {
-    float4 q[4], nq[4];
+  for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
+    float4 q[NPT], nq[NPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPT; ++j) {
       const int i = i0 + j * 1024;
       q[j]  = i < pd.nm ? load(i) : make_float4(0.f, 0.f, 0.f, 0.f);
       nq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -513,10 +535,10 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPT; ++j) {
       const int i = i0 + j * 1024;
       if (i >= pd.nm) continue;
-      const int pos = atomicAdd(&hist[morton_key(q[j], bbs, bits)], 1);
+      const int pos = atomicAdd(&hist[key_of(q[j])], 1);
       q[j].w        = __int_as_float(i);
       out_pts[pd.moff + pos] = q[j];
       if (nbase) out_nrm[pd.moff + pos] = nq[j];
