@@ -320,6 +320,41 @@ def test_randomised_batches(oracle, product, seed):
         assert r["last"] == g["last"]
 
 
+@pytest.mark.parametrize("dim,K", [(3, 6), (3, 40), (2, 9)])
+def test_batch_sort_edge_cases(oracle, product, dim, K):
+    """Batches go through the one-workgroup-per-cloud Morton sort (5-bit keys up to 32 clouds, 4-bit beyond): clouds with
+    non-finite points, an empty cloud, a single point, a degenerate (collinear) cloud, SE(2) batches."""
+    kind = abi.SE3_QUAT_RIGHT if dim == 3 else abi.SE2_RIGHT
+    rng = np.random.default_rng(8800 + K)
+    if dim == 3:
+        probs = syn.batch_3d(K=K, n=1500, seed=8800, shared_fixed_group=64, t_max=0.05, rpy_max_deg=1.0)
+        fixed, fixed_n = probs[0]["fixed"], probs[0]["fixed_normals"]
+        movs = [p["moving"].copy() for p in probs]
+        nrms = [p["moving_normals"].copy() for p in probs]
+        ident, gate, sk = syn.identity(3), 0.3, abi.SLICE_P2PLANE
+    else:
+        d = syn.scan_pair_2d(sigma=0.0)
+        fixed, fixed_n = d["fixed"], d["fixed_normals"]
+        movs = [np.ascontiguousarray(d["moving"][rng.permutation(len(d["moving"]))[: 600 + 20 * k]]) for k in range(K)]
+        nrms = [np.zeros_like(m) for m in movs]
+        ident, gate, sk = syn.identity(2), 0.5, abi.SLICE_P2P
+    movs[1][::7] = np.nan                       # non-finite points (last Morton cell, never matched)
+    movs[2] = movs[2][:0]; nrms[2] = nrms[2][:0]  # empty cloud
+    movs[3] = movs[3][:1]; nrms[3] = nrms[3][:1]  # one point
+    movs[4][:, 1:] = movs[4][0, 1:]             # collinear: zero extent on the other axes
+    res = []
+    for al in _pair(oracle, product, kind):
+        al.set_params(max_iterations=6)
+        si = al.add_slice(cue_config(kind, sk, gate, abi.ROBUST_CAUCHY, 0.05))
+        al.set_fixed(si, fixed, fixed_n)
+        res.append(al.compute_batch(movs, [ident] * K, nrms))
+    for r, g in zip(*res):
+        assert r["status"] == g["status"]
+        assert r["num_iterations"] == g["num_iterations"]
+        assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes()
+        assert r["last"] == g["last"]
+
+
 @pytest.mark.parametrize("dim", [3, 2])
 def test_ties_and_duplicates(oracle, product, dim):
     """Fixed points on a lattice (every moving point at a cell centre is equidistant to 2^dim of them), exact duplicates
