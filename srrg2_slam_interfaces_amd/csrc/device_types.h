@@ -75,7 +75,8 @@ struct SliceDev {
   uint8_t* gcorr_stat;
   const float4* moving_raw;     // moving clouds in ingest order (moving_idx is the caller's index)
   unsigned long long* dbg;  // -DSRRG2_TIMELINE builds only: [iteration < 32][wave][16] shader-clock stamps, or null
-  int tune;             // debug/tuning bit flags (env SRRG2_AMD_TUNE): 1 = skip phase 2 (WRONG results, timing only)
+  int tune;             // strategy switches (env SRRG2_AMD_TUNE; all exact); the result-changing timing knobs exist only
+                        // in -DSRRG2_TIMING_KNOBS builds (kernels.hip: KNOB)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
 };
 
@@ -142,7 +143,7 @@ struct CtlParams {
   int has_term;
   srrg2_termination_params term;
   int max_stats;  // capacity of the per-problem stats array
-  int tune;       // debug flags (SRRG2_AMD_TUNE); 256 = keep iterating when the association fails (timing only)
+  int tune;       // SRRG2_AMD_TUNE (see SliceDev::tune)
   int probe_it;   // iteration after which the use of the deferred-search queue is decided (-1: never)
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

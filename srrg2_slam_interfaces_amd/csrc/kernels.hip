@@ -19,6 +19,15 @@
 
 #include "det_math.h"
 
+// Timing knobs (SRRG2_AMD_TUNE bits 1, 2, 8, 16, 32, 64, 128, 256, 1024, 2048) switch parts of the kernels OFF to see what
+// they cost: WRONG results, so they only exist in profiling builds (make EXTRA=-DSRRG2_TIMING_KNOBS).  The other bits
+// choose between exact strategies and stay available.
+#ifdef SRRG2_TIMING_KNOBS
+#define KNOB(t, bit) (((t) & (bit)) != 0)
+#else
+#define KNOB(t, bit) false
+#endif
+
 namespace {
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) {
@@ -1116,13 +1125,13 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
   if (inrange) {
     if (active) {
       bool found = bidx != NO_MATCH && best <= g.gate2;
-      if (S.tune & 8) found = false;
+      if (KNOB(S.tune, 8)) found = false;
       float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (found && (PLANE || S.use_normal_gate)) nf = (S.tune & 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[bpos];
+      if (found && (PLANE || S.use_normal_gate)) nf = KNOB(S.tune, 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[bpos];
       // (with nf: one round trip, not one after the normal gate; a kept neighbour comes with its coordinates)
       if (bidx != NO_MATCH) fm = kept ? kept_f : g.pts[bpos];
       if (found && S.use_normal_gate) {
-        const float4 nm = (S.tune & 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : S.mnrm[gi];
+        const float4 nm = KNOB(S.tune, 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : S.mnrm[gi];
         float dot;
         if constexpr (DIM == 3) {
           float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
@@ -1192,7 +1201,7 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
             J[r][2] = m[r][1] * p.x - m[r][0] * p.y;
           }
         }
-        fstat = factor_accumulate<D, ROWS>(J, e, false, rk, thr, scale, (S.tune & 64) != 0, acc);
+        fstat = factor_accumulate<D, ROWS>(J, e, false, rk, thr, scale, KNOB(S.tune, 64), acc);
       }
     }
     if (!kept) {  // (a skipped search keeps its neighbour: only the exclusion radius changes)
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   float pad       = 0.02f * g.h;  // margin of the scans beyond the nearest neighbour (grows with the motion)
   __shared__ int coop_lds[4][264];
   STAMP(tl, 1);  // moving point + prior loaded
-  if (active && !(S.tune & 16)) {
+  if (active && !KNOB(S.tune, 16)) {
     transform_point<DIM>(T, p, qx, qy, qz);
     // Temporal coherence, exactly.  The previous iteration of this compute() left, per moving point, its nearest
     // neighbour f* and an exclusion radius m: no OTHER fixed point lies within m of the previous query q'.
@@ -1332,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   // Converged iterations: a handful of lanes per wave still need a search (near-ties, lost exclusion radius) and would
   // make the whole wave pay the search latency.  Hand them to the deferred-search kernel, which is launched anyway.
   bool straggler = false;
-  if (use_q && use_prior && rfar > 1 && !(S.tune & (16 | 8192))) {
+  if (use_q && use_prior && rfar > 1 && !KNOB(S.tune, 16) && !(S.tune & 8192)) {
     const bool need  = active && !skipped;
     const int n_need = __popcll(__ballot(need));
     if (need && n_need <= 8) {
@@ -1341,7 +1350,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       r2        = ball2 <= bound2_of(2, g.h) ? 2 : rfar;
     }
   }
-  if (active && !(S.tune & 16)) {
+  if (active && !KNOB(S.tune, 16)) {
     if (!skipped && !straggler) {
       cx = cell_coord(qx, g.ox, g.inv_h);
       cy = cell_coord(qy, g.oy, g.inv_h);
@@ -1423,7 +1432,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     }
   } else {
     // radius-2 cube per lane, then the cooperative scan for what is still open
-    if (r2 > 1 && rfar >= 2 && !(S.tune & 2)) {
+    if (r2 > 1 && rfar >= 2 && !KNOB(S.tune, 2)) {
       // (starts from scratch: the cube contains the 3^DIM block again, and the runner-up tracking must meet every
       // fixed point exactly once)
       unsigned long long bkey = NO_KEY;
@@ -1447,7 +1456,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       }
     }
     unsigned long long need = __ballot(r2 > 1);
-    if (S.tune & 1) need = 0;
+    if (KNOB(S.tune, 1)) need = 0;
     while (need) {
       const int src = __ffsll((long long) need) - 1;
       need &= need - 1;
@@ -1536,7 +1545,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
       q.i = 0; q.r2 = -1; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0; q.qx = q.qy = q.qz = 0.f;
       q.ball2 = 0.f; q.pad_ = 0;
       if (live) q = queue[e];
-      const bool skip = (S.tune & 2048) != 0;
+      const bool skip = KNOB(S.tune, 2048);
       const int cx = cell_coord(q.qx, g.ox, g.inv_h);
       const int cy = cell_coord(q.qy, g.oy, g.inv_h);
       const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
@@ -1570,7 +1579,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
   }
   for (int e = blockIdx.x * 4 + wid; e < count_far; e += W) {
     const QEntry q  = queue[pd.nm - 1 - e];
-    const bool skip = (S.tune & 1024) != 0;
+    const bool skip = KNOB(S.tune, 1024);
     const int cx = cell_coord(q.qx, g.ox, g.inv_h);
     const int cy = cell_coord(q.qy, g.oy, g.inv_h);
     const int cz = DIM == 3 ? cell_coord(q.qz, g.oz, g.inv_h) : 0;
@@ -2077,7 +2086,7 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
     st->ncorr[s] = nc;
     good |= nc > sc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
   }
-  if (!good && !(C.tune & 256)) {
+  if (!good && !KNOB(C.tune, 256)) {
     for (int s = 0; s < C.nslices; ++s)
       if (C.slices[s].qcount) C.slices[s].qcount[2 * prob] = C.slices[s].qcount[2 * prob + 1] = 0;
     st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;  // multi_aligner_impl.cpp:107-111

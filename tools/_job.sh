@@ -1,3 +1,14 @@
 #!/bin/bash
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu --timeout 300 -k "batch" 2>&1 | tail -15
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/t_gpu.log 2>&1
+tail -2 gpurun_out/t_gpu.log
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/q_bench_c2.json 2>/dev/null
+timeout 300 python bench.py --workload c4 --steps 100 --warmup 10 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/q_bench_c4.json 2>/dev/null
+python - <<'PY'
+import json
+for f in ("q_bench_c2","q_bench_c4"):
+    try:
+        d=json.loads(open("gpurun_out/%s.json"%f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"])
+    except Exception as e: print(f, "ERR", e)
+PY
