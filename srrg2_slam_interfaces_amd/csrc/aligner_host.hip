@@ -300,6 +300,9 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   int r       = 1;
   while (bound2_of_host(r, h) < g.gate2_ext && r < 4096) ++r;
   g.rmax          = r;
+  int rg          = 1;
+  while (rg < r && bound2_of_host(rg, h) < g.gate2) ++rg;
+  g.rfar_gate     = rg;
   const int ncell = g.nx * g.ny * g.nz;
   if ((rc = s->cell_start.reserve((size_t) ncell + 1))) return rc;
   if ((rc = s->cursor.reserve((size_t) ncell + 1))) return rc;
@@ -616,6 +619,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       dm::se3_inverse(s->cfg.sensor_in_robot, d.Sinv);
     else
       dm::se2_inverse(s->cfg.sensor_in_robot, d.Sinv);
+    std::memcpy(sc.Sinv, d.Sinv, sizeof(sc.Sinv));
   }
   if (K > 1 && first_cue >= 0) {
     for (int si = 0; si < nslices; ++si)

@@ -28,7 +28,8 @@ struct GridDev {
   float ox, oy, oz;
   float h, inv_h;
   int nx, ny, nz;
-  int rmax;        // cube radius that covers the gate
+  int rmax;        // cube radius that covers the extended gate
+  int rfar_gate;   // cube radius that covers the ball of radius max_distance (<= rmax; computed by the host)
   float gate2;     // max_distance^2
   float gate2_ext; // (1.25 max_distance)^2: how far scans of unmatched points reach (rmax covers it)
   int n;           // number of fixed points (entries of pts)
@@ -98,6 +99,9 @@ struct ProblemState {
   int ncorr[SRRG2_MAX_SLICES];  // correspondences of the last finder pass per slice
   int ninl[SRRG2_MAX_SLICES];   // inliers of the last linearisation per slice
   int qmode[SRRG2_MAX_SLICES];  // 1: open points are deferred to the queue; 0: finished inside the step kernel
+  // finder transform robot_in_sensor * X of every cue slice (rows [r0 r1 r2 t], SE(2) spread into the same slots) for
+  // the coming passes and for the previous ones: computed once by the init / control kernels instead of by every wave
+  float Tf[SRRG2_MAX_SLICES][12], Tfprev[SRRG2_MAX_SLICES][12];
   int w_count;
   double w_corr[TERM_WINDOW_MAX], w_inl[TERM_WINDOW_MAX], w_out[TERM_WINDOW_MAX], w_chi[TERM_WINDOW_MAX];
   double last_H[36], last_b[6], last_dx[6];
@@ -133,6 +137,7 @@ struct SliceCtl {
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
   const unsigned* finf_bits;      // [1] max |coordinate| of the fixed cloud (given-correspondences slices)
   const int* gcorr_off;           // [K + 1] offsets of the given correspondences (or null)
+  float Sinv[12];                 // robot_in_sensor = sensor_in_robot^-1 (SliceDev::Sinv)
 };
 
 struct CtlParams {

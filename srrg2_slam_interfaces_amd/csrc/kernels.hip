@@ -950,19 +950,24 @@ struct QEntry {  // a moving point whose search did not settle inside the 3^DIM 
 };
 static_assert(sizeof(QEntry) == 40, "host reserves 10 words per entry");
 
-template <int DIM>
-__device__ __forceinline__ void load_finder_transform(const SliceDev& S, const float* X, float* T) {
-  // finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35
-  if constexpr (DIM == 3) {
-    dm::se3_compose(S.Sinv, X, T);
+// finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35.  Computed once per iteration
+// by the init / control kernels (ProblemState::Tf, Tfprev) -- two float64 3x4 compositions per WAVE were a fifth of the
+// vector instructions of a converged pass -- and read here through the scalar cache.
+__device__ __forceinline__ void finder_transform_of(const float* Sinv, int dim, const float* X, float* T) {
+  if (dim == 3) {
+    dm::se3_compose(Sinv, X, T);
   } else {
     float t9[9];
-    dm::se2_compose(S.Sinv, X, t9);
-    // spread the 3x3 into the 3x4 slots used below: rows [r0 r1 . t]
+    dm::se2_compose(Sinv, X, t9);
+    // spread the 3x3 into the 3x4 slots used by the kernels: rows [r0 r1 . t]
     T[0] = t9[0]; T[1] = t9[1]; T[2] = 0.f; T[3] = t9[2];
     T[4] = t9[3]; T[5] = t9[4]; T[6] = 0.f; T[7] = t9[5];
     T[8] = 0.f; T[9] = 0.f; T[10] = 1.f; T[11] = 0.f;
   }
+}
+__device__ __forceinline__ void load_T(const float* src, float* T) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T[i] = src[i];
 }
 
 template <int DIM>
@@ -1230,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   float T[12];
-  load_finder_transform<DIM>(S, st->X, T);
+  load_T(st->Tf[S.slice_idx], T);
   const int kexp     = st->kexp[S.slice_idx];
   const double scale = dm::pow2(kexp);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
@@ -1245,10 +1250,10 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   // Scans of points without a neighbour inside the gate reach 25% beyond it once a prior exists: what they find (a
   // point just outside the gate, or nothing) then certifies "no match" for the following iterations without a search.
   const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
-  int rfar         = 1;  // cube radius that covers the ball of radius sqrt(gfar) (g.rmax covers the extended gate)
-  while (rfar < g.rmax && bound2_of(rfar, g.h) < gfar) ++rfar;
+  // cube radius that covers the ball of radius sqrt(gfar) (both computed by the host with the same bound)
+  const int rfar = (use_prior && !(S.tune & 65536)) ? g.rmax : g.rfar_gate;
   float Tprev[12];  // the finder transform of the previous iteration (its queries: q' = Tprev * p)
-  load_finder_transform<DIM>(S, st->Xprev, Tprev);
+  load_T(st->Tfprev[S.slice_idx], Tprev);
 
   long long acc[ACC_N];
 #pragma unroll
@@ -1494,7 +1499,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   float T[12];
-  load_finder_transform<DIM>(S, st->X, T);
+  load_T(st->Tf[S.slice_idx], T);
   const int kexp     = st->kexp[S.slice_idx];
   const double scale = dm::pow2(kexp);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
@@ -1647,7 +1652,7 @@ __global__ __launch_bounds__(256) void k_icp_step_corr(SliceDev S, const Problem
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   float T[12];
-  load_finder_transform<DIM>(S, st->X, T);
+  load_T(st->Tf[S.slice_idx], T);
   const double scale = dm::pow2(st->kexp[S.slice_idx]);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
   const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
@@ -1744,7 +1749,7 @@ __device__ __forceinline__ int project_point(const SliceDev& S, float qx, float 
 }
 
 __device__ __forceinline__ void finder_transform3(const SliceDev& S, const ProblemState* st, float* T) {
-  dm::se3_compose(S.Sinv, st->X, T);  // finder->setLocalMapInSensor(robot_in_sensor * X), aligner_slice_processor_impl.cpp:35
+  load_T(st->Tf[S.slice_idx], T);  // robot_in_sensor * X (finder_transform_of)
 }
 
 }  // namespace
@@ -2161,6 +2166,11 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   }
   for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];  // the estimate this iteration's finder passes ran with
   if (!bad) dm::box_plus(C.variable_kind, st->X, dx);  // solver Success: multi_aligner_impl.cpp:118-121
+  for (int s = 0; s < C.nslices; ++s) {
+    if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
+    for (int i = 0; i < 12; ++i) st->Tfprev[s][i] = st->Tf[s][i];
+    if (!bad) finder_transform_of(C.slices[s].Sinv, C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3, st->X, st->Tf[s]);
+  }
   for (int s = 0; s < C.nslices; ++s)  // the fixed-point scale of given-correspondences slices follows the estimate
     if (C.slices[s].finder == SRRG2_FINDER_CORRESPONDENCES && C.slices[s].kind != SRRG2_SLICE_PRIOR)
       st->kexp[s] = slice_exponent(C, C.slices[s], prob, 0, st->X);
@@ -2226,8 +2236,12 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
       nm_of[s] = pd.nm;
     }
   }
-  for (int s = 0; s < C.nslices; ++s)  // (after the loop: a prior slice may have replaced the initial guess)
-    if (C.slices[s].kind != SRRG2_SLICE_PRIOR) st->kexp[s] = slice_exponent(C, C.slices[s], prob, nm_of[s], st->X);
+  for (int s = 0; s < C.nslices; ++s) {  // (after the loop: a prior slice may have replaced the initial guess)
+    if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
+    st->kexp[s] = slice_exponent(C, C.slices[s], prob, nm_of[s], st->X);
+    finder_transform_of(C.slices[s].Sinv, C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3, st->X, st->Tf[s]);
+    for (int i = 0; i < 12; ++i) st->Tfprev[s][i] = st->Tf[s][i];
+  }
 }
 
 // one 256-thread block per problem: sum the per-block partials of every cue slice (exact integer sums, any
