@@ -1119,7 +1119,8 @@ template <int DIM, bool PLANE>
 __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, int rk, float thr, float kk, double scale,
                                              bool inrange, bool active, int gi, int oi, const float4 p, float qx, float qy,
                                              float qz, float best, int bidx, int bpos, float excl, bool kept,
-                                             const float4 kept_f, long long (&acc)[ACC_N]) {
+                                             const float4 kept_f, const float4 kept_n, const float4 early_nm, bool have_nm,
+                                             long long (&acc)[ACC_N]) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   const GridDev& g   = S.grid;
@@ -1132,11 +1133,13 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       bool found = bidx != NO_MATCH && best <= g.gate2;
       if (KNOB(S.tune, 8)) found = false;
       float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (found && (PLANE || S.use_normal_gate)) nf = KNOB(S.tune, 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : g.nrm[bpos];
+      // (a kept neighbour comes with its normal, loaded together with the prior: one round trip less on the chain)
+      if (found && (PLANE || S.use_normal_gate))
+        nf = KNOB(S.tune, 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : (kept ? kept_n : g.nrm[bpos]);
       // (with nf: one round trip, not one after the normal gate; a kept neighbour comes with its coordinates)
       if (bidx != NO_MATCH) fm = kept ? kept_f : g.pts[bpos];
       if (found && S.use_normal_gate) {
-        const float4 nm = KNOB(S.tune, 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : S.mnrm[gi];
+        const float4 nm = KNOB(S.tune, 128) ? make_float4(0.f, 0.f, 1.f, 0.f) : (have_nm ? early_nm : S.mnrm[gi]);
         float dot;
         if constexpr (DIM == 3) {
           float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
@@ -1275,6 +1278,8 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
   int ppos           = -1;
   float4 pf          = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pn          = make_float4(0.f, 0.f, 0.f, 0.f);   // its normal
+  float4 pnm         = make_float4(0.f, 0.f, 0.f, 0.f);   // this moving point's normal
   float pm           = 0.f;
   if (inrange) {
     p = S.mpts[gi];
@@ -1282,8 +1287,11 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
       ppos = S.prev_pos[gi];
       pf   = S.prev_f[gi];
       pm   = S.prev_m[gi];
+      if (S.use_normal_gate) pnm = S.mnrm[gi];
     }
   }
+  // the normal of the previous neighbour, in flight while the skip test runs: converged iterations keep the neighbour
+  if (use_prior && (PLANE || S.use_normal_gate) && ppos >= 0 && ppos < g.n) pn = g.nrm[ppos];
   // moving points are stored spatially sorted; p.w carries the caller's index within the problem
   const int oi      = pd.moff + __float_as_int(p.w);
   const bool active = inrange && finite3(p.x, p.y, p.z);
@@ -1482,7 +1490,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   if (excl_wide != 0.f || r2 != 0) excl = excl_wide;  // finished by the wider scans above
   if (!deferred)
     finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, excl, skipped,
-                             pf, acc);
+                             pf, pn, pnm, use_prior && S.use_normal_gate, acc);
   STAMP(tl, 6);  // gates, rows, factor arithmetic, per-point outputs
   block_reduce_store(acc, S.partials, prob, blockIdx.x);
   STAMP(tl, 7);  // reduction + atomics issued
@@ -1533,7 +1541,8 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
 #pragma unroll
     for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
     finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, have, have, pd.moff + my_i, pd.moff + __float_as_int(mp.w), mp, mx, my,
-                             mz, my_best, my_bidx, my_bpos, my_excl, false, make_float4(0.f, 0.f, 0.f, 0.f), acc);
+                             mz, my_best, my_bidx, my_bpos, my_excl, false, make_float4(0.f, 0.f, 0.f, 0.f),
+                             make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), false, acc);
     int my_index;
     const long long total = wave_transpose_reduce(acc, lane, my_index);
     if ((lane & 1) == 0) wave_acc[wid][my_index] += total;
