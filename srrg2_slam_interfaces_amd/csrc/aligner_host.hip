@@ -650,7 +650,17 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   const int probe_it = C.probe_it;
   std::vector<char> queue_on((size_t) std::max(nslices, 1), 1);
   bool probed = false;
-  auto run_phase = [&](int slot0) -> int {
+  bool final_launched = false;  // the last control step of compute() carried the post / finalize steps
+  auto control = [&](int it, bool last_phase) {
+    if (last_phase && it == a->params.max_iterations - 1) {
+      srrg2amd::launch_icp_control_final(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                         !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
+      final_launched = true;
+    } else {
+      srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
+    }
+  };
+  auto run_phase = [&](int slot0, bool last_phase) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
       if (!probed && slot0 == 0 && probe_it >= 0 && it == probe_it + 2) {
         probed = true;
@@ -697,7 +707,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         srrg2amd::launch_proj_step_pack(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
         for (int si : proj_group) sdev[si].zbuf_parity ^= 1;
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
-        srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
+        control(it, last_phase);
         continue;
       }
       for (int si = 0; si < nslices; ++si) {
@@ -739,18 +749,20 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         }
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }
-      srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
+      control(it, last_phase);
     }
     return 0;
   };
-  if ((rc = run_phase(0))) return rc;
-  srrg2amd::launch_icp_post(C, a->states.p, a->stats.p, a->stream);
+  if ((rc = run_phase(0, !a->params.enable_inlier_only_runs))) return rc;
   if (a->params.enable_inlier_only_runs) {
-    if ((rc = run_phase(a->params.max_iterations))) return rc;
+    srrg2amd::launch_icp_post(C, a->states.p, a->stats.p, a->stream);
+    if ((rc = run_phase(a->params.max_iterations, true))) return rc;
   }
   // results land in pinned host memory (written by k_icp_finalize): the only host-device interaction of compute() after
   // the launches is this wait
-  srrg2amd::launch_icp_finalize(C, a->states.p, a->stats.p, a->outs_host, a->stats_host, a->stream);
+  if (!final_launched)  // (max_iterations < 1)
+    srrg2amd::launch_icp_finalize(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                  !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(a->stream));
   if (const char* tl_path = std::getenv("SRRG2_AMD_TIMELINE")) {  // dump of the last compute(): u64 nwaves, then stamps

@@ -2255,11 +2255,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
 
 // one 256-thread block per problem: sum the per-block partials of every cue slice (exact integer sums, any
 // order), then thread 0 runs the sequential part of the iteration
-__global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* __restrict__ states,
-                                                     srrg2_iteration_stats* __restrict__ stats) {
-  const int prob   = blockIdx.x;
-  ProblemState* st = &states[prob];
-  if (st->done || st->finished) return;
+__device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob) {
   __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
   __shared__ long long part[8][ACC_N];
   const int a = threadIdx.x & 31, c = threadIdx.x >> 5;
@@ -2291,11 +2287,16 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
     control_body<6>(C, st, stats, prob, sums);
 }
 
-// after the main _runSolver: multi_aligner_impl.cpp:75-85 and the start of _postCompute (:165-171)
-__global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const srrg2_iteration_stats* __restrict__ stats) {
-  int prob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (prob >= C.K) return;
+__global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* __restrict__ states,
+                                                     srrg2_iteration_stats* __restrict__ stats) {
+  const int prob   = blockIdx.x;
   ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  icp_control_block(C, st, stats, prob);
+}
+
+// after the main _runSolver: multi_aligner_impl.cpp:75-85 and the start of _postCompute (:165-171)
+__device__ void icp_post_one(const CtlParams& C, ProblemState* st, const srrg2_iteration_stats* stats, int prob) {
   if (st->nstats == 0) {
     st->status   = SRRG2_FAIL;
     st->finished = 1;
@@ -2313,15 +2314,21 @@ __global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const
   }
 }
 
+__global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const srrg2_iteration_stats* __restrict__ stats) {
+  int prob = blockIdx.x * blockDim.x + threadIdx.x;
+  if (prob >= C.K) return;
+  icp_post_one(C, &states[prob], stats, prob);
+}
+
 // end of compute(): _pruneCorrespondences bookkeeping, fixTransform, Success (:88-94).  One block per problem; the
 // results (ProblemOut + the IterationStats appended by this compute()) are written straight into pinned host memory:
 // the host only waits for the stream, there are no device-to-host copies.
-__global__ __launch_bounds__(64) void k_icp_finalize(CtlParams C, ProblemState* __restrict__ states,
-                                                     const srrg2_iteration_stats* __restrict__ stats,
-                                                     ProblemOut* __restrict__ outs_host,
-                                                     srrg2_iteration_stats* __restrict__ stats_host) {
-  const int prob   = blockIdx.x;
-  ProblemState* st = &states[prob];
+__device__ void icp_finalize_block(const CtlParams& C, ProblemState* st, const srrg2_iteration_stats* stats,
+                                   ProblemOut* outs_host, srrg2_iteration_stats* stats_host, int prob, bool with_post) {
+  if (with_post) {  // without an inlier-only run nothing lies between the two steps: one launch
+    if (threadIdx.x == 0) icp_post_one(C, st, stats, prob);
+    __syncthreads();
+  }
   {  // the iteration statistics, 8 words each
     const int n       = min(st->nstats, C.max_stats) * (int) (sizeof(srrg2_iteration_stats) / sizeof(int));
     const int* src    = reinterpret_cast<const int*>(stats + (size_t) prob * C.max_stats);
@@ -2345,6 +2352,27 @@ __global__ __launch_bounds__(64) void k_icp_finalize(CtlParams C, ProblemState* 
   o->status = st->status;
   o->nstats = st->nstats;
   for (int s = 0; s < SRRG2_MAX_SLICES; ++s) o->ncorr[s] = st->ncorr[s];
+}
+
+__global__ __launch_bounds__(64) void k_icp_finalize(CtlParams C, ProblemState* __restrict__ states,
+                                                     const srrg2_iteration_stats* __restrict__ stats,
+                                                     ProblemOut* __restrict__ outs_host,
+                                                     srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
+  icp_finalize_block(C, &states[blockIdx.x], stats, outs_host, stats_host, blockIdx.x, with_post != 0);
+}
+
+// The control step of the LAST iteration of compute() with the (post and) finalize steps behind it: nothing lies
+// between them, two launches less per compute().
+__global__ __launch_bounds__(256) void k_icp_control_final(CtlParams C, ProblemState* __restrict__ states,
+                                                           srrg2_iteration_stats* __restrict__ stats,
+                                                           ProblemOut* __restrict__ outs_host,
+                                                           srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
+  const int prob   = blockIdx.x;
+  ProblemState* st = &states[prob];
+  if (!st->done && !st->finished) icp_control_block(C, st, stats, prob);
+  __threadfence();  // (thread 0's state and statistics, read by the whole block below)
+  __syncthreads();
+  icp_finalize_block(C, st, stats, outs_host, stats_host, prob, with_post != 0);
 }
 
 // ============================================================================================
@@ -2533,12 +2561,17 @@ void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDe
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_control, dim3(C.K), dim3(256), 0, s, C, states, stats);
 }
+void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
+                               srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_control_final, dim3(C.K), dim3(256), 0, s, C, states, stats, outs_host, stats_host,
+                     with_post ? 1 : 0);
+}
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_post, dim3((C.K + 63) / 64), dim3(64), 0, s, C, states, stats);
 }
 void launch_icp_finalize(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats,
-                         ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_finalize, dim3(C.K), dim3(64), 0, s, C, states, stats, outs_host, stats_host);
+                         ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
+  hipLaunchKernelGGL(k_icp_finalize, dim3(C.K), dim3(64), 0, s, C, states, stats, outs_host, stats_host, with_post ? 1 : 0);
 }
 
 }  // namespace srrg2amd
