@@ -490,6 +490,22 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   C.tune          = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
   C.probe_it      = std::getenv("SRRG2_AMD_QPROBE") ? std::atoi(std::getenv("SRRG2_AMD_QPROBE")) : 1;
   if (a->params.max_iterations <= C.probe_it + 3 || K > 4) C.probe_it = -1;
+  // Small problems (laser scans, landmark maps) with one nearest-neighbour cue slice (plus priors): one workgroup per
+  // problem runs the whole compute() (k_icp_small) instead of ~24 launches of a few microseconds of work each.
+  bool small = false;
+  {
+    int ncue = 0, fc = -1;
+    for (int si = 0; si < nslices; ++si)
+      if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR) {
+        if (fc < 0) fc = si;
+        ++ncue;
+      }
+    // (measured, tools/bench_small.py: ahead of one launch per pass up to ~1000 points -- 1000-beam scan 0.33 -> 0.23 ms,
+    // 360 beams 0.18 -> 0.12 ms, 500 3-D points 0.34 -> 0.25 ms -- and behind it from ~2000 points on)
+    static const int small_max = std::getenv("SRRG2_AMD_SMALL_MAX") ? std::atoi(std::getenv("SRRG2_AMD_SMALL_MAX")) : 1024;
+    small = ncue == 1 && a->slices[fc]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm <= small_max &&
+            !std::getenv("SRRG2_AMD_TIMELINE");
+  }
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {
@@ -519,7 +535,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     for (int k = 0; k < K; ++k) nm_max_s = std::max(nm_max_s, all[(size_t) si * K + k].nm);
     // deferred-search queue: a win in the latency regime (few alignments per launch: C2 0.78 -> 0.63 ms); with many
     // alignments per launch the in-kernel path has more throughput (C4: 2.46 vs 2.74 ms per 32 x 50k batch)
-    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0 && K <= 4;
+    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0 && K <= 4 && !small;
     const int nblocks    = PARTIAL_SLOTS;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
     if (use_queue) {
@@ -629,6 +645,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
   srrg2amd::launch_icp_init(C, a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, a->stream);
 
+  if (small) {
+    Slice* s = a->slices[first_cue];
+    srrg2amd::launch_icp_small(a->dim, s->cfg.kind == SRRG2_SLICE_P2PLANE, sdev[first_cue], C,
+                               a->probs.p + (size_t) first_cue * K, a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                               a->stream);
+  }
   // all cue slices projective (RGB-D: point-to-plane + reprojection): one launch pair per iteration for all of them
   std::vector<int> proj_group;
   {
@@ -753,10 +775,14 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     return 0;
   };
-  if ((rc = run_phase(0, !a->params.enable_inlier_only_runs))) return rc;
-  if (a->params.enable_inlier_only_runs) {
-    srrg2amd::launch_icp_post(C, a->states.p, a->stats.p, a->stream);
-    if ((rc = run_phase(a->params.max_iterations, true))) return rc;
+  if (small) {
+    final_launched = true;  // (k_icp_small did everything)
+  } else {
+    if ((rc = run_phase(0, !a->params.enable_inlier_only_runs))) return rc;
+    if (a->params.enable_inlier_only_runs) {
+      srrg2amd::launch_icp_post(C, a->states.p, a->stats.p, a->stream);
+      if ((rc = run_phase(a->params.max_iterations, true))) return rc;
+    }
   }
   // results land in pinned host memory (written by k_icp_finalize): the only host-device interaction of compute() after
   // the launches is this wait

@@ -917,17 +917,23 @@ __device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], 
 // at <= ceil(blocks/32) per address, and the control kernel has 32 x 32 values to sum instead of blocks x 32.
 // (History: one atomic target per entry serialised 391 blocks -> ~90 us; plain per-block partials made the control
 // kernel read 100 KB -> ~10 us.  profiles/r1a, r1b.)
+// NW = waves per workgroup.  local != null: the workgroup owns the whole problem (k_icp_small) and adds into its LDS sums.
+template <int NW>
 __device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long long* __restrict__ partials, int prob,
-                                                   int block) {
-  __shared__ long long red[4][ACC_N];
+                                                   int block, long long* local = nullptr) {
+  __shared__ long long red[NW][ACC_N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int my_index;
   const long long total = wave_transpose_reduce(acc, lane, my_index);
   if ((lane & 1) == 0) red[wid][my_index] = total;
   __syncthreads();
   if (threadIdx.x < ACC_N) {
-    const long long v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (v != 0)
+    long long v = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][threadIdx.x];
+    if (local)
+      local[threadIdx.x] += v;
+    else if (v != 0)
       atomicAdd(reinterpret_cast<unsigned long long*>(partials) +
                   ((size_t) prob * PARTIAL_SLOTS + (block & (PARTIAL_SLOTS - 1))) * ACC_N + threadIdx.x,
                 (unsigned long long) v);
@@ -1230,13 +1236,11 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
 // One moving point per thread.  Lanes whose nearest neighbour is not settled by the 3^DIM block are either pushed
 // to the per-problem queue (S.queue != null; k_icp_step_queue finishes them with all waves of the chip sharing
 // the work) or, without a queue, handled here: radius-2 scan per lane, then wave-cooperative scans.
-template <int DIM, bool PLANE>
-__global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                  ProblemState* __restrict__ states) {
-  const int prob   = blockIdx.y;
-  ProblemState* st = &states[prob];
-  if (st->done || st->finished) return;
-  const ProblemDev pd = probs[prob];
+// (body shared by k_icp_step -- 4 waves, tile = blockIdx.x, sums to the global slot sets -- and k_icp_small -- NW waves
+// looping over the tiles of its problem, state and sums in LDS)
+template <int DIM, bool PLANE, int NW>
+__device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDev pd, const ProblemState* st, int prob,
+                                              int tile, int ntiles, int nprob, long long* local_sums) {
   float T[12];
   load_T(st->Tf[S.slice_idx], T);
   const int kexp     = st->kexp[S.slice_idx];
@@ -1263,14 +1267,14 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
 #ifdef SRRG2_TIMELINE
   unsigned long long* tl = (S.dbg && st->nstats < 32 && st->phase == 0)
-                             ? S.dbg + (((size_t) st->nstats * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)) * 16
+                             ? S.dbg + (((size_t) st->nstats * nprob + prob) * ntiles * NW + tile * NW + (threadIdx.x >> 6)) * 16
                              : nullptr;
 #else
   unsigned long long* tl = nullptr;
 #endif
   STAMP(tl, 0);  // state + transform loaded
 
-  const int i        = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i        = tile * (NW * 64) + threadIdx.x;
   const int lane     = threadIdx.x & 63;
   const int wid      = threadIdx.x >> 6;
   const bool inrange = i < pd.nm;
@@ -1306,7 +1310,7 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   bool skipped = false;     // the previous nearest neighbour is provably still the nearest
   float excl_wide = 0.f;
   float pad       = 0.02f * g.h;  // margin of the scans beyond the nearest neighbour (grows with the motion)
-  __shared__ int coop_lds[4][264];
+  __shared__ int coop_lds[NW][264];
   STAMP(tl, 1);  // moving point + prior loaded
   if (active && !KNOB(S.tune, 16)) {
     transform_point<DIM>(T, p, qx, qy, qz);
@@ -1412,14 +1416,16 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     const unsigned long long need_far  = __ballot(r2 > 2);
     // one atomic per BLOCK and kind (same-address device atomics serialise at ~10 ns each: per-wave atomics cost
     // ~15 us on the misaligned first iteration of C2)
-    __shared__ int q_cnt[2][4], q_base[2];
+    __shared__ int q_cnt[2][NW], q_base[2];
     if (lane == 0) {
       q_cnt[0][wid] = __popcll(need_near);
       q_cnt[1][wid] = __popcll(need_far);
     }
     __syncthreads();
     if (threadIdx.x < 2) {
-      const int tot = (q_cnt[threadIdx.x][0] + q_cnt[threadIdx.x][1]) + (q_cnt[threadIdx.x][2] + q_cnt[threadIdx.x][3]);
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += q_cnt[threadIdx.x][w];
       q_base[threadIdx.x] = tot ? atomicAdd(&S.qcount[2 * prob + threadIdx.x], tot) : 0;
     }
     __syncthreads();
@@ -1492,8 +1498,17 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
     finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, excl, skipped,
                              pf, pn, pnm, use_prior && S.use_normal_gate, acc);
   STAMP(tl, 6);  // gates, rows, factor arithmetic, per-point outputs
-  block_reduce_store(acc, S.partials, prob, blockIdx.x);
+  block_reduce_store<NW>(acc, S.partials, prob, tile, local_sums);
   STAMP(tl, 7);  // reduction + atomics issued
+}
+
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                  ProblemState* __restrict__ states) {
+  const int prob   = blockIdx.y;
+  ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  icp_step_body<DIM, PLANE, 4>(S, probs[prob], st, prob, blockIdx.x, gridDim.x, gridDim.y, nullptr);
 }
 
 // Deferred searches: every wave takes queue entries w, w + W, ... of its problem, runs the cooperative exact scan
@@ -1733,7 +1748,7 @@ __global__ __launch_bounds__(256) void k_icp_step_corr(SliceDev S, const Problem
     // (a pair with a non-finite point gives a non-finite chi: Suppressed)
     S.gcorr_stat[c] = factor_accumulate<D, ROWS>(J, e, false, rk, S.robust_thr, scale, false, acc);
   }
-  block_reduce_store(acc, S.partials, prob, blockIdx.x);
+  block_reduce_store<4>(acc, S.partials, prob, blockIdx.x);
 }
 
 // ============================================================================================
@@ -1918,7 +1933,7 @@ __device__ __forceinline__ void step_proj_body(const SliceDev& S, const ProblemD
     S.corr_resp[gi]  = resp;
     S.corr_stat[gi]  = fstat;
   }
-  block_reduce_store(acc, S.partials, prob, blockIdx.x);
+  block_reduce_store<4>(acc, S.partials, prob, blockIdx.x);
 }
 
 template <bool REPRO>
@@ -2376,6 +2391,56 @@ __global__ __launch_bounds__(256) void k_icp_control_final(CtlParams C, ProblemS
 }
 
 // ============================================================================================
+// Small alignments (laser scans, landmark maps: up to ~1000 moving points).  With one launch per pass such a compute()
+// is ~24 launch floors and little else (C1: 0.33 ms on the GPU against 0.66 ms on one CPU core; 0.23 ms here).  ONE
+// workgroup owns the problem for the whole compute(): the state and the sums live in LDS, the passes loop over the
+// problem's tiles, thread 0 runs the control step between them -- the same per-point and control code as the
+// launch-per-pass path, so the same bits.  A batch of small problems runs one workgroup per problem.
+// ============================================================================================
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, const ProblemDev* __restrict__ probs,
+                                                   ProblemState* __restrict__ states, srrg2_iteration_stats* __restrict__ stats,
+                                                   ProblemOut* __restrict__ outs_host,
+                                                   srrg2_iteration_stats* __restrict__ stats_host) {
+  constexpr int NW = 8;  // (16 waves would cap the registers at 128 per lane: the SE(3) control step spills, measured slower)
+  constexpr int D  = DIM == 3 ? 6 : 3;
+  const int prob   = blockIdx.x;
+  __shared__ ProblemState sst;
+  __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
+  constexpr int STATE_WORDS = (int) (sizeof(ProblemState) / sizeof(int));
+  static_assert(sizeof(ProblemState) % sizeof(int) == 0, "the state is copied word-wise");
+  for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
+    reinterpret_cast<int*>(&sst)[k] = reinterpret_cast<const int*>(&states[prob])[k];
+  __syncthreads();
+  const ProblemDev pd = probs[prob];
+  const int ntiles    = (pd.nm + NW * 64 - 1) / (NW * 64);
+  const int nrun      = C.params.enable_inlier_only_runs ? 2 : 1;
+  for (int run = 0; run < nrun; ++run) {
+    for (int it = 0; it < C.params.max_iterations; ++it) {
+      if (sst.done || sst.finished) break;  // (uniform: LDS)
+      if (threadIdx.x < ACC_N) sums[S.slice_idx][threadIdx.x] = 0;
+      __syncthreads();
+      for (int tile = 0; tile < ntiles; ++tile) {
+        icp_step_body<DIM, PLANE, NW>(S, pd, &sst, prob, tile, ntiles, C.K, sums[S.slice_idx]);
+        __syncthreads();  // (the body's shared scratch is reused by the next tile)
+      }
+      if (threadIdx.x == 0) control_body<D>(C, &sst, stats, prob, sums);
+      __syncthreads();
+    }
+    if (run == 0 && nrun == 2) {  // multi_aligner_impl.cpp:75-85, then the inlier-only run
+      if (threadIdx.x == 0) icp_post_one(C, &sst, stats, prob);
+      __syncthreads();
+    }
+  }
+  __threadfence();  // (the statistics thread 0 wrote are read back by the whole workgroup below)
+  __syncthreads();
+  icp_finalize_block(C, &sst, stats, outs_host, stats_host, prob, nrun == 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
+    reinterpret_cast<int*>(&states[prob])[k] = reinterpret_cast<const int*>(&sst)[k];
+}
+
+// ============================================================================================
 // launchers
 // ============================================================================================
 namespace srrg2amd {
@@ -2560,6 +2625,21 @@ void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDe
 }
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_control, dim3(C.K), dim3(256), 0, s, C, states, stats);
+}
+void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C, const ProblemDev* probs, ProblemState* states,
+                      srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s) {
+  if (C.K <= 0) return;
+  if (dim == 3) {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_small<3, true>), dim3(C.K), dim3(512), 0, s, S, C, probs, states, stats, outs_host, stats_host);
+    else
+      hipLaunchKernelGGL((k_icp_small<3, false>), dim3(C.K), dim3(512), 0, s, S, C, probs, states, stats, outs_host, stats_host);
+  } else {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_small<2, true>), dim3(C.K), dim3(512), 0, s, S, C, probs, states, stats, outs_host, stats_host);
+    else
+      hipLaunchKernelGGL((k_icp_small<2, false>), dim3(C.K), dim3(512), 0, s, S, C, probs, states, stats, outs_host, stats_host);
+  }
 }
 void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
                                srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {

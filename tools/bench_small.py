@@ -31,11 +31,16 @@ def timed(al, n, guess):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--beams", type=int, nargs="*", default=[])
+    ap.add_argument("--points", type=int, nargs="*", default=[2000, 10000, 30000])
     args = ap.parse_args()
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import pyoracle
     cases = [("C1 2D scan 1000 beams, SE(2) p2p", abi.SE2_RIGHT, syn.scan_pair_2d(), cue_config(abi.SE2_RIGHT, abi.SLICE_P2P, 0.5))]
-    for n in (2000, 10000, 30000):
+    for beams in args.beams:
+        cases.append(("2D scan %d beams, SE(2) p2p" % beams, abi.SE2_RIGHT, syn.scan_pair_2d(beams=beams),
+                      cue_config(abi.SE2_RIGHT, abi.SLICE_P2P, 0.5)))
+    for n in args.points:
         cases.append(("3D %d pts, SE(3) point-to-plane" % n, abi.SE3_QUAT_RIGHT, syn.cloud_pair_3d(n=n, seed=2000),
                       cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.05, 0.8)))
     out = []
