@@ -287,7 +287,16 @@ int build_grid(srrg2_aligner* a, Slice* s) {
       const float target    = std::getenv("SRRG2_AMD_CELL_TARGET") ? (float) std::atof(std::getenv("SRRG2_AMD_CELL_TARGET")) : 8.0f;
       float scale           = std::sqrt(target / occupancy);
       scale                 = std::fmin(std::fmax(scale, 0.5f), 4.0f);
-      h                     = fit_cell(std::fmin(h * scale, gate));
+      h                     = std::fmin(h * scale, gate);
+      // 2-D scans are points along lines: their occupancy grows like h, not h^2, and the density rule above shrinks
+      // the cells until the gate spans 10-20 of them, so that every misaligned point becomes a far (whole-wave)
+      // search.  Keep the cube that covers the extended gate at radius <= 3 there (measured, tools/bench_small.py:
+      // 2000 beams 0.48 -> 0.26 ms, 4000 beams 0.67 -> 0.39 ms per compute(); 3-D clouds are better off with the
+      // density rule: 1 M points 4.5 k it/s without a cap, 4.0 / 3.0 / 2.8 k with radius <= 3 / 4 / 6).
+      float rcap = dim == 2 ? 3.f : 0.f;
+      if (const char* cap = std::getenv("SRRG2_AMD_RMAX_CAP")) rcap = (float) std::atof(cap);
+      if (rcap > 1.f) h = std::fmax(h, gate * 1.25f / (rcap - 0.011f));
+      h                     = fit_cell(h);
       s->probe_h = h; s->probe_n = nvalid; s->probe_ext = ext; s->probe_gate = gate;
     }
     }

@@ -1,6 +1,8 @@
 #!/bin/bash
 cd /root/repo
-for i in 1 2 3; do
-timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2', d['value'], d['roofline']['avg_launch_ms'])"
-done
-git stash -q 2>/dev/null
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/t_gpu.log 2>&1
+tail -2 gpurun_out/t_gpu.log
+timeout 300 python tools/bench_small.py --beams 360 2000 4000 > gpurun_out/r1h_bench_small.json 2>/dev/null; python -c "
+import json
+for c in json.load(open('gpurun_out/r1h_bench_small.json'))['small_alignments']: print('  %-40s gpu %.4f ms oracle %.3f  identical %s' % (c['case'], c['gpu_ms'], c['oracle_ms'], c['X_bit_identical']))"
