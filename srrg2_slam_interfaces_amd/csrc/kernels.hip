@@ -1,7 +1,6 @@
-// kernels.hip -- hand-written gfx950 kernels of the aligner hot path.
+// kernels.hip -- hand-written gfx950 kernels of the aligner hot path: the ICP passes and their control steps.
+// (ingest, grid build and sorting, once per set_fixed / set_moving, are in kernels_prep.hip)
 //
-//   ingest / grid build      : CorrespondenceFinder_ search-structure construction, once per setFixed
-//                              (S/registration/correspondence_finder.h:80-91)
 //   icp_step<DIM,PLANE>      : ONE kernel per slice per ICP iteration = finder->compute()
 //                              (aligner_slice_processor_impl.cpp:39-48) fused with the factor's
 //                              per-correspondence linearisation + robustifier + JtJ/Jtr reduction
@@ -28,532 +27,7 @@
 #define KNOB(t, bit) false
 #endif
 
-namespace {
-
-__device__ __forceinline__ bool finite3(float x, float y, float z) {
-  return isfinite(x) && isfinite(y) && isfinite(z);
-}
-
-// monotone float -> unsigned key (for atomicMin/atomicMax on floats of either sign)
-__device__ __forceinline__ unsigned fkey(float f) {
-  unsigned b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-__device__ __forceinline__ int cell_coord(float x, float o, float inv_h) {
-  float u = (x - o) * inv_h;
-  u       = fminf(fmaxf(u, -2048.f), 4096.f);
-  return (int) floorf(u);
-}
-
-__device__ __forceinline__ float bound2_of(int r, float h) {
-  float b = ((float) r - 0.01f) * h;
-  return (b * b) * 0.9999f;
-}
-
-__device__ __forceinline__ long long wave_sum(long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
-}  // namespace
-
-// ============================================================================================
-// ingest: strided raw floats -> float4 (x,y,z|0,w) ; also max |coord| over finite points
-// ============================================================================================
-__global__ void k_ingest(const float* __restrict__ src, int stride_floats, int n, int dim, float4* __restrict__ dst,
-                         unsigned* __restrict__ maxabs_bits, int finite_per_point) {
-  int i      = blockIdx.x * blockDim.x + threadIdx.x;
-  float amax = 0.f;
-  if (i < n) {
-    const float* p = src + (size_t) i * stride_floats;
-    float x = p[0], y = p[1], z = dim == 3 ? p[2] : 0.f;
-    dst[i] = make_float4(x, y, z, 0.f);
-    bool ok = finite3(x, y, z);
-    if (finite_per_point) {
-      if (ok) amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
-    } else {
-      if (isfinite(x)) amax = fmaxf(amax, fabsf(x));
-      if (isfinite(y)) amax = fmaxf(amax, fabsf(y));
-      if (isfinite(z)) amax = fmaxf(amax, fabsf(z));
-    }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  if ((threadIdx.x & 63) == 0 && maxabs_bits && amax > 0.f) atomicMax(maxabs_bits, __float_as_uint(amax));
-}
-
-// the clouds of a batch in ONE launch: blockIdx.y = problem (its points are [moff, moff + nm) of src and dst)
-__global__ void k_ingest_batch(const float* __restrict__ src, int stride_floats, const ProblemDev* __restrict__ probs,
-                               int dim, float4* __restrict__ dst, unsigned* __restrict__ maxabs_bits /* [K] or null */,
-                               int finite_per_point) {
-  const ProblemDev pd = probs[blockIdx.y];
-  float amax          = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
-    const float* p = src + (size_t) (pd.moff + i) * stride_floats;
-    float x = p[0], y = p[1], z = dim == 3 ? p[2] : 0.f;
-    dst[pd.moff + i] = make_float4(x, y, z, 0.f);
-    if (finite_per_point) {
-      if (finite3(x, y, z)) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)));
-    } else {
-      if (isfinite(x)) amax = fmaxf(amax, fabsf(x));
-      if (isfinite(y)) amax = fmaxf(amax, fabsf(y));
-      if (isfinite(z)) amax = fmaxf(amax, fabsf(z));
-    }
-  }
-  if (!maxabs_bits) return;
-  // block maximum, then one atomic per block (same-address atomics serialise at tens of ns each)
-  __shared__ float red[4];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (amax > 0.f) atomicMax(maxabs_bits + blockIdx.y, __float_as_uint(amax));
-  }
-}
-
-// ============================================================================================
-// grid build
-// ============================================================================================
-__global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
-                       int* __restrict__ nvalid) {
-  unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-  int valid = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 p = pts[i];
-    if (finite3(p.x, p.y, p.z)) {
-      valid += 1;
-      const unsigned k[3] = {fkey(p.x), fkey(p.y), fkey(p.z)};
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        mn[d] = min(mn[d], k[d]);
-        mx[d] = max(mx[d], k[d]);
-      }
-    }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      mn[d] = min(mn[d], (unsigned) __shfl_xor((int) mn[d], off));
-      mx[d] = max(mx[d], (unsigned) __shfl_xor((int) mx[d], off));
-    }
-    valid += __shfl_xor(valid, off);
-  }
-  // one atomic per block and value (a few grid-striding blocks): same-address atomics serialise at tens of ns each
-  __shared__ unsigned red[4][7];
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      red[threadIdx.x >> 6][d]     = mn[d];
-      red[threadIdx.x >> 6][3 + d] = mx[d];
-    }
-    red[threadIdx.x >> 6][6] = (unsigned) valid;
-  }
-  __syncthreads();
-  if (threadIdx.x < 7) {
-    const int d = threadIdx.x;
-    if (d < 3) {
-      const unsigned v = min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]));
-      if (v != 0xffffffffu) atomicMin(&mn_out[d], v);
-    } else if (d < 6) {
-      const unsigned v = max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
-      if (v != 0u) atomicMax(&mx_out[d - 3], v);
-    } else {
-      const int v = (int) (red[0][6] + red[1][6] + red[2][6] + red[3][6]);
-      if (v) atomicAdd(nvalid, v);
-    }
-  }
-}
-
-__device__ __forceinline__ int grid_cell_of(const GridDev& g, float4 p) {
-  int cx = cell_coord(p.x, g.ox, g.inv_h);
-  int cy = cell_coord(p.y, g.oy, g.inv_h);
-  int cz = cell_coord(p.z, g.oz, g.inv_h);
-  cx     = min(max(cx, 0), g.nx - 1);
-  cy     = min(max(cy, 0), g.ny - 1);
-  cz     = min(max(cz, 0), g.nz - 1);
-  return (cz * g.ny + cy) * g.nx + cx;
-}
-
-__global__ void k_grid_count(GridDev g, const float4* __restrict__ pts, int n, int* __restrict__ counts) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pts[i];
-  if (!finite3(p.x, p.y, p.z)) return;
-  atomicAdd(&counts[grid_cell_of(g, p)], 1);
-}
-
-// number of non-empty cells (density probe for the automatic cell size)
-__global__ void k_count_nonzero(const int* __restrict__ counts, int n, int* __restrict__ out) {
-  int c = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += counts[i] != 0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-  __shared__ int red[4];  // one atomic per block (same-address atomics serialise: per-wave ones cost 47 us here)
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = (red[0] + red[1]) + (red[2] + red[3]);
-    if (t) atomicAdd(out, t);
-  }
-}
-
-// exclusive scan, 3 kernels: per-block scan of SCAN_TILE elements, scan of block sums, add back
-#define SCAN_THREADS 256
-#define SCAN_ITEMS 8
-#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
-
-__device__ int block_exclusive_scan(int v, int* total) {
-  __shared__ int wsum[SCAN_THREADS / 64];
-  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int t = __shfl_up(inc, off);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) wsum[wid] = inc;
-  __syncthreads();
-  int base = 0, tot = 0;
-  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
-    if (w < wid) base += wsum[w];
-    tot += wsum[w];
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
-
-__global__ void k_scan_tiles(int* __restrict__ data, int n, int* __restrict__ block_sums) {
-  int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int v[SCAN_ITEMS];
-  int s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    v[k] = (base + k < n) ? data[base + k] : 0;
-    s += v[k];
-  }
-  int total;
-  int ex = block_exclusive_scan(s, &total);
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    if (base + k < n) data[base + k] = ex;
-    ex += v[k];
-  }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ void k_scan_sums(int* __restrict__ block_sums, int nblocks, int* __restrict__ grand_total) {
-  // single block; nblocks <= SCAN_TILE * 64 handled by looping tiles with a carry
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int t0 = 0; t0 < nblocks; t0 += SCAN_TILE) {
-    int base = t0 + threadIdx.x * SCAN_ITEMS;
-    int v[SCAN_ITEMS];
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-      v[k] = (base + k < nblocks) ? block_sums[base + k] : 0;
-      s += v[k];
-    }
-    int total;
-    int ex = block_exclusive_scan(s, &total) + carry;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-      if (base + k < nblocks) block_sums[base + k] = ex;
-      ex += v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *grand_total = carry;
-}
-
-__global__ void k_scan_add(int* __restrict__ data, int n, const int* __restrict__ block_sums,
-                           const int* __restrict__ grand_total) {
-  int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int add  = block_sums[blockIdx.x];
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k)
-    if (base + k < n) data[base + k] += add;
-  if (blockIdx.x == 0 && threadIdx.x == 0) data[n] = *grand_total;  // cell_start[ncell]
-}
-
-__global__ void k_grid_scatter(GridDev g, const float4* __restrict__ pts, const float4* __restrict__ nrm, int n,
-                               int* __restrict__ cursor, float4* __restrict__ out_pts, float4* __restrict__ out_nrm) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pts[i];
-  if (!finite3(p.x, p.y, p.z)) return;
-  int pos      = atomicAdd(&cursor[grid_cell_of(g, p)], 1);
-  p.w          = __int_as_float(i);
-  out_pts[pos] = p;
-  if (nrm) out_nrm[pos] = nrm[i];
-}
-
-// ============================================================================================
-// spatial sort of the moving cloud(s): Morton order inside each problem's bounding box, so that the 64
-// lanes of a wave query neighbouring cells of the fixed grid (L1/L2-coherent candidate loads).  The
-// order has no effect on results: outputs are addressed by the caller's index (kept in .w) and every
-// sum is exact.
-// ============================================================================================
-__device__ __forceinline__ unsigned spread3(unsigned v) {  // v < 64: insert two zero bits between bits
-  v = (v | (v << 8)) & 0x0000f00fu;
-  v = (v | (v << 4)) & 0x000c30c3u;
-  v = (v | (v << 2)) & 0x00249249u;
-  return v;
-}
-
-__device__ __forceinline__ unsigned morton_key(const float4 p, const unsigned* bb, int bits) {
-  const unsigned ncell = 1u << (3 * bits);
-  if (!finite3(p.x, p.y, p.z)) return ncell - 1;
-  const float res = (float) (1 << bits);
-  unsigned c[3];
-  const float v[3] = {p.x, p.y, p.z};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    unsigned kmn = bb[d], kmx = bb[3 + d];
-    unsigned bmn = (kmn & 0x80000000u) ? (kmn & 0x7fffffffu) : ~kmn;
-    unsigned bmx = (kmx & 0x80000000u) ? (kmx & 0x7fffffffu) : ~kmx;
-    float mn = __uint_as_float(bmn), mx = __uint_as_float(bmx);
-    float ext = mx - mn;
-    float u   = ext > 0.f ? (v[d] - mn) / ext * res : 0.f;
-    int ci    = (int) u;
-    ci        = min(max(ci, 0), (1 << bits) - 1);
-    c[d]      = (unsigned) ci;
-  }
-  return spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
-}
-
-__global__ void k_msort_bbox(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
-                             unsigned* __restrict__ bb /* [K][6] */) {
-  const ProblemDev pd = probs[blockIdx.y];
-  unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
-    float4 p = pts[pd.moff + i];
-    if (!finite3(p.x, p.y, p.z)) continue;
-    const unsigned k[3] = {fkey(p.x), fkey(p.y), fkey(p.z)};
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      mn[d] = min(mn[d], k[d]);
-      mx[d] = max(mx[d], k[d]);
-    }
-  }
-  // wave reduction first: one atomic per wave and bound instead of one per point (same-address atomics serialise)
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      mn[d] = min(mn[d], (unsigned) __shfl_xor((int) mn[d], off));
-      mx[d] = max(mx[d], (unsigned) __shfl_xor((int) mx[d], off));
-    }
-  }
-  // ... then the 4 waves of the block through LDS: one atomic per block and bound (measured: per-wave atomics on the
-  // 6 addresses of a problem cost 109 us at C2 and 541 us for a 32 x 50k batch)
-  __shared__ unsigned red[4][6];
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      red[threadIdx.x >> 6][d]     = mn[d];
-      red[threadIdx.x >> 6][3 + d] = mx[d];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int d = threadIdx.x;
-    unsigned* b = bb + blockIdx.y * 6;
-    if (d < 3) {
-      const unsigned v = min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]));
-      if (v != 0xffffffffu) atomicMin(&b[d], v);
-    } else {
-      const unsigned v = max(max(red[0][d], red[1][d]), max(red[2][d], red[3][d]));
-      if (v != 0u) atomicMax(&b[d], v);
-    }
-  }
-}
-
-__global__ void k_msort_count(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
-                              const unsigned* __restrict__ bb, int bits, int* __restrict__ counts) {
-  const ProblemDev pd = probs[blockIdx.y];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
-    unsigned key = morton_key(pts[pd.moff + i], bb + blockIdx.y * 6, bits);
-    atomicAdd(&counts[((size_t) blockIdx.y << (3 * bits)) + key], 1);
-  }
-}
-
-__global__ void k_msort_scatter(const float4* __restrict__ pts, const float4* __restrict__ nrm,
-                                const ProblemDev* __restrict__ probs, const unsigned* __restrict__ bb, int bits,
-                                int* __restrict__ cursor, float4* __restrict__ out_pts, float4* __restrict__ out_nrm) {
-  const ProblemDev pd = probs[blockIdx.y];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
-    float4 p     = pts[pd.moff + i];
-    unsigned key = morton_key(p, bb + blockIdx.y * 6, bits);
-    int pos      = atomicAdd(&cursor[((size_t) blockIdx.y << (3 * bits)) + key], 1);
-    p.w          = __int_as_float(i);
-    out_pts[pos] = p;
-    if (nrm) out_nrm[pos] = nrm[pd.moff + i];
-  }
-}
-
-// Morton sort of a batch with a small key space (<= 32 Ki cells per problem: the histogram fits in LDS): ONE workgroup per
-// problem does everything -- bounding box and max |coordinate| of the raw strided input, histogram with LDS atomics,
-// exclusive scan in place, scatter of the widened points (and normals) through LDS cursors.  Replaces two ingest
-// kernels, the bounding-box / count / scan x 3 / copy / scatter kernels and their 2 x nm global atomics per problem
-// (a 32 x 50k batch: 68 + 188 us -> one kernel).  Each thread keeps eight points in flight per round.
-__global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ src, int sf, const float* __restrict__ nsrc,
-                                                      int nsf, const ProblemDev* __restrict__ probs, int dim, int bits,
-                                                      float4* __restrict__ out_pts, float4* __restrict__ out_nrm,
-                                                      unsigned* __restrict__ maxabs_bits /* [K] */) {
-  constexpr int NPT = 8;  // points in flight per thread and round
-  extern __shared__ int hist[];  // 1 << (3 * bits) counters, then cursors
-  __shared__ unsigned red[16][6];
-  __shared__ unsigned bbs[6];
-  __shared__ float kmn[3], kscale[3];  // cell coordinate = (v - kmn) * kscale (one reciprocal per axis, not a division per point)
-  __shared__ int wsum[16];
-  const ProblemDev pd = probs[blockIdx.x];
-  const int ncell     = 1 << (3 * bits);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const float* base = src + (size_t) pd.moff * sf;
-  auto load = [&](int i) {
-    const float* p = base + (size_t) i * sf;
-    return make_float4(p[0], p[1], dim == 3 ? p[2] : 0.f, 0.f);
-  };
-  for (int c = tid; c < ncell; c += 1024) hist[c] = 0;
-  // ---- pass 1: bounding box of the finite points (order-preserving unsigned keys, like k_msort_bbox)
-  unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
-  for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
-    float4 q[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) q[j] = (i0 + j * 1024 < pd.nm) ? load(i0 + j * 1024) : make_float4(NAN, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      if (!finite3(q[j].x, q[j].y, q[j].z)) continue;
-      const unsigned k[3] = {fkey(q[j].x), fkey(q[j].y), fkey(q[j].z)};
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        mn[d] = min(mn[d], k[d]);
-        mx[d] = max(mx[d], k[d]);
-      }
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      mn[d] = min(mn[d], (unsigned) __shfl_xor((int) mn[d], off));
-      mx[d] = max(mx[d], (unsigned) __shfl_xor((int) mx[d], off));
-    }
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      red[wid][d]     = mn[d];
-      red[wid][3 + d] = mx[d];
-    }
-  }
-  __syncthreads();
-  if (tid < 6) {
-    unsigned v = red[0][tid];
-    for (int w = 1; w < 16; ++w) v = tid < 3 ? min(v, red[w][tid]) : max(v, red[w][tid]);
-    bbs[tid] = v;
-  }
-  __syncthreads();
-  if (tid == 0 && maxabs_bits) {  // max |coordinate| over the finite points = the largest |bound|
-    float amax = 0.f;
-    if (bbs[0] != 0xffffffffu) {
-#pragma unroll
-      for (int d = 0; d < 6; ++d) {
-        const unsigned k = bbs[d];
-        const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-        amax             = fmaxf(amax, fabsf(__uint_as_float(b)));
-      }
-    }
-    maxabs_bits[blockIdx.x] = __float_as_uint(amax);
-  }
-  if (tid < 3) {
-    const unsigned a = bbs[tid], z = bbs[3 + tid];
-    const float mnf  = __uint_as_float((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
-    const float mxf  = __uint_as_float((z & 0x80000000u) ? (z & 0x7fffffffu) : ~z);
-    const float ext  = mxf - mnf;
-    kmn[tid]         = mnf;
-    kscale[tid]      = (bbs[0] != 0xffffffffu && ext > 0.f) ? (float) (1 << bits) / ext : 0.f;
-  }
-  __syncthreads();
-  // (any monotone cell assignment gives a valid sort: the keys only order the points)
-  auto key_of = [&](const float4 p) -> unsigned {
-    if (!finite3(p.x, p.y, p.z)) return (unsigned) ncell - 1u;
-    const int hi = (1 << bits) - 1;
-    const int cx = min(max((int) ((p.x - kmn[0]) * kscale[0]), 0), hi);
-    const int cy = min(max((int) ((p.y - kmn[1]) * kscale[1]), 0), hi);
-    const int cz = min(max((int) ((p.z - kmn[2]) * kscale[2]), 0), hi);
-    return spread3((unsigned) cx) | (spread3((unsigned) cy) << 1) | (spread3((unsigned) cz) << 2);
-  };
-  // ---- pass 2: histogram
-  for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
-    float4 q[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) q[j] = (i0 + j * 1024 < pd.nm) ? load(i0 + j * 1024) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < NPT; ++j)
-      if (i0 + j * 1024 < pd.nm) atomicAdd(&hist[key_of(q[j])], 1);
-  }
-  __syncthreads();
-  // ---- exclusive scan in place.  Wave w owns the cells [w * seg, (w + 1) * seg) and walks them 64 at a time (lane =
-  // consecutive cell: no bank conflicts; a thread owning consecutive cells would put all 64 lanes on one bank), carrying
-  // the running total; then every cell gets the total of the waves before its own.
-  {
-    const int seg = (ncell + 15) / 16;
-    int carry     = 0;
-    for (int c = wid * seg + lane; c - lane < min((wid + 1) * seg, ncell); c += 64) {
-      const bool in = c < min((wid + 1) * seg, ncell);
-      const int v   = in ? hist[c] : 0;
-      int incl      = v;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-      }
-      if (in) hist[c] = carry + incl - v;
-      carry += __shfl(incl, 63);
-    }
-    if (lane == 0) wsum[wid] = carry;
-    __syncthreads();
-    int before = 0;
-    for (int w = 0; w < wid; ++w) before += wsum[w];
-    for (int c = wid * seg + lane; c < min((wid + 1) * seg, ncell); c += 64) hist[c] += before;
-  }
-  __syncthreads();
-  // ---- pass 3: scatter (the caller's index travels in .w; the order inside a cell does not matter: see above)
-  const float* nbase = nsrc ? nsrc + (size_t) pd.moff * nsf : nullptr;
-  for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
-    float4 q[NPT], nq[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      const int i = i0 + j * 1024;
-      q[j]  = i < pd.nm ? load(i) : make_float4(0.f, 0.f, 0.f, 0.f);
-      nq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nbase && i < pd.nm) {
-        const float* p = nbase + (size_t) i * nsf;
-        nq[j]          = make_float4(p[0], p[1], dim == 3 ? p[2] : 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      const int i = i0 + j * 1024;
-      if (i >= pd.nm) continue;
-      const int pos = atomicAdd(&hist[key_of(q[j])], 1);
-      q[j].w        = __int_as_float(i);
-      out_pts[pd.moff + pos] = q[j];
-      if (nbase) out_nrm[pd.moff + pos] = nq[j];
-    }
-  }
-}
+#include "device_util.h"
 
 // ============================================================================================
 // the fused ICP step kernel
@@ -2444,90 +1918,6 @@ __global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, cons
 // launchers
 // ============================================================================================
 namespace srrg2amd {
-
-void launch_ingest(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits,
-                   int finite_per_point, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_ingest, dim3((n + 255) / 256), dim3(256), 0, s, src, stride_floats, n, dim, dst, maxabs_bits,
-                     finite_per_point);
-}
-
-void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* probs, int K, int max_nm, int dim,
-                         float4* dst, unsigned* maxabs_bits, int finite_per_point, hipStream_t s) {
-  if (K <= 0 || max_nm <= 0) return;
-  int bx = (max_nm + 255) / 256;
-  if (bx > 256) bx = 256;
-  hipLaunchKernelGGL(k_ingest_batch, dim3(bx, K), dim3(256), 0, s, src, stride_floats, probs, dim, dst, maxabs_bits,
-                     finite_per_point);
-}
-
-void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s) {
-  if (n <= 0) return;
-  const int bx = (n + 255) / 256;
-  hipLaunchKernelGGL(k_bbox, dim3(bx < 64 ? bx : 64), dim3(256), 0, s, pts, n, mn, mx, nvalid);
-}
-
-void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, n, counts);
-}
-
-void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s) {
-  if (n <= 0) return;
-  int nb = (n + 255) / 256;
-  if (nb > 256) nb = 256;
-  hipLaunchKernelGGL(k_count_nonzero, dim3(nb), dim3(256), 0, s, counts, n, out);
-}
-
-int scan_num_blocks(int n) {
-  return (n + SCAN_TILE - 1) / SCAN_TILE;
-}
-
-void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s) {
-  int nb = scan_num_blocks(n);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(SCAN_THREADS), 0, s, data, n, block_sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, grand_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, s, data, n, block_sums, grand_total);
-}
-
-void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
-                         float4* out_nrm, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_grid_scatter, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, nrm, n, cursor, out_pts, out_nrm);
-}
-
-void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
-                  unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
-                  float4* out_nrm, hipStream_t s) {
-  if (K <= 0 || max_nm <= 0) return;
-  int bx = (max_nm + 255) / 256;
-  if (bx > 1024) bx = 1024;
-  dim3 grid(bx, K);
-  const int ncell = K << (3 * bits);
-  // (few, grid-striding blocks per problem for the bounding box: its cost is the atomics, not the reads)
-  hipLaunchKernelGGL(k_msort_bbox, dim3(bx < 32 ? bx : 32, K), dim3(256), 0, s, pts, probs, bb);
-  hipLaunchKernelGGL(k_msort_count, grid, dim3(256), 0, s, pts, probs, bb, bits, counts);
-  launch_exclusive_scan(counts, ncell, scan_sums, scan_total, s);
-  (void) hipMemcpyAsync(cursor, counts, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(k_msort_scatter, grid, dim3(256), 0, s, pts, nrm, probs, bb, bits, cursor, out_pts, out_nrm);
-}
-
-// false: the key space does not fit in LDS (the caller takes the ingest + global-histogram path)
-bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int bits,
-                        float4* out_pts, float4* out_nrm, unsigned* maxabs_bits, hipStream_t s) {
-  if (bits > 5) return false;
-  if (K <= 0) return true;
-  const size_t lds = sizeof(int) << (3 * bits);
-  static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msort_local),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (sizeof(int) << 15)) == hipSuccess;
-  if (!attr_ok) {
-    (void) hipGetLastError();
-    return false;
-  }
-  hipLaunchKernelGGL(k_msort_local, dim3(K), dim3(1024), lds, s, src, sf, nsrc, nsf, probs, dim, bits, out_pts, out_nrm,
-                     maxabs_bits);
-  return true;
-}
 
 int icp_step_blocks(int max_nm) {
   return (max_nm + 255) / 256;  // one moving point per thread

@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /root/repo
-export TMPDIR=/tmp
-rm -rf /tmp/tr; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/tr -o t -- python bench.py --points 1000000 --steps 10 --warmup 2 --no-cpu-all-cores --no-cpu-baseline > /tmp/tr.log 2>&1
-python tools/rocpd_summary.py /tmp/s.txt k=$(ls /tmp/tr/*.db | head -1); cut -c1-120 /tmp/s.txt | head -12
-python tools/trace_steps.py $(ls /tmp/tr/*.db | head -1) | cut -c1-330
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/t_gpu.log 2>&1
+tail -2 gpurun_out/t_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-all-cores --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2', d['value'])"
