@@ -1,7 +1,18 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 > gpurun_out/t_gpu.log 2>&1
-tail -2 gpurun_out/t_gpu.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-all-cores --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c2', d['value'])"
+python - <<'PY'
+import sys, time, numpy as np
+sys.path.insert(0, "tests")
+import torch
+import srrg2_slam_interfaces_amd as pkg
+from srrg2_slam_interfaces_amd import _abi as abi, synthetic as syn
+from helpers import cue_config, setup_pair
+d = syn.cloud_pair_3d(n=1_000_000, seed=2000)
+al = pkg.MultiAligner(abi.SE3_QUAT_RIGHT, 0)
+setup_pair(al, d, cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.05, 0.8))
+ts = []
+for k in range(25):
+    al.set_moving_in_fixed(syn.identity(3))
+    t0 = time.perf_counter(); al.compute(); ts.append((time.perf_counter() - t0) * 1e3)
+print("ms per compute:", [round(t, 2) for t in ts])
+PY
