@@ -109,9 +109,9 @@ def main():
         def step():
             al.set_moving_in_fixed(ident)
             st = al.compute()
-            stats = al.iteration_stats()
+            nst, last = al.last_iteration_stats()
             return [D.pack_record(rank, {"moving_in_fixed": al.moving_in_fixed(), "status": st,
-                                         "num_iterations": len(stats), "last": stats[-1]})]
+                                         "num_iterations": nst, "last": last})]
     elif args.workload == "c3":
         # C3: 2-slice MultiAligner (projective + point-to-plane, projective + reprojection) on a 640x480 depth pair
         data = syn.rgbd_pair(seed=3000 + 10 * rank)
@@ -134,9 +134,9 @@ def main():
         def step():
             al.set_moving_in_fixed(ident)
             st = al.compute()
-            stats = al.iteration_stats()
+            nst, last = al.last_iteration_stats()
             return [D.pack_record(rank, {"moving_in_fixed": al.moving_in_fixed(), "status": st,
-                                         "num_iterations": len(stats), "last": stats[-1]})]
+                                         "num_iterations": nst, "last": last})]
     else:
         # C4: K_total alignments sharded k -> k mod G; this rank's moving clouds are resident in HBM
         K_total = args.batch * world

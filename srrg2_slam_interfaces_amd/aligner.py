@@ -162,6 +162,19 @@ class MultiAligner:
         self._check(self._b.fn("get_iteration_stats")(self._h, buf, C.byref(n2)))
         return [buf[i].as_dict() for i in range(n2.value)]
 
+    def last_iteration_stats(self):
+        """(number of IterationStats of the last compute(), the last one as a dict): what the batch callers' gates read
+        (multi_loop_detector_brute_force_impl.cpp:80-91), without building one dict per iteration."""
+        buf = getattr(self, "_stats_buf", None)
+        if buf is None:
+            buf = self._stats_buf = (abi.IterationStats * 256)()
+        n = C.c_int(256)
+        self._check(self._b.fn("get_iteration_stats")(self._h, buf, C.byref(n)))
+        if n.value > 256:  # (more than the scratch holds: take the general path)
+            stats = self.iteration_stats()
+            return len(stats), stats[-1]
+        return n.value, (buf[n.value - 1].as_dict() if n.value > 0 else None)
+
     def num_correspondences(self):
         n = C.c_int(0)
         self._check(self._b.fn("num_correspondences")(self._h, C.byref(n)))

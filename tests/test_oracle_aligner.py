@@ -37,6 +37,7 @@ def test_c1_se2_scan_matching(oracle):
     setup_pair(al, d, cue_config(abi.SE2_RIGHT, abi.SLICE_P2P, 0.5))
     assert al.compute() == abi.SUCCESS
     assert len(al.iteration_stats()) == 10  # aligner.h:30, no termination criterion
+    assert al.last_iteration_stats() == (10, al.iteration_stats()[-1])  # (the light accessor of the batch callers' gates)
     assert np.max(np.abs(al.moving_in_fixed() - d["X_gt"])) < 2e-2
     al2 = oracle.OracleAligner(abi.SE2_RIGHT)
     setup_pair(al2, d, cue_config(abi.SE2_RIGHT, abi.SLICE_P2PLANE, 0.5))

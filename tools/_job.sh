@@ -1,10 +1,6 @@
 #!/bin/bash
 cd /root/repo
-for n in 300000 1000000; do
-for c in 0 3 4 5 6 8; do
-echo -n "RMAX_CAP=$c  "; SRRG2_AMD_RMAX_CAP=$c python tools/loop_compute.py $n 15
+for i in 1 2; do
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench c2', d['value'], d['ms_per_step'])"
 done
-for t in 4 16 32; do
-echo -n "CELL_TARGET=$t  "; SRRG2_AMD_CELL_TARGET=$t python tools/loop_compute.py $n 15
-done
-done
+timeout 300 python bench.py --workload c3 --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench c3', d['value'], d['ms_per_step'])"
