@@ -810,7 +810,10 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
         best    = key_best(k1);
         bidx    = key_idx(k1);
         bpos    = ppos;
-        excl    = pm * 0.99999f - dl * 1.00001f;
+        // (the stored radius shrinks by the motion and by its own rounding -- 0.9999999 > one ulp -- not by the
+        // comparison's 1e-5 safety factor, which alone ate the margin of a few points per iteration, each of which then
+        // made its whole wave pay a search)
+        excl    = pm * 0.9999999f - dl * 1.00001f;
       } else {
         pad            = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
         const float rr = (d1 + pad) * 1.00001f;
@@ -825,7 +828,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
       const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
       if (sqrtf(g.gate2) * 1.00001f + dl * 1.00001f < pm * 0.99999f) {
         skipped = true;
-        excl    = pm * 0.99999f - dl * 1.00001f;  // (best = inf, bidx = NO_MATCH: stays "none")
+        excl    = pm * 0.9999999f - dl * 1.00001f;  // (best = inf, bidx = NO_MATCH: stays "none")
       }
     }
   }
