@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -432,6 +433,7 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
 }
 
 int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null for K == 1 */, const float* guesses) {
+  auto t_begin = std::chrono::steady_clock::now();
   int rc;
   if ((rc = set_device(a))) return rc;
   const int nslices = (int) a->slices.size();
@@ -799,7 +801,15 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     srrg2amd::launch_icp_finalize(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                   !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
   HIP_TRY(hipGetLastError());
+  static const bool hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
+  auto t_enq = std::chrono::steady_clock::now();
   HIP_TRY(hipStreamSynchronize(a->stream));
+  if (hosttime) {
+    auto t_end = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "compute: enqueue %.1f us, wait %.1f us\n",
+                 std::chrono::duration<double, std::micro>(t_enq - t_begin).count(),
+                 std::chrono::duration<double, std::micro>(t_end - t_enq).count());
+  }
   if (const char* tl_path = std::getenv("SRRG2_AMD_TIMELINE")) {  // dump of the last compute(): u64 nwaves, then stamps
     for (int si = 0; si < nslices; ++si) {
       Slice* s = a->slices[si];

@@ -1,6 +1,4 @@
 #!/bin/bash
 cd /root/repo
-python tools/loop_compute.py 100000 200
-SRRG2_AMD_TUNE=33554432 python tools/loop_compute.py 100000 200
-python tools/loop_compute.py 100000 200
-SRRG2_AMD_TUNE=33554432 python tools/loop_compute.py 100000 200
+SRRG2_AMD_HOSTTIME=1 python tools/loop_compute.py 100000 10 2>&1 | tail -6
+SRRG2_AMD_HOSTTIME=1 python tools/loop_compute.py 10000 10 2>&1 | tail -4
