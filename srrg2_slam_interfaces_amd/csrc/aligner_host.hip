@@ -546,7 +546,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     for (int k = 0; k < K; ++k) nm_max_s = std::max(nm_max_s, all[(size_t) si * K + k].nm);
     // deferred-search queue: a win in the latency regime (few alignments per launch: C2 0.78 -> 0.63 ms); with many
     // alignments per launch the in-kernel path has more throughput (C4: 2.46 vs 2.74 ms per 32 x 50k batch)
-    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s > 0 && K <= 4 && !small;
+    // ... and with few points per launch the extra launches cost more than they save (measured, tools/loop_compute.py:
+    // without the queue 3 k / 10 k / 30 k / 60 k points take 0.286 / 0.249 / 0.254 / 0.272 ms per compute() instead of
+    // 0.307 / 0.271 / 0.264 / 0.277 ms; equal at 80-100 k; 150 k: 0.356 ms with the queue, 0.462 ms without)
+    // (read on every compute(): the tests run every scenario on both paths)
+    const int queue_min = std::getenv("SRRG2_AMD_QUEUE_MIN") ? std::atoi(std::getenv("SRRG2_AMD_QUEUE_MIN")) : 90000;
+    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small;
     const int nblocks    = PARTIAL_SLOTS;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
     if (use_queue) {

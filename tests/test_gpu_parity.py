@@ -9,6 +9,13 @@ from srrg2_slam_interfaces_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["deferred-search kernel", "searches finished in the step kernel"])
+def search_path(request, monkeypatch):
+    """Single alignments defer their open searches to k_icp_step_queue from 90 000 moving points on and finish them
+    inside k_icp_step below (SRRG2_AMD_QUEUE_MIN): every scenario of this module runs on both paths."""
+    monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", "0" if request.param.startswith("deferred") else "1000000000")
+
+
 def _pair(oracle, product, kind):
     return oracle.OracleAligner(kind), product.MultiAligner(kind)
 
