@@ -1,6 +1,7 @@
 #!/bin/bash
 cd /root/repo
-timeout 1500 python -m pytest tests -x -q -m gpu --timeout 300 2>&1 | tail -3
-python tools/loop_compute.py 100000 200
-python tools/loop_compute.py 10000 200
-timeout 300 python tools/bench_tracker.py 2>/dev/null | tail -1 | cut -c1-420
+mkdir -p gpurun_out
+timeout 300 python tools/bench_small.py --beams 360 2000 4000 > gpurun_out/r1i_bench_small.json 2>/dev/null; python -c "
+import json
+for c in json.load(open('gpurun_out/r1i_bench_small.json'))['small_alignments']: print('  %-40s gpu %.4f ms oracle %.3f  x%.1f identical %s' % (c['case'], c['gpu_ms'], c['oracle_ms'], c['speedup'], c['X_bit_identical']))"
+timeout 300 python tools/bench_tracker.py > gpurun_out/r1i_bench_tracker.json 2>/dev/null
