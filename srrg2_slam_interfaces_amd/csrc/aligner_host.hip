@@ -116,6 +116,7 @@ struct srrg2_aligner_s {
   DevBuf<char> staging;  // raw strided input staged on the device
   // pinned host mirrors
   ProblemOut* outs_host = nullptr; size_t outs_host_cap = 0;
+  int seq = 0;  // sequence number of the last compute() (completion flags in outs_host)
   srrg2_iteration_stats* stats_host = nullptr; size_t stats_host_cap = 0;
   float* guesses_host = nullptr; size_t guesses_host_cap = 0;
   ProblemDev* probs_host = nullptr; size_t probs_host_cap = 0;
@@ -498,6 +499,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   C.has_term      = a->has_term ? 1 : 0;
   C.term          = a->term;
   C.max_stats     = slots;
+  C.seq           = ++a->seq;
+  if (C.seq <= 0) C.seq = a->seq = 1;
+  for (int k = 0; k < K; ++k) a->outs_host[k].seq = 0;  // (never a sequence number: fresh pinned memory is not zeroed)
   C.tune          = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
   C.probe_it      = std::getenv("SRRG2_AMD_QPROBE") ? std::atoi(std::getenv("SRRG2_AMD_QPROBE")) : 1;
   if (a->params.max_iterations <= C.probe_it + 3 || K > 4) C.probe_it = -1;
@@ -808,7 +812,21 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   HIP_TRY(hipGetLastError());
   static const bool hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
   auto t_enq = std::chrono::steady_clock::now();
-  HIP_TRY(hipStreamSynchronize(a->stream));
+  // The last kernel of compute() writes every result into pinned host memory and, behind a system-scope fence, the
+  // sequence number of this compute() into ProblemOut::seq: the host polls those words instead of waiting for the
+  // stream to retire (hipStreamSynchronize returns ~5 us after the results are visible).  The stream is only waited for
+  // when something else needs it idle (event timing, the timeline dump) or when it reports an error.
+  bool seen = true;
+  for (int k = 0; k < K && seen; ++k) {
+    volatile int* flag = &a->outs_host[k].seq;
+    int spins          = 0;
+    while (*flag != C.seq)
+      if ((++spins & 4095) == 0 && hipStreamQuery(a->stream) != hipErrorNotReady) {
+        seen = *flag == C.seq;  // (drained: either the flag has just arrived or a launch failed)
+        break;
+      }
+  }
+  if (!seen || a->profile || std::getenv("SRRG2_AMD_TIMELINE")) HIP_TRY(hipStreamSynchronize(a->stream));
   if (hosttime) {
     auto t_end = std::chrono::steady_clock::now();
     std::fprintf(stderr, "compute: enqueue %.1f us, wait %.1f us\n",

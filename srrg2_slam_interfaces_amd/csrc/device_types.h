@@ -113,6 +113,7 @@ struct ProblemOut {
   int status;
   int nstats;
   int ncorr[SRRG2_MAX_SLICES];
+  int seq;  // CtlParams::seq of the compute() that wrote this record: written last, behind a system-scope fence
 };
 
 struct SliceCtl {
@@ -150,5 +151,6 @@ struct CtlParams {
   int max_stats;  // capacity of the per-problem stats array
   int tune;       // SRRG2_AMD_TUNE (see SliceDev::tune)
   int probe_it;   // iteration after which the use of the deferred-search queue is decided (-1: never)
+  int seq;        // sequence number of this compute() (completion flag in ProblemOut)
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

@@ -1827,6 +1827,8 @@ __device__ void icp_finalize_block(const CtlParams& C, ProblemState* st, const s
     int* dst          = reinterpret_cast<int*>(stats_host + (size_t) prob * C.max_stats);
     for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = src[k];
   }
+  __threadfence_system();  // (the statistics above are in host memory before the completion flag below)
+  __syncthreads();
   if (threadIdx.x != 0) return;
   if (!st->finished) {
     if (C.params.keep_only_inlier_correspondences) {
@@ -1844,6 +1846,8 @@ __device__ void icp_finalize_block(const CtlParams& C, ProblemState* st, const s
   o->status = st->status;
   o->nstats = st->nstats;
   for (int s = 0; s < SRRG2_MAX_SLICES; ++s) o->ncorr[s] = st->ncorr[s];
+  __threadfence_system();
+  *reinterpret_cast<volatile int*>(&o->seq) = C.seq;  // the host polls this word instead of waiting for the stream
 }
 
 __global__ __launch_bounds__(64) void k_icp_finalize(CtlParams C, ProblemState* __restrict__ states,
