@@ -663,7 +663,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         return fail(SRRG2_E_UNSUPPORTED, "compute_batch supports one cue slice (plus prior slices)");
   }
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
+  auto t_prep = std::chrono::steady_clock::now();
   srrg2amd::launch_icp_init(C, a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, a->stream);
+  auto t_init = std::chrono::steady_clock::now();
 
   if (small) {
     Slice* s = a->slices[first_cue];
@@ -829,7 +831,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   if (!seen || a->profile || std::getenv("SRRG2_AMD_TIMELINE")) HIP_TRY(hipStreamSynchronize(a->stream));
   if (hosttime) {
     auto t_end = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "compute: enqueue %.1f us, wait %.1f us\n",
+    std::fprintf(stderr, "compute: prep %.1f us, first launch %.1f us, enqueue %.1f us, wait %.1f us\n",
+                 std::chrono::duration<double, std::micro>(t_prep - t_begin).count(),
+                 std::chrono::duration<double, std::micro>(t_init - t_prep).count(),
                  std::chrono::duration<double, std::micro>(t_enq - t_begin).count(),
                  std::chrono::duration<double, std::micro>(t_end - t_enq).count());
   }
