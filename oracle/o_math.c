@@ -355,27 +355,31 @@ void o_box_plus(int variable_kind, float* X, const double* dx) {
   memcpy(X, out, sizeof(out));
 }
 
-/* ---- dense Cholesky solve H dx = -b ---------------------------------------- */
+/* ---- dense solve H dx = -b (H symmetric positive definite) -------------------
+ * Square-root-free L D L^T, one division per column and none in the substitutions: the operation order is the
+ * specification shared with the GPU's control step (srrg2_slam_interfaces_amd/csrc/det_math.h, dm::solve: statement
+ * for statement).  Returns 1 for a pivot <= 0 or a non-finite solution.
+ * ([EXT] the reference's Solver is srrg2_solver's, not under /root/reference: parity unpinned) */
 int o_solve(int D, const double* H, const double* b, double* dx) {
   double L[36];
-  double y[6];
+  double d[6], inv[6], y[6];
   memset(L, 0, sizeof(L));
   for (int j = 0; j < D; ++j) {
     double s = H[j * D + j];
     for (int k = 0; k < j; ++k) {
-      s = s - L[j * D + k] * L[j * D + k];
+      s = s - (L[j * D + k] * L[j * D + k]) * d[k];
     }
     if (!(s > 0.0)) {
       return 1;
     }
-    double d     = sqrt(s);
-    L[j * D + j] = d;
+    d[j]   = s;
+    inv[j] = 1.0 / s;
     for (int i = j + 1; i < D; ++i) {
       double v = H[i * D + j];
       for (int k = 0; k < j; ++k) {
-        v = v - L[i * D + k] * L[j * D + k];
+        v = v - (L[i * D + k] * L[j * D + k]) * d[k];
       }
-      L[i * D + j] = v / d;
+      L[i * D + j] = v * inv[j];
     }
   }
   for (int i = 0; i < D; ++i) {
@@ -383,14 +387,14 @@ int o_solve(int D, const double* H, const double* b, double* dx) {
     for (int k = 0; k < i; ++k) {
       s = s - L[i * D + k] * y[k];
     }
-    y[i] = s / L[i * D + i];
+    y[i] = s;
   }
   for (int i = D - 1; i >= 0; --i) {
-    double s = y[i];
+    double s = y[i] * inv[i];
     for (int k = i + 1; k < D; ++k) {
       s = s - L[k * D + i] * dx[k];
     }
-    dx[i] = s / L[i * D + i];
+    dx[i] = s;
   }
   for (int i = 0; i < D; ++i) {
     if (!(dx[i] == dx[i]) || dx[i] > 1e300 || dx[i] < -1e300) {

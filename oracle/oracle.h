@@ -56,7 +56,7 @@ void o_se3_fix_transform(float* T);
 void o_se2_fix_transform(float* T);
 /* X <- X * v2t(dx) */
 void o_box_plus(int variable_kind, float* X, const double* dx);
-/* Cholesky solve of H dx = -b (D = 3 or 6, H full row-major DxD). returns 0 ok, 1 not PD */
+/* L D L^T solve of H dx = -b (D = 3 or 6, H full row-major DxD). returns 0 ok, 1 not PD */
 int o_solve(int D, const double* H, const double* b, double* dx);
 /* exponent k of the fixed-point accumulators (DESIGN.md "fixed-point reduction") */
 int o_fixed_point_exponent(int n_terms, double term_bound);

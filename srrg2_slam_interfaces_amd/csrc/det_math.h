@@ -264,28 +264,33 @@ DM_HD void box_plus(int variable_kind, float* X, const double* dx) {
   for (int i = 0; i < 12; ++i) X[i] = out[i];
 }
 
-// Cholesky solve of H dx = -b, D in {3, 6}; H full row-major. returns 0 ok, 1 not positive definite
+// Solve of H dx = -b, D in {3, 6}; H full row-major, symmetric positive definite.  Returns 0 ok, 1 not positive
+// definite (a pivot <= 0) or a non-finite solution.  Square-root-free L D L^T with ONE division per column (the
+// reciprocal of the pivot) and none in the substitutions: the control step is a chain of dependent float64 operations
+// run by one thread, and a correctly rounded division or square root is ~150 cycles of it -- a Cholesky solve has 24 of
+// them on its critical path, this form 6.  The operation order is part of the arithmetic specification (oracle:
+// o_solve in oracle/o_math.c, statement for statement).
 template <int D>
 DM_HD int solve(const double* H, const double* b, double* dx) {
-  // fully unrolled so that L, y live in registers on the device
-  double L[D * D];
-  double y[D];
+  // fully unrolled so that L, d, y live in registers on the device
+  double L[D * D];  // multipliers (strictly lower part)
+  double d[D], inv[D], y[D];
 #pragma unroll
   for (int i = 0; i < D * D; ++i) L[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     double s = H[j * D + j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) s = s - L[j * D + k] * L[j * D + k];
+    for (int k = 0; k < j; ++k) s = s - (L[j * D + k] * L[j * D + k]) * d[k];
     if (!(s > 0.0)) return 1;
-    double d     = sqrt(s);
-    L[j * D + j] = d;
+    d[j]   = s;
+    inv[j] = 1.0 / s;
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double v = H[i * D + j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) v = v - L[i * D + k] * L[j * D + k];
-      L[i * D + j] = v / d;
+      for (int k = 0; k < j; ++k) v = v - (L[i * D + k] * L[j * D + k]) * d[k];
+      L[i * D + j] = v * inv[j];
     }
   }
 #pragma unroll
@@ -293,14 +298,14 @@ DM_HD int solve(const double* H, const double* b, double* dx) {
     double s = -b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s = s - L[i * D + k] * y[k];
-    y[i] = s / L[i * D + i];
+    y[i] = s;
   }
 #pragma unroll
   for (int i = D - 1; i >= 0; --i) {
-    double s = y[i];
+    double s = y[i] * inv[i];
 #pragma unroll
     for (int k = i + 1; k < D; ++k) s = s - L[k * D + i] * dx[k];
-    dx[i] = s / L[i * D + i];
+    dx[i] = s;
   }
 #pragma unroll
   for (int i = 0; i < D; ++i) {

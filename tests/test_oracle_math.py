@@ -80,7 +80,7 @@ def test_fix_transform_orthonormalises(oracle):
     assert abs(F2[0, 0] ** 2 + F2[1, 0] ** 2 - 1) < 1e-6 and F2[0, 1] == -F2[1, 0] and F2[1, 1] == F2[0, 0]
 
 
-def test_cholesky_solve(oracle):
+def test_dense_solve(oracle):
     rng = np.random.default_rng(3)
     for D in (3, 6):
         A = rng.normal(size=(20, D))
