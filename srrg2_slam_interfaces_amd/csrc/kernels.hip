@@ -1577,8 +1577,10 @@ __device__ bool has_to_stop(const CtlParams& C, ProblemState* st, const srrg2_it
 }
 
 template <int D>
+// sums: the exact integer sums of every cue slice; scaled: (double) sums[s][k] * 2^-kexp[s], converted by one lane per
+// entry before this (sequential) body runs -- the same operation it used to do itself, 30 times in a row.
 __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob,
-                             const long long (*sums)[ACC_N]) {
+                             const long long (*sums)[ACC_N], const double (*scaled)[ACC_N]) {
   // association check: association_good |= slice->correspondencesGood(), multi_aligner.h:126-138
   bool good = false;
   for (int s = 0; s < C.nslices; ++s) {
@@ -1633,24 +1635,24 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
       continue;
     }
     const long long* acc = sums[s];
-    const double inv     = dm::pow2(-st->kexp[s]);
+    const double* sc_    = scaled[s];
 #pragma unroll
     for (int a = 0; a < D; ++a) {
 #pragma unroll
       for (int c = a; c < D; ++c) {
-        double v     = (double) acc[hidx(a, c)] * inv;
+        double v     = sc_[hidx(a, c)];
         H[a * D + c] = H[a * D + c] + v;
         if (c != a) H[c * D + a] = H[c * D + a] + v;
       }
-      b[a] = b[a] + (double) acc[ACC_B + a] * inv;
+      b[a] = b[a] + sc_[ACC_B + a];
     }
     int n_in = (int) acc[ACC_N_IN], n_out = (int) acc[ACC_N_OUT];
     int n_c  = (int) acc[ACC_N_CORR];
     cur.num_inliers += n_in;
     cur.num_outliers += n_out;
     cur.num_suppressed += n_c - n_in - n_out;
-    chi_in      = chi_in + (double) acc[ACC_CHI_IN] * inv;
-    chi_out     = chi_out + (double) acc[ACC_CHI_OUT] * inv;
+    chi_in      = chi_in + sc_[ACC_CHI_IN];
+    chi_out     = chi_out + sc_[ACC_CHI_OUT];
     st->ninl[s] = n_in;
   }
   cur.num_correspondences = num_correspondences(C, st);
@@ -1749,6 +1751,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
 // order), then thread 0 runs the sequential part of the iteration
 __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob) {
   __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
+  __shared__ double scaled[SRRG2_MAX_SLICES][ACC_N];
   __shared__ long long part[8][ACC_N];
   const int a = threadIdx.x & 31, c = threadIdx.x >> 5;
   for (int s = 0; s < C.nslices; ++s) {
@@ -1768,15 +1771,16 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
       long long t = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
-      sums[s][threadIdx.x] = t;
+      sums[s][threadIdx.x]   = t;
+      scaled[s][threadIdx.x] = (double) t * dm::pow2(-st->kexp[s]);
     }
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
   if (C.variable_kind == SRRG2_SE2_RIGHT)
-    control_body<3>(C, st, stats, prob, sums);
+    control_body<3>(C, st, stats, prob, sums, scaled);
   else
-    control_body<6>(C, st, stats, prob, sums);
+    control_body<6>(C, st, stats, prob, sums, scaled);
 }
 
 __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* __restrict__ states,
@@ -1888,6 +1892,7 @@ __global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, cons
   const int prob   = blockIdx.x;
   __shared__ ProblemState sst;
   __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
+  __shared__ double scaled[SRRG2_MAX_SLICES][ACC_N];
   constexpr int STATE_WORDS = (int) (sizeof(ProblemState) / sizeof(int));
   static_assert(sizeof(ProblemState) % sizeof(int) == 0, "the state is copied word-wise");
   for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
@@ -1905,7 +1910,10 @@ __global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, cons
         icp_step_body<DIM, PLANE, NW>(S, pd, &sst, prob, tile, ntiles, C.K, sums[S.slice_idx]);
         __syncthreads();  // (the body's shared scratch is reused by the next tile)
       }
-      if (threadIdx.x == 0) control_body<D>(C, &sst, stats, prob, sums);
+      if (threadIdx.x < ACC_N)
+        scaled[S.slice_idx][threadIdx.x] = (double) sums[S.slice_idx][threadIdx.x] * dm::pow2(-sst.kexp[S.slice_idx]);
+      __syncthreads();
+      if (threadIdx.x == 0) control_body<D>(C, &sst, stats, prob, sums, scaled);
       __syncthreads();
     }
     if (run == 0 && nrun == 2) {  // multi_aligner_impl.cpp:75-85, then the inlier-only run
