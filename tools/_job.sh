@@ -1,7 +1,11 @@
 #!/bin/bash
+# scratch: the command file of the last `gpurun -- 'bash tools/_job.sh'` call of the session
 cd /root/repo
-for w in c2 c3 c4; do
-timeout 300 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-all-cores --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', d['value'], d['ms_per_step'])"
-done
-SRRG2_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 50 --warmup 5 2>/dev/null | tail -1 | cut -c1-160
-timeout 600 python -m pytest tests/test_multi_gpu_gloo.py -q 2>&1 | tail -1
+mkdir -p gpurun_out
+timeout 600 python bench.py > gpurun_out/r1l_bench_c2.json 2>/dev/null
+timeout 300 python bench.py --workload c3 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/r1l_bench_c3.json 2>/dev/null
+timeout 300 python bench.py --workload c4 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/r1l_bench_c4.json 2>/dev/null
+timeout 300 python bench.py --workload c4 --batch 256 --steps 20 --warmup 3 --no-cpu-all-cores --no-cpu-baseline > gpurun_out/r1l_bench_c4_256.json 2>/dev/null
+for f in c2 c3 c4 c4_256; do python -c "
+import json
+d=json.loads(open('gpurun_out/r1l_bench_$f.json').read().strip().splitlines()[-1]); print('$f', round(d['value'],1), round(d['ms_per_step'],4), round(d['roofline']['frac'],4), d['roofline']['avg_launch_ms'], d.get('speedup_vs_cpu_baseline'), d.get('speedup_vs_cpu_all_cores'))"; done
