@@ -754,8 +754,18 @@ static int slice_exponent(const o_aligner* a, const o_slice* s) {
   return o_fixed_point_exponent(n_terms, B);
 }
 
-static inline int64_t to_fixed(double v, int k) {
-  return (int64_t) llrint(ldexp(v, k));
+/* Fixed-point terms: every product (w 2^k J_ra) * J_rb is rounded ONCE, to nearest-even, onto the
+ * integer grid by a fused multiply-add onto FX_MAGIC = 1.5 * 2^52 (a double in [2^52, 2^53) has ulp 1, so the fma result
+ * is FX_MAGIC + integer; the rows of one correspondence are chained r = 0, 1, ... on the same accumulator).  The integer is
+ * read back from the bit pattern.  |integer| < 2^51 is guaranteed by slice_exponent.  C99 fma() is exact (one rounding)
+ * by definition; -march=x86-64-v3 compiles it to vfmadd. */
+#define FX_MAGIC 6755399441055744.0
+static inline int64_t fx_bits(double biased) {
+  int64_t a, m;
+  const double magic = FX_MAGIC;
+  memcpy(&a, &biased, 8);
+  memcpy(&m, &magic, 8);
+  return a - m;
 }
 
 static int slice_linearize(o_aligner* a, o_slice* s) {
@@ -861,27 +871,30 @@ static int slice_linearize(o_aligner* a, o_slice* s) {
     }
     int kernelized;
     float w = robust_weight(s->robust_kind, s->robust_thr, chi, &kernelized);
+    const double scale = ldexp(1.0, k);
+    const int64_t chi_fx = fx_bits(fma((double) chi, scale, FX_MAGIC)); /* chi 2^k is exact: rne to the grid */
     if (kernelized) {
       s->fstat[c] = SRRG2_FACTOR_KERNELIZED;
       s->acc[ACC_N_OUT] += 1;
-      s->acc[ACC_CHI_OUT] += to_fixed((double) chi, k);
+      s->acc[ACC_CHI_OUT] += chi_fx;
     } else {
       s->fstat[c] = SRRG2_FACTOR_INLIER;
       s->acc[ACC_N_IN] += 1;
-      s->acc[ACC_CHI_IN] += to_fixed((double) chi, k);
+      s->acc[ACC_CHI_IN] += chi_fx;
     }
     if (w == 0.f) continue;
+    const double ws = (double) w * scale; /* exact */
     for (int aa = 0; aa < D; ++aa) {
       double wj[3];
-      for (int r = 0; r < rows; ++r) wj[r] = (double) w * (double) J[r][aa];
+      for (int r = 0; r < rows; ++r) wj[r] = ws * (double) J[r][aa]; /* exact: 24 x 24 bits */
       for (int bb = aa; bb < D; ++bb) {
-        double t = wj[0] * (double) J[0][bb];
-        for (int r = 1; r < rows; ++r) t = t + wj[r] * (double) J[r][bb];
-        s->acc[hidx(aa, bb)] += to_fixed(t, k);
+        double t = FX_MAGIC;
+        for (int r = 0; r < rows; ++r) t = fma(wj[r], (double) J[r][bb], t);
+        s->acc[hidx(aa, bb)] += fx_bits(t);
       }
-      double t = wj[0] * (double) e[0];
-      for (int r = 1; r < rows; ++r) t = t + wj[r] * (double) e[r];
-      s->acc[21 + aa] += to_fixed(t, k);
+      double t = FX_MAGIC;
+      for (int r = 0; r < rows; ++r) t = fma(wj[r], (double) e[r], t);
+      s->acc[21 + aa] += fx_bits(t);
     }
   }
   return 0;

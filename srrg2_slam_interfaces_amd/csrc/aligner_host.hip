@@ -66,6 +66,7 @@ struct Slice {
   int* qprobe_host = nullptr; size_t qprobe_cap = 0;  // pinned: deferred counts of the last finished iteration
   ProblemDev* ms_probs_host = nullptr; size_t ms_probs_host_cap = 0;  // pinned: problem table of the last moving batch
   bool ms_pending = false;  // a sort that reads ms_probs_host may still be in flight
+  bool fast_queue_only = false;  // the queue exists for the converged pass of a batch only (k_icp_step does not use it)
   DevBuf<float4> prev_f;
   DevBuf<float> prev_m;
   DevBuf<unsigned long long> dbg;   // SRRG2_AMD_TIMELINE (debug builds): per-wave stamps of the step kernel
@@ -521,6 +522,14 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     small = ncue == 1 && a->slices[fc]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm <= small_max &&
             !std::getenv("SRRG2_AMD_TIMELINE");
   }
+  // The converged pass kernel takes over from iteration `fast_from` of the first run (all of the inlier-only run): by
+  // then nearly every point keeps its neighbour.  Batches give it `fast_ppt` points per thread and a queue.
+  const int fast_from = std::getenv("SRRG2_AMD_FAST_FROM") ? std::atoi(std::getenv("SRRG2_AMD_FAST_FROM")) : 3;
+  // (measured on C4, 32 x 50k, profiles/r2c: one point per thread with the failed certificates searched by their own wave
+  // 37.7 us per pass / 268.8 k it/s; two points per thread 45 us -- the accumulators stay live across the search, 181
+  // registers -- ; with a queue the nearly idle deferred-search launch costs 15 us per iteration: 31 + 15 us, 254 k it/s)
+  const int fast_ppt  = std::getenv("SRRG2_AMD_FAST_PPT") ? std::atoi(std::getenv("SRRG2_AMD_FAST_PPT")) : 1;
+  const bool fast_batch_queue = std::getenv("SRRG2_AMD_FAST_QUEUE") ? std::atoi(std::getenv("SRRG2_AMD_FAST_QUEUE")) != 0 : false;
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {
@@ -556,13 +565,17 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // (read on every compute(): the tests run every scenario on both paths)
     const int queue_min = std::getenv("SRRG2_AMD_QUEUE_MIN") ? std::atoi(std::getenv("SRRG2_AMD_QUEUE_MIN")) : 90000;
     const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small;
+    // batches: the converged pass (k_icp_step_fast) hands the points whose certificate failed to the deferred-search
+    // kernel; the first iterations (k_icp_step) finish their open points themselves
+    const bool fast_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && K > 4 && !small && fast_batch_queue;
+    s->fast_queue_only = fast_queue && !use_queue;
     const int nblocks    = PARTIAL_SLOTS;
     if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
-    if (use_queue) {
+    if (use_queue || fast_queue) {
       if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 10))) return rc;  // QEntry = 10 x 4 bytes
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
     }
-    sc.qcount = use_queue ? s->qcount.p : nullptr;
+    sc.qcount = (use_queue || fast_queue) ? s->qcount.p : nullptr;
     sc.qprobe_host = nullptr;
     sc.probs       = nullptr;
     if (use_queue) {
@@ -595,8 +608,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       d.dbg = s->dbg.p;
     }
     d.partials        = s->partials.p;
-    d.queue           = use_queue ? (void*) s->queue.p : nullptr;
-    d.qcount          = use_queue ? s->qcount.p : nullptr;
+    d.queue           = (use_queue || fast_queue) ? (void*) s->queue.p : nullptr;
+    d.qcount          = (use_queue || fast_queue) ? s->qcount.p : nullptr;
     d.slice_idx       = si;
     d.robust_kind     = s->cfg.robustifier;
     d.robust_thr      = s->cfg.robustifier_chi_threshold;
@@ -785,11 +798,16 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           // The deferred-search kernel pays off while many points are open; once the searches are mostly skipped
           // its launch costs more than finishing a few near points inside the step kernel (queue_on, decided below).
           SliceDev sd = sdev[si];
-          if (!queue_on[si]) {
+          const bool fast = (slot0 > 0 || it >= fast_from) && !(C.tune & 4);
+          if (!queue_on[si] || (s->fast_queue_only && !fast)) {
             sd.queue  = nullptr;
             sd.qcount = nullptr;
           }
-          srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
+          if (fast)
+            srrg2amd::launch_icp_step_fast(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, fast_ppt,
+                                           a->stream);
+          else
+            srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
         }
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }

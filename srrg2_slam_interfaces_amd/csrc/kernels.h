@@ -24,6 +24,9 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
                   float4* out_nrm, hipStream_t s);
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s);
+// iterations >= 1 of a compute(): the converged pass, ppt moving points per thread, + the deferred-search kernel if S.queue
+void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                          int max_nm, int ppt, hipStream_t s);
 int icp_step_blocks(int max_nm);
 int icp_queue_blocks(int max_nm, int K);
 // projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)

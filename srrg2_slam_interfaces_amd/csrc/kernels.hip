@@ -34,13 +34,13 @@
 // ============================================================================================
 namespace {
 
-// exact double -> 64-bit fixed point for |v| < 2^51: round-to-nearest-even integer of v, i.e. the value
-// llrint(v) returns; one f64 add instead of a ~10-instruction conversion.  The bound is guaranteed by
-// dm::fixed_point_exponent (every scaled term is <= 2^50).
-__device__ __forceinline__ long long to_fixed(double v) {
-  const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
-  return __double_as_longlong(v + MAGIC) - __double_as_longlong(MAGIC);
-}
+// Fixed-point terms: every product (w 2^k J_ra) * J_rb is rounded ONCE, to nearest-even, onto the
+// integer grid by a fused multiply-add onto FX_MAGIC = 1.5 * 2^52 (a double in [2^52, 2^53) has ulp 1, so the result is
+// FX_MAGIC + integer); the rows of one correspondence are chained on the same accumulator.  The integer is the bit
+// pattern minus that of FX_MAGIC.  |integer| < 2^51 is guaranteed by dm::fixed_point_exponent.  One v_fma_f64 per term.
+#define FX_MAGIC 6755399441055744.0               // 1.5 * 2^52
+#define FX_MAGIC_BITS 0x4338000000000000ll        // its bit pattern
+__device__ __forceinline__ long long fx_bits(double biased) { return __double_as_longlong(biased) - FX_MAGIC_BITS; }
 
 // One candidate: squared distance in the specified float32 operation order, then ONE 64-bit unsigned compare of the
 // key (d2 bits << 32 | fixed index) -- d2 >= 0, so the bit pattern orders like the value and the low word breaks ties
@@ -354,15 +354,14 @@ __device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], 
     kernelized = true;
     w = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
   }
-  const long long chi_fx = to_fixed((double) chi * scale);
+  const long long chi_fx = fx_bits(__fma_rn((double) chi, scale, FX_MAGIC));  // (chi 2^k is exact: rne to the grid)
   // (branch-free on purpose: an if/else here gets merged into a dynamically indexed acc[] access = scratch memory)
   acc[ACC_N_OUT] += kernelized ? 1 : 0;
   acc[ACC_CHI_OUT] += kernelized ? chi_fx : 0;
   acc[ACC_N_IN] += kernelized ? 0 : 1;
   acc[ACC_CHI_IN] += kernelized ? 0 : chi_fx;
   if (w != 0.f && !skip_terms) {
-    // (w * 2^k) is exact, (w * 2^k) * J is exact (24 x 24 bits): scaling commutes with the one
-    // rounding of the final product, so these are the specified terms times 2^k exactly.
+    // (w * 2^k) is exact, (w * 2^k) * J is exact (24 x 24 bits); the fma rounds each product once onto the grid
     const double ws = (double) w * scale;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -371,15 +370,15 @@ __device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], 
       for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
 #pragma unroll
       for (int b = a; b < D; ++b) {
-        double t = wj[0] * (double) J[0][b];
+        double t = FX_MAGIC;
 #pragma unroll
-        for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) J[r][b];
-        acc[hidx(a, b)] += to_fixed(t);
+        for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) J[r][b], t);
+        acc[hidx(a, b)] += fx_bits(t);
       }
-      double t = wj[0] * (double) e[0];
+      double t = FX_MAGIC;
 #pragma unroll
-      for (int r = 1; r < ROWS; ++r) t = t + wj[r] * (double) e[r];
-      acc[ACC_B + a] += to_fixed(t);
+      for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) e[r], t);
+      acc[ACC_B + a] += fx_bits(t);
     }
   }
   return kernelized ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
@@ -986,6 +985,363 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   icp_step_body<DIM, PLANE, 4>(S, probs[prob], st, prob, blockIdx.x, gridDim.x, gridDim.y, nullptr);
+}
+
+// ============================================================================================
+// The converged pass.  From the second iteration of a compute() on, nearly every moving point keeps its nearest
+// neighbour (exclusion-radius certificate, see icp_step_body): such a pass is a streaming kernel -- load the point, its
+// previous neighbour and the neighbour's normal, prove that the neighbour is unchanged, linearise, reduce -- and in
+// k_icp_step it pays for the generality of the search code around it (941 vector instructions per wave and point
+// on converged C4 passes, the pass is VALU-issue bound; profiles/r2a).  k_icp_step_fast is that pass alone:
+//   * PPT moving points per thread share ONE 32-value transposing reduction (the reduction is ~230 of the ~500
+//     vector instructions of a point; the accumulators are plain int64 registers, no search state is live);
+//   * the fixed-point terms stay in their fma-biased form (bit pattern of FX_MAGIC + integer) and are summed as
+//     integers; the bias FX_MAGIC_BITS x (number of contributions) is removed once per workgroup from the counters;
+//   * points whose certificate fails are handed to the deferred-search kernel (S.queue) exactly like the stragglers of
+//     k_icp_step, or -- without a queue -- searched here by the whole wave (coop_scan), one at a time.
+// Same per-point arithmetic, same exact integer sums: bit-identical results.
+// ============================================================================================
+namespace {
+
+#define ACC_N_TERMS_SHIFT 32  // acc[ACC_N_CORR] carries the number of term contributions in its upper half
+
+template <int NW>
+__device__ __forceinline__ void block_reduce_store_biased(long long (&acc)[ACC_N], long long* __restrict__ partials,
+                                                          int prob, int block) {
+  __shared__ long long red[NW][ACC_N];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int my_index;
+  const long long total = wave_transpose_reduce(acc, lane, my_index);
+  if ((lane & 1) == 0) red[wid][my_index] = total;
+  __syncthreads();
+  if (threadIdx.x < ACC_N) {
+    long long v = 0, n_ct = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      v += red[w][threadIdx.x];
+      n_ct += red[w][ACC_N_CORR];
+    }
+    const long long n_terms = (long long) ((unsigned long long) n_ct >> ACC_N_TERMS_SHIFT);
+    // remove the bias (wrapping arithmetic: the biased sums may have wrapped, the true sums fit by construction)
+    unsigned long long u = (unsigned long long) v;
+    if (threadIdx.x < ACC_CHI_IN) u -= (unsigned long long) FX_MAGIC_BITS * (unsigned long long) n_terms;
+    if (threadIdx.x == ACC_N_CORR) u &= 0xffffffffull;
+    if (u != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(partials) +
+                  ((size_t) prob * PARTIAL_SLOTS + (block & (PARTIAL_SLOTS - 1))) * ACC_N + threadIdx.x, u);
+  }
+}
+
+// the factor arithmetic of factor_accumulate on biased accumulators (bit patterns of FX_MAGIC + integer, summed as
+// integers; the number of contributions is counted so that the bias can be removed per workgroup)
+template <int D, int ROWS>
+__device__ __forceinline__ uint8_t factor_accumulate_biased(const float (&J)[ROWS][D], const float (&e)[ROWS], int rk,
+                                                            float thr, double scale, long long (&acc)[ACC_N]) {
+  float chi = e[0] * e[0];
+#pragma unroll
+  for (int r = 1; r < ROWS; ++r) chi = chi + e[r] * e[r];
+  acc[ACC_N_CORR] += 1;
+  if (!isfinite(chi)) return SRRG2_FACTOR_SUPPRESSED;
+  float w         = 1.f;
+  bool kernelized = false;
+  if (rk != SRRG2_ROBUST_NONE && !(chi < thr)) {
+    kernelized = true;
+    w = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
+  }
+  const long long chi_b = fx_bits(__fma_rn((double) chi, scale, FX_MAGIC));
+  acc[ACC_N_OUT] += kernelized ? 1 : 0;
+  acc[ACC_CHI_OUT] += kernelized ? chi_b : 0;
+  acc[ACC_N_IN] += kernelized ? 0 : 1;
+  acc[ACC_CHI_IN] += kernelized ? 0 : chi_b;
+  if (w != 0.f) {
+    acc[ACC_N_CORR] += 1ll << ACC_N_TERMS_SHIFT;
+    const double ws = (double) w * scale;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double wj[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        double t = FX_MAGIC;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) J[r][b], t);
+        acc[hidx(a, b)] += __double_as_longlong(t);
+      }
+      double t = FX_MAGIC;
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) e[r], t);
+      acc[ACC_B + a] += __double_as_longlong(t);
+    }
+  }
+  return kernelized ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
+}
+
+// residual rows of one matched point (the arithmetic of finish_point)
+template <int DIM, bool PLANE>
+__device__ __forceinline__ void point_rows(const float* T, float kk, const float4 p, float qx, float qy, float qz,
+                                           const float4 f, const float4 nf,
+                                           float (&J)[PLANE ? 1 : DIM][DIM == 3 ? 6 : 3], float (&e)[PLANE ? 1 : DIM]) {
+  constexpr int D    = DIM == 3 ? 6 : 3;
+  constexpr int ROWS = PLANE ? 1 : DIM;
+  if constexpr (DIM == 3) {
+    float m[ROWS][3];
+    if (PLANE) {
+      e[0]    = (nf.x * (qx - f.x) + nf.y * (qy - f.y)) + nf.z * (qz - f.z);
+      m[0][0] = (T[0] * nf.x + T[4] * nf.y) + T[8] * nf.z;
+      m[0][1] = (T[1] * nf.x + T[5] * nf.y) + T[9] * nf.z;
+      m[0][2] = (T[2] * nf.x + T[6] * nf.y) + T[10] * nf.z;
+    } else {
+      const float q[3]  = {qx, qy, qz};
+      const float ff[3] = {f.x, f.y, f.z};
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        e[r]    = q[r] - ff[r];
+        m[r][0] = T[r * 4 + 0];
+        m[r][1] = T[r * 4 + 1];
+        m[r][2] = T[r * 4 + 2];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      J[r][0]     = m[r][0];
+      J[r][1]     = m[r][1];
+      J[r][2]     = m[r][2];
+      J[r][D - 3] = kk * (p.y * m[r][2] - p.z * m[r][1]);
+      J[r][D - 2] = kk * (p.z * m[r][0] - p.x * m[r][2]);
+      J[r][D - 1] = kk * (p.x * m[r][1] - p.y * m[r][0]);
+    }
+  } else {
+    float m[ROWS][2];
+    if (PLANE) {
+      e[0]    = nf.x * (qx - f.x) + nf.y * (qy - f.y);
+      m[0][0] = T[0] * nf.x + T[4] * nf.y;
+      m[0][1] = T[1] * nf.x + T[5] * nf.y;
+    } else {
+      const float q[2]  = {qx, qy};
+      const float ff[2] = {f.x, f.y};
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        e[r]    = q[r] - ff[r];
+        m[r][0] = T[r * 4 + 0];
+        m[r][1] = T[r * 4 + 1];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      J[r][0] = m[r][0];
+      J[r][1] = m[r][1];
+      J[r][2] = m[r][1] * p.x - m[r][0] * p.y;
+    }
+  }
+}
+
+}  // namespace
+
+template <int DIM, bool PLANE, int PPT>
+__global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                       ProblemState* __restrict__ states) {
+  constexpr int D    = DIM == 3 ? 6 : 3;
+  constexpr int ROWS = PLANE ? 1 : DIM;
+  const int prob     = blockIdx.y;
+  const ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  if ((int) blockIdx.x * (256 * PPT) >= pd.nm) return;  // (batches of unequal clouds)
+  float T[12], Tprev[12];
+  load_T(st->Tf[S.slice_idx], T);
+  load_T(st->Tfprev[S.slice_idx], Tprev);
+  const double scale = dm::pow2(st->kexp[S.slice_idx]);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float thr    = S.robust_thr;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  const GridDev& g   = S.grid;
+  const bool ext     = !(S.tune & 65536);
+  const float gfar   = ext ? g.gate2_ext : g.gate2;
+  const int rfar     = ext ? g.rmax : g.rfar_gate;
+  const float gate_r = sqrtf(g.gate2);
+  const bool ngate   = S.use_normal_gate != 0;
+  const bool use_q   = S.queue != nullptr && st->qmode[S.slice_idx] != 0;
+  const int lane     = threadIdx.x & 63;
+  const int wid      = threadIdx.x >> 6;
+  __shared__ int coop_lds[4][264];
+
+  long long acc[ACC_N];
+#pragma unroll
+  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+
+  // all loads of the PPT points first (independent: one round trip for the lot, then the normals of the neighbours)
+  float4 p[PPT], pf[PPT], pnm[PPT], pn[PPT];
+  int ppos[PPT];
+  float pm[PPT];
+  int gi_[PPT];
+  bool inr[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
+    inr[k]      = i < pd.nm;
+    gi_[k]      = pd.moff + (inr[k] ? i : 0);
+    p[k]        = make_float4(__int_as_float(0x7fc00000), 0.f, 0.f, 0.f);  // (out of range = not finite = inactive)
+    pf[k]       = make_float4(0.f, 0.f, 0.f, 0.f);
+    pnm[k]      = make_float4(0.f, 0.f, 0.f, 0.f);
+    ppos[k]     = -1;
+    pm[k]       = 0.f;
+    if (inr[k]) {
+      p[k]    = S.mpts[gi_[k]];
+      ppos[k] = S.prev_pos[gi_[k]];
+      pf[k]   = S.prev_f[gi_[k]];
+      pm[k]   = S.prev_m[gi_[k]];
+      if (ngate) pnm[k] = S.mnrm[gi_[k]];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    pn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((PLANE || ngate) && ppos[k] >= 0 && ppos[k] < g.n) pn[k] = g.nrm[ppos[k]];
+  }
+
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i       = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
+    const int gi      = gi_[k];
+    const bool active = inr[k] && finite3(p[k].x, p[k].y, p[k].z);
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    bool have = false;  // the nearest neighbour of this point is known: kept (certificate) or searched below
+    bool open = false;
+    float best = INFINITY, excl = 0.f, r2box = INFINITY;
+    int bidx = NO_MATCH;
+    if (active) {
+      transform_point<DIM>(T, p[k], qx, qy, qz);
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p[k], px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      if (ppos[k] >= 0 && ppos[k] < g.n) {
+        // (a) of icp_step_body: d(q, f*) + |q - q'| < m  =>  f* is still the unique nearest neighbour
+        unsigned long long k1 = NO_KEY;
+        int pos1              = 0;
+        test_candidate<DIM>(pf[k], qx, qy, qz, ppos[k], true, k1, pos1);
+        const float d1 = sqrtf(key_best(k1));
+        if (d1 * 1.00001f + dl * 1.00001f < pm[k] * 0.99999f && !(S.tune & 4096)) {
+          have = true;
+          best = key_best(k1);
+          bidx = key_idx(k1);
+          excl = pm[k] * 0.9999999f - dl * 1.00001f;
+        } else {
+          const float pad = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+          const float rr  = (d1 + pad) * 1.00001f;
+          r2box           = fminf(rr * rr, gfar);
+        }
+      } else if (ppos[k] < 0 && pm[k] > 0.f && !(S.tune & (4096 | 65536))) {
+        // (c): nothing within m of q'; gate + |q - q'| < m  =>  still no match
+        if (gate_r * 1.00001f + dl * 1.00001f < pm[k] * 0.99999f) {
+          have = true;
+          excl = pm[k] * 0.9999999f - dl * 1.00001f;
+        }
+      }
+      open = !have;
+    }
+    // points whose certificate failed: to the deferred-search kernel like the stragglers of k_icp_step, or searched by
+    // the whole wave here, one at a time (exact: the ball contains the previous neighbour, hence the nearest one)
+    bool searched = false;
+    const unsigned long long need = __ballot(open);
+    if (need) {
+      const float ball2 = fminf(r2box, gfar);
+      const int r2      = ball2 <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
+      if (use_q) {
+        const unsigned long long need_near = __ballot(open && r2 == 2);
+        const unsigned long long need_far  = need & ~need_near;
+        int base_near = 0, base_far = 0;
+        if (lane == 0) {  // one atomic per wave and kind (rare once the estimate has settled)
+          if (need_near) base_near = atomicAdd(&S.qcount[2 * prob], __popcll(need_near));
+          if (need_far) base_far = atomicAdd(&S.qcount[2 * prob + 1], __popcll(need_far));
+        }
+        base_near = __shfl(base_near, 0);
+        base_far  = __shfl(base_far, 0);
+        if (open) {
+          const unsigned long long below = (1ull << lane) - 1ull;
+          QEntry q;
+          q.i = i; q.r2 = r2; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0;
+          q.qx = qx; q.qy = qy; q.qz = qz;
+          q.ball2 = ball2; q.pad_ = 0;
+          QEntry* qbase = reinterpret_cast<QEntry*>(S.queue) + pd.moff;
+          if (r2 == 2)
+            qbase[base_near + __popcll(need_near & below)] = q;
+          else
+            qbase[pd.nm - 1 - (base_far + __popcll(need_far & below))] = q;
+        }
+      } else {
+        unsigned long long todo = need;
+        while (todo) {
+          const int src = __ffsll((long long) todo) - 1;
+          todo &= todo - 1;
+          const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
+          const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
+          const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
+          float wbest, wexcl2;
+          int widx, wpos;
+          coop_scan<DIM, 64>(g, lane, coop_lds[wid], sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(ball2, src),
+                             wbest, widx, wpos, wexcl2);
+          if (lane == src) {
+            best    = wbest;
+            bidx    = widx;
+            ppos[k] = widx != NO_MATCH ? wpos : -1;
+            excl    = sqrtf(wexcl2) * 0.99999f;
+          }
+        }
+        // the new neighbours and their normals (one round trip for all searched lanes of the wave)
+        if (open) {
+          searched = true;
+          have     = true;
+          pf[k]    = make_float4(0.f, 0.f, 0.f, 0.f);
+          pn[k]    = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bidx != NO_MATCH) {
+            pf[k] = g.pts[ppos[k]];
+            if (PLANE || ngate) pn[k] = g.nrm[ppos[k]];
+          }
+        }
+      }
+    }
+    if (have) {
+      bool found = bidx != NO_MATCH && best <= g.gate2;
+      if (found && ngate) {
+        const float4 nm = pnm[k];
+        float dot;
+        if constexpr (DIM == 3) {
+          const float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
+          const float ry = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
+          const float rz = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
+          dot            = (pn[k].x * rx + pn[k].y * ry) + pn[k].z * rz;
+        } else {
+          const float rx = T[0] * nm.x + T[1] * nm.y;
+          const float ry = T[4] * nm.x + T[5] * nm.y;
+          dot            = pn[k].x * rx + pn[k].y * ry;
+        }
+        if (!(dot > S.normal_cos)) found = false;
+      }
+      int match     = -1;
+      float resp    = 0.f;
+      uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
+      if (found) {
+        match = bidx;
+        resp  = best;
+        float J[ROWS][D], e[ROWS];
+        point_rows<DIM, PLANE>(T, kk, p[k], qx, qy, qz, pf[k], pn[k], J, e);
+        fstat = factor_accumulate_biased<D, ROWS>(J, e, rk, thr, scale, acc);
+      }
+      S.prev_m[gi] = excl;
+      if (searched) {
+        S.prev_pos[gi] = ppos[k];
+        S.prev_f[gi]   = pf[k];
+      }
+      if (bidx != NO_MATCH || searched) {  // (certified-unmatched points keep the record of the pass that searched them)
+        S.corr_fixed[gi] = match;
+        S.corr_resp[gi]  = resp;
+        S.corr_stat[gi]  = fstat;
+      }
+    }
+  }
+  block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x);
 }
 
 // Deferred searches: every wave takes queue entries w, w + W, ... of its problem, runs the cooperative exact scan
@@ -1945,6 +2301,23 @@ int icp_queue_blocks(int max_nm, int K) {
   return b < cap ? b : cap;
 }
 
+static void launch_icp_queue(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                             int max_nm, hipStream_t s) {
+  const int qb = icp_queue_blocks(max_nm, K);
+  dim3 qgrid(qb, K);
+  if (dim == 3) {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_queue<3, true>), qgrid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_queue<3, false>), qgrid, dim3(256), 0, s, S, probs, states);
+  } else {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_queue<2, true>), qgrid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_queue<2, false>), qgrid, dim3(256), 0, s, S, probs, states);
+  }
+}
+
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
@@ -1961,21 +2334,37 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
     else
       hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), 0, s, S, probs, states);
   }
-  if (S.queue) {
-    const int qb = icp_queue_blocks(max_nm, K);
-    dim3 qgrid(qb, K);
-    if (dim == 3) {
-      if (plane)
-        hipLaunchKernelGGL((k_icp_step_queue<3, true>), qgrid, dim3(256), 0, s, S, probs, states);
-      else
-        hipLaunchKernelGGL((k_icp_step_queue<3, false>), qgrid, dim3(256), 0, s, S, probs, states);
-    } else {
-      if (plane)
-        hipLaunchKernelGGL((k_icp_step_queue<2, true>), qgrid, dim3(256), 0, s, S, probs, states);
-      else
-        hipLaunchKernelGGL((k_icp_step_queue<2, false>), qgrid, dim3(256), 0, s, S, probs, states);
-    }
+  if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
+}
+
+template <int PPT>
+static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                            int max_nm, hipStream_t s) {
+  dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
+  if (dim == 3) {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_fast<3, false, PPT>), grid, dim3(256), 0, s, S, probs, states);
+  } else {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_fast<2, true, PPT>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_fast<2, false, PPT>), grid, dim3(256), 0, s, S, probs, states);
   }
+}
+
+// the converged pass (k_icp_step_fast) + the deferred-search kernel for the points whose certificate failed (S.queue)
+void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                          int max_nm, int ppt, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  if (ppt >= 4)
+    launch_fast_ppt<4>(dim, plane, S, probs, states, K, max_nm, s);
+  else if (ppt >= 2)
+    launch_fast_ppt<2>(dim, plane, S, probs, states, K, max_nm, s);
+  else
+    launch_fast_ppt<1>(dim, plane, S, probs, states, K, max_nm, s);
+  if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }
 
 void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,

@@ -9,11 +9,31 @@ from srrg2_slam_interfaces_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["deferred-search kernel", "searches finished in the step kernel"])
+# (deferred-search kernel for single alignments?, first iteration run by the converged-pass kernel, points per thread of
+# that kernel in batches, batches hand their failed certificates to the deferred-search kernel?)
+_PATHS = {
+    "deferred-search kernel": ("0", None, None, None),
+    "searches finished in the step kernel": ("1000000000", None, None, None),
+    "converged-pass kernel from iteration 1, deferred searches": ("0", "1", "4", "1"),
+    "converged-pass kernel from iteration 1, wave-cooperative searches": ("1000000000", "1", "1", "0"),
+    "converged-pass kernel never": ("0", "1000000", None, None),
+}
+
+
+@pytest.fixture(autouse=True, params=list(_PATHS))
 def search_path(request, monkeypatch):
     """Single alignments defer their open searches to k_icp_step_queue from 90 000 moving points on and finish them
-    inside k_icp_step below (SRRG2_AMD_QUEUE_MIN): every scenario of this module runs on both paths."""
-    monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", "0" if request.param.startswith("deferred") else "1000000000")
+    inside k_icp_step below (SRRG2_AMD_QUEUE_MIN); the converged-pass kernel k_icp_step_fast takes over from iteration 3
+    (SRRG2_AMD_FAST_FROM) with 1 / 2 / 4 points per thread (SRRG2_AMD_FAST_PPT), its failed certificates go to the
+    deferred-search kernel or are searched by the whole wave (SRRG2_AMD_FAST_QUEUE for batches).  Every scenario of this
+    module runs on all of these paths: they must give the same bits."""
+    qmin, fast_from, ppt, fq = _PATHS[request.param]
+    monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", qmin)
+    for name, val in (("SRRG2_AMD_FAST_FROM", fast_from), ("SRRG2_AMD_FAST_PPT", ppt), ("SRRG2_AMD_FAST_QUEUE", fq)):
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, val)
 
 
 def _pair(oracle, product, kind):
