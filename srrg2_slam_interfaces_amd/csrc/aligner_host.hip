@@ -70,7 +70,8 @@ struct Slice {
   DevBuf<float4> prev_f;
   DevBuf<float> prev_m;
   DevBuf<unsigned long long> dbg;   // SRRG2_AMD_TIMELINE (debug builds): per-wave stamps of the step kernel
-  DevBuf<int> prev_pos;             // previous nearest neighbour per moving point (search bound of the next iteration)
+  DevBuf<float4> prev_n;            // normal of the previous nearest neighbour per moving point
+  DevBuf<int> prev_pos;             // its position in the sorted fixed cloud (batches gather through it)
   DevBuf<float> corr_resp;
   DevBuf<uint8_t> corr_stat;
   DevBuf<long long> partials;
@@ -92,7 +93,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); gcorr.release(); gcorr_off.release(); gcorr_stat.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
+    corr_fixed.release(); gcorr.release(); gcorr_off.release(); gcorr_stat.release(); prev_n.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
   }
 };
 
@@ -125,6 +126,11 @@ struct srrg2_aligner_s {
   std::vector<srrg2_iteration_stats> last_stats;  // of problem K-1 (== the only one for compute())
   int last_ncorr[SRRG2_MAX_SLICES]{};
   bool computed = false;
+  // The nearest-neighbour passes do not store correspondence records; they are derived on demand (k_icp_outputs) from
+  // the state of the last compute(): 0 = the arrays are current, 1 = to be derived, 2 = lost (the clouds changed since)
+  int records_state = 0;
+  std::vector<SliceDev> last_sdev;
+  std::vector<int> last_nm_max;
   // profiling
   bool profile = false;
   double prof_ms = 0.0;
@@ -344,12 +350,14 @@ int check_slice(srrg2_aligner* a, int si, const char* what) {
 int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const float* normals, int ns,
                   const int32_t* offsets, int K, int mem) {
   Slice* s    = a->slices[si];
+  if (a->records_state == 1) a->records_state = 2;  // (the records of the last compute() can no longer be derived)
   const int n = offsets[K] - offsets[0];
   int rc;
   if ((rc = s->moving.reserve((size_t) std::max(n, 1)))) return rc;
   if (normals && (rc = s->moving_nrm.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->pinf.reserve((size_t) K))) return rc;
   if ((rc = s->corr_fixed.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->prev_n.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->prev_pos.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->prev_f.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->prev_m.reserve((size_t) std::max(n, 1)))) return rc;
@@ -529,6 +537,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // 37.7 us per pass / 268.8 k it/s; two points per thread 45 us -- the accumulators stay live across the search, 181
   // registers -- ; with a queue the nearly idle deferred-search launch costs 15 us per iteration: 31 + 15 us, 254 k it/s)
   const int fast_ppt  = std::getenv("SRRG2_AMD_FAST_PPT") ? std::atoi(std::getenv("SRRG2_AMD_FAST_PPT")) : 1;
+  // batches gather the kept neighbour from the cache-resident fixed cloud (36 -> 8 streamed bytes per point); single
+  // alignments read it from per-point arrays (no dependent load on the chain of a latency-bound launch)
+  const bool fast_gather = std::getenv("SRRG2_AMD_FAST_GATHER") ? std::atoi(std::getenv("SRRG2_AMD_FAST_GATHER")) != 0 : K > 4;
   const bool fast_batch_queue = std::getenv("SRRG2_AMD_FAST_QUEUE") ? std::atoi(std::getenv("SRRG2_AMD_FAST_QUEUE")) != 0 : false;
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
@@ -597,6 +608,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.corr_fixed      = s->corr_fixed.p;
     d.corr_resp       = s->corr_resp.p;
     d.corr_stat       = s->corr_stat.p;
+    d.prev_n          = s->prev_n.p;
     d.prev_pos        = s->prev_pos.p;
     d.prev_f          = s->prev_f.p;
     d.prev_m          = s->prev_m.p;
@@ -805,7 +817,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           }
           if (fast)
             srrg2amd::launch_icp_step_fast(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, fast_ppt,
-                                           a->stream);
+                                           fast_gather, a->stream);
           else
             srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
         }
@@ -890,6 +902,28 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   a->last_stats.assign(a->stats_host + (size_t) (K - 1) * slots, a->stats_host + (size_t) (K - 1) * slots + ns);
   for (int si = 0; si < SRRG2_MAX_SLICES; ++si) a->last_ncorr[si] = o.ncorr[si];
   a->computed = true;
+  a->last_sdev = sdev;
+  a->last_nm_max.assign((size_t) nslices, 0);
+  for (int si = 0; si < nslices; ++si)
+    for (int k = 0; k < K; ++k) a->last_nm_max[(size_t) si] = std::max(a->last_nm_max[(size_t) si], all[(size_t) si * K + k].nm);
+  a->records_state = 1;
+  return 0;
+}
+
+// correspondence records of the nearest-neighbour slices of the last compute(), derived on demand
+int materialize_records(srrg2_aligner* a) {
+  if (a->records_state != 1) return 0;
+  int rc;
+  if ((rc = set_device(a))) return rc;
+  for (size_t si = 0; si < a->slices.size() && si < a->last_sdev.size(); ++si) {
+    Slice* s = a->slices[si];
+    if (s->cfg.kind == SRRG2_SLICE_PRIOR || s->cfg.finder != SRRG2_FINDER_NN_GATED) continue;
+    srrg2amd::launch_icp_outputs(a->dim, s->cfg.kind == SRRG2_SLICE_P2PLANE, a->last_sdev[si], a->probs.p + si * (size_t) a->K,
+                                 a->states.p, a->K, a->last_nm_max[si], a->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  a->records_state = 0;
   return 0;
 }
 
@@ -1065,6 +1099,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   Slice* s = a->slices[si];
   if (s->cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_fixed on a prior slice: use set_prior_measurement");
   if ((rc = set_device(a))) return rc;
+  if (a->records_state == 1) a->records_state = 2;
   if ((rc = s->fixed_raw.reserve((size_t) std::max(n, 1)))) return rc;
   if (normals && (rc = s->fixed_nrm_raw.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->scalars.reserve(16))) return rc;
@@ -1163,11 +1198,13 @@ static int fetch_dense(srrg2_aligner* a, int si, std::vector<int>& cf, std::vect
   Slice* s = a->slices[si];
   int rc;
   if ((rc = set_device(a))) return rc;
-  if (!a->computed || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving) {
+  if (!a->computed || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving ||
+      (a->records_state == 2 && s->cfg.finder == SRRG2_FINDER_NN_GATED)) {
     cf.clear(); cr.clear(); cst.clear();
     *moff_out = 0;
     return 0;
   }
+  if ((rc = materialize_records(a))) return rc;
   // problem K-1 of the last run
   int moff = 0, nm = s->nm_total;
   if (a->K > 1) {
@@ -1208,6 +1245,8 @@ int aligner_slice_view(srrg2_aligner_s* a, int si, AlignerSliceView* v) {
   Slice* s = a->slices[si];
   if (!a->computed || a->K != 1 || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving || !s->has_fixed)
     return fail(SRRG2_E_STATE, "aligner_slice_view: needs a cue slice after a single-problem compute()");
+  if (a->records_state == 2) return fail(SRRG2_E_STATE, "aligner_slice_view: the clouds changed since the last compute()");
+  if ((rc = materialize_records(a))) return rc;
   v->moving_sorted = s->moving.p;
   v->corr_fixed    = s->corr_fixed.p;
   v->corr_resp     = s->corr_resp.p;

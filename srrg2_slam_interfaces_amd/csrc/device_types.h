@@ -43,12 +43,17 @@ struct SliceDev {
   GridDev grid;
   const float4* mpts;   // moving points of all problems of the batch, concatenated
   const float4* mnrm;   // moving normals or null
-  int* corr_fixed;      // per moving point: matched fixed index or -1
-  float* corr_resp;     // per moving point: response (squared distance)
-  uint8_t* corr_stat;   // per moving point: srrg2_factor_status of the last linearisation
-  int* prev_pos;        // per moving point (sorted order): position in grid.pts of the nearest neighbour found by the
-                        // previous iteration of this compute() (-1: none); an upper bound for the next search
-  float4* prev_f;       // ... and that fixed point {x, y, z, bits(index)} (saves the dependent load)
+  // Correspondence records per moving point.  Projective / given-correspondences passes write them; the nearest-
+  // neighbour passes do not (9 bytes per point and iteration that nobody reads before compute() returns): k_icp_outputs
+  // derives them on demand from the neighbour state and the transform of the last pass (ProblemState::Tlast).
+  int* corr_fixed;      // matched fixed index or -1
+  float* corr_resp;     // response (squared distance)
+  uint8_t* corr_stat;   // srrg2_factor_status of the last linearisation
+  float4* prev_f;       // per moving point (sorted order): the nearest neighbour {x, y, z, bits(index)} found by the
+                        // previous iteration of this compute() (.w = NO_MATCH: none); an upper bound for the next search
+  float4* prev_n;       // ... and its normal (plane factors / normal gate): a kept neighbour needs no dependent load
+  int* prev_pos;        // ... and its position in grid.pts (-1: none): batches gather the neighbour from the cache-resident
+                        // fixed cloud instead of streaming 32 bytes per moving point (k_icp_step_fast<.., GATHER>)
   float* prev_m;        // ... and its exclusion radius: no other fixed point within prev_m of the previous query
   long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N]: fixed-point partial sums, added with 64-bit atomics
   void* queue;          // deferred searches: QEntry[total moving points] (per problem at its moving offset), or null
@@ -102,6 +107,8 @@ struct ProblemState {
   // finder transform robot_in_sensor * X of every cue slice (rows [r0 r1 r2 t], SE(2) spread into the same slots) for
   // the coming passes and for the previous ones: computed once by the init / control kernels instead of by every wave
   float Tf[SRRG2_MAX_SLICES][12], Tfprev[SRRG2_MAX_SLICES][12];
+  float Tlast[SRRG2_MAX_SLICES][12];  // finder transforms of the last EXECUTED finder passes (k_icp_outputs)
+  int npasses;                          // finder passes executed by this compute()
   int w_count;
   double w_corr[TERM_WINDOW_MAX], w_inl[TERM_WINDOW_MAX], w_out[TERM_WINDOW_MAX], w_chi[TERM_WINDOW_MAX];
   double last_H[36], last_b[6], last_dx[6];

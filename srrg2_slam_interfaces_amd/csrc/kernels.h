@@ -26,7 +26,10 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
                      int max_nm, hipStream_t s);
 // iterations >= 1 of a compute(): the converged pass, ppt moving points per thread, + the deferred-search kernel if S.queue
 void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                          int max_nm, int ppt, hipStream_t s);
+                          int max_nm, int ppt, bool gather, hipStream_t s);
+// correspondence records of a nearest-neighbour slice, derived on demand from the state the last pass left behind
+void launch_icp_outputs(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, const ProblemState* states, int K,
+                        int max_nm, hipStream_t s);
 int icp_step_blocks(int max_nm);
 int icp_queue_blocks(int max_nm, int K);
 // projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)

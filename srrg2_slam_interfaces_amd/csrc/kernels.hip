@@ -16,6 +16,8 @@
 // a single bit of H, b or the statistics.
 #include "kernels.h"
 
+#include <type_traits>
+
 #include "det_math.h"
 
 // Timing knobs (SRRG2_AMD_TUNE bits 1, 2, 8, 16, 32, 64, 128, 256, 1024, 2048) switch parts of the kernels OFF to see what
@@ -606,14 +608,15 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
   int match     = -1;
   float resp    = 0.f;
   uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
-  float4 fm     = make_float4(0.f, 0.f, 0.f, 0.f);  // the nearest fixed point {x, y, z, index}
+  float4 fm     = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));  // the nearest fixed point {x, y, z, index}
+  float4 nf     = make_float4(0.f, 0.f, 0.f, 0.f);                        // ... and its normal
   if (inrange) {
     if (active) {
       bool found = bidx != NO_MATCH && best <= g.gate2;
       if (KNOB(S.tune, 8)) found = false;
-      float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
-      // (a kept neighbour comes with its normal, loaded together with the prior: one round trip less on the chain)
-      if (found && (PLANE || S.use_normal_gate))
+      // (a kept neighbour comes with its normal, loaded together with the prior: one round trip less on the chain; the
+      // normal of a neighbour beyond the gate is fetched too: it is stored with the neighbour for the next iteration)
+      if (bidx != NO_MATCH && (PLANE || S.use_normal_gate))
         nf = KNOB(S.tune, 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : (kept ? kept_n : g.nrm[bpos]);
       // (with nf: one round trip, not one after the normal gate; a kept neighbour comes with its coordinates)
       if (bidx != NO_MATCH) fm = kept ? kept_f : g.pts[bpos];
@@ -692,14 +695,13 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       }
     }
     if (!kept) {  // (a skipped search keeps its neighbour: only the exclusion radius changes)
+      S.prev_f[gi]   = fm;  // (.w = NO_MATCH: none)
       S.prev_pos[gi] = (active && bidx != NO_MATCH) ? bpos : -1;
-      S.prev_f[gi]   = fm;
+      if (PLANE || S.use_normal_gate) S.prev_n[gi] = nf;
     }
-    S.prev_m[gi]     = excl;
-    // (stored in the sorted order of the moving cloud: coalesced; the host API maps back to the caller's order)
-    S.corr_fixed[gi] = match;
-    S.corr_resp[gi]  = resp;
-    S.corr_stat[gi]  = fstat;
+    S.prev_m[gi] = excl;
+    // (the correspondence record {match, resp, fstat} is not stored: k_icp_outputs derives it on demand)
+    (void) match; (void) resp; (void) fstat;
   }
 
 }
@@ -753,22 +755,20 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
   const bool inrange = i < pd.nm;
   const int gi       = pd.moff + (inrange ? i : 0);
   float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
-  int ppos           = -1;
-  float4 pf          = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pf          = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
   float4 pn          = make_float4(0.f, 0.f, 0.f, 0.f);   // its normal
   float4 pnm         = make_float4(0.f, 0.f, 0.f, 0.f);   // this moving point's normal
   float pm           = 0.f;
   if (inrange) {
     p = S.mpts[gi];
-    if (use_prior) {  // previous nearest neighbour: position in grid.pts, its {x, y, z, index}, exclusion radius
-      ppos = S.prev_pos[gi];
+    if (use_prior) {  // previous nearest neighbour {x, y, z, index}, its normal, exclusion radius: independent loads
       pf   = S.prev_f[gi];
       pm   = S.prev_m[gi];
+      if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
       if (S.use_normal_gate) pnm = S.mnrm[gi];
     }
   }
-  // the normal of the previous neighbour, in flight while the skip test runs: converged iterations keep the neighbour
-  if (use_prior && (PLANE || S.use_normal_gate) && ppos >= 0 && ppos < g.n) pn = g.nrm[ppos];
+  const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
   // moving points are stored spatially sorted; p.w carries the caller's index within the problem
   const int oi      = pd.moff + __float_as_int(p.w);
   const bool active = inrange && finite3(p.x, p.y, p.z);
@@ -795,10 +795,10 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
     //      exact (d2, index) minimum, and the runner-up distance / the ball / the 3^DIM block leave a new m behind.
     // All float32 roundings here are relative (~1e-6: differences and squares of exact float coordinates); the
     // factors 1.00001 / 0.99999 keep every inequality on the safe side.  The oracle searches from scratch.
-    if (use_prior && ppos >= 0 && ppos < g.n) {
+    if (use_prior && has_prev) {
       unsigned long long k1 = NO_KEY;
       int pos1              = 0;
-      test_candidate<DIM>(pf, qx, qy, qz, ppos, true, k1, pos1);
+      test_candidate<DIM>(pf, qx, qy, qz, 0, true, k1, pos1);
       float px, py, pz;
       transform_point<DIM>(Tprev, p, px, py, pz);
       const float ex = qx - px, ey = qy - py, ez = qz - pz;
@@ -808,7 +808,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
         skipped = true;
         best    = key_best(k1);
         bidx    = key_idx(k1);
-        bpos    = ppos;
+        bpos    = 0;  // (unused: a kept neighbour comes with its coordinates and normal)
         // (the stored radius shrinks by the motion and by its own rounding -- 0.9999999 > one ulp -- not by the
         // comparison's 1e-5 safety factor, which alone ate the margin of a few points per iteration, each of which then
         // made its whole wave pay a search)
@@ -818,7 +818,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
         const float rr = (d1 + pad) * 1.00001f;
         r2box          = fminf(rr * rr, gfar);
       }
-    } else if (use_prior && ppos < 0 && pm > 0.f && !(S.tune & (4096 | 65536))) {
+    } else if (use_prior && !has_prev && pm > 0.f && !(S.tune & (4096 | 65536))) {
       // (c) no fixed point at all within m of q' (an empty scan left m behind): if gate + |q - q'| < m there is still
       //     none within the gate of q: no match, no search
       float px, py, pz;
@@ -1003,78 +1003,103 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 // ============================================================================================
 namespace {
 
-#define ACC_N_TERMS_SHIFT 32  // acc[ACC_N_CORR] carries the number of term contributions in its upper half
-
+// NW = waves that reduce together (through LDS); NW == 1: every wave on its own, no barrier (the rare second phase of
+// the converged pass).  Every lane contributed `per_lane` biased values to each of the entries [0, ACC_CHI_IN).
 template <int NW>
 __device__ __forceinline__ void block_reduce_store_biased(long long (&acc)[ACC_N], long long* __restrict__ partials,
-                                                          int prob, int block) {
-  __shared__ long long red[NW][ACC_N];
+                                                          int prob, int block, int per_lane) {
+  __shared__ long long red[4][ACC_N];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   int my_index;
   const long long total = wave_transpose_reduce(acc, lane, my_index);
   if ((lane & 1) == 0) red[wid][my_index] = total;
-  __syncthreads();
-  if (threadIdx.x < ACC_N) {
-    long long v = 0, n_ct = 0;
+  if (NW > 1)
+    __syncthreads();
+  else
+    wave_lds_sync();
+  const int t = NW > 1 ? (int) threadIdx.x : lane;
+  if (t < ACC_N) {
+    long long v = 0;
+    if (NW > 1) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      v += red[w][threadIdx.x];
-      n_ct += red[w][ACC_N_CORR];
+      for (int w = 0; w < NW; ++w) v += red[w][t];
+    } else {
+      v = red[wid][t];
     }
-    const long long n_terms = (long long) ((unsigned long long) n_ct >> ACC_N_TERMS_SHIFT);
     // remove the bias (wrapping arithmetic: the biased sums may have wrapped, the true sums fit by construction)
     unsigned long long u = (unsigned long long) v;
-    if (threadIdx.x < ACC_CHI_IN) u -= (unsigned long long) FX_MAGIC_BITS * (unsigned long long) n_terms;
-    if (threadIdx.x == ACC_N_CORR) u &= 0xffffffffull;
+    if (t < ACC_CHI_IN) u -= (unsigned long long) FX_MAGIC_BITS * (unsigned long long) (NW * 64 * per_lane);
     if (u != 0)
       atomicAdd(reinterpret_cast<unsigned long long*>(partials) +
-                  ((size_t) prob * PARTIAL_SLOTS + (block & (PARTIAL_SLOTS - 1))) * ACC_N + threadIdx.x, u);
+                  ((size_t) prob * PARTIAL_SLOTS + ((block + wid * (NW == 1 ? 7 : 0)) & (PARTIAL_SLOTS - 1))) * ACC_N + t, u);
   }
 }
 
-// the factor arithmetic of factor_accumulate on biased accumulators (bit patterns of FX_MAGIC + integer, summed as
-// integers; the number of contributions is counted so that the bias can be removed per workgroup)
-template <int D, int ROWS>
-__device__ __forceinline__ uint8_t factor_accumulate_biased(const float (&J)[ROWS][D], const float (&e)[ROWS], int rk,
-                                                            float thr, double scale, long long (&acc)[ACC_N]) {
+// The factor arithmetic of factor_accumulate, straight-line: EVERY lane adds one biased value (the bit pattern of
+// FX_MAGIC + integer) to each of the H / b entries -- a lane without a contribution adds FX_MAGIC itself (weight 0, rows
+// forced to 0) --, so that the compiler sees no control flow around the 32 accumulators (with branches it re-materialises
+// all of them on every path: ~150 register moves per point) and the bias is the same for every lane.
+// FIRST: the accumulators are written, not added to (one point per thread: no adds at all).
+template <int D, int ROWS, bool FIRST>
+__device__ __forceinline__ uint8_t factor_accumulate_flat(float (&J)[ROWS][D], float (&e)[ROWS], bool found, int rk, float thr,
+                                                          double scale, long long (&acc)[ACC_N]) {
   float chi = e[0] * e[0];
 #pragma unroll
   for (int r = 1; r < ROWS; ++r) chi = chi + e[r] * e[r];
-  acc[ACC_N_CORR] += 1;
-  if (!isfinite(chi)) return SRRG2_FACTOR_SUPPRESSED;
-  float w         = 1.f;
-  bool kernelized = false;
-  if (rk != SRRG2_ROBUST_NONE && !(chi < thr)) {
-    kernelized = true;
-    w = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
+  const bool ok         = found && isfinite(chi);
+  const bool kernelized = ok && rk != SRRG2_ROBUST_NONE && !(chi < thr);
+  float w               = 1.f;
+  if (__any(kernelized)) {  // (wave-uniform branch around the divisions; one value merges)
+    const float wk = rk == SRRG2_ROBUST_CLAMP ? 0.f : (rk == SRRG2_ROBUST_SATURATED ? thr / chi : 1.0f / (1.0f + chi / thr));
+    w              = kernelized ? wk : 1.f;
   }
-  const long long chi_b = fx_bits(__fma_rn((double) chi, scale, FX_MAGIC));
-  acc[ACC_N_OUT] += kernelized ? 1 : 0;
-  acc[ACC_CHI_OUT] += kernelized ? chi_b : 0;
-  acc[ACC_N_IN] += kernelized ? 0 : 1;
-  acc[ACC_CHI_IN] += kernelized ? 0 : chi_b;
-  if (w != 0.f) {
-    acc[ACC_N_CORR] += 1ll << ACC_N_TERMS_SHIFT;
-    const double ws = (double) w * scale;
+  const bool contrib = ok && w != 0.f;
+  const long long chi_fx = fx_bits(__fma_rn((double) (ok ? chi : 0.f), scale, FX_MAGIC));
+  const long long c_corr = found ? 1 : 0, c_in = (ok && !kernelized) ? 1 : 0, c_out = kernelized ? 1 : 0;
+  const long long x_in = (ok && !kernelized) ? chi_fx : 0, x_out = kernelized ? chi_fx : 0;
+  if (FIRST) {
+    acc[ACC_N_CORR] = c_corr; acc[ACC_N_IN] = c_in; acc[ACC_N_OUT] = c_out; acc[ACC_CHI_IN] = x_in; acc[ACC_CHI_OUT] = x_out;
+  } else {
+    acc[ACC_N_CORR] += c_corr; acc[ACC_N_IN] += c_in; acc[ACC_N_OUT] += c_out; acc[ACC_CHI_IN] += x_in; acc[ACC_CHI_OUT] += x_out;
+  }
+  const double ws = contrib ? (double) w * scale : 0.0;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      double wj[ROWS];
+  for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
+    for (int a = 0; a < D; ++a) J[r][a] = contrib ? J[r][a] : 0.f;
+    e[r] = contrib ? e[r] : 0.f;
+  }
 #pragma unroll
-      for (int b = a; b < D; ++b) {
-        double t = FX_MAGIC;
+  for (int a = 0; a < D; ++a) {
+    double wj[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) J[r][b], t);
-        acc[hidx(a, b)] += __double_as_longlong(t);
-      }
+    for (int r = 0; r < ROWS; ++r) wj[r] = ws * (double) J[r][a];
+#pragma unroll
+    for (int b = a; b < D; ++b) {
       double t = FX_MAGIC;
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) e[r], t);
-      acc[ACC_B + a] += __double_as_longlong(t);
+      for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) J[r][b], t);
+      if (FIRST) acc[hidx(a, b)] = __double_as_longlong(t); else acc[hidx(a, b)] += __double_as_longlong(t);
+    }
+    double t = FX_MAGIC;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) t = __fma_rn(wj[r], (double) e[r], t);
+    if (FIRST) acc[ACC_B + a] = __double_as_longlong(t); else acc[ACC_B + a] += __double_as_longlong(t);
+  }
+  if (D == 3) {  // (the 3-dof layout leaves entries of the 6 x 6 table unused: they carry the bias too)
+#pragma unroll
+    for (int k = 0; k < ACC_CHI_IN; ++k) {
+      bool used = false;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+#pragma unroll
+        for (int b = a; b < D; ++b) used |= k == hidx(a, b);
+        used |= k == ACC_B + a;
+      }
+      if (!used) { if (FIRST) acc[k] = FX_MAGIC_BITS; else acc[k] += FX_MAGIC_BITS; }
     }
   }
-  return kernelized ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
+  return !ok ? SRRG2_FACTOR_SUPPRESSED : (kernelized ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER);
 }
 
 // residual rows of one matched point (the arithmetic of finish_point)
@@ -1138,7 +1163,10 @@ __device__ __forceinline__ void point_rows(const float* T, float kk, const float
 
 }  // namespace
 
-template <int DIM, bool PLANE, int PPT>
+// GATHER: the previous neighbour and its normal are gathered from the fixed cloud through prev_pos (batches: the cloud
+// is shared by all alignments and stays in L2; 8 instead of 36 streamed bytes per point) instead of read from prev_f / prev_n
+// (single alignments: no dependent load on the chain).
+template <int DIM, bool PLANE, int PPT, bool GATHER>
 __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const ProblemDev* __restrict__ probs,
                                                        ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
@@ -1159,20 +1187,41 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   const bool ext     = !(S.tune & 65536);
   const float gfar   = ext ? g.gate2_ext : g.gate2;
   const int rfar     = ext ? g.rmax : g.rfar_gate;
-  const float gate_r = sqrtf(g.gate2);
+  const float gate_r = S.gate * 1.000001f;  // (>= sqrt(gate2))
   const bool ngate   = S.use_normal_gate != 0;
   const bool use_q   = S.queue != nullptr && st->qmode[S.slice_idx] != 0;
+  const bool cert_a  = !(S.tune & 4096), cert_c = !(S.tune & (4096 | 65536));
   const int lane     = threadIdx.x & 63;
   const int wid      = threadIdx.x >> 6;
   __shared__ int coop_lds[4][264];
 
-  long long acc[ACC_N];
-#pragma unroll
-  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+  // gates, rows and factor terms of a point whose nearest neighbour {fk, nk} is known (valid); straight-line
+  auto linearize = [&](auto first, long long (&acc)[ACC_N], bool valid, const float4 pk, const float4 fk, const float4 nk,
+                       const float4 nmk, float qx, float qy, float qz, float best) {
+    bool found = valid && __float_as_int(fk.w) != NO_MATCH && best <= g.gate2;
+    if (ngate) {
+      float dot;
+      if constexpr (DIM == 3) {
+        const float rx = (T[0] * nmk.x + T[1] * nmk.y) + T[2] * nmk.z;
+        const float ry = (T[4] * nmk.x + T[5] * nmk.y) + T[6] * nmk.z;
+        const float rz = (T[8] * nmk.x + T[9] * nmk.y) + T[10] * nmk.z;
+        dot            = (nk.x * rx + nk.y * ry) + nk.z * rz;
+      } else {
+        const float rx = T[0] * nmk.x + T[1] * nmk.y;
+        const float ry = T[4] * nmk.x + T[5] * nmk.y;
+        dot            = nk.x * rx + nk.y * ry;
+      }
+      found = found && dot > S.normal_cos;
+    }
+    float J[ROWS][D], e[ROWS];
+    point_rows<DIM, PLANE>(T, kk, pk, qx, qy, qz, fk, nk, J, e);
+    (void) factor_accumulate_flat<D, ROWS, decltype(first)::value>(J, e, found, rk, thr, scale, acc);
+  };
 
-  // all loads of the PPT points first (independent: one round trip for the lot, then the normals of the neighbours)
+  long long acc[ACC_N];
+
+  // all loads of the PPT points first (independent: one round trip for the lot)
   float4 p[PPT], pf[PPT], pnm[PPT], pn[PPT];
-  int ppos[PPT];
   float pm[PPT];
   int gi_[PPT];
   bool inr[PPT];
@@ -1180,168 +1229,222 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   for (int k = 0; k < PPT; ++k) {
     const int i = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
     inr[k]      = i < pd.nm;
-    gi_[k]      = pd.moff + (inr[k] ? i : 0);
-    p[k]        = make_float4(__int_as_float(0x7fc00000), 0.f, 0.f, 0.f);  // (out of range = not finite = inactive)
-    pf[k]       = make_float4(0.f, 0.f, 0.f, 0.f);
+    gi_[k]      = pd.moff + (inr[k] ? i : 0);  // (out of range: the loads below read point 0 of the problem, masked out later)
+    int ppos    = -1;
+    p[k]        = S.mpts[gi_[k]];
+    pm[k]       = S.prev_m[gi_[k]];
+    pf[k]       = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
+    pn[k]       = make_float4(0.f, 0.f, 0.f, 0.f);
     pnm[k]      = make_float4(0.f, 0.f, 0.f, 0.f);
-    ppos[k]     = -1;
-    pm[k]       = 0.f;
-    if (inr[k]) {
-      p[k]    = S.mpts[gi_[k]];
-      ppos[k] = S.prev_pos[gi_[k]];
-      pf[k]   = S.prev_f[gi_[k]];
-      pm[k]   = S.prev_m[gi_[k]];
-      if (ngate) pnm[k] = S.mnrm[gi_[k]];
+    if (GATHER) {
+      ppos = S.prev_pos[gi_[k]];
+    } else {
+      pf[k] = S.prev_f[gi_[k]];
+      if (PLANE || ngate) pn[k] = S.prev_n[gi_[k]];
     }
-  }
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    pn[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((PLANE || ngate) && ppos[k] >= 0 && ppos[k] < g.n) pn[k] = g.nrm[ppos[k]];
+    if (ngate) pnm[k] = S.mnrm[gi_[k]];
+    if (GATHER && ppos >= 0 && ppos < g.n) {
+      pf[k] = g.pts[ppos];
+      if (PLANE || ngate) pn[k] = g.nrm[ppos];
+    }
   }
 
+  // Phase 1: the certificates; points that keep their neighbour are linearised.  A failed certificate leaves the squared
+  // radius of the ball to search (the ball contains the previous neighbour, hence the nearest one) behind.
+  float open_ball2[PPT];  // < 0: not open
+  bool any_open = false;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int i       = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
-    const int gi      = gi_[k];
     const bool active = inr[k] && finite3(p[k].x, p[k].y, p[k].z);
+    float qx, qy, qz, px, py, pz;
+    transform_point<DIM>(T, p[k], qx, qy, qz);
+    transform_point<DIM>(Tprev, p[k], px, py, pz);
+    const float ex = qx - px, ey = qy - py, ez = qz - pz;
+    // (hardware square roots, ~1 ulp: every use below carries a 1e-5 safety factor)
+    const float dl   = __builtin_amdgcn_sqrtf((ex * ex + ey * ey) + ez * ez);
+    const bool hasp  = __float_as_int(pf[k].w) != NO_MATCH;
+    unsigned long long k1 = NO_KEY;
+    int pos1              = 0;
+    test_candidate<DIM>(pf[k], qx, qy, qz, 0, true, k1, pos1);
+    const float best = key_best(k1);
+    const float d1   = __builtin_amdgcn_sqrtf(best);
+    const float rhs  = pm[k] * 0.99999f;
+    // (a) of icp_step_body: d(q, f*) + |q - q'| < m  =>  f* is still the unique nearest neighbour
+    // (c): nothing within m of q'; gate + |q - q'| < m  =>  still no match
+    const bool ca   = hasp && cert_a && (d1 * 1.00001f + dl * 1.00001f < rhs);
+    const bool cc   = !hasp && cert_c && pm[k] > 0.f && (gate_r * 1.00001f + dl * 1.00001f < rhs);
+    const bool have = active && (ca || cc);
+    const float excl = pm[k] * 0.9999999f - dl * 1.00001f;
+    const float pad  = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+    const float rr   = (d1 + pad) * 1.00001f;
+    const float r2box = hasp ? fminf(rr * rr, gfar) : gfar;
+    open_ball2[k]     = (active && !have) ? r2box : -1.f;
+    any_open |= active && !have;
+    if (k == 0)
+      linearize(std::true_type{}, acc, have && ca, p[k], pf[k], pn[k], pnm[k], qx, qy, qz, best);
+    else
+      linearize(std::false_type{}, acc, have && ca, p[k], pf[k], pn[k], pnm[k], qx, qy, qz, best);
+    if (have) S.prev_m[gi_[k]] = excl;
+  }
+  if (use_q) {
+    // failed certificates go to the deferred-search kernel like the stragglers of k_icp_step
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const bool open               = open_ball2[k] >= 0.f;
+      const unsigned long long need = __ballot(open);
+      if (!need) continue;
+      const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
+      const unsigned long long need_near = __ballot(open && r2 == 2);
+      const unsigned long long need_far  = need & ~need_near;
+      int base_near = 0, base_far = 0;
+      if (lane == 0) {  // one atomic per wave and kind (rare once the estimate has settled)
+        if (need_near) base_near = atomicAdd(&S.qcount[2 * prob], __popcll(need_near));
+        if (need_far) base_far = atomicAdd(&S.qcount[2 * prob + 1], __popcll(need_far));
+      }
+      base_near = __shfl(base_near, 0);
+      base_far  = __shfl(base_far, 0);
+      if (open) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        QEntry q;
+        q.i = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
+        q.r2 = r2; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0;
+        transform_point<DIM>(T, p[k], q.qx, q.qy, q.qz);
+        q.ball2 = open_ball2[k]; q.pad_ = 0;
+        QEntry* qbase = reinterpret_cast<QEntry*>(S.queue) + pd.moff;
+        if (r2 == 2)
+          qbase[base_near + __popcll(need_near & below)] = q;
+        else
+          qbase[pd.nm - 1 - (base_far + __popcll(need_far & below))] = q;
+      }
+    }
+  }
+  block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, PPT);
+  if (use_q || !__any(any_open)) return;
+
+  // Phase 2 (waves with a failed certificate and no queue; rare once the estimate has settled): the whole wave searches
+  // the ball of each such point, one at a time, then the points are linearised into a second set of sums which the wave
+  // reduces and adds on its own.  Phase 1's accumulators are dead by now: the search runs at the register footprint
+  // of the scan, not on top of 64 accumulator registers.
+  float sbest[PPT], sexcl[PPT];
+  int sidx[PPT], spos[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    sbest[k] = INFINITY; sexcl[k] = 0.f; sidx[k] = NO_MATCH; spos[k] = 0;
+    const bool open = open_ball2[k] >= 0.f;
+    unsigned long long todo = __ballot(open);
+    if (!todo) continue;
     float qx = 0.f, qy = 0.f, qz = 0.f;
-    bool have = false;  // the nearest neighbour of this point is known: kept (certificate) or searched below
-    bool open = false;
-    float best = INFINITY, excl = 0.f, r2box = INFINITY;
-    int bidx = NO_MATCH;
-    if (active) {
-      transform_point<DIM>(T, p[k], qx, qy, qz);
-      float px, py, pz;
-      transform_point<DIM>(Tprev, p[k], px, py, pz);
-      const float ex = qx - px, ey = qy - py, ez = qz - pz;
-      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
-      if (ppos[k] >= 0 && ppos[k] < g.n) {
-        // (a) of icp_step_body: d(q, f*) + |q - q'| < m  =>  f* is still the unique nearest neighbour
-        unsigned long long k1 = NO_KEY;
-        int pos1              = 0;
-        test_candidate<DIM>(pf[k], qx, qy, qz, ppos[k], true, k1, pos1);
-        const float d1 = sqrtf(key_best(k1));
-        if (d1 * 1.00001f + dl * 1.00001f < pm[k] * 0.99999f && !(S.tune & 4096)) {
-          have = true;
-          best = key_best(k1);
-          bidx = key_idx(k1);
-          excl = pm[k] * 0.9999999f - dl * 1.00001f;
-        } else {
-          const float pad = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
-          const float rr  = (d1 + pad) * 1.00001f;
-          r2box           = fminf(rr * rr, gfar);
-        }
-      } else if (ppos[k] < 0 && pm[k] > 0.f && !(S.tune & (4096 | 65536))) {
-        // (c): nothing within m of q'; gate + |q - q'| < m  =>  still no match
-        if (gate_r * 1.00001f + dl * 1.00001f < pm[k] * 0.99999f) {
-          have = true;
-          excl = pm[k] * 0.9999999f - dl * 1.00001f;
-        }
-      }
-      open = !have;
-    }
-    // points whose certificate failed: to the deferred-search kernel like the stragglers of k_icp_step, or searched by
-    // the whole wave here, one at a time (exact: the ball contains the previous neighbour, hence the nearest one)
-    bool searched = false;
-    const unsigned long long need = __ballot(open);
-    if (need) {
-      const float ball2 = fminf(r2box, gfar);
-      const int r2      = ball2 <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
-      if (use_q) {
-        const unsigned long long need_near = __ballot(open && r2 == 2);
-        const unsigned long long need_far  = need & ~need_near;
-        int base_near = 0, base_far = 0;
-        if (lane == 0) {  // one atomic per wave and kind (rare once the estimate has settled)
-          if (need_near) base_near = atomicAdd(&S.qcount[2 * prob], __popcll(need_near));
-          if (need_far) base_far = atomicAdd(&S.qcount[2 * prob + 1], __popcll(need_far));
-        }
-        base_near = __shfl(base_near, 0);
-        base_far  = __shfl(base_far, 0);
-        if (open) {
-          const unsigned long long below = (1ull << lane) - 1ull;
-          QEntry q;
-          q.i = i; q.r2 = r2; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0;
-          q.qx = qx; q.qy = qy; q.qz = qz;
-          q.ball2 = ball2; q.pad_ = 0;
-          QEntry* qbase = reinterpret_cast<QEntry*>(S.queue) + pd.moff;
-          if (r2 == 2)
-            qbase[base_near + __popcll(need_near & below)] = q;
-          else
-            qbase[pd.nm - 1 - (base_far + __popcll(need_far & below))] = q;
-        }
-      } else {
-        unsigned long long todo = need;
-        while (todo) {
-          const int src = __ffsll((long long) todo) - 1;
-          todo &= todo - 1;
-          const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
-          const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
-          const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
-          float wbest, wexcl2;
-          int widx, wpos;
-          coop_scan<DIM, 64>(g, lane, coop_lds[wid], sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(ball2, src),
-                             wbest, widx, wpos, wexcl2);
-          if (lane == src) {
-            best    = wbest;
-            bidx    = widx;
-            ppos[k] = widx != NO_MATCH ? wpos : -1;
-            excl    = sqrtf(wexcl2) * 0.99999f;
-          }
-        }
-        // the new neighbours and their normals (one round trip for all searched lanes of the wave)
-        if (open) {
-          searched = true;
-          have     = true;
-          pf[k]    = make_float4(0.f, 0.f, 0.f, 0.f);
-          pn[k]    = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (bidx != NO_MATCH) {
-            pf[k] = g.pts[ppos[k]];
-            if (PLANE || ngate) pn[k] = g.nrm[ppos[k]];
-          }
-        }
+    if (open) transform_point<DIM>(T, p[k], qx, qy, qz);
+    const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
+    while (todo) {
+      const int src = __ffsll((long long) todo) - 1;
+      todo &= todo - 1;
+      const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
+      const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
+      const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
+      float wbest, wexcl2;
+      int widx, wpos;
+      coop_scan<DIM, 64>(g, lane, coop_lds[wid], sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(open_ball2[k], src),
+                         wbest, widx, wpos, wexcl2);
+      if (lane == src) {
+        sbest[k] = wbest;
+        sidx[k]  = widx;
+        spos[k]  = wpos;
+        sexcl[k] = sqrtf(wexcl2) * 0.99999f;
       }
     }
-    if (have) {
-      bool found = bidx != NO_MATCH && best <= g.gate2;
-      if (found && ngate) {
-        const float4 nm = pnm[k];
+  }
+  long long acc2[ACC_N];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const bool open = open_ball2[k] >= 0.f;
+    float4 fk = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH)), nk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (open && sidx[k] != NO_MATCH) {  // the new neighbour and its normal
+      fk = g.pts[spos[k]];
+      if (PLANE || ngate) nk = g.nrm[spos[k]];
+    }
+    float qx, qy, qz;
+    transform_point<DIM>(T, p[k], qx, qy, qz);
+    if (k == 0)
+      linearize(std::true_type{}, acc2, open, p[k], fk, nk, pnm[k], qx, qy, qz, sbest[k]);
+    else
+      linearize(std::false_type{}, acc2, open, p[k], fk, nk, pnm[k], qx, qy, qz, sbest[k]);
+    if (open) {
+      S.prev_m[gi_[k]]   = sexcl[k];
+      S.prev_f[gi_[k]]   = fk;
+      S.prev_pos[gi_[k]] = sidx[k] != NO_MATCH ? spos[k] : -1;
+      if (PLANE || ngate) S.prev_n[gi_[k]] = nk;
+    }
+  }
+  block_reduce_store_biased<1>(acc2, S.partials, prob, blockIdx.x, PPT);
+}
+
+// The correspondence records of the nearest-neighbour passes, on demand (get_correspondences, factor status, the scene
+// merger): slice->correspondences() and the factor statistics of the last linearisation (multi_aligner_impl.cpp:215,244)
+// re-derived from what the last executed pass left behind -- every point's nearest neighbour (prev_f / prev_n) and the
+// transform that pass ran with (ProblemState::Tlast) -- with the arithmetic of the pass: same bits.
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_outputs(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                     const ProblemState* __restrict__ states) {
+  constexpr int D    = DIM == 3 ? 6 : 3;
+  constexpr int ROWS = PLANE ? 1 : DIM;
+  const int prob     = blockIdx.y;
+  const ProblemState* st = &states[prob];
+  const ProblemDev pd    = probs[prob];
+  const int i            = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pd.nm) return;
+  const int gi  = pd.moff + i;
+  int match     = -1;
+  float resp    = 0.f;
+  uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
+  const float4 p = S.mpts[gi];
+  if (st->npasses > 0 && finite3(p.x, p.y, p.z)) {
+    const float4 f = S.prev_f[gi];
+    if (__float_as_int(f.w) != NO_MATCH) {
+      float T[12];
+      load_T(st->Tlast[S.slice_idx], T);
+      float qx, qy, qz;
+      transform_point<DIM>(T, p, qx, qy, qz);
+      unsigned long long k1 = NO_KEY;
+      int pos1              = 0;
+      test_candidate<DIM>(f, qx, qy, qz, 0, true, k1, pos1);
+      const float best = key_best(k1);
+      bool found       = best <= S.grid.gate2;
+      float4 nf        = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (found && (PLANE || S.use_normal_gate)) nf = S.prev_n[gi];
+      if (found && S.use_normal_gate) {
+        const float4 nm = S.mnrm[gi];
         float dot;
         if constexpr (DIM == 3) {
           const float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
           const float ry = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
           const float rz = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
-          dot            = (pn[k].x * rx + pn[k].y * ry) + pn[k].z * rz;
+          dot            = (nf.x * rx + nf.y * ry) + nf.z * rz;
         } else {
           const float rx = T[0] * nm.x + T[1] * nm.y;
           const float ry = T[4] * nm.x + T[5] * nm.y;
-          dot            = pn[k].x * rx + pn[k].y * ry;
+          dot            = nf.x * rx + nf.y * ry;
         }
         if (!(dot > S.normal_cos)) found = false;
       }
-      int match     = -1;
-      float resp    = 0.f;
-      uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
       if (found) {
-        match = bidx;
+        match = key_idx(k1);
         resp  = best;
+        const float kk = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
         float J[ROWS][D], e[ROWS];
-        point_rows<DIM, PLANE>(T, kk, p[k], qx, qy, qz, pf[k], pn[k], J, e);
-        fstat = factor_accumulate_biased<D, ROWS>(J, e, rk, thr, scale, acc);
-      }
-      S.prev_m[gi] = excl;
-      if (searched) {
-        S.prev_pos[gi] = ppos[k];
-        S.prev_f[gi]   = pf[k];
-      }
-      if (bidx != NO_MATCH || searched) {  // (certified-unmatched points keep the record of the pass that searched them)
-        S.corr_fixed[gi] = match;
-        S.corr_resp[gi]  = resp;
-        S.corr_stat[gi]  = fstat;
+        point_rows<DIM, PLANE>(T, kk, p, qx, qy, qz, f, nf, J, e);
+        float chi = e[0] * e[0];
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) chi = chi + e[r] * e[r];
+        const int rk = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+        if (isfinite(chi))
+          fstat = (rk != SRRG2_ROBUST_NONE && !(chi < S.robust_thr)) ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
       }
     }
   }
-  block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x);
+  S.corr_fixed[gi] = match;
+  S.corr_resp[gi]  = resp;
+  S.corr_stat[gi]  = fstat;
 }
 
 // Deferred searches: every wave takes queue entries w, w + W, ... of its problem, runs the cooperative exact scan
@@ -1937,6 +2040,10 @@ template <int D>
 // entry before this (sequential) body runs -- the same operation it used to do itself, 30 times in a row.
 __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob,
                              const long long (*sums)[ACC_N], const double (*scaled)[ACC_N]) {
+  st->npasses++;
+  for (int s = 0; s < C.nslices; ++s)  // the transforms the passes of this iteration ran with (k_icp_outputs)
+    if (C.slices[s].kind != SRRG2_SLICE_PRIOR)
+      for (int i = 0; i < 12; ++i) st->Tlast[s][i] = st->Tf[s][i];
   // association check: association_good |= slice->correspondencesGood(), multi_aligner.h:126-138
   bool good = false;
   for (int s = 0; s < C.nslices; ++s) {
@@ -2076,6 +2183,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   st->nstats   = 0;
   st->phase    = 0;
   st->w_count  = 0;
+  st->npasses  = 0;
   for (int s = 0; s < SRRG2_MAX_SLICES; ++s) st->qmode[s] = 1;
   int nm_of[SRRG2_MAX_SLICES];
   for (int s = 0; s < C.nslices; ++s) {
@@ -2337,34 +2445,60 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }
 
-template <int PPT>
+template <int PPT, bool GATHER>
 static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                             int max_nm, hipStream_t s) {
   dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
   if (dim == 3) {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step_fast<3, false, PPT>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<3, false, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
   } else {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step_fast<2, true, PPT>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<2, true, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step_fast<2, false, PPT>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<2, false, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
   }
 }
 
 // the converged pass (k_icp_step_fast) + the deferred-search kernel for the points whose certificate failed (S.queue)
 void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                          int max_nm, int ppt, hipStream_t s) {
+                          int max_nm, int ppt, bool gather, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
-  if (ppt >= 4)
-    launch_fast_ppt<4>(dim, plane, S, probs, states, K, max_nm, s);
-  else if (ppt >= 2)
-    launch_fast_ppt<2>(dim, plane, S, probs, states, K, max_nm, s);
-  else
-    launch_fast_ppt<1>(dim, plane, S, probs, states, K, max_nm, s);
+  if (gather) {
+    if (ppt >= 4)
+      launch_fast_ppt<4, true>(dim, plane, S, probs, states, K, max_nm, s);
+    else if (ppt >= 2)
+      launch_fast_ppt<2, true>(dim, plane, S, probs, states, K, max_nm, s);
+    else
+      launch_fast_ppt<1, true>(dim, plane, S, probs, states, K, max_nm, s);
+  } else {
+    if (ppt >= 4)
+      launch_fast_ppt<4, false>(dim, plane, S, probs, states, K, max_nm, s);
+    else if (ppt >= 2)
+      launch_fast_ppt<2, false>(dim, plane, S, probs, states, K, max_nm, s);
+    else
+      launch_fast_ppt<1, false>(dim, plane, S, probs, states, K, max_nm, s);
+  }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
+}
+
+void launch_icp_outputs(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, const ProblemState* states, int K,
+                        int max_nm, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  dim3 grid((max_nm + 255) / 256, K);
+  if (dim == 3) {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_outputs<3, true>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_outputs<3, false>), grid, dim3(256), 0, s, S, probs, states);
+  } else {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_outputs<2, true>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_outputs<2, false>), grid, dim3(256), 0, s, S, probs, states);
+  }
 }
 
 void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,

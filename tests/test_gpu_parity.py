@@ -10,13 +10,15 @@ pytestmark = pytest.mark.gpu
 
 
 # (deferred-search kernel for single alignments?, first iteration run by the converged-pass kernel, points per thread of
-# that kernel in batches, batches hand their failed certificates to the deferred-search kernel?)
+# that kernel, batches hand their failed certificates to the deferred-search kernel?, kept neighbours gathered from the
+# fixed cloud?)
 _PATHS = {
-    "deferred-search kernel": ("0", None, None, None),
-    "searches finished in the step kernel": ("1000000000", None, None, None),
-    "converged-pass kernel from iteration 1, deferred searches": ("0", "1", "4", "1"),
-    "converged-pass kernel from iteration 1, wave-cooperative searches": ("1000000000", "1", "1", "0"),
-    "converged-pass kernel never": ("0", "1000000", None, None),
+    "deferred-search kernel": ("0", None, None, None, None),
+    "searches finished in the step kernel": ("1000000000", None, None, None, None),
+    "converged-pass kernel from iteration 1, deferred searches, 4 points per thread": ("0", "1", "4", "1", "0"),
+    "converged-pass kernel from iteration 1, wave-cooperative searches, gathered neighbours": ("1000000000", "1", "1", "0", "1"),
+    "converged-pass kernel from iteration 2, 2 points per thread, streamed neighbours": ("1000000000", "2", "2", "0", "0"),
+    "converged-pass kernel never": ("0", "1000000", None, None, None),
 }
 
 
@@ -25,11 +27,13 @@ def search_path(request, monkeypatch):
     """Single alignments defer their open searches to k_icp_step_queue from 90 000 moving points on and finish them
     inside k_icp_step below (SRRG2_AMD_QUEUE_MIN); the converged-pass kernel k_icp_step_fast takes over from iteration 3
     (SRRG2_AMD_FAST_FROM) with 1 / 2 / 4 points per thread (SRRG2_AMD_FAST_PPT), its failed certificates go to the
-    deferred-search kernel or are searched by the whole wave (SRRG2_AMD_FAST_QUEUE for batches).  Every scenario of this
-    module runs on all of these paths: they must give the same bits."""
-    qmin, fast_from, ppt, fq = _PATHS[request.param]
+    deferred-search kernel or are searched by their wave (SRRG2_AMD_FAST_QUEUE for batches), kept neighbours are streamed
+    from per-point arrays or gathered from the fixed cloud (SRRG2_AMD_FAST_GATHER).  Every scenario of this module runs
+    on all of these paths: they must give the same bits."""
+    qmin, fast_from, ppt, fq, gather = _PATHS[request.param]
     monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", qmin)
-    for name, val in (("SRRG2_AMD_FAST_FROM", fast_from), ("SRRG2_AMD_FAST_PPT", ppt), ("SRRG2_AMD_FAST_QUEUE", fq)):
+    for name, val in (("SRRG2_AMD_FAST_FROM", fast_from), ("SRRG2_AMD_FAST_PPT", ppt), ("SRRG2_AMD_FAST_QUEUE", fq),
+                      ("SRRG2_AMD_FAST_GATHER", gather)):
         if val is None:
             monkeypatch.delenv(name, raising=False)
         else:
