@@ -4,14 +4,19 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one blocking MultiAligner::compute() (S/registration/aligners/multi_aligner_impl.cpp:47-95)
-= `iterations` ICP iterations (finder + linearise/reduce + 6x6 solve + update) on clouds that are already
-resident in HBM.  Workload at every N: BASELINE config C2 (SE(3) point-to-plane slice, 100k-pt synthetic
-cloud pair) per rank -- rank r aligns its own seeded pair, i.e. the loop-closure
-candidates of multi_loop_detector_brute_force_impl.cpp:64-91 sharded one per GPU (weak scaling, no
-collective on the data path; the per-alignment result records are all-gathered after every step).
+BASELINE.json's metric has two halves and the default workload follows N:
+  N = 1  "ICP iterations/sec (100k-pt SE(3) point-to-plane) @1 GPU": config C2.  One step = set the guess + one blocking
+         MultiAligner::compute() (S/registration/aligners/multi_aligner_impl.cpp:47-95) = `iterations` ICP iterations
+         (finder + linearise/reduce + 6x6 solve + update) on clouds resident in HBM + read status and estimate.
+  N > 1  "8-GPU batched aligns/sec": config C4, the loop-closure candidate batch of
+         multi_loop_detector_brute_force_impl.cpp:64-91 -- a FIXED job of --total-alignments (256) independent 50k-point
+         alignments against one query map, sharded k -> k mod N (STRONG scaling: 32 per GPU at N = 8), one
+         compute_batch() per rank per step, no collective on the data path; the result records (X, statistics, H) are
+         exchanged ONCE after the timed region by an all-reduce(sum) (distributed.py).  After the timed region rank 0
+         also runs the whole job alone for a few steps, so that every line carries its own one-GPU reference.
+`--workload c2|c3|c4` overrides (c4 at N = 1: --batch alignments on the one GPU).
 
-Prints ONE JSON line on rank 0.  `value` = ICP iterations/s summed over all ranks.
+Prints ONE JSON line on rank 0.  `value` = ICP iterations/s over all ranks (`alignments_per_sec` beside it for C4).
 """
 import argparse
 import json
@@ -28,19 +33,30 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--iterations", type=int, default=10)  # aligner.h:30
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
-    ap.add_argument("--batch", type=int, default=32, help="c4: alignments per GPU per step")
+    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4"])
+    ap.add_argument("--batch", type=int, default=32, help="c4 at N = 1: alignments per step")
+    ap.add_argument("--total-alignments", type=int, default=256, help="c4 at N > 1: the job all ranks share")
     ap.add_argument("--batch-points", type=int, default=50_000)
     ap.add_argument("--cell-size", type=float, default=0.0)
     ap.add_argument("--overlap", type=float, default=1.0, help="c2 experiment: keep this x-quantile of the fixed cloud")
+    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "all_gather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-all-cores", action="store_true")
+    ap.add_argument("--no-one-gpu-reference", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.workload is None:
+        a.workload = "c2" if world == 1 else "c4"
+    if a.steps is None:
+        a.steps = 200 if a.workload == "c2" else (100 if a.workload == "c3" else 20)
+    if a.warmup is None:
+        a.warmup = 20 if a.workload != "c4" else 3
+    return a
 
 
 def make_aligner(pkg_or_oracle_ctor, abi, iterations, cell_size=0.0):
@@ -140,19 +156,26 @@ def main():
             nst, last = al.last_iteration_stats()
             return [D.pack_record(rank, {"moving_in_fixed": res[1], "status": res[0], "num_iterations": nst, "last": last})]
     else:
-        # C4: K_total alignments sharded k -> k mod G; this rank's moving clouds are resident in HBM
-        K_total = args.batch * world
+        # C4: K_total alignments sharded k -> k mod G; this rank's moving clouds are resident in HBM.  At N > 1 the job is
+        # fixed (strong scaling); every rank generates the same seeded problems and keeps its shard.
+        K_total = args.total_alignments if world > 1 else args.batch
         mine = D.shard(K_total, world, rank)
-        probs = syn.batch_3d(K=args.batch, n=args.batch_points, seed=4000 + 1000 * rank, shared_fixed_group=1 << 30)
+        probs = syn.batch_3d(K=K_total, n=args.batch_points, seed=4000, shared_fixed_group=1 << 30)
         al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
-        coords = torch.from_numpy(np.concatenate([p["moving"] for p in probs], axis=0)).cuda()
-        normals = torch.from_numpy(np.concatenate([p["moving_normals"] for p in probs], axis=0)).cuda()
-        offsets = np.arange(args.batch + 1, dtype=np.int32) * args.batch_points
-        guesses = np.stack([ident] * args.batch)
-        units_per_step = args.iterations * args.batch
-        alg_bytes_per_launch = args.batch * 48 * args.batch_points
 
-        def step():  # (the batch call returns status, estimate and last statistics of every alignment)
+        def resident(indices):
+            c = torch.from_numpy(np.concatenate([probs[k]["moving"] for k in indices], axis=0)).cuda()
+            n = torch.from_numpy(np.concatenate([probs[k]["moving_normals"] for k in indices], axis=0)).cuda()
+            o = np.arange(len(indices) + 1, dtype=np.int32) * args.batch_points
+            return c, n, o, np.stack([ident] * len(indices))
+
+        coords, normals, offsets, guesses = resident(mine) if mine else (None, None, None, None)
+        units_per_step = args.iterations * len(mine)
+        alg_bytes_per_launch = len(mine) * 48 * args.batch_points
+
+        def step():  # (the batch call returns status, estimate, last statistics and H of every alignment)
+            if not mine:
+                return []
             return al.compute_batch_device(coords.data_ptr(), 12, normals.data_ptr(), 12, offsets, guesses)
 
         def records(res):
@@ -165,7 +188,7 @@ def main():
     res = step()
     for _ in range(args.warmup):
         res = step()
-    D.all_gather_records(records(res), K_total, device=coll_device)  # (warms the process group up, untimed)
+    D.exchange_records(records(res), K_total, device=coll_device, mode=args.exchange)  # (warms the group up, untimed)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -176,8 +199,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    table = D.all_gather_records(records(res), K_total, device=coll_device)
+    table = D.exchange_records(records(res), K_total, device=coll_device, mode=args.exchange)
     assert table.shape[0] == K_total
+    all_success = bool(np.all(table[:, 12] == 0)) and bool(np.all(table[:, 13] == args.iterations))
+    total_units = args.iterations * K_total if args.workload == "c4" else units_per_step * world
     if world > 1:
         t = torch.tensor([dt], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,27 +228,49 @@ def main():
             dist.destroy_process_group()
         return
 
+    # N > 1: the same job on ONE GPU (rank 0 alone, after the timed region), so that the line carries its own reference
+    # for the strong-scaling ratio
+    one_gpu = None
+    if world > 1 and args.workload == "c4" and not args.no_one_gpu_reference:
+        c1, n1, o1, g1 = resident(list(range(K_total)))
+        for _ in range(2):
+            al.compute_batch_device(c1.data_ptr(), 12, n1.data_ptr(), 12, o1, g1)
+        torch.cuda.synchronize()
+        reps = max(2, min(5, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            al.compute_batch_device(c1.data_ptr(), 12, n1.data_ptr(), 12, o1, g1)
+        torch.cuda.synchronize()
+        one_gpu = args.iterations * K_total * reps / (time.perf_counter() - t1)
+
     # HBM-side bytes per launch of the timed kernels: PMC counters cannot be read from inside this process, so the
     # number comes from the committed rocprofv3 --pmc passes of this same command (tools/traffic_from_pmc.py: separate
     # FETCH_SIZE / WRITE_SIZE passes, KiB -> bytes, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes); only
     # reported when the passes were taken at the default problem size of the workload
+    # reported when the passes were taken at this very problem size (C4: the same number of alignments per launch)
     traffic, traffic_source = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_%s.json" % args.workload)
-    default_size = (args.points == 100_000 and args.overlap == 1.0) if args.workload == "c2" else True
+    tname = "traffic_%s.json" % args.workload
+    if args.workload == "c4" and len(mine) != 32:
+        tname = "traffic_c4_%d.json" % len(mine)
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname)
+    default_size = ((args.points == 100_000 and args.overlap == 1.0) if args.workload == "c2" else
+                    (args.batch_points == 50_000) if args.workload == "c4" else True)
     if os.path.exists(tpath) and default_size:
         with open(tpath) as fh:
-            traffic = json.load(fh)["bytes_per_slice_pass"]
-        traffic_source = "profiles/traffic_%s.json" % args.workload
+            tj = json.load(fh)
+        if args.workload != "c4" or tj.get("alignments_per_launch", 32) == len(mine):
+            traffic = tj["bytes_per_slice_pass"]
+            traffic_source = "profiles/" + tname
     out = {
         "metric": "icp_iterations_per_sec",
-        "value": units_per_step * args.steps * world / dt,
+        "value": total_units * args.steps / dt,
         "unit": "iterations/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (args.workload == "c4" and world > 1) else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -233,19 +280,23 @@ def main():
                          (args.points, args.iterations)) if args.workload == "c2" else
                         ("C3: MultiAligner with 2 slices (projective + point-to-plane, projective + reprojection), "
                          "640x480 depth pair, %d iterations per compute()" % args.iterations) if args.workload == "c3" else
-                        ("C4-shard: %d x %d-pt SE(3) point-to-plane alignments per GPU per step, %d iterations" %
-                         (args.batch, args.batch_points, args.iterations)),
+                        ("C4: batched loop closure, %d independent %d-pt SE(3) point-to-plane alignments against one "
+                         "query map, sharded k -> k mod %d (%d per GPU per step), %d iterations each" %
+                         (K_total, args.batch_points, world, len(mine), args.iterations)),
             "points": args.points if args.workload == "c2" else (int(data["moving"].shape[0]) if args.workload == "c3" else args.batch_points),
             "iterations_per_step": args.iterations,
-            "alignments_per_step_per_gpu": args.batch if args.workload == "c4" else 1,
+            "alignments_per_step_per_gpu": len(mine) if args.workload == "c4" else 1,
+            "alignments_total": K_total,
+            "all_success": all_success,
             "last_status": status,
             "last_num_inliers": stats[-1]["num_inliers"] if stats else None,
-            "parallelism": "1 alignment stream per GPU, results all-gathered" if world > 1 else "single GPU",
+            "parallelism": ("alignment k on rank k mod %d, no collective on the data path; result records (X, statistics, "
+                            "H) exchanged once by %s after the timed region" % (world, args.exchange)) if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("k_icp_step<3,true> + k_icp_step_queue<3,true> (one finder+factor pass of the slice)" if args.workload == "c2" else
-                       "k_icp_step<3,true>" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
+            "kernel": ("k_icp_step<3,true> [+ k_icp_step_queue<3,true>] / k_icp_step_fast<3,true> (one finder+factor pass of the slice)" if args.workload == "c2" else
+                       "k_icp_step<3,true> / k_icp_step_fast<3,true> (one finder+factor pass over all alignments of the launch)" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",
@@ -258,9 +309,30 @@ def main():
         },
     }
 
+    if args.workload == "c4":
+        out["alignments_per_sec"] = K_total * args.steps / dt
+        if one_gpu is not None:
+            out["one_gpu_same_job"] = {"value": one_gpu, "unit": "iterations/s",
+                                       "note": "rank 0 alone runs all %d alignments per step (after the timed region)" % K_total}
+            out["strong_scaling_speedup"] = out["value"] / one_gpu
     if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
         # CPU baseline = the oracle (a port: the reference cannot be built here), single
         # thread like the reference, same clouds, same iteration count; bounded sample.
+        # built for THIS host's cores (-march=native) from the committed oracle sources; the
+        # prebuilt x86-64-v3 library is the fallback when there is no compiler on the box
+        import glob
+        import subprocess
+        import tempfile
+
+        flags = "-O3 -march=native -ffp-contract=off -fno-fast-math -fPIC -std=c99"
+        try:
+            native = os.path.join(tempfile.mkdtemp(prefix="oracle_native_"), "liboracle.so")
+            srcs = sorted(glob.glob(os.path.join(ROOT, "oracle", "o_*.c")))
+            subprocess.check_call(["gcc"] + flags.split() + ["-shared", "-o", native] + srcs + ["-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.environ["SRRG2_ORACLE_LIB"] = native
+        except Exception:
+            flags = "-O3 -march=x86-64-v3 -ffp-contract=off (prebuilt: no compiler on this box)"
         from oracle import pyoracle
 
         ref = make_aligner(lambda: pyoracle.OracleAligner(abi.SE3_QUAT_RIGHT), abi, args.iterations)
@@ -288,8 +360,8 @@ def main():
             "unit": "iterations/s",
             "cores": 1,
             "kind": "port",
-            "sample": "%d compute() calls x %d iterations on the full %d-pt C2 pair (%.1f s), oracle/liboracle.so "
-                      "-O3 -march=x86-64-v3 -ffp-contract=off, voxel-grid finder" % (n, args.iterations, args.points, cdt),
+            "sample": "%d compute() calls x %d iterations on the full %d-pt C2 pair (%.1f s), oracle/*.c built here with "
+                      "gcc %s, voxel-grid finder" % (n, args.iterations, args.points, cdt, flags),
             "host_cpus": os.cpu_count(),
             "parity_indices_bit_exact_and_X_within_1e-5": bool(parity),
         }
@@ -297,8 +369,6 @@ def main():
         if not args.no_cpu_all_cores:
             # secondary number: the same single-threaded oracle on every host CPU at once, one independent
             # alignment stream per process; run in a helper process (no HIP state is forked)
-            import subprocess
-
             try:
                 helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "cpu_all_cores.py")
                 r = subprocess.run([sys.executable, helper, "--points", str(args.points), "--iterations", str(args.iterations),

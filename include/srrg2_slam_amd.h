@@ -19,9 +19,13 @@
  *                SE(2) = row-major 3x3 homogeneous float (9 floats).
  *    `moving_in_fixed` maps moving-frame points into the fixed frame
  *    (S/registration/aligners/aligner.h:103-109).
- *  - clouds are borrowed for the duration of the call only: set_fixed/set_moving
- *    ingest (copy + reorder) the data into HBM, so the caller may free or reuse
- *    its buffer on return.  `mem` says where the caller's pointer lives.
+ *  - clouds are borrowed for the duration of the call only: set_fixed/set_moving/
+ *    compute_batch ingest (copy + reorder) the data into HBM and return when they
+ *    have finished reading, so the caller may free or reuse its buffer on return.
+ *    `mem` says where the caller's pointer lives.  SRRG2_MEM_DEVICE buffers are read
+ *    on the handle's own (non-blocking) stream, which is NOT ordered after the
+ *    stream that produced them: the producer must have completed (stream/event/
+ *    device synchronised) before the call.
  *  - all arithmetic is float32 / int32 at the interface.
  */
 #ifndef SRRG2_SLAM_AMD_H
@@ -33,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SRRG2_AMD_ABI_VERSION 1
+#define SRRG2_AMD_ABI_VERSION 2
 #define SRRG2_MAX_SLICES 8
 
 /* ---- enums -------------------------------------------------------------- */
@@ -172,6 +176,13 @@ typedef struct srrg2_batch_result {
   int32_t status;              /* srrg2_status */
   int32_t num_iterations;      /* IterationStats entries produced */
   srrg2_iteration_stats last;  /* iterationStats().back() */
+  int32_t num_correspondences; /* aligner->numCorrespondences() AFTER compute(), i.e. after _pruneCorrespondences when
+                                  keep_only_inlier_correspondences is set (what the accept gates read:
+                                  multi_loop_detector_brute_force_impl.cpp:89, multi_relocalizer_impl.cpp:101) */
+  int32_t reserved_;
+  float   information[36];     /* H = sum w J^T J (+ priors) of the last Gauss-Newton iteration, D x D row-major in the
+                                  first D*D entries (D = 3 | 6): the information of the estimate, e.g. for a closure edge
+                                  or for the all-reduce of SURVEY.md section 8e */
 } srrg2_batch_result;
 
 typedef struct srrg2_aligner_s* srrg2_aligner_h;
@@ -216,6 +227,11 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h h, int slice_idx, const float* coord
 int srrg2_aligner_set_moving(srrg2_aligner_h h, int slice_idx, const float* coords,
                              int coord_stride_bytes, const float* normals,
                              int normal_stride_bytes, int n, int mem);
+
+/* slice->setSensorInRobot() with the transform the slice looks up on EVERY setMovingInFixed
+ * (aligner_slice_processor_impl.cpp:20-36: platform TF frame_id -> base_frame_id): call it whenever the sensor pose
+ * changed; valid between computes, takes effect from the next compute() on.  T: 12 (SE3) / 9 (SE2) floats. */
+int srrg2_aligner_set_sensor_in_robot(srrg2_aligner_h h, int slice_idx, const float* T);
 
 /* prior slices: the measurement the factor gets in setupFactor()
  * (aligner_slice_odometry_prior.cpp:6-14,23-29; aligner_slice_motion_model.hpp:75-79) */
@@ -272,6 +288,24 @@ int srrg2_aligner_compute_batch_correspondences(srrg2_aligner_h h, int K, const 
                                                 int mem, const srrg2_correspondence* correspondences,
                                                 const int32_t* corr_offsets, const float* guesses,
                                                 srrg2_batch_result* results);
+
+/* ---- multi-GPU (no reference counterpart) ------------------------------------------
+ * Loop-closure candidate alignments are independent: alignment k of K lives on rank k mod G, one process per GPU, one
+ * aligner handle per process on its own device; there is no exchange while the alignments run.  The library does not
+ * own a communicator (the host side's torch.distributed / RCCL process group does); these helpers fix the sharding
+ * rule and the wire format of the one exchange at the end, so that every binding produces the same table.
+ *   multi_gpu_init       binds the calling process to device local_rank mod device_count, checks it, returns its ordinal
+ *   shard_count/indices  the alignments of `rank`: k = rank, rank + world, ...
+ *   pack / unpack        srrg2_batch_result <-> SRRG2_RECORD_FLOATS float64 (X 12, status, num_iterations, num_inliers,
+ *                        num_outliers, num_correspondences (after compute), chi_inliers, k, D, H upper triangle 21)
+ *   An all-gather of the packed records = the all-reduce(sum) of a K-row table in which every rank fills its own rows
+ *   and leaves the others zero: both forms are offered by the host side (distributed.py). */
+#define SRRG2_RECORD_FLOATS 41
+int srrg2_multi_gpu_init(int local_rank, int* device_out);
+int srrg2_multi_gpu_shard_count(int K, int world, int rank);
+int srrg2_multi_gpu_shard_indices(int K, int world, int rank, int32_t* indices_out);
+int srrg2_multi_gpu_pack_record(int k, int variable_kind, const srrg2_batch_result* r, double* record_out);
+int srrg2_multi_gpu_unpack_record(const double* record, int variable_kind, int* k_out, srrg2_batch_result* r_out);
 
 /* ---- pose graph: the global Solver of MultiGraphSLAM_ ---------------------- */
 /* MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317): graph->bindFactors();

@@ -132,6 +132,9 @@ public:
   void setCorrespondences(int slice, const std::vector<srrg2_correspondence>& c) {
     check(srrg2_aligner_set_correspondences(_h, slice, c.data(), (int) c.size()));
   }
+  // slice->setSensorInRobot(); the reference re-reads the platform TF on every setMovingInFixed
+  // (aligner_slice_processor_impl.cpp:20-36): call it whenever the sensor pose changed
+  void setSensorInRobot(int slice, const EstimateType& T) { check(srrg2_aligner_set_sensor_in_robot(_h, slice, T.data())); }
   void setPriorMeasurement(int slice, const EstimateType& Z) { check(srrg2_aligner_set_prior_measurement(_h, slice, Z.data())); }
 
   void setMovingInFixed(const EstimateType& X) { check(srrg2_aligner_set_moving_in_fixed(_h, X.data())); }

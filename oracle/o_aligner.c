@@ -499,6 +499,15 @@ int oracle_aligner_set_moving(o_aligner* h, int si, const float* coords, int cs,
   return 0;
 }
 
+/* slice->setSensorInRobot with the transform looked up on every setMovingInFixed, aligner_slice_processor_impl.cpp:20-36 */
+int oracle_aligner_set_sensor_in_robot(o_aligner* h, int si, const float* T) {
+  if (!h || !T || si < 0 || si >= h->nslices) return fail(SRRG2_E_INVALID, "set_sensor_in_robot");
+  for (int i = 0; i < h->tsize; ++i)
+    if (!isfinite(T[i])) return fail(SRRG2_E_INVALID, "set_sensor_in_robot: non-finite transform");
+  memcpy(h->slices[si].cfg.sensor_in_robot, T, sizeof(float) * h->tsize);
+  return 0;
+}
+
 int oracle_aligner_set_prior_measurement(o_aligner* h, int si, const float* T) {
   if (!h || !T || si < 0 || si >= h->nslices) return fail(SRRG2_E_INVALID, "set_prior_measurement");
   o_slice* s = &h->slices[si];
@@ -1295,6 +1304,11 @@ int oracle_aligner_compute_batch_correspondences(o_aligner* h, int K, const floa
     results[k].status         = st;
     results[k].num_iterations = h->nstats;
     if (h->nstats) results[k].last = h->stats[h->nstats - 1];
+    int nc = 0;
+    oracle_aligner_num_correspondences(h, &nc); /* after _pruneCorrespondences */
+    results[k].num_correspondences = nc;
+    if (h->nstats)
+      for (int i = 0; i < h->dof * h->dof; ++i) results[k].information[i] = (float) h->last_H[i];
   }
   return 0;
 }
@@ -1318,6 +1332,11 @@ int oracle_aligner_compute_batch(o_aligner* h, int K, const float* coords, int c
     results[k].status         = st;
     results[k].num_iterations = h->nstats;
     if (h->nstats) results[k].last = h->stats[h->nstats - 1];
+    int nc = 0;
+    oracle_aligner_num_correspondences(h, &nc); /* after _pruneCorrespondences */
+    results[k].num_correspondences = nc;
+    if (h->nstats)
+      for (int i = 0; i < h->dof * h->dof; ++i) results[k].information[i] = (float) h->last_H[i];
   }
   return 0;
 }

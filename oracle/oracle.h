@@ -76,6 +76,7 @@ int oracle_aligner_set_fixed(o_aligner* h, int slice_idx, const float* coords, i
                              const float* normals, int normal_stride_bytes, int n, int mem);
 int oracle_aligner_set_moving(o_aligner* h, int slice_idx, const float* coords, int coord_stride_bytes,
                               const float* normals, int normal_stride_bytes, int n, int mem);
+int oracle_aligner_set_sensor_in_robot(o_aligner* h, int slice_idx, const float* T);
 int oracle_aligner_set_prior_measurement(o_aligner* h, int slice_idx, const float* T);
 int oracle_aligner_set_moving_in_fixed(o_aligner* h, const float* T);
 int oracle_aligner_get_moving_in_fixed(o_aligner* h, float* T_out);

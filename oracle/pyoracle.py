@@ -23,7 +23,9 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        # SRRG2_ORACLE_LIB: another build of the same sources (bench.py's cpu_baseline leg compiles one with
+        # -march=native on the box it times)
+        path = os.environ.get("SRRG2_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)

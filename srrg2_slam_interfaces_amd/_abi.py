@@ -5,7 +5,7 @@ Shared by the product binding (``_capi.py``) and by the test-side oracle binding
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SLICES = 8
 
 # enum srrg2_variable_kind  (S/registration/aligners/multi_aligner.h:152-158)
@@ -90,6 +90,9 @@ class BatchResult(C.Structure):
         ("status", C.c_int32),
         ("num_iterations", C.c_int32),
         ("last", IterationStats),
+        ("num_correspondences", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("information", C.c_float * 36),
     ]
 
 

@@ -128,6 +128,13 @@ class MultiAligner:
                                       C.cast(normals_ptr, C.POINTER(C.c_float)) if normals_ptr else None,
                                       C.c_int(normal_stride), C.c_int(n), C.c_int(abi.MEM_DEVICE)))
 
+    def set_sensor_in_robot(self, slice_idx, T):
+        """slice->setSensorInRobot with the transform looked up on every setMovingInFixed
+        (aligner_slice_processor_impl.cpp:20-36); takes effect from the next compute() on."""
+        T = _as_f32(T).reshape(-1)
+        assert T.size == self.tsize
+        self._check(self._b.fn("set_sensor_in_robot")(self._h, C.c_int(slice_idx), _fptr(T)))
+
     def set_prior_measurement(self, slice_idx, T):
         T = _as_f32(T).reshape(-1)
         assert T.size == self.tsize
@@ -259,6 +266,7 @@ class MultiAligner:
 
     def _unpack_batch(self, res, K):
         out = []
+        D = 3 if self.dim == 2 else 6
         for k in range(K):
             T = np.array(res[k].moving_in_fixed[:self.tsize], dtype=np.float32)
             out.append({
@@ -266,6 +274,9 @@ class MultiAligner:
                 "status": res[k].status,
                 "num_iterations": res[k].num_iterations,
                 "last": res[k].last.as_dict(),
+                # numCorrespondences() after compute() (after pruning) and H of the last Gauss-Newton iteration
+                "num_correspondences": res[k].num_correspondences,
+                "information": np.array(res[k].information[:D * D], dtype=np.float32).reshape(D, D),
             })
         return out
 

@@ -398,10 +398,8 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     if (srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, bits, s->moving.p,
                                      normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
       HIP_TRY(hipGetLastError());
-      if (mem == SRRG2_MEM_HOST)
-        HIP_TRY(hipStreamSynchronize(a->stream));  // caller may reuse its buffer on return
-      else
-        s->ms_pending = true;
+      // the caller may reuse its buffer on return (host or device memory: the ingest has finished reading it)
+      HIP_TRY(hipStreamSynchronize(a->stream));
       s->nm_total           = n;
       s->has_moving         = true;
       s->moving_has_normals = normals != nullptr;
@@ -435,7 +433,7 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
                          s->ms_bb.p, s->ms_counts.p, s->ms_cursor.p, s->ms_sums.p, s->ms_sums.p + s->ms_sums.cap - 1,
                          s->moving.p, normals ? s->moving_nrm.p : nullptr, a->stream);
   HIP_TRY(hipGetLastError());
-  if (mem == SRRG2_MEM_HOST) HIP_TRY(hipStreamSynchronize(a->stream));  // caller may reuse its buffer on return
+  HIP_TRY(hipStreamSynchronize(a->stream));  // the caller may reuse its buffer on return (host or device memory)
   s->nm_total           = n;
   s->has_moving         = true;
   s->moving_has_normals = normals != nullptr;
@@ -742,7 +740,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             while (mirror[2 * k] == 0x7f7f7f7f || mirror[2 * k + 1] == 0x7f7f7f7f) {  // not reported yet
               // (a problem that stopped before the probe iteration never reports: once the stream has drained, give up
               // and keep the queue)
-              if ((++spins & 1023) == 0 && hipStreamQuery(a->stream) == hipSuccess) break;
+              if ((++spins & 1023) == 0 && hipStreamQuery(a->stream) != hipErrorNotReady) break;  // drained or failed
             }
             const int near = mirror[2 * k], far = mirror[2 * k + 1];
             if (near == 0x7f7f7f7f || far > 32 || near > std::max(1024, all[(size_t) si * K + k].nm / 64)) small = false;
@@ -1136,6 +1134,17 @@ int srrg2_aligner_set_moving(srrg2_aligner_h a, int si, const float* coords, int
   return upload_moving(a, si, coords, cs, normals, ns, offsets, 1, mem);
 }
 
+int srrg2_aligner_set_sensor_in_robot(srrg2_aligner_h a, int si, const float* T) {
+  int rc = check_slice(a, si, "set_sensor_in_robot");
+  if (rc) return rc;
+  if (!T) return fail(SRRG2_E_INVALID, "set_sensor_in_robot: null transform");
+  for (int i = 0; i < a->tsize; ++i)
+    if (!std::isfinite(T[i])) return fail(SRRG2_E_INVALID, "set_sensor_in_robot: non-finite transform");
+  // (run_compute inverts it into robot_in_sensor for every compute(): aligner_slice_processor_impl.cpp:24-35)
+  std::memcpy(a->slices[si]->cfg.sensor_in_robot, T, sizeof(float) * a->tsize);
+  return 0;
+}
+
 int srrg2_aligner_set_prior_measurement(srrg2_aligner_h a, int si, const float* T) {
   int rc = check_slice(a, si, "set_prior_measurement");
   if (rc) return rc;
@@ -1361,6 +1370,11 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
       break;
     }
   if (cue != 0) return fail(SRRG2_E_UNSUPPORTED, "compute_batch: slice 0 must be the cue slice");
+  if (K > 65535) return fail(SRRG2_E_INVALID, "compute_batch: at most 65535 alignments per call (grid.y)");
+  if (offsets[0] < 0) return fail(SRRG2_E_INVALID, "compute_batch: negative offset");
+  for (int k = 0; k < K; ++k)
+    if (offsets[k + 1] < offsets[k]) return fail(SRRG2_E_INVALID, "compute_batch: offsets must not decrease");
+  if (offsets[K] > offsets[0] && !coords) return fail(SRRG2_E_INVALID, "compute_batch: null cloud");
   int rc;
   if ((rc = set_device(a))) return rc;
   if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem))) return rc;
@@ -1373,7 +1387,16 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
     results[k].status         = o.status;
     results[k].num_iterations = o.nstats;
     if (o.nstats > 0) results[k].last = a->stats_host[(size_t) k * slots + std::min(o.nstats, slots) - 1];
+    int tot = 0;  // multi_aligner_impl.cpp:275-285, after pruning (k_icp_finalize)
+    for (size_t si = 0; si < a->slices.size(); ++si) {
+      const int c = a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR ? 1 : o.ncorr[si];
+      if (c >= 0) tot += c;
+    }
+    results[k].num_correspondences = tot;
+    std::memcpy(results[k].information, o.H, sizeof(o.H));
   }
+  // the handle's moving cloud is now the concatenation of the batch: a later compute() must bind its own
+  if (K > 1) a->slices[0]->has_moving = false;
   return 0;
 }
 
@@ -1406,6 +1429,72 @@ int srrg2_aligner_compute_batch_correspondences(srrg2_aligner_h a, int K, const 
   s->h_gcorr_off.resize((size_t) K + 1);
   for (int k = 0; k <= K; ++k) s->h_gcorr_off[(size_t) k] = corr_offsets[k] - corr_offsets[0];
   return srrg2_aligner_compute_batch(a, K, coords, cs, normals, ns, offsets, mem, guesses, results);
+}
+
+int srrg2_multi_gpu_init(int local_rank, int* device_out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(SRRG2_E_NO_DEVICE, "multi_gpu_init: no HIP device visible");
+  if (local_rank < 0) return fail(SRRG2_E_INVALID, "multi_gpu_init: negative local rank");
+  const int dev = local_rank % n;
+  HIP_TRY(hipSetDevice(dev));
+  HIP_TRY(hipFree(nullptr));  // (creates the context: a broken device fails here, not in the first kernel)
+  if (device_out) *device_out = dev;
+  return 0;
+}
+
+int srrg2_multi_gpu_shard_count(int K, int world, int rank) {
+  if (K < 0 || world < 1 || rank < 0 || rank >= world) return fail(SRRG2_E_INVALID, "shard_count: bad arguments");
+  return K > rank ? (K - rank + world - 1) / world : 0;
+}
+
+int srrg2_multi_gpu_shard_indices(int K, int world, int rank, int32_t* out) {
+  const int n = srrg2_multi_gpu_shard_count(K, world, rank);
+  if (n < 0) return n;
+  if (n > 0 && !out) return fail(SRRG2_E_INVALID, "shard_indices: null output");
+  for (int i = 0; i < n; ++i) out[i] = rank + i * world;
+  return n;
+}
+
+int srrg2_multi_gpu_pack_record(int k, int variable_kind, const srrg2_batch_result* r, double* rec) {
+  if (!r || !rec || variable_kind < 0 || variable_kind > 2) return fail(SRRG2_E_INVALID, "pack_record: bad arguments");
+  const int tsize = variable_kind == SRRG2_SE2_RIGHT ? 9 : 12, D = variable_kind == SRRG2_SE2_RIGHT ? 3 : 6;
+  for (int i = 0; i < SRRG2_RECORD_FLOATS; ++i) rec[i] = 0.0;
+  for (int i = 0; i < tsize; ++i) rec[i] = (double) r->moving_in_fixed[i];
+  rec[12] = r->status;
+  rec[13] = r->num_iterations;
+  rec[14] = r->last.num_inliers;
+  rec[15] = r->last.num_outliers;
+  rec[16] = r->num_correspondences;
+  rec[17] = (double) r->last.chi_inliers;
+  rec[18] = k;
+  rec[19] = D;
+  int t   = 20;
+  for (int a_ = 0; a_ < D; ++a_)
+    for (int b_ = a_; b_ < D; ++b_) rec[t++] = (double) r->information[a_ * D + b_];
+  return 0;
+}
+
+int srrg2_multi_gpu_unpack_record(const double* rec, int variable_kind, int* k_out, srrg2_batch_result* r) {
+  if (!r || !rec || variable_kind < 0 || variable_kind > 2) return fail(SRRG2_E_INVALID, "unpack_record: bad arguments");
+  const int tsize = variable_kind == SRRG2_SE2_RIGHT ? 9 : 12, D = variable_kind == SRRG2_SE2_RIGHT ? 3 : 6;
+  std::memset(r, 0, sizeof(*r));
+  for (int i = 0; i < tsize; ++i) r->moving_in_fixed[i] = (float) rec[i];
+  r->status                   = (int) rec[12];
+  r->num_iterations           = (int) rec[13];
+  r->last.num_inliers         = (int) rec[14];
+  r->last.num_outliers        = (int) rec[15];
+  r->num_correspondences      = (int) rec[16];
+  r->last.num_correspondences = (int) rec[16];
+  r->last.chi_inliers         = (float) rec[17];
+  if (k_out) *k_out = (int) rec[18];
+  int t = 20;
+  for (int a_ = 0; a_ < D; ++a_)
+    for (int b_ = a_; b_ < D; ++b_) {
+      r->information[a_ * D + b_] = (float) rec[t];
+      r->information[b_ * D + a_] = (float) rec[t++];
+    }
+  return 0;
 }
 
 int srrg2_aligner_profile_enable(srrg2_aligner_h a, int enable) {

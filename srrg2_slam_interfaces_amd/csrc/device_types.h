@@ -120,6 +120,7 @@ struct ProblemOut {
   int status;
   int nstats;
   int ncorr[SRRG2_MAX_SLICES];
+  float H[36];  // H of the last Gauss-Newton iteration, D x D row-major
   int seq;  // CtlParams::seq of the compute() that wrote this record: written last, behind a system-scope fence
 };
 

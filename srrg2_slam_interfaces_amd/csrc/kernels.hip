@@ -2314,6 +2314,10 @@ __device__ void icp_finalize_block(const CtlParams& C, ProblemState* st, const s
   o->status = st->status;
   o->nstats = st->nstats;
   for (int s = 0; s < SRRG2_MAX_SLICES; ++s) o->ncorr[s] = st->ncorr[s];
+  {
+    const int DD = C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 36;
+    for (int i = 0; i < 36; ++i) o->H[i] = (i < DD && st->nstats > 0) ? (float) st->last_H[i] : 0.f;
+  }
   __threadfence_system();
   *reinterpret_cast<volatile int*>(&o->seq) = C.seq;  // the host polls this word instead of waiting for the stream
 }

@@ -3,13 +3,20 @@
 Loop-closure candidate alignments are mutually independent (the aligner state is fully reset per compute():
 S/registration/aligners/multi_aligner_impl.cpp:58-59,66,102; caller loop
 S/registration/loop_detector/multi_loop_detector_brute_force_impl.cpp:64-133), so alignment k goes to rank
-k mod G with NO collective on the data path.  The only exchange is ONE all-gather of the fixed-size result
-records at the end so that every rank can apply the accept gates (:94-112).  Backend: torch.distributed
-("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+k mod G with NO collective on the data path.  The only exchange is ONE collective over the fixed-size result
+records at the end so that every rank can apply the accept gates (:94-112) and emit closures with their
+information matrix.  Two equivalent forms (same table on every rank, bit for bit):
+  * all-gather of the ranks' own rows;
+  * all-reduce(sum) of a K-row table in which every rank fills its own rows and leaves the others zero -- the
+    "all-reduce of the final Hessian" of BASELINE.json's north_star: the rows carry H (upper triangle) next to X and the
+    statistics, x + 0 = x is exact, so the sum reproduces every row unchanged.
+Backend: torch.distributed ("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  The record layout is the
+C ABI's (srrg2_multi_gpu_pack_record, include/srrg2_slam_amd.h); tests/test_multi_gpu_gloo.py checks both agree.
 """
 import numpy as np
 
-RECORD_FLOATS = 20  # X (12) + status, num_iterations, num_inliers, num_outliers, num_correspondences, chi_inliers, k, pad
+RECORD_FLOATS = 41  # X 12 | status, num_iterations, num_inliers, num_outliers, num_correspondences, chi_inliers, k, D | H upper 21
+_K_SLOT = 18
 
 
 def shard(K, world, rank):
@@ -21,30 +28,58 @@ def pack_record(k, result):
     r = np.zeros(RECORD_FLOATS, dtype=np.float64)
     X = np.asarray(result["moving_in_fixed"], dtype=np.float64).reshape(-1)
     r[:X.size] = X
-    last = result["last"]
-    r[12:19] = [result["status"], result["num_iterations"], last["num_inliers"], last["num_outliers"],
-                last["num_correspondences"], last["chi_inliers"], k]
+    last = result["last"] or {"num_inliers": 0, "num_outliers": 0, "num_correspondences": 0, "chi_inliers": 0.0}
+    D = 3 if X.size == 9 else 6
+    r[12:20] = [result["status"], result["num_iterations"], last["num_inliers"], last["num_outliers"],
+                result.get("num_correspondences", last["num_correspondences"]), last["chi_inliers"], k, D]
+    H = result.get("information")
+    if H is not None:
+        H = np.asarray(H, dtype=np.float64).reshape(D, D)
+        r[20:20 + D * (D + 1) // 2] = H[np.triu_indices(D)]
     return r
 
 
 def unpack_record(r, tsize=12):
     shape = (3, 3) if tsize == 9 else (3, 4)
-    return {"k": int(r[18]), "moving_in_fixed": r[:tsize].astype(np.float32).reshape(shape), "status": int(r[12]),
+    D = 3 if tsize == 9 else 6
+    H = np.zeros((D, D), np.float32)
+    iu = np.triu_indices(D)
+    H[iu] = r[20:20 + len(iu[0])].astype(np.float32)
+    H = H + np.triu(H, 1).T
+    return {"k": int(r[_K_SLOT]), "moving_in_fixed": r[:tsize].astype(np.float32).reshape(shape), "status": int(r[12]),
             "num_iterations": int(r[13]), "num_inliers": int(r[14]), "num_outliers": int(r[15]),
-            "num_correspondences": int(r[16]), "chi_inliers": float(np.float32(r[17]))}
+            "num_correspondences": int(r[16]), "chi_inliers": float(np.float32(r[17])), "information": H}
+
+
+def _local_table(local_records, K):
+    table = np.zeros((K, RECORD_FLOATS))
+    for r in local_records:
+        table[int(r[_K_SLOT])] = r
+    return table
+
+
+def all_reduce_records(local_records, K, device=None):
+    """The (K, RECORD_FLOATS) table on every rank by ONE all-reduce(sum): every rank contributes its own rows, zeros
+    elsewhere (K x 328 B: 84 kB at K = 256, latency bound on any link)."""
+    import torch
+    import torch.distributed as dist
+
+    table = _local_table(local_records, K)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return table
+    t = torch.from_numpy(table).to(device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
 
 
 def all_gather_records(local_records, K, device=None):
     """local_records: list of pack_record() rows of this rank.  Returns the (K, RECORD_FLOATS) table in
-    alignment order on every rank.  One collective, ~160 B per alignment (latency bound)."""
+    alignment order on every rank.  One collective, 328 B per alignment (latency bound)."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        table = np.zeros((K, RECORD_FLOATS))
-        for r in local_records:
-            table[int(r[18])] = r
-        return table
+        return _local_table(local_records, K)
     world = dist.get_world_size()
     per_rank = (K + world - 1) // world
     buf = torch.full((per_rank, RECORD_FLOATS), -1.0, dtype=torch.float64, device=device)
@@ -55,6 +90,10 @@ def all_gather_records(local_records, K, device=None):
     table = np.zeros((K, RECORD_FLOATS))
     for t in out:
         for row in t.cpu().numpy():
-            if row[18] >= 0:
-                table[int(row[18])] = row
+            if row[_K_SLOT] >= 0:
+                table[int(row[_K_SLOT])] = row
     return table
+
+
+def exchange_records(local_records, K, device=None, mode="all_reduce"):
+    return (all_reduce_records if mode == "all_reduce" else all_gather_records)(local_records, K, device=device)

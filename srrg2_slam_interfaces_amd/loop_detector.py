@@ -55,7 +55,8 @@ class MultiLoopDetectorBruteForce:
                 self.drops.append((h.local_map_id, "ALIGNER DROP [code: %d]" % r["status"]))
                 continue
             last = r["last"]
-            num_correspondences = last["num_correspondences"]
+            # aligner->numCorrespondences() AFTER compute(), i.e. after _pruneCorrespondences (:89)
+            num_correspondences = r.get("num_correspondences", last["num_correspondences"])
             num_inliers = last["num_inliers"]
             chi_inliers = np.float32(last["chi_inliers"]) / np.float32(num_inliers)  # :91
             if num_inliers < self.relocalize_min_inliers:  # :94-97
@@ -219,7 +220,8 @@ class MultiRelocalizer:
                 self.drops.append((c["target"], "ALIGNER DROP [code: %d]" % r["status"]))
                 continue
             last = r["last"]
-            num_inliers, num_correspondences = last["num_inliers"], last["num_correspondences"]
+            # numCorrespondences() after compute(), i.e. after pruning (multi_relocalizer_impl.cpp:101)
+            num_inliers, num_correspondences = last["num_inliers"], r.get("num_correspondences", last["num_correspondences"])
             chi_inliers = np.float32(last["chi_inliers"]) / np.float32(num_inliers)  # :102
             if num_inliers < self.relocalize_min_inliers:  # :108-111
                 self.drops.append((c["target"], "NUM_INLIERS DROP"))

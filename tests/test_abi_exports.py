@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
-    assert lib.srrg2_amd_abi_version() == 1
+    assert lib.srrg2_amd_abi_version() == 2
 
 
 def test_oracle_mirrors_the_call_surface(oracle):
@@ -42,7 +42,7 @@ def test_pod_layouts_match_ctypes():
     assert C.sizeof(abi.AlignerParams) == 16
     assert C.sizeof(abi.TerminationParams) == 20
     assert C.sizeof(abi.SliceConfig) == 8 * 4 + 12 * 4 + 9 * 4 + 4 * 4 + 6 * 4 + 4
-    assert C.sizeof(abi.BatchResult) == 48 + 8 + 32
+    assert C.sizeof(abi.BatchResult) == 48 + 8 + 32 + 8 + 144
 
 
 def test_no_cpu_fallback_without_device():

@@ -235,6 +235,29 @@ def test_c3_full_resolution(oracle, product):
     assert a_gpu.iteration_stats()[-1]["num_correspondences"] > 250000
 
 
+def test_c3_full_resolution_two_slices(oracle, product):
+    """BASELINE config C3 exactly as benchmarked (bench.py --workload c3): MultiAligner with 2 slices -- projective +
+    point-to-plane, projective + reprojection -- on the 640 x 480 pair, both slices' passes in one launch pair
+    (k_proj_zbuf_pack / k_icp_step_proj_pack).  Against the oracle, bit for bit, at the benchmark's own size."""
+    from helpers import projective_config
+
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.rgbd_pair(seed=3000)
+    runs = []
+    for al in _pair(oracle, product, kind):
+        for sk in (abi.SLICE_P2PLANE, abi.SLICE_REPROJECTION):
+            si = al.add_slice(projective_config(kind, sk, d, gate=0.05))
+            al.set_fixed(si, d["fixed"], d["fixed_normals"])
+            al.set_moving(si, d["moving"], d["moving_normals"])
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+        runs.append(al)
+    assert runs[0].status() == abi.SUCCESS
+    assert_same_run(runs[0], runs[1], slices=(0, 1))
+    assert len(runs[1].iteration_stats()) == 10
+    assert runs[1].iteration_stats()[-1]["num_correspondences"] > 400000  # both slices count
+
+
 @pytest.mark.parametrize("offset", [0.0, 900.0, -7000.0])
 @pytest.mark.parametrize("cell", [0.0, 0.05, 0.4])
 def test_ball_trimmed_search_is_exact(oracle, product, offset, cell):

@@ -1,6 +1,9 @@
-"""CPU, world_size 2, gloo: the N>1 path of the batched loop-closure alignment -- sharding k -> k mod G and the
-single all-gather of result records -- must reproduce the single-process results exactly.  The per-rank compute
-uses the oracle backend here (no GPU); bench.py runs the same module with the HIP backend over RCCL."""
+"""world_size 2, gloo: the N>1 path of the batched loop-closure alignment -- sharding k -> k mod G and the ONE exchange of
+result records at the end (all-gather, or the all-reduce(sum) form of BASELINE.json's north_star) -- must reproduce the
+single-process results exactly.  CPU legs shard the ORACLE backend (no GPU here); the -m gpu legs shard the PRODUCT
+backend (two ranks on device 0, gloo for the collective: RCCL refuses two ranks on one GPU; the 8-GPU RCCL run is the
+driver's) and compare the table's bytes with the single-process product run."""
+import ctypes as C
 import os
 import socket
 import sys
@@ -24,81 +27,155 @@ def _free_port():
     return p
 
 
-def _run_alignments(indices, K):
+def _run_alignments(indices, K, backend):
     from helpers import cue_config
-    from oracle import pyoracle
     from srrg2_slam_interfaces_amd import _abi as abi
     from srrg2_slam_interfaces_amd import distributed as D
     from srrg2_slam_interfaces_amd import synthetic as syn
 
     probs = syn.batch_3d(K=K, n=1500, seed=4300)
-    al = pyoracle.OracleAligner(abi.SE3_QUAT_RIGHT)
+    if backend == "oracle":
+        from oracle import pyoracle
+
+        al = pyoracle.OracleAligner(abi.SE3_QUAT_RIGHT)
+    else:
+        import srrg2_slam_interfaces_amd as pkg
+
+        al = pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=0)
     si = al.add_slice(cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.35))
     al.set_fixed(si, probs[0]["fixed"], probs[0]["fixed_normals"])
     mine = [probs[k] for k in indices]
+    if not mine:
+        return []
     res = al.compute_batch([p["moving"] for p in mine], [syn.identity(3)] * len(mine),
                            [p["moving_normals"] for p in mine])
     return [D.pack_record(k, r) for k, r in zip(indices, res)]
 
 
-def _worker(rank, world, port, K, out_dir):
+def _worker(rank, world, port, K, out_dir, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from srrg2_slam_interfaces_amd import distributed as D
 
-    recs = _run_alignments(D.shard(K, world, rank), K)
-    table = D.all_gather_records(recs, K)
-    np.save(os.path.join(out_dir, "table_%d.npy" % rank), table)
+    recs = _run_alignments(D.shard(K, world, rank), K, backend)
+    np.save(os.path.join(out_dir, "gather_%d.npy" % rank), D.all_gather_records(recs, K))
+    np.save(os.path.join(out_dir, "reduce_%d.npy" % rank), D.all_reduce_records(recs, K))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_shard_covers_every_alignment_once():
+    from srrg2_slam_interfaces_amd import _capi
     from srrg2_slam_interfaces_amd import distributed as D
 
+    lib = _capi.lib()
     for K in (0, 1, 7, 256):
         for world in (1, 2, 8):
             seen = sorted(k for r in range(world) for k in D.shard(K, world, r))
             assert seen == list(range(K))
+            for r in range(world):  # the C ABI's rule is the same rule
+                n = lib.srrg2_multi_gpu_shard_count(K, world, r)
+                buf = (C.c_int32 * max(n, 1))()
+                assert lib.srrg2_multi_gpu_shard_indices(K, world, r, buf) == n
+                assert list(buf[:n]) == D.shard(K, world, r)
     assert D.shard(256, 8, 3)[:3] == [3, 11, 19] and len(D.shard(256, 8, 3)) == 32
+    assert lib.srrg2_multi_gpu_shard_count(5, 0, 0) < 0
+
+
+def test_record_layout_is_the_c_abis():
+    """distributed.pack_record (host side) and srrg2_multi_gpu_pack_record / unpack_record (C ABI) agree"""
+    from srrg2_slam_interfaces_amd import _abi as abi
+    from srrg2_slam_interfaces_amd import _capi
+    from srrg2_slam_interfaces_amd import distributed as D
+
+    lib = _capi.lib()
+    assert D.RECORD_FLOATS == 41
+    rng = np.random.default_rng(7)
+    for kind, tsize, Dd in ((abi.SE3_QUAT_RIGHT, 12, 6), (abi.SE2_RIGHT, 9, 3)):
+        r = abi.BatchResult()
+        for i in range(tsize):
+            r.moving_in_fixed[i] = float(np.float32(rng.normal()))
+        r.status, r.num_iterations, r.num_correspondences = 0, 10, 4321
+        r.last.num_inliers, r.last.num_outliers, r.last.chi_inliers = 4000, 321, 0.125
+        A = rng.normal(size=(Dd, Dd)).astype(np.float32)
+        H = (A @ A.T).astype(np.float32)
+        H = np.triu(H) + np.triu(H, 1).T
+        for i, v in enumerate(H.reshape(-1)):
+            r.information[i] = float(v)
+        rec = (C.c_double * 41)()
+        assert lib.srrg2_multi_gpu_pack_record(17, kind, C.byref(r), rec) == 0
+        shape = (3, 3) if tsize == 9 else (3, 4)
+        py = D.pack_record(17, {"moving_in_fixed": np.array(r.moving_in_fixed[:tsize], np.float32).reshape(shape),
+                                "status": 0, "num_iterations": 10, "num_correspondences": 4321, "information": H,
+                                "last": {"num_inliers": 4000, "num_outliers": 321, "num_correspondences": 9999,
+                                         "chi_inliers": 0.125}})
+        assert np.array_equal(np.array(rec[:]), py)
+        back, k = abi.BatchResult(), C.c_int(-1)
+        assert lib.srrg2_multi_gpu_unpack_record(rec, kind, C.byref(k), C.byref(back)) == 0
+        assert k.value == 17 and back.num_correspondences == 4321 and back.last.num_inliers == 4000
+        assert np.array_equal(np.array(back.information[:Dd * Dd], np.float32).reshape(Dd, Dd), H)
+        u = D.unpack_record(py, tsize)
+        assert u["k"] == 17 and np.array_equal(u["information"], H)
+
+
+def _check_tables(tmp_path, K, backend):
+    from srrg2_slam_interfaces_amd import distributed as D
+
+    single = D.all_gather_records(_run_alignments(list(range(K)), K, backend), K)
+    for form in ("gather", "reduce"):
+        t0 = np.load(tmp_path / ("%s_0.npy" % form))
+        t1 = np.load(tmp_path / ("%s_1.npy" % form))
+        assert t0.tobytes() == t1.tobytes()      # every rank holds the full table
+        assert t0.tobytes() == single.tobytes()  # and it equals the unsharded run bit for bit (X, statistics, H)
+    t0 = np.load(tmp_path / "reduce_0.npy")
+    for k in range(K):
+        r = D.unpack_record(t0[k])
+        assert r["k"] == k and r["status"] == 0 and r["num_iterations"] == 10
+        H = r["information"]
+        assert np.all(np.linalg.eigvalsh(H.astype(np.float64)) > 0)  # information of a converged alignment: SPD
+    return single
 
 
 def test_two_ranks_gloo_equal_single_process(tmp_path):
     K, world = 5, 2
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, K, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), K, str(tmp_path), "oracle"), nprocs=world, join=True)
+    _check_tables(tmp_path, K, "oracle")
+
+
+@pytest.mark.gpu
+def test_two_ranks_shard_the_product_backend(tmp_path):
+    """the same check with the HIP library doing the alignments in both ranks (device 0), and against the oracle's table"""
+    K, world = 6, 2
+    mp.spawn(_worker, args=(world, _free_port(), K, str(tmp_path), "product"), nprocs=world, join=True)
+    table = _check_tables(tmp_path, K, "product")
     from srrg2_slam_interfaces_amd import distributed as D
 
-    single = D.all_gather_records(_run_alignments(list(range(K)), K), K)
-    t0 = np.load(tmp_path / "table_0.npy")
-    t1 = np.load(tmp_path / "table_1.npy")
-    assert np.array_equal(t0, t1)          # every rank holds the full table
-    assert np.array_equal(t0, single)      # and it equals the unsharded run bit for bit
-    for k in range(K):
-        r = D.unpack_record(t0[k])
-        assert r["k"] == k and r["status"] == 0 and r["num_iterations"] == 10
+    ref = D.all_gather_records(_run_alignments(list(range(K)), K, "oracle"), K)
+    assert table.tobytes() == ref.tobytes()
 
 
 @pytest.mark.gpu
 def test_bench_multi_rank_control_flow_on_one_gpu():
-    """bench.py under torch.distributed.run with 2 ranks (barriers, max-over-ranks timing, the all-gather of the result
-    records, rank 0 prints the one JSON line).  A one-GPU box cannot run two RCCL ranks, so the test hook
-    SRRG2_BENCH_SHARE_GPU=1 puts both ranks on device 0 and the process group on gloo; the 8-GPU run is the driver's."""
+    """bench.py under torch.distributed.run with 2 ranks (barriers, max-over-ranks timing, the exchange of the result
+    records, rank 0 prints the one JSON line): N > 1 measures BASELINE's second metric, the 256-alignment batched
+    loop-closure job, strong scaling.  A one-GPU box cannot run two RCCL ranks, so the test hook SRRG2_BENCH_SHARE_GPU=1
+    puts both ranks on device 0 and the process group on gloo; the 8-GPU run is the driver's."""
     import json
-    import os
     import subprocess
-    import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SRRG2_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--points", "20000"],
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--total-alignments", "16",
+                          "--batch-points", "20000"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0 and rec["config"]["last_status"] == 0
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["alignments_total"] == 16 and rec["config"]["alignments_per_step_per_gpu"] == 8
+    assert rec["alignments_per_sec"] > 0 and rec["config"]["all_success"] is True
     assert "cpu_baseline" not in rec  # rank 0 at N = 1 only
