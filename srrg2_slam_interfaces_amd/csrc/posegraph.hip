@@ -1,4 +1,4 @@
-// posegraph.hip -- block-sparse Gauss-Newton + block-Jacobi PCG for the pose graph.
+// posegraph.hip -- block-sparse Gauss-Newton + multigrid-preconditioned CG for the pose graph.
 //
 // Replaces global_solver->compute() as called from MultiGraphSLAM_::optimize()
 // (S/system/multi_graph_slam_impl.cpp:300-317) on the graph built at :52-90 / :241-293: only pose variables
@@ -8,15 +8,18 @@
 //   k_pg_edges<D>     one thread per factor: e, Ji, Jj, Omega products -> Ho[e] = Ji^T W Jj and the factor's
 //                     contributions to H_ii, H_jj, b_i, b_j, chi (stored per factor: no atomics)
 //   k_pg_vertices<D>  one thread per variable: gathers its factors' contributions in incidence order
-//                     (deterministic), adds damping, handles Fixed variables, inverts the 6x6 block (preconditioner)
-//   k_pg_pcg_init / k_pg_spmv / k_pg_update_xr / k_pg_update_p   the PCG loop; scalars (alpha, beta, convergence)
-//                     are recomputed by every block from the per-block partial dot products, so the loop needs no
-//                     host round trip and no atomics
+//                     (deterministic), adds damping, handles Fixed variables, inverts the 6x6 block (level-0 smoother)
+//   k_mg_*            the aggregation-multigrid preconditioner (see "Linear solver" below)
+//   k_pg_pcg_init / k_pg_spmv / k_pg_update_xr / k_pg_converged / k_pg_dot_rz / k_pg_update_p   the PCG loop; scalars
+//                     (alpha, beta, convergence) are recomputed by every block from the per-block partial dot
+//                     products, so the loop needs no host round trip and no atomics
 //   k_pg_apply<D>     X_v <- X_v [+] dx_v
 //
 // float64 throughout (the float32 poses are the only float32 state).  Results agree with the CPU oracle to PCG
 // tolerance, not bit for bit (dot-product order differs); tests bound the pose difference.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -220,28 +223,457 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
   for (int k = 0; k < D; ++k) b[(size_t) v * D + k] = bv[k];
 }
 
-// Vertex-major copy of the off-diagonal blocks for the PCG loop: incidence q of a variable gets the D x D block that
-// multiplies p[other] (H_ij, or its transpose for the `to` end), so k_pg_spmv streams contiguous memory instead of
-// gathering 288-byte blocks by factor index and reading columns with a 48-byte stride.  Written once per
-// linearisation, read once per PCG iteration.  other = -1: the term is skipped (disabled factor, fixed neighbour).
+// =====================================================================================================================
+// Linear solver: conjugate gradients preconditioned by an aggregation multigrid V-cycle.
+//
+// Block-Jacobi PCG needs ~2700 iterations on BASELINE's C5 graph (50 000 poses on a 112 x 112 x 4 lattice of loop
+// closures, one gauge vertex: the accumulated odometry drift is the slowest mode of a grounded lattice Laplacian) and
+// was cut at 200 per Gauss-Newton iteration in round 1 without converging.  The hierarchy:
+//   * aggregates by greedy pairwise matching (three passes per level: <= 8 poses per aggregate), a pose is matched with
+//     its nearest unmatched graph neighbour; built on the host when the graph's structure changes;
+//   * interpolation = the rigid-body motion of the aggregate: dx_i = P_i eta_I with P_i = Ad(X_i^-1 X_I) in the
+//     (translation, quaternion-vector) coordinates of the right perturbation -- the near-null space of H (global
+//     rigid motions) is represented exactly on every level;
+//   * coarse operators by the Galerkin product P^T H P, assembled per coarse block from fixed lists (no atomics:
+//     deterministic), float64; recomputed every Gauss-Newton iteration on the device;
+//   * V(1,1) cycle with damped block-Jacobi smoothing (omega = 0.6); the coarsest level (<= 64 nodes) is solved by its
+//     dense inverse; levels of <= MG_FUSE_NODES nodes run inside ONE single-workgroup launch (they are launch floors
+//     otherwise).
+// The cycle is symmetric and positive definite, so PCG applies.  Off-diagonal blocks are stored once per factor
+// (H_ij; the `to` end reads it transposed): (E + V) x 288 bytes per SpMV instead of (2E + V) x 288.  They stay float64:
+// the smallest eigenvalue of a 50 000-pose graph with one gauge vertex is ~1e-9 of the largest, float32 blocks
+// (relative error 6e-8) make the operator indefinite in exactly the drift modes the solve is about -- measured: with
+// float32 blocks PCG needed 151 / 175 / 200 iterations on C5 and the coarsest Cholesky failed in the fourth
+// Gauss-Newton iteration (profiles/r2k_bench_c5_float32_blocks.json).
+// Measured with the numpy prototype of this scheme on the C5 generator at 12.5 k poses: 62 PCG iterations / 220
+// fine-SpMV equivalents against 1373 / 1373 for block-Jacobi.
+// =====================================================================================================================
+#define MG_OMEGA 0.6
+#define MG_MAX_LEVELS 16
+#define MG_FUSE_NODES 170   // levels of at most this many nodes run inside the single-workgroup launch (one row per thread)
+#define MG_COARSEST_NODES 32
+
+struct MgLevel {  // device view of one level (level 0 = the pose graph without its Fixed variables' couplings)
+  int n, ne, nc, nce;
+  const int2* eij;              // [ne] endpoints of the off-diagonal blocks (this level's node ids)
+  const int* inc_start;         // [n + 1]
+  const int2* inc_adj;          // incidences: {other node, (edge << 1) | side (1: this node is the edge's second endpoint)}
+  const int* agg;               // [n] aggregate of the next level, or -1 (Fixed variables)
+  const int* mem_start;         // [nc + 1] members of every aggregate
+  const int* mem_list;
+  const int* rep0;              // [n] graph vertex whose pose represents this node
+  const int* cd_start;          // [nc + 1] edges of this level inside an aggregate
+  const int* cd_list;
+  const int* ce_start;          // [nce + 1] edges of this level that make up a coarse edge: (edge << 1) | flipped
+  const int* ce_list;
+  double* Hd;                   // [n][D*D] diagonal blocks
+  double* Ho;                   // [ne][D*D] off-diagonal blocks H_ij (i = eij.x, j = eij.y), stored once per edge
+  float* P;                     // [n][D*D] interpolation blocks
+  double* Dinv;                 // [n][D*D] inverse diagonal blocks (smoother)
+  double *x, *r, *res;          // [n][D] work vectors of the cycle
+};
+
+// ---- device pieces of the cycle; (tid, nth) = this thread / number of threads sharing the loop --------------------
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_build_csr(int n_inc, const int2* __restrict__ ij,
-                                                             const int* __restrict__ inc_edge,
-                                                             const uint8_t* __restrict__ enabled,
-                                                             const uint8_t* __restrict__ fixed,
-                                                             const double* __restrict__ Ho, double* __restrict__ Hcsr,
-                                                             int* __restrict__ inc_other) {
+__device__ __forceinline__ void mg_smooth0(const MgLevel& L, int tid, int nth) {
+  for (int t = tid; t < L.n * D; t += nth) {
+    const int v = t / D, row = t - v * D;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s = s + L.Dinv[((size_t) v * D + row) * D + c] * L.r[(size_t) v * D + c];
+    L.x[t] = MG_OMEGA * s;
+  }
+}
+
+// y_t = (H x)_t for row t of this level.  The incidence records carry the neighbour, so the loads of four incidences
+// (record, block row, neighbour's x) are independent and issued together: small levels are pure load latency.
+template <int D>
+__device__ __forceinline__ double mg_row(const MgLevel& L, const double* __restrict__ x, int v, int row) {
+  double y = 0.0;
+#pragma unroll
+  for (int c = 0; c < D; ++c) y = y + L.Hd[((size_t) v * D + row) * D + c] * x[(size_t) v * D + c];
+  const int q1 = L.inc_start[v + 1];
+  for (int q0 = L.inc_start[v]; q0 < q1; q0 += 4) {
+    int2 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = q0 + k < q1 ? L.inc_adj[q0 + k] : make_int2(-1, 0);
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] = 0.0;
+      if (a[k].x >= 0) {
+        const double* B  = L.Ho + (size_t) (a[k].y >> 1) * D * D;
+        const double* xo = x + (size_t) a[k].x * D;
+        if (a[k].y & 1) {  // this node is j: H_ji = H_ij^T
+#pragma unroll
+          for (int c = 0; c < D; ++c) s[k] = s[k] + B[c * D + row] * xo[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < D; ++c) s[k] = s[k] + B[row * D + c] * xo[c];
+        }
+      }
+    }
+    y = y + ((s[0] + s[1]) + (s[2] + s[3]));
+  }
+  return y;
+}
+
+template <int D>
+__device__ __forceinline__ void mg_residual(const MgLevel& L, int tid, int nth) {
+  for (int t = tid; t < L.n * D; t += nth) {
+    const int v = t / D, row = t - v * D;
+    L.res[t]    = L.r[t] - mg_row<D>(L, L.x, v, row);
+  }
+}
+
+// r_coarse = P^T res
+template <int D>
+__device__ __forceinline__ void mg_restrict(const MgLevel& L, double* __restrict__ rc, int tid, int nth) {
+  for (int t = tid; t < L.nc * D; t += nth) {
+    const int I = t / D, a = t - I * D;
+    double s = 0.0;
+    for (int m = L.mem_start[I]; m < L.mem_start[I + 1]; ++m) {
+      const int i = L.mem_list[m];
+#pragma unroll
+      for (int b = 0; b < D; ++b) s = s + (double) L.P[((size_t) i * D + b) * D + a] * L.res[(size_t) i * D + b];
+    }
+    rc[t] = s;
+  }
+}
+
+// x += P x_coarse
+template <int D>
+__device__ __forceinline__ void mg_prolong(const MgLevel& L, const double* __restrict__ xc, int tid, int nth) {
+  for (int t = tid; t < L.n * D; t += nth) {
+    const int v = t / D, row = t - v * D;
+    const int I = L.agg[v];
+    if (I < 0) continue;
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) s = s + (double) L.P[((size_t) v * D + row) * D + a] * xc[(size_t) I * D + a];
+    L.x[t] = L.x[t] + s;
+  }
+}
+
+// x += omega Dinv res   (res = r - H x computed by mg_residual beforehand: Jacobi, no race)
+template <int D>
+__device__ __forceinline__ void mg_update(const MgLevel& L, int tid, int nth) {
+  for (int t = tid; t < L.n * D; t += nth) {
+    const int v = t / D, row = t - v * D;
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s = s + L.Dinv[((size_t) v * D + row) * D + c] * L.res[(size_t) v * D + c];
+    L.x[t] = L.x[t] + MG_OMEGA * s;
+  }
+}
+
+// x = Cinv r on the coarsest level (dense N x N inverse, N = n * D)
+template <int D>
+__device__ __forceinline__ void mg_coarsest(const MgLevel& L, const double* __restrict__ Cinv, int tid, int nth) {
+  const int N = L.n * D;
+  for (int t = tid; t < N; t += nth) {
+    double s = 0.0;
+    for (int c = 0; c < N; ++c) s = s + Cinv[(size_t) t * N + c] * L.r[c];
+    L.x[t] = s;
+  }
+}
+
+enum { MG_OP_SMOOTH0 = 0, MG_OP_RESIDUAL = 1, MG_OP_RESTRICT = 2, MG_OP_PROLONG = 3, MG_OP_UPDATE = 4 };
+
+// one phase of the cycle on one (large) level
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_op(int op, const MgLevel* __restrict__ levels, int l,
+                                                      const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = levels[l];
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+  if (op == MG_OP_SMOOTH0) mg_smooth0<D>(L, tid, nth);
+  else if (op == MG_OP_RESIDUAL) mg_residual<D>(L, tid, nth);
+  else if (op == MG_OP_RESTRICT) mg_restrict<D>(L, levels[l + 1].r, tid, nth);
+  else if (op == MG_OP_PROLONG) mg_prolong<D>(L, levels[l + 1].x, tid, nth);
+  else mg_update<D>(L, tid, nth);
+}
+
+// levels lf .. nl-1 (small) + the coarsest level nl in ONE workgroup: down, coarsest solve, up
+template <int D>
+__global__ __launch_bounds__(1024) void k_mg_coarse_cycle(const MgLevel* __restrict__ levels, int lf, int nl,
+                                                          const double* __restrict__ Cinv, int coarsest_dense,
+                                                          const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int l = lf; l < nl; ++l) {
+    const MgLevel L = levels[l];
+    mg_smooth0<D>(L, tid, nth);
+    __syncthreads();
+    mg_residual<D>(L, tid, nth);
+    __syncthreads();
+    mg_restrict<D>(L, levels[l + 1].r, tid, nth);
+    __syncthreads();
+  }
+  {
+    const MgLevel L = levels[nl];
+    if (coarsest_dense) {
+      mg_coarsest<D>(L, Cinv, tid, nth);
+    } else {  // (coarsening stalled above the dense limit: smoothing only)
+      mg_smooth0<D>(L, tid, nth);
+      for (int k = 0; k < 3; ++k) {
+        __syncthreads();
+        mg_residual<D>(L, tid, nth);
+        __syncthreads();
+        mg_update<D>(L, tid, nth);
+      }
+    }
+    __syncthreads();
+  }
+  for (int l = nl - 1; l >= lf; --l) {
+    const MgLevel L = levels[l];
+    mg_prolong<D>(L, levels[l + 1].x, tid, nth);
+    __syncthreads();
+    mg_residual<D>(L, tid, nth);
+    __syncthreads();
+    mg_update<D>(L, tid, nth);
+    __syncthreads();
+  }
+}
+
+// ---- numeric set-up of the hierarchy (every Gauss-Newton iteration) -------------------------------------------------
+// level 0: the diagonal blocks and the active factors' off-diagonal blocks in the level's compact edge order
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_pack0(int V, int ne, const int* __restrict__ act_edge,
+                                                         const double* __restrict__ Hd, const double* __restrict__ Ho,
+                                                         double* __restrict__ Hd0, double* __restrict__ Ho0) {
   const size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t) n_inc * D * D) return;
-  const int q = (int) (idx / (D * D)), k = (int) (idx - (size_t) q * D * D);
-  const int code = inc_edge[q];
-  const int e    = code >> 1;
-  const int2 vv  = ij[e];
-  const int other = (code & 1) ? vv.x : vv.y;
-  const bool skip = !enabled[e] || fixed[other];
-  const int r = k / D, c = k - r * D;
-  Hcsr[idx] = skip ? 0.0 : ((code & 1) ? Ho[(size_t) e * D * D + c * D + r] : Ho[(size_t) e * D * D + k]);
-  if (k == 0) inc_other[q] = skip ? -1 : other;
+  if (idx < (size_t) V * D * D) Hd0[idx] = Hd[idx];
+  if (idx < (size_t) ne * D * D) {
+    const int k = (int) (idx / (D * D));
+    Ho0[idx]    = Ho[(size_t) act_edge[k] * D * D + (idx - (size_t) k * D * D)];
+  }
+}
+
+// P_i = Ad(X_i^-1 X_I): the aggregate's rigid motion seen from member i (right perturbations, rotation part = quaternion vector)
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_interp(const MgLevel* __restrict__ levels, int l, int T,
+                                                          const float* __restrict__ poses) {
+  const MgLevel L = levels[l];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L.n) return;
+  float* P = L.P + (size_t) i * D * D;
+  const int I = L.agg[i];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) P[k] = 0.f;
+  if (I < 0) return;
+  const float* Xi = poses + (size_t) L.rep0[i] * T;
+  const float* XI = poses + (size_t) L.rep0[L.mem_list[L.mem_start[I]]] * T;
+  float Xi_inv[12], A[12];
+  if (D == 6) {
+    dm::se3_inverse(Xi, Xi_inv);
+    dm::se3_compose(Xi_inv, XI, A);
+    const float t[3] = {A[3], A[7], A[11]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        P[r * 6 + c]           = A[r * 4 + c];
+        P[(r + 3) * 6 + c + 3] = A[r * 4 + c];
+      }
+    // 2 [t]x R
+    for (int c = 0; c < 3; ++c) {
+      const float r0 = A[0 * 4 + c], r1 = A[1 * 4 + c], r2 = A[2 * 4 + c];
+      P[0 * 6 + c + 3] = 2.f * (t[1] * r2 - t[2] * r1);
+      P[1 * 6 + c + 3] = 2.f * (t[2] * r0 - t[0] * r2);
+      P[2 * 6 + c + 3] = 2.f * (t[0] * r1 - t[1] * r0);
+    }
+  } else {
+    dm::se2_inverse(Xi, Xi_inv);
+    dm::se2_compose(Xi_inv, XI, A);
+    P[0] = A[0]; P[1] = A[1]; P[2] = A[5];
+    P[3] = A[3]; P[4] = A[4]; P[5] = -A[2];
+    P[8] = 1.f;
+  }
+}
+
+// row `r` of  Pi^T B Pj  (B, Pi, Pj: D x D)
+template <int D>
+__device__ __forceinline__ void mg_ptbp_row(const float* Pi, const double* B, const float* Pj, int r, double* out) {
+  double w[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) s = s + (double) Pi[a * D + r] * (double) B[a * D + c];
+    w[c] = s;
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) s = s + w[a] * (double) Pj[a * D + c];
+    out[c] = s;
+  }
+}
+// row `r` of (Pi^T B Pj)^T = Pj^T B^T Pi
+template <int D>
+__device__ __forceinline__ void mg_ptbp_row_t(const float* Pi, const double* B, const float* Pj, int r, double* out) {
+  double w[D];  // w = B Pj[:, r]
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s = s + (double) B[a * D + c] * (double) Pj[c * D + r];
+    w[a] = s;
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) s = s + (double) Pi[a * D + c] * w[a];
+    out[c] = s;
+  }
+}
+
+// Galerkin product of level l into level l + 1: one thread per (coarse block, row); fixed lists, fixed order
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(const MgLevel* __restrict__ levels, int l) {
+  const MgLevel L = levels[l];
+  const MgLevel C = levels[l + 1];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < L.nc * D) {  // diagonal block of aggregate I
+    const int I = t / D, r = t - I * D;
+    double acc[D], tmp[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    for (int m = L.mem_start[I]; m < L.mem_start[I + 1]; ++m) {
+      const int i = L.mem_list[m];
+      mg_ptbp_row<D>(L.P + (size_t) i * D * D, L.Hd + (size_t) i * D * D, L.P + (size_t) i * D * D, r, tmp);
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
+    }
+    for (int q = L.cd_start[I]; q < L.cd_start[I + 1]; ++q) {
+      const int e   = L.cd_list[q];
+      const int2 vv = L.eij[e];
+      const float *Pi = L.P + (size_t) vv.x * D * D, *Pj = L.P + (size_t) vv.y * D * D;
+      const double* B = L.Ho + (size_t) e * D * D;
+      mg_ptbp_row<D>(Pi, B, Pj, r, tmp);
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
+      mg_ptbp_row_t<D>(Pi, B, Pj, r, tmp);
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) C.Hd[((size_t) I * D + r) * D + c] = acc[c];
+  } else if (t < (L.nc + L.nce) * D) {  // off-diagonal block of a coarse edge
+    const int ce = (t - L.nc * D) / D, r = (t - L.nc * D) - ce * D;
+    double acc[D], tmp[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    for (int q = L.ce_start[ce]; q < L.ce_start[ce + 1]; ++q) {
+      const int code = L.ce_list[q], e = code >> 1;
+      const int2 vv  = L.eij[e];
+      const float *Pi = L.P + (size_t) vv.x * D * D, *Pj = L.P + (size_t) vv.y * D * D;
+      const double* B = L.Ho + (size_t) e * D * D;
+      if (code & 1)
+        mg_ptbp_row_t<D>(Pi, B, Pj, r, tmp);
+      else
+        mg_ptbp_row<D>(Pi, B, Pj, r, tmp);
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) C.Ho[((size_t) ce * D + r) * D + c] = acc[c];
+  }
+}
+
+// inverse diagonal blocks of level l (the smoother)
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(const MgLevel* __restrict__ levels, int l, PgScalars* __restrict__ sc) {
+  const MgLevel L = levels[l];
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= L.n) return;
+  double H[D * D], Mi[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) H[k] = L.Hd[(size_t) v * D * D + k];
+#pragma unroll
+  for (int a = 0; a < D; ++a)  // (rows are accumulated independently: make the block exactly symmetric for the factorisation)
+#pragma unroll
+    for (int c = a + 1; c < D; ++c) H[c * D + a] = H[a * D + c];
+  // A coarse block that is not positive definite belongs to an aggregate whose rigid motion is a null vector of H (a
+  // component of the graph that no Fixed variable anchors): no smoothing there, the cycle leaves those coordinates alone.
+  bool bad = false;
+  for (int c = 0; c < D; ++c) {
+    double rhs[D], x[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) rhs[r] = r == c ? -1.0 : 0.0;
+    if (dm::solve<D>(H, rhs, x)) bad = true;
+#pragma unroll
+    for (int r = 0; r < D; ++r) Mi[r * D + c] = x[r];
+  }
+  (void) sc;
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) L.Dinv[(size_t) v * D * D + k] = bad ? 0.0 : Mi[k];
+}
+
+// dense inverse of the coarsest operator: assemble, Cholesky in place, then one thread per column solves for the inverse
+template <int D>
+__global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(const MgLevel* __restrict__ levels, int l, double* __restrict__ A,
+                                                              double* __restrict__ Cinv, PgScalars* __restrict__ sc) {
+  const MgLevel L = levels[l];
+  const int N = L.n * D, tid = threadIdx.x, nth = blockDim.x;
+  for (int k = tid; k < N * N; k += nth) A[k] = 0.0;
+  __syncthreads();
+  for (int k = tid; k < L.n * D * D; k += nth) {
+    const int v = k / (D * D), rc = k - v * D * D, r = rc / D, c = rc - r * D;
+    A[(size_t) (v * D + r) * N + v * D + c] = 0.5 * (L.Hd[(size_t) v * D * D + r * D + c] + L.Hd[(size_t) v * D * D + c * D + r]);
+  }
+  __syncthreads();
+  for (int k = tid; k < L.ne * D * D; k += nth) {
+    const int e = k / (D * D), rc = k - e * D * D, r = rc / D, c = rc - r * D;
+    const int2 vv = L.eij[e];
+    const double b = L.Ho[(size_t) e * D * D + rc];
+    // (parallel factors between the same two poses share entries when level 0 itself is the coarsest level)
+    atomicAdd(&A[(size_t) (vv.x * D + r) * N + vv.y * D + c], b);
+    atomicAdd(&A[(size_t) (vv.y * D + c) * N + vv.x * D + r], b);
+  }
+  __syncthreads();
+  // right-looking Cholesky, lower triangle, column by column.  A pivot that has (numerically) vanished belongs to a
+  // component of the graph that no Fixed variable anchors (its rigid motion is a null vector of H; the right-hand side
+  // has no component there and CG leaves it alone): the coarse correction of that coordinate is switched off by an
+  // "infinitely stiff" pivot instead of failing the solve.
+  __shared__ double s_thr;
+  if (tid == 0) {
+    double m = 0.0;
+    for (int k = 0; k < N; ++k) m = fmax(m, A[(size_t) k * N + k]);
+    s_thr = 1e-11 * m;
+  }
+  for (int k = 0; k < N; ++k) {
+    __syncthreads();
+    if (tid == 0) {
+      const double d = A[(size_t) k * N + k];
+      A[(size_t) k * N + k] = d > s_thr ? sqrt(d) : 1e150;
+    }
+    __syncthreads();
+    const double piv = A[(size_t) k * N + k];
+    for (int i = k + 1 + tid; i < N; i += nth) A[(size_t) i * N + k] = A[(size_t) i * N + k] / piv;
+    __syncthreads();
+    const int m = N - k - 1;
+    for (int idx = tid; idx < m * m; idx += nth) {
+      const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+      if (j <= i) A[(size_t) i * N + j] -= A[(size_t) i * N + k] * A[(size_t) j * N + k];
+    }
+  }
+  __syncthreads();
+  // column c of the inverse: L y = e_c, L^T x = y   (Cinv is symmetric: stored row = column)
+  for (int c = tid; c < N; c += nth) {
+    double* x = Cinv + (size_t) c * N;
+    for (int i = 0; i < N; ++i) {
+      double s = i == c ? 1.0 : 0.0;
+      for (int k = (c < i ? c : i); k < i; ++k) s -= A[(size_t) i * N + k] * x[k];
+      x[i] = i < c ? 0.0 : s / A[(size_t) i * N + i];
+    }
+    for (int i = N - 1; i >= 0; --i) {
+      double s = x[i];
+      for (int k = i + 1; k < N; ++k) s -= A[(size_t) k * N + i] * x[k];
+      x[i] = s / A[(size_t) i * N + i];
+    }
+  }
 }
 
 // ---- deterministic block reduction of one double per thread -> partial[blockIdx.x] ------------------------------
@@ -284,38 +716,22 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_chi(int E, const uint8_t* __r
   }
 }
 
-// n = V*D scalars; thread t handles entry t (vertex t/D, row t%D)
-template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_pcg_init(int n, const double* __restrict__ b,
-                                                            const double* __restrict__ Minv, double* __restrict__ x,
-                                                            double* __restrict__ r, double* __restrict__ p,
-                                                            double* __restrict__ part_rz, double* __restrict__ part_bb,
-                                                            PgScalars* __restrict__ sc,
-                                                            const double* __restrict__ partial_chi,
+// ---- PCG ------------------------------------------------------------------------------------------------------------
+// x = 0, r = -b -> level 0's r (the cycle's input); statistics of the linearisation
+__global__ __launch_bounds__(PG_THREADS) void k_pg_pcg_init(int n, const double* __restrict__ b, double* __restrict__ x,
+                                                            double* __restrict__ r, double* __restrict__ part_bb,
+                                                            PgScalars* __restrict__ sc, const double* __restrict__ partial_chi,
                                                             const int* __restrict__ partial_n, int n_chi_partials) {
-  double rz = 0.0, bb = 0.0;
-  for (int tile = 0; tile < PG_TILES; ++tile) {
-    const int t = (blockIdx.x * PG_TILES + tile) * PG_ROWS + threadIdx.x;
-    if (threadIdx.x < PG_ROWS && t < n) {
-      const int v = t / D, row = t - v * D;
-      double z = 0.0;
-#pragma unroll
-      for (int c = 0; c < D; ++c) z = z + Minv[((size_t) v * D + row) * D + c] * (-b[(size_t) v * D + c]);
-      const double ri = -b[t];
-      x[t] = 0.0;
-      r[t] = ri;
-      p[t] = z;
-      rz   = rz + ri * z;
-      bb   = bb + ri * ri;
-    }
+  double bb = 0.0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const double ri = -b[t];
+    x[t] = 0.0;
+    r[t] = ri;
+    bb   = bb + ri * ri;
   }
-  rz = block_sum(rz);
   bb = block_sum(bb);
-  if (threadIdx.x == 0) {
-    part_rz[blockIdx.x] = rz;
-    part_bb[blockIdx.x] = bb;
-  }
-  if (blockIdx.x == 0) {  // statistics of the linearisation
+  if (threadIdx.x == 0) part_bb[blockIdx.x] = bb;
+  if (blockIdx.x == 0) {
     double c = 0.0, m = 0.0;
     for (int k = threadIdx.x; k < n_chi_partials; k += PG_THREADS) {
       c += partial_chi[k];
@@ -332,100 +748,77 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_pcg_init(int n, const double*
   }
 }
 
-// Ap = A p; partial p.Ap.  First launch of an iteration also folds the scalars of the init / previous update.
-template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(int n, const uint8_t* __restrict__ fixed,
-                                                        const int* __restrict__ inc_start,
-                                                        const int* __restrict__ inc_other,
-                                                        const double* __restrict__ Hd, const double* __restrict__ Hcsr,
-                                                        const double* __restrict__ p, double* __restrict__ Ap,
-                                                        double* __restrict__ part_pAp, const PgScalars* __restrict__ sc) {
+// after the cycle: z = level 0's x.  first: p = z, rz = r.z ; later: beta = rz_new / rz, p = z + beta p.
+// (two kernels: the dot product needs a grid-wide sum before p can be updated)
+__global__ __launch_bounds__(PG_THREADS) void k_pg_dot_rz(int n, const double* __restrict__ r, const double* __restrict__ z,
+                                                          double* __restrict__ part_rz_new, const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const int t = blockIdx.x * PG_ROWS + threadIdx.x;
+  double s = 0.0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) s = s + r[t] * z[t];
+  s = block_sum(s);
+  if (threadIdx.x == 0) part_rz_new[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(PG_THREADS) void k_pg_update_p(int n, int nblocks, int first, const double* __restrict__ z,
+                                                            double* __restrict__ p, const double* __restrict__ part_rz,
+                                                            const double* __restrict__ part_rz_new, PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const double rz_new = sum_partials(part_rz_new, nblocks);
+  double beta         = 0.0;
+  if (!first) {
+    const double rz = sum_partials(part_rz, nblocks);
+    beta            = rz != 0.0 ? rz_new / rz : 0.0;
+  }
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = first ? z[t] : z[t] + beta * p[t];
+  if (blockIdx.x == 0 && threadIdx.x == 0) sc->rz = rz_new;
+}
+
+// Ap = H p on level 0 (float32 blocks, float64 accumulation); partial p.Ap
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(const MgLevel* __restrict__ levels, const double* __restrict__ p,
+                                                        double* __restrict__ Ap, double* __restrict__ part_pAp,
+                                                        const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = levels[0];
   double pap = 0.0;
-  if (threadIdx.x < PG_ROWS && t < n) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < L.n * D; t += gridDim.x * blockDim.x) {
     const int v = t / D, row = t - v * D;
-    double y = 0.0;
-#pragma unroll
-    for (int c = 0; c < D; ++c) y = y + Hd[((size_t) v * D + row) * D + c] * p[(size_t) v * D + c];
-    if (!fixed[v]) {
-      // the D row-threads of a variable read consecutive rows of consecutive blocks: one contiguous stream per block
-      for (int q = inc_start[v]; q < inc_start[v + 1]; ++q) {
-        const int other = inc_other[q];
-        if (other < 0) continue;
-        const double* B = Hcsr + ((size_t) q * D + row) * D;
-        double s        = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) s = s + B[c] * p[(size_t) other * D + c];
-        y = y + s;
-      }
-    }
+    const double y = mg_row<D>(L, p, v, row);
     Ap[t] = y;
-    pap   = y * p[t];
+    pap   = pap + y * p[t];
   }
   pap = block_sum(pap);
   if (threadIdx.x == 0) part_pAp[blockIdx.x] = pap;
 }
 
-// x += alpha p ; r -= alpha Ap ; z = Minv r ; partial rr, rz_new.   alpha = rz / (p.Ap) from the partials.
-template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_update_xr(int n, int nblocks, const double* __restrict__ Minv,
-                                                             const double* __restrict__ p, const double* __restrict__ Ap,
-                                                             double* __restrict__ x, double* __restrict__ r,
-                                                             double* __restrict__ z, const double* __restrict__ part_rz,
-                                                             const double* __restrict__ part_pAp,
-                                                             double* __restrict__ part_rr, double* __restrict__ part_rz_new,
-                                                             const PgScalars* __restrict__ sc, int nblocks_spmv) {
+// x += alpha p ; r -= alpha Ap ; partial r.r ; convergence test |r| <= tol |b| (published by block 0)
+__global__ __launch_bounds__(PG_THREADS) void k_pg_update_xr(int n, int nblocks, double tol, const double* __restrict__ p,
+                                                             const double* __restrict__ Ap, double* __restrict__ x,
+                                                             double* __restrict__ r, const double* __restrict__ part_rz,
+                                                             const double* __restrict__ part_pAp, double* __restrict__ part_rr,
+                                                             const double* __restrict__ part_bb, PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
   const double rz  = sum_partials(part_rz, nblocks);
-  const double pap = sum_partials(part_pAp, nblocks_spmv);
+  const double pap = sum_partials(part_pAp, nblocks);
   const double alpha = pap > 0.0 ? rz / pap : 0.0;
-  double rr = 0.0, rzn = 0.0;
-  for (int tile = 0; tile < PG_TILES; ++tile) {
-    const int t       = (blockIdx.x * PG_TILES + tile) * PG_ROWS + threadIdx.x;
-    const bool active = threadIdx.x < PG_ROWS && t < n;
-    if (active) {
-      x[t] = x[t] + alpha * p[t];
-      r[t] = r[t] - alpha * Ap[t];
-    }
-    __syncthreads();  // all D rows of a variable live in this tile (PG_ROWS is a multiple of D)
-    if (active) {
-      const int v = t / D, row = t - v * D;
-      double zi = 0.0;
-#pragma unroll
-      for (int c = 0; c < D; ++c) zi = zi + Minv[((size_t) v * D + row) * D + c] * r[(size_t) v * D + c];
-      z[t] = zi;
-      rr   = rr + r[t] * r[t];
-      rzn  = rzn + r[t] * zi;
-    }
+  double rr = 0.0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    x[t] = x[t] + alpha * p[t];
+    const double ri = r[t] - alpha * Ap[t];
+    r[t] = ri;
+    rr   = rr + ri * ri;
   }
-  rr  = block_sum(rr);
-  rzn = block_sum(rzn);
-  if (threadIdx.x == 0) {
-    part_rr[blockIdx.x]     = rr;
-    part_rz_new[blockIdx.x] = rzn;
-  }
+  rr = block_sum(rr);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = rr;
 }
 
-// p = z + beta p ; beta = rz_new / rz ; convergence test |r| <= tol |b| ; block 0 publishes the scalars
-__global__ __launch_bounds__(PG_THREADS) void k_pg_update_p(int n, int nblocks, double tol, const double* __restrict__ z,
-                                                            double* __restrict__ p, const double* __restrict__ part_rz,
-                                                            const double* __restrict__ part_rz_new,
-                                                            const double* __restrict__ part_rr,
-                                                            const double* __restrict__ part_bb, PgScalars* __restrict__ sc) {
+// block 0 of a tiny launch: sums r.r, publishes the iteration's scalars, raises `done`
+__global__ __launch_bounds__(PG_THREADS) void k_pg_converged(int nblocks, double tol, const double* __restrict__ part_rr,
+                                                             const double* __restrict__ part_bb, PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const double rz     = sum_partials(part_rz, nblocks);
-  const double rz_new = sum_partials(part_rz_new, nblocks);
-  const double rr     = sum_partials(part_rr, nblocks);
-  const double bb     = sum_partials(part_bb, nblocks);
-  const double beta   = rz != 0.0 ? rz_new / rz : 0.0;
-  for (int tile = 0; tile < PG_TILES; ++tile) {
-    const int t = (blockIdx.x * PG_TILES + tile) * PG_ROWS + threadIdx.x;
-    if (threadIdx.x < PG_ROWS && t < n) p[t] = z[t] + beta * p[t];
-  }
-  // (the host swaps the rz / rz_new partial buffers for the next iteration: no in-kernel copy, no race)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    sc->rz = rz_new;
+  const double rr = sum_partials(part_rr, nblocks);
+  const double bb = sum_partials(part_bb, nblocks);
+  if (threadIdx.x == 0) {
     sc->rr = rr;
     sc->bb = bb;
     sc->pcg_iters += 1;
@@ -450,6 +843,21 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int T, int varia
 
 }  // namespace
 
+// host side of one level: structure (built when the graph changes) + device buffers
+struct MgLevelBufs {
+  int n = 0, ne = 0, nc = 0, nce = 0;
+  DevBuf<int2> eij;
+  DevBuf<int> inc_start, agg, mem_start, mem_list, rep0, cd_start, cd_list, ce_start, ce_list;
+  DevBuf<int2> inc_adj;
+  DevBuf<float> P;
+  DevBuf<double> Hd, Ho, Dinv, x, r, res;
+  void release() {
+    eij.release(); inc_start.release(); inc_adj.release(); agg.release(); mem_start.release(); mem_list.release();
+    rep0.release(); cd_start.release(); cd_list.release(); ce_start.release(); ce_list.release(); Hd.release();
+    Ho.release(); P.release(); Dinv.release(); x.release(); r.release(); res.release();
+  }
+};
+
 struct srrg2_posegraph_s {
   int kind = 2, D = 6, T = 12, device = 0;
   hipStream_t stream = nullptr;
@@ -457,36 +865,254 @@ struct srrg2_posegraph_s {
   DevBuf<float> poses, Z;
   DevBuf<uint8_t> fixed, enabled;
   DevBuf<int2> ij;
-  DevBuf<double> omega, Hd, Ho, Hcsr, b, Minv, x, r, z, p, Ap, contrib;
+  DevBuf<double> omega, Hd, Ho, b, Minv, x, r, p, Ap, contrib;
   DevBuf<double> part_rz, part_rz_new, part_pAp, part_rr, part_bb, part_chi;
-  DevBuf<int> part_n, inc_start, inc_edge, inc_other;
+  DevBuf<int> part_n, inc_start, inc_edge, act_edge;
   DevBuf<PgScalars> sc;
+  // multigrid hierarchy
+  std::vector<MgLevelBufs*> levels;
+  DevBuf<MgLevel> levels_dev;
+  DevBuf<double> coarse_A, coarse_inv;
+  int coarsest_dense = 1;
+  bool mg_dirty      = true;
   // host mirrors for the incremental interface (incidence lists are rebuilt lazily from these)
   std::vector<int> h_ij;
-  std::vector<uint8_t> h_enabled, h_removed;
+  std::vector<uint8_t> h_enabled, h_removed, h_fixed;
   bool inc_dirty = false;
 };
 
 namespace {
+
+template <typename T>
+int upload(DevBuf<T>& b, const std::vector<T>& v) {
+  int rc = b.reserve(std::max<size_t>(v.size(), 1));
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Aggregation hierarchy from the graph's structure and the current poses (host; only when the structure changed).
+int build_hierarchy(srrg2_posegraph_s* g) {
+  const int V = g->V, E = g->E, D = g->D, T = g->T;
+  for (MgLevelBufs* L : g->levels) {
+    L->release();
+    delete L;
+  }
+  g->levels.clear();
+  std::vector<float> poses((size_t) std::max(V, 1) * T);
+  HIP_TRY(hipMemcpy(poses.data(), g->poses.p, sizeof(float) * (size_t) V * T, hipMemcpyDeviceToHost));
+  auto position = [&](int v, float* out) {
+    const float* X = poses.data() + (size_t) v * T;
+    if (D == 6) { out[0] = X[3]; out[1] = X[7]; out[2] = X[11]; } else { out[0] = X[2]; out[1] = X[5]; out[2] = 0.f; }
+  };
+  // level 0: every variable is a node; edges = enabled factors between two free variables
+  int n = V;
+  std::vector<int> eij, rep0((size_t) n), act;
+  std::vector<char> excluded((size_t) n, 0);
+  for (int v = 0; v < n; ++v) {
+    rep0[(size_t) v]     = v;
+    excluded[(size_t) v] = g->h_fixed[(size_t) v] ? 1 : 0;
+  }
+  for (int e = 0; e < E; ++e) {
+    const int i = g->h_ij[2 * (size_t) e], j = g->h_ij[2 * (size_t) e + 1];
+    if (!g->h_enabled[(size_t) e] || g->h_fixed[(size_t) i] || g->h_fixed[(size_t) j]) continue;
+    eij.push_back(i);
+    eij.push_back(j);
+    act.push_back(e);
+  }
+  int rc;
+  if ((rc = upload(g->act_edge, act))) return rc;
+  g->coarsest_dense = 1;
+  // matching passes per level: 2 -> aggregates of <= 4 poses, 3 -> <= 8 (fewer levels, slower convergence; measured in
+  // DESIGN.md section 6)
+  const int match_passes = std::getenv("SRRG2_AMD_PG_PASSES") ? std::max(1, std::atoi(std::getenv("SRRG2_AMD_PG_PASSES"))) : 2;
+  for (int level = 0; level < MG_MAX_LEVELS; ++level) {
+    const int ne = (int) (eij.size() / 2);
+    MgLevelBufs* L = new MgLevelBufs();
+    g->levels.push_back(L);
+    L->n  = n;
+    L->ne = ne;
+    // incidence lists in (node, edge) order
+    std::vector<int> inc_start((size_t) n + 1, 0);
+    std::vector<int2> inc_adj((size_t) std::max(2 * ne, 1), make_int2(-1, 0));
+    for (int e = 0; e < ne; ++e) {
+      inc_start[(size_t) eij[2 * (size_t) e] + 1]++;
+      inc_start[(size_t) eij[2 * (size_t) e + 1] + 1]++;
+    }
+    for (int v = 0; v < n; ++v) inc_start[(size_t) v + 1] += inc_start[(size_t) v];
+    {
+      std::vector<int> cur(inc_start.begin(), inc_start.end() - 1);
+      for (int e = 0; e < ne; ++e) {
+        inc_adj[(size_t) cur[(size_t) eij[2 * (size_t) e]]++]     = make_int2(eij[2 * (size_t) e + 1], 2 * e);
+        inc_adj[(size_t) cur[(size_t) eij[2 * (size_t) e + 1]]++] = make_int2(eij[2 * (size_t) e], 2 * e + 1);
+      }
+    }
+    std::vector<int2> e2((size_t) std::max(ne, 1));
+    for (int e = 0; e < ne; ++e) e2[(size_t) e] = make_int2(eij[2 * (size_t) e], eij[2 * (size_t) e + 1]);
+    if ((rc = L->eij.reserve(e2.size()))) return rc;
+    HIP_TRY(hipMemcpy(L->eij.p, e2.data(), sizeof(int2) * e2.size(), hipMemcpyHostToDevice));
+    if ((rc = upload(L->inc_start, inc_start)) || (rc = upload(L->rep0, rep0))) return rc;
+    if ((rc = L->inc_adj.reserve(inc_adj.size()))) return rc;
+    HIP_TRY(hipMemcpy(L->inc_adj.p, inc_adj.data(), sizeof(int2) * inc_adj.size(), hipMemcpyHostToDevice));
+    if ((rc = L->Hd.reserve((size_t) std::max(n, 1) * D * D)) || (rc = L->Ho.reserve((size_t) std::max(ne, 1) * D * D)) ||
+        (rc = L->P.reserve((size_t) std::max(n, 1) * D * D)) || (rc = L->Dinv.reserve((size_t) std::max(n, 1) * D * D)) ||
+        (rc = L->x.reserve((size_t) std::max(n, 1) * D)) || (rc = L->r.reserve((size_t) std::max(n, 1) * D)) ||
+        (rc = L->res.reserve((size_t) std::max(n, 1) * D)))
+      return rc;
+    int free_nodes = 0;
+    for (int v = 0; v < n; ++v) free_nodes += excluded[(size_t) v] ? 0 : 1;
+    if (free_nodes <= MG_COARSEST_NODES && level > 0) break;  // this is the coarsest level
+    if (level == 0 && free_nodes <= MG_COARSEST_NODES && n <= MG_COARSEST_NODES) break;
+    // two passes of greedy pairwise matching with the nearest unmatched neighbour: aggregates of <= 4 nodes
+    std::vector<int> agg((size_t) n);
+    for (int v = 0; v < n; ++v) agg[(size_t) v] = excluded[(size_t) v] ? -1 : v;  // singletons first
+    int nagg = n;
+    {
+      // pass structure: cur_id[v] = aggregate after the previous pass; adjacency between aggregates through the edges
+      std::vector<int> cur(agg);
+      for (int pass = 0; pass < match_passes; ++pass) {
+        // representative position of each current aggregate = position of its first member
+        std::vector<int> first((size_t) n, -1);
+        for (int v = 0; v < n; ++v)
+          if (cur[(size_t) v] >= 0 && first[(size_t) cur[(size_t) v]] < 0) first[(size_t) cur[(size_t) v]] = v;
+        // neighbours of every current aggregate
+        std::vector<std::vector<int>> nb((size_t) n);
+        for (int e = 0; e < ne; ++e) {
+          const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
+          if (a < 0 || b < 0 || a == b) continue;
+          nb[(size_t) a].push_back(b);
+          nb[(size_t) b].push_back(a);
+        }
+        std::vector<int> match((size_t) n, -1);
+        for (int a = 0; a < n; ++a) {
+          if (first[(size_t) a] < 0 || match[(size_t) a] >= 0) continue;
+          float pa[3];
+          position(rep0[(size_t) first[(size_t) a]], pa);
+          int best = -1;
+          float bd = 3.0e38f;
+          for (int b : nb[(size_t) a]) {
+            if (match[(size_t) b] >= 0 || b == a) continue;
+            float pb[3];
+            position(rep0[(size_t) first[(size_t) b]], pb);
+            const float d = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]);
+            if (d < bd || (d == bd && b < best)) { bd = d; best = b; }
+          }
+          match[(size_t) a] = a;
+          if (best >= 0) match[(size_t) best] = a;
+        }
+        for (int v = 0; v < n; ++v)
+          if (cur[(size_t) v] >= 0) cur[(size_t) v] = match[(size_t) cur[(size_t) v]];
+      }
+      // renumber the aggregates in order of their first member
+      std::vector<int> renum((size_t) n, -1);
+      nagg = 0;
+      for (int v = 0; v < n; ++v) {
+        if (cur[(size_t) v] < 0) continue;
+        if (renum[(size_t) cur[(size_t) v]] < 0) renum[(size_t) cur[(size_t) v]] = nagg++;
+        agg[(size_t) v] = renum[(size_t) cur[(size_t) v]];
+      }
+    }
+    if (nagg == 0 || nagg > (int) (0.8 * free_nodes)) {  // coarsening stalled: this level is the coarsest
+      if (free_nodes > 256) g->coarsest_dense = 0;
+      break;
+    }
+    const int nc = nagg;
+    std::vector<int> mem_start((size_t) nc + 1, 0), mem_list((size_t) std::max(free_nodes, 1), 0), crep0((size_t) nc, 0);
+    for (int v = 0; v < n; ++v)
+      if (agg[(size_t) v] >= 0) mem_start[(size_t) agg[(size_t) v] + 1]++;
+    for (int I = 0; I < nc; ++I) mem_start[(size_t) I + 1] += mem_start[(size_t) I];
+    {
+      std::vector<int> cur(mem_start.begin(), mem_start.end() - 1);
+      for (int v = 0; v < n; ++v)
+        if (agg[(size_t) v] >= 0) mem_list[(size_t) cur[(size_t) agg[(size_t) v]]++] = v;
+    }
+    for (int I = 0; I < nc; ++I) crep0[(size_t) I] = rep0[(size_t) mem_list[(size_t) mem_start[(size_t) I]]];
+    // coarse edges: unique unordered pairs of aggregates, in order of first appearance; internal edges per aggregate
+    std::vector<std::pair<long long, int>> keyed;  // (key, fine edge code)
+    std::vector<std::vector<int>> internal((size_t) nc);
+    for (int e = 0; e < ne; ++e) {
+      const int I = agg[(size_t) eij[2 * (size_t) e]], J = agg[(size_t) eij[2 * (size_t) e + 1]];
+      if (I < 0 || J < 0) continue;
+      if (I == J) {
+        internal[(size_t) I].push_back(e);
+        continue;
+      }
+      const int lo = std::min(I, J), hi = std::max(I, J);
+      keyed.emplace_back((long long) lo * nc + hi, (e << 1) | (I > J ? 1 : 0));
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first < b.first; });
+    std::vector<int> ceij, ce_start(1, 0), ce_list;
+    for (size_t k = 0; k < keyed.size(); ++k) {
+      if (k == 0 || keyed[k].first != keyed[k - 1].first) {
+        if (k) ce_start.push_back((int) ce_list.size());
+        ceij.push_back((int) (keyed[k].first / nc));
+        ceij.push_back((int) (keyed[k].first % nc));
+      }
+      ce_list.push_back(keyed[k].second);
+    }
+    ce_start.push_back((int) ce_list.size());
+    const int nce = (int) (ceij.size() / 2);
+    if (nce == 0) ce_start.assign(1, 0);
+    std::vector<int> cd_start((size_t) nc + 1, 0), cd_list;
+    for (int I = 0; I < nc; ++I) {
+      for (int e : internal[(size_t) I]) cd_list.push_back(e);
+      cd_start[(size_t) I + 1] = (int) cd_list.size();
+    }
+    L->nc  = nc;
+    L->nce = nce;
+    if ((rc = upload(L->agg, agg)) || (rc = upload(L->mem_start, mem_start)) || (rc = upload(L->mem_list, mem_list)) ||
+        (rc = upload(L->cd_start, cd_start)) || (rc = upload(L->cd_list, cd_list)) || (rc = upload(L->ce_start, ce_start)) ||
+        (rc = upload(L->ce_list, ce_list)))
+      return rc;
+    // next level
+    n = nc;
+    eij.swap(ceij);
+    rep0.swap(crep0);
+    excluded.assign((size_t) n, 0);
+  }
+  if (std::getenv("SRRG2_AMD_PG_DEBUG")) {
+    std::fprintf(stderr, "posegraph hierarchy:");
+    for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks ->", L->n, L->ne);
+    std::fprintf(stderr, " coarsest %s\n", g->coarsest_dense ? "dense" : "smoothed");
+  }
+  // device views
+  const int nl = (int) g->levels.size();
+  std::vector<MgLevel> views((size_t) nl);
+  for (int l = 0; l < nl; ++l) {
+    MgLevelBufs* L = g->levels[(size_t) l];
+    MgLevel& v     = views[(size_t) l];
+    v.n = L->n; v.ne = L->ne; v.nc = L->nc; v.nce = L->nce;
+    v.eij = L->eij.p; v.inc_start = L->inc_start.p; v.inc_adj = L->inc_adj.p; v.agg = L->agg.p;
+    v.mem_start = L->mem_start.p; v.mem_list = L->mem_list.p; v.rep0 = L->rep0.p; v.cd_start = L->cd_start.p;
+    v.cd_list = L->cd_list.p; v.ce_start = L->ce_start.p; v.ce_list = L->ce_list.p;
+    v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Dinv = L->Dinv.p; v.x = L->x.p; v.r = L->r.p; v.res = L->res.p;
+  }
+  if ((rc = g->levels_dev.reserve((size_t) nl))) return rc;
+  HIP_TRY(hipMemcpy(g->levels_dev.p, views.data(), sizeof(MgLevel) * (size_t) nl, hipMemcpyHostToDevice));
+  const size_t N = (size_t) g->levels.back()->n * D;
+  if (g->coarsest_dense) {
+    if ((rc = g->coarse_A.reserve(std::max<size_t>(N * N, 1))) || (rc = g->coarse_inv.reserve(std::max<size_t>(N * N, 1)))) return rc;
+  }
+  g->mg_dirty = false;
+  return 0;
+}
 
 template <int D>
 int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_posegraph_stats* stats, int* n_inout) {
   const int V = g->V, E = g->E, T = g->T;
   const int n = V * D;
   int rc;
-  const int nb  = std::max((n + PG_ROWS - 1) / PG_ROWS, 1);          // SpMV blocks (one tile each)
-  const int nbt = std::max((nb + PG_TILES - 1) / PG_TILES, 1);        // element-wise kernels: PG_TILES tiles per block
+  if (g->mg_dirty && (rc = build_hierarchy(g))) return rc;
+  const int nl  = (int) g->levels.size() - 1;  // index of the coarsest level
+  const int nb  = std::max(std::min((n + PG_THREADS - 1) / PG_THREADS, 1024), 1);  // grid-stride element-wise kernels
   const int nbv = std::max((V + PG_THREADS - 1) / PG_THREADS, 1);
   const int nbe = std::max((E + PG_THREADS - 1) / PG_THREADS, 1);
   const int nchi = std::min(nbe, 1024);
-  if (nb > PG_MAX_PARTIALS * 64) return fail(SRRG2_E_UNSUPPORTED, "posegraph: too many variables");
   if ((rc = g->Hd.reserve((size_t) std::max(V, 1) * D * D))) return rc;
   if ((rc = g->Minv.reserve((size_t) std::max(V, 1) * D * D))) return rc;
   if ((rc = g->Ho.reserve((size_t) std::max(E, 1) * D * D))) return rc;
-  if ((rc = g->Hcsr.reserve((size_t) std::max(2 * E, 1) * D * D))) return rc;
-  if ((rc = g->inc_other.reserve((size_t) std::max(2 * E, 1)))) return rc;
   if ((rc = g->contrib.reserve((size_t) std::max(E, 1) * (sizeof(EdgeContrib<D>) / sizeof(double))))) return rc;
-  for (DevBuf<double>* v : {&g->b, &g->x, &g->r, &g->z, &g->p, &g->Ap})
+  for (DevBuf<double>* v : {&g->b, &g->x, &g->r, &g->p, &g->Ap})
     if ((rc = v->reserve((size_t) std::max(n, 1)))) return rc;
   for (DevBuf<double>* v : {&g->part_rz, &g->part_rz_new, &g->part_pAp, &g->part_rr, &g->part_bb})
     if ((rc = v->reserve((size_t) nb))) return rc;
@@ -496,37 +1122,81 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   EdgeContrib<D>* contrib = reinterpret_cast<EdgeContrib<D>*>(g->contrib.p);
   const int cstride = (int) (sizeof(EdgeContrib<D>) / sizeof(double));
   const int chi_off = (int) (offsetof(EdgeContrib<D>, chi) / sizeof(double));
+  MgLevelBufs* L0 = g->levels[0];
+  // first level that runs inside the single-workgroup launch
+  int lf = nl;
+  for (int l = 0; l < nl; ++l)
+    if (g->levels[(size_t) l]->n <= MG_FUSE_NODES) { lf = l; break; }
+  auto blocks_for = [](int items) { return std::max(std::min((items + PG_THREADS - 1) / PG_THREADS, 2048), 1); };
+  // z = V-cycle(r): input levels[0].r (= g->r aliased below), output levels[0].x
+  auto vcycle = [&]() {
+    for (int l = 0; l < lf; ++l) {
+      const int bl = blocks_for(g->levels[(size_t) l]->n * D), bc = blocks_for(g->levels[(size_t) l]->nc * D);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bc), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, g->levels_dev.p, l, g->sc.p);
+    }
+    hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
+                       g->coarsest_dense, g->sc.p);
+    for (int l = lf - 1; l >= 0; --l) {
+      const int bl = blocks_for(g->levels[(size_t) l]->n * D);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, g->levels_dev.p, l, g->sc.p);
+    }
+  };
   int nstats = 0;
   for (int it = 0; it < p->max_iterations; ++it) {
     HIP_TRY(hipMemsetAsync(g->sc.p, 0, sizeof(PgScalars), g->stream));
     if (E > 0)
       hipLaunchKernelGGL(k_pg_edges<D>, dim3(nbe), dim3(PG_THREADS), 0, g->stream, E, T, g->poses.p, g->ij.p, g->Z.p,
                          g->omega.p, g->enabled.p, g->Ho.p, contrib);
-    if (E > 0) {
-      const size_t nel = (size_t) 2 * E * D * D;
-      hipLaunchKernelGGL(k_pg_build_csr<D>, dim3((unsigned) ((nel + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0,
-                         g->stream, 2 * E, g->ij.p, g->inc_edge.p, g->enabled.p, g->fixed.p, g->Ho.p, g->Hcsr.p,
-                         g->inc_other.p);
-    }
     hipLaunchKernelGGL(k_pg_chi, dim3(nchi), dim3(PG_THREADS), 0, g->stream, E, g->enabled.p, (const void*) contrib,
                        cstride, chi_off, g->part_chi.p, g->part_n.p);
     hipLaunchKernelGGL(k_pg_vertices<D>, dim3(nbv), dim3(PG_THREADS), 0, g->stream, V, g->fixed.p, g->inc_start.p,
                        g->inc_edge.p, g->enabled.p, contrib, (double) p->damping, g->Hd.p, g->b.p, g->Minv.p, g->sc.p);
-    hipLaunchKernelGGL(k_pg_pcg_init<D>, dim3(nbt), dim3(PG_THREADS), 0, g->stream, n, g->b.p, g->Minv.p, g->x.p, g->r.p,
-                       g->p.p, g->part_rz.p, g->part_bb.p, g->sc.p, g->part_chi.p, g->part_n.p, nchi);
+    // hierarchy numerics: level 0 = float32 copies; then interpolation, Galerkin product, smoother of every level
+    {
+      const size_t nel = std::max((size_t) V, (size_t) L0->ne) * D * D;
+      hipLaunchKernelGGL(k_mg_pack0<D>, dim3((unsigned) ((nel + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
+                         V, L0->ne, g->act_edge.p, g->Hd.p, g->Ho.p, L0->Hd.p, L0->Ho.p);
+      HIP_TRY(hipMemcpyAsync(L0->Dinv.p, g->Minv.p, sizeof(double) * (size_t) V * D * D, hipMemcpyDeviceToDevice, g->stream));
+      for (int l = 0; l < nl; ++l) {
+        MgLevelBufs* L = g->levels[(size_t) l];
+        hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l, T, g->poses.p);
+        if (L->nc + L->nce > 0)
+          hipLaunchKernelGGL(k_mg_galerkin<D>, dim3((unsigned) (((size_t) (L->nc + L->nce) * D + PG_THREADS - 1) / PG_THREADS)),
+                             dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
+        hipLaunchKernelGGL(k_mg_dinv<D>, dim3((unsigned) ((L->nc + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
+                           g->levels_dev.p, l + 1, g->sc.p);
+      }
+      if (g->coarsest_dense)
+        hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, nl, g->coarse_A.p,
+                           g->coarse_inv.p, g->sc.p);
+    }
+    // PCG: r lives in level 0's r (the cycle's input), z = level 0's x (its output)
+    double* r = L0->r.p;
+    double* z = L0->x.p;
+    hipLaunchKernelGGL(k_pg_pcg_init, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->b.p, g->x.p, r, g->part_bb.p, g->sc.p,
+                       g->part_chi.p, g->part_n.p, nchi);
+    vcycle();
+    hipLaunchKernelGGL(k_pg_dot_rz, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, r, z, g->part_rz.p, g->sc.p);
+    hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, 1, z, g->p.p, g->part_rz.p, g->part_rz.p, g->sc.p);
     PgScalars h{};
     int launched = 0;
     while (launched < p->pcg_max_iterations) {
-      const int chunk = std::min(25, p->pcg_max_iterations - launched);
+      const int chunk = std::min(10, p->pcg_max_iterations - launched);
       for (int k = 0; k < chunk; ++k) {
         double* rz_cur = ((launched + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
         double* rz_nxt = ((launched + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
-        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->fixed.p, g->inc_start.p,
-                           g->inc_other.p, g->Hd.p, g->Hcsr.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
-        hipLaunchKernelGGL(k_pg_update_xr<D>, dim3(nbt), dim3(PG_THREADS), 0, g->stream, n, nbt, g->Minv.p, g->p.p, g->Ap.p,
-                           g->x.p, g->r.p, g->z.p, rz_cur, g->part_pAp.p, g->part_rr.p, rz_nxt, g->sc.p, nb);
-        hipLaunchKernelGGL(k_pg_update_p, dim3(nbt), dim3(PG_THREADS), 0, g->stream, n, nbt, (double) p->pcg_tolerance,
-                           g->z.p, g->p.p, rz_cur, rz_nxt, g->part_rr.p, g->part_bb.p, g->sc.p);
+        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
+        hipLaunchKernelGGL(k_pg_update_xr, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance, g->p.p,
+                           g->Ap.p, g->x.p, r, rz_cur, g->part_pAp.p, g->part_rr.p, g->part_bb.p, g->sc.p);
+        hipLaunchKernelGGL(k_pg_converged, dim3(1), dim3(PG_THREADS), 0, g->stream, nb, (double) p->pcg_tolerance, g->part_rr.p,
+                           g->part_bb.p, g->sc.p);
+        vcycle();
+        hipLaunchKernelGGL(k_pg_dot_rz, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, r, z, rz_nxt, g->sc.p);
+        hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, 0, z, g->p.p, rz_cur, rz_nxt, g->sc.p);
       }
       launched += chunk;
       HIP_TRY(hipMemcpyAsync(&h, g->sc.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
@@ -563,7 +1233,7 @@ extern "C" {
 void srrg2_posegraph_default_params(srrg2_posegraph_params* p) {
   if (!p) return;
   p->max_iterations     = 10;
-  p->pcg_max_iterations = 200;
+  p->pcg_max_iterations = 600;
   p->pcg_tolerance      = 1e-6f;
   p->damping            = 0.f;
 }
@@ -636,10 +1306,16 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   (void) hipSetDevice(g->device);
   if (g->stream) (void) hipStreamSynchronize(g->stream);
   g->poses.release(); g->Z.release(); g->fixed.release(); g->enabled.release(); g->ij.release(); g->omega.release();
-  g->Hd.release(); g->Ho.release(); g->Hcsr.release(); g->inc_other.release(); g->b.release(); g->Minv.release(); g->x.release(); g->r.release(); g->z.release();
+  g->Hd.release(); g->Ho.release(); g->b.release(); g->Minv.release(); g->x.release(); g->r.release();
   g->p.release(); g->Ap.release(); g->contrib.release(); g->part_rz.release(); g->part_rz_new.release();
   g->part_pAp.release(); g->part_rr.release(); g->part_bb.release(); g->part_chi.release(); g->part_n.release();
-  g->inc_start.release(); g->inc_edge.release(); g->sc.release();
+  g->inc_start.release(); g->inc_edge.release(); g->sc.release(); g->act_edge.release(); g->levels_dev.release();
+  g->coarse_A.release(); g->coarse_inv.release();
+  for (MgLevelBufs* L : g->levels) {
+    L->release();
+    delete L;
+  }
+  g->levels.clear();
   if (g->stream) (void) hipStreamDestroy(g->stream);
   delete g;
   return 0;
@@ -687,6 +1363,8 @@ int srrg2_posegraph_set(srrg2_posegraph_h g, int V, const float* poses, const ui
   g->h_ij.assign(ij, ij + 2 * (size_t) E);
   g->h_enabled.assign(en.begin(), en.begin() + E);
   g->h_removed.assign((size_t) E, 0);
+  g->h_fixed.assign(fx.begin(), fx.begin() + V);
+  g->mg_dirty = true;
   return upload_incidence(g);
 }
 
@@ -706,7 +1384,9 @@ int srrg2_posegraph_add_variable(srrg2_posegraph_h g, const float* pose, int fix
   HIP_TRY(hipMemcpy(g->fixed.p + V, &fx, 1, hipMemcpyHostToDevice));
   if (id_out) *id_out = V;  // graph ids are indices
   g->V         = V + 1;
+  g->h_fixed.push_back(fx);
   g->inc_dirty = true;
+  g->mg_dirty  = true;
   return 0;
 }
 
@@ -738,6 +1418,7 @@ int srrg2_posegraph_add_factor(srrg2_posegraph_h g, int i, int j, const float* Z
   if (id_out) *id_out = E;
   g->E         = E + 1;
   g->inc_dirty = true;
+  g->mg_dirty  = true;
   return 0;
 }
 
@@ -748,6 +1429,7 @@ int srrg2_posegraph_set_factor_enabled(srrg2_posegraph_h g, int factor_id, int e
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipStreamSynchronize(g->stream));
   const uint8_t en = enabled ? 1 : 0;
+  if (g->h_enabled[(size_t) factor_id] != en) g->mg_dirty = true;  // (the hierarchy covers the enabled factors)
   g->h_enabled[(size_t) factor_id] = en;
   HIP_TRY(hipMemcpy(g->enabled.p + factor_id, &en, 1, hipMemcpyHostToDevice));
   return 0;
@@ -759,6 +1441,7 @@ int srrg2_posegraph_remove_factor(srrg2_posegraph_h g, int factor_id) {
   HIP_TRY(hipSetDevice(g->device));
   HIP_TRY(hipStreamSynchronize(g->stream));
   const uint8_t en = 0;
+  if (g->h_enabled[(size_t) factor_id]) g->mg_dirty = true;
   g->h_enabled[(size_t) factor_id] = 0;
   g->h_removed[(size_t) factor_id] = 1;
   HIP_TRY(hipMemcpy(g->enabled.p + factor_id, &en, 1, hipMemcpyHostToDevice));
@@ -784,6 +1467,7 @@ int srrg2_posegraph_set_enabled(srrg2_posegraph_h g, const uint8_t* enabled) {
   std::vector<uint8_t> en((size_t) std::max(g->E, 1), 1);
   for (int e = 0; e < g->E; ++e) en[e] = (enabled[e] && !g->h_removed[(size_t) e]) ? 1 : 0;
   g->h_enabled.assign(en.begin(), en.begin() + g->E);
+  g->mg_dirty = true;
   HIP_TRY(hipMemcpy(g->enabled.p, en.data(), (size_t) std::max(g->E, 1), hipMemcpyHostToDevice));
   return 0;
 }

@@ -25,7 +25,7 @@ class PoseGraphStats(C.Structure):
 
 
 def default_params():
-    return PoseGraphParams(10, 200, 1e-6, 0.0)
+    return PoseGraphParams(10, 600, 1e-6, 0.0)
 
 
 class PoseGraph:

@@ -69,21 +69,25 @@ def test_c4_full_size_batch_properties(oracle, product):
 
 
 def test_c5_full_size_pose_graph_properties(product):
-    """C5: 50 000 SE(3) poses, 200 000 factors, 10 Gauss-Newton iterations x <= 200 PCG iterations."""
+    """C5: 50 000 SE(3) poses, 200 000 factors, 10 Gauss-Newton iterations; every linear solve converges to its
+    tolerance (multigrid-preconditioned CG), chi decreases monotonically to the noise floor, the accumulated odometry
+    drift of the initial guess (tens of metres) is gone."""
     g = syn.pose_graph_3d(V=50_000, E=200_000, seed=5000)
     pg = product.PoseGraph(abi.SE3_QUAT_RIGHT)
     pg.set_graph(g["poses_init"], g["ij"], g["Z"])
-    stats = pg.solve(pgm.default_params())
+    params = pgm.default_params()
+    stats = pg.solve(params)
     chi = [s["chi"] for s in stats]
     assert len(stats) == 10 and all(s["solver_status"] == 0 and s["num_factors"] == 200_000 for s in stats)
-    assert all(b <= a * 1.01 for a, b in zip(chi, chi[1:])), chi  # monotone (the PCG is cut at 200 iterations: 1 % at the floor)
-    # noise floor: sigma_t = 0.01, sigma_r = 0.005, Omega = I => E[chi] ~ E * (3 * 1e-4 + 3 * 2.5e-5) = 75
-    assert chi[-1] < 1e-3 * chi[0] and chi[-1] < 5e3
+    # the PCG left on its tolerance, not on the iteration cap, in every Gauss-Newton iteration
+    assert all(s["pcg_iterations"] < params.pcg_max_iterations and s["pcg_residual"] <= 1.01e-6 for s in stats), stats
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(chi, chi[1:])), chi  # monotone (float32 rounding of the reported chi)
+    # noise floor: sigma_t = 0.01, sigma_r = 0.005 (quaternion part 0.0025), Omega = I
+    #   => E[chi] ~ (E - (V - 1)) * (3 * 1e-4 + 3 * 6.25e-6) = 48 for the 150 001 loop closures' worth of redundancy
+    assert chi[-1] < 1e-5 * chi[0] and chi[-1] < 100.0
     poses = pg.poses()
     assert np.array_equal(poses[0], g["poses_init"][0])  # the gauge vertex is Fixed (multi_graph_slam_impl.cpp:86)
     assert np.isfinite(poses).all()
-    # 10 x 200 block-Jacobi PCG iterations (the configured budget) bring chi to the noise floor but not yet the slowest
-    # mode of a 50 000-pose chain (the accumulated odometry drift, 62 m here) to zero: it must shrink, not vanish
     e0 = np.max(np.abs(g["poses_init"][:, :, 3] - g["poses_gt"][:, :, 3]))
     e1 = np.max(np.abs(poses[:, :, 3] - g["poses_gt"][:, :, 3]))
-    assert e1 < 0.5 * e0, (e0, e1)
+    assert e1 < 0.05 * e0, (e0, e1)

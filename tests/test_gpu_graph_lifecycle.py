@@ -64,7 +64,9 @@ def test_lifecycle_matches_one_shot_graph_and_oracle(oracle, product):
     assert inc.poses().tobytes() == one.poses().tobytes()
     ref = oracle.OraclePoseGraph(kind)
     ref.set_graph(poses0, ij1, Z1, fixed_mask=fixed, enabled=en1)
-    stats_ref = ref.solve(params)
+    # (the oracle's block-Jacobi PCG needs far more than 100 iterations for what the product's multigrid-preconditioned
+    # PCG does in 100: give it the budget to converge to the same tolerance)
+    stats_ref = ref.solve(pgm.PoseGraphParams(5, 5000, 1e-8, 0.0))
     assert np.max(np.abs(ref.poses() - inc.poses())) < 1e-4
     assert abs(stats_ref[-1]["chi"] - stats_inc[-1]["chi"]) <= 1e-3 * max(1.0, stats_ref[-1]["chi"])
     assert stats_inc[-1]["chi"] < 0.05 * stats_inc[0]["chi"]

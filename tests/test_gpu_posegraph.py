@@ -1,4 +1,4 @@
-"""-m gpu: the HIP pose-graph solve (block-sparse GN + block-Jacobi PCG, through the C ABI) against the CPU oracle
+"""-m gpu: the HIP pose-graph solve (block-sparse GN + multigrid-preconditioned CG, through the C ABI) against the CPU oracle
 and against the SciPy golden fixture.  Dot-product order differs between the two PCGs, so this is a tolerance
 test: poses within 1e-5 (BASELINE.json north_star: increments within 1e-5)."""
 import os
@@ -83,7 +83,7 @@ def test_larger_graph_properties(product):
     pg.set_graph(g["poses_init"], g["ij"], g["Z"])
     st = pg.solve()
     chis = [s["chi"] for s in st]
-    assert all(s["solver_status"] == 0 and s["pcg_iterations"] <= 200 for s in st)
+    assert all(s["solver_status"] == 0 and s["pcg_iterations"] < 200 and s["pcg_residual"] <= 1.01e-6 for s in st)
     assert chis[1] < chis[0] and chis[-1] <= chis[1] * 1.001
     # layers of the lawn-mower trajectory are only weakly tied together, so the optimum keeps part of the drift
     assert np.max(np.abs(pg.poses()[:, :, 3] - g["poses_gt"][:, :, 3])) < 0.6 * np.max(
