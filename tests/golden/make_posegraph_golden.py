@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""tests/golden/posegraph_golden.npz: ONE Gauss-Newton step of a 100-pose / 300-edge SE(3) graph, assembled by an
-independent numpy implementation (numerical Jacobians of the residual, float64) and solved with
-scipy.sparse.linalg.spsolve.  SciPy exists only in the build container, hence the committed fixture.
+"""tests/golden/posegraph_golden.npz, posegraph_golden_2k.npz: ONE Gauss-Newton step of a 100-pose / 300-edge and of a
+2 048-pose / 8 192-edge SE(3) graph, assembled by an independent numpy implementation (numerical Jacobians of the
+residual, float64) and solved with the sparse DIRECT solver scipy.sparse.linalg.spsolve.  SciPy exists only in the build container, hence the committed fixture.
 Run from the repo root:  python tests/golden/make_posegraph_golden.py"""
 import os
 import sys
@@ -28,8 +28,8 @@ def residual(Xi, Xj, Z):
     return t2v(syn.se3_mul(syn.se3_inv(Z), syn.se3_mul(syn.se3_inv(Xi), Xj)))
 
 
-def main():
-    g = syn.pose_graph_3d(V=100, E=300, seed=11)
+def gauss_newton_step(V, E, seed):
+    g = syn.pose_graph_3d(V=V, E=E, seed=seed)
     X = g["poses_init"].astype(np.float64)
     V, E = X.shape[0], g["ij"].shape[0]
     rows, cols, vals = [], [], []
@@ -51,11 +51,9 @@ def main():
                            residual(X[i], syn.se3_mul(X[j], syn._quat_v2t(-d)), Z)) / (2 * eps)
         H = J.T @ J
         idx = np.concatenate([np.arange(6 * i, 6 * i + 6), np.arange(6 * j, 6 * j + 6)])
-        for a in range(12):
-            for c in range(12):
-                rows.append(idx[a]); cols.append(idx[c]); vals.append(H[a, c])
+        rows.append(np.repeat(idx, 12)); cols.append(np.tile(idx, 12)); vals.append(H.ravel())
         b[idx] += J.T @ r0
-    H = sp.coo_matrix((vals, (rows, cols)), shape=(6 * V, 6 * V)).tolil()
+    H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(6 * V, 6 * V)).tolil()
     H[:6, :] = 0
     H[:, :6] = 0
     for a in range(6):
@@ -65,8 +63,20 @@ def main():
     after = np.zeros_like(X)
     for v in range(V):
         after[v] = syn.se3_mul(X[v], syn._quat_v2t(dx[6 * v:6 * v + 6]))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "posegraph_golden.npz")
+    return chi, dx, after
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    chi, dx, after = gauss_newton_step(100, 300, 11)
+    path = os.path.join(here, "posegraph_golden.npz")
     np.savez_compressed(path, chi0=chi, dx=dx, poses_after_1=after.astype(np.float32))
+    print("wrote", path, os.path.getsize(path), "chi0", chi)
+    # a graph large enough for the multigrid hierarchy to have several levels (2 048 poses, 8 192 factors): one
+    # Gauss-Newton step with the sparse direct solver; only the float32 poses are kept (98 kB)
+    chi, dx, after = gauss_newton_step(2048, 8192, 12)
+    path = os.path.join(here, "posegraph_golden_2k.npz")
+    np.savez_compressed(path, chi0=chi, poses_after_1=after.astype(np.float32), max_abs_dx=np.max(np.abs(dx)))
     print("wrote", path, os.path.getsize(path), "chi0", chi)
 
 

@@ -75,6 +75,24 @@ def test_matches_scipy_golden(product):
     assert np.max(np.abs(pg.poses() - G["poses_after_1"])) < 1e-5
 
 
+def test_matches_scipy_direct_solve_2k(oracle, product):
+    """2 048 poses / 8 192 factors (a hierarchy of several levels): one Gauss-Newton step against the committed result
+    of SciPy's sparse DIRECT solver on an independently assembled system (tests/golden/make_posegraph_golden.py);
+    the oracle's block-Jacobi PCG is held to the same fixture."""
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posegraph_golden_2k.npz"))
+    g = syn.pose_graph_3d(V=2048, E=8192, seed=12)
+    p = _tight()
+    p.max_iterations = 1
+    p.pcg_max_iterations = 20000
+    for pg in (product.PoseGraph(abi.SE3_QUAT_RIGHT), oracle.OraclePoseGraph(abi.SE3_QUAT_RIGHT)):
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+        st = pg.solve(p)
+        assert st[0]["solver_status"] == 0 and st[0]["pcg_iterations"] < p.pcg_max_iterations
+        assert abs(st[0]["chi"] - float(G["chi0"])) / float(G["chi0"]) < 1e-4
+        # |dx| reaches 0.3: relative agreement 1e-4 (float32 poses, numerical Jacobians on the golden side)
+        assert np.max(np.abs(pg.poses() - G["poses_after_1"])) < 1e-4 * max(1.0, float(G["max_abs_dx"])) + 2e-5
+
+
 def test_larger_graph_properties(product):
     """size-independent properties at a size the oracle would need seconds for: chi decreases monotonically to the
     noise floor, PCG converges within its budget, the optimum is near the ground truth."""

@@ -97,3 +97,22 @@ def test_matches_scipy_sparse_golden(oracle):
     st = pg.solve(p)
     assert abs(st[0]["chi"] - float(G["chi0"])) / float(G["chi0"]) < 1e-4
     assert np.max(np.abs(pg.poses() - G["poses_after_1"])) < 1e-5
+
+
+def test_oracle_matches_scipy_direct_solve_2k(oracle):
+    """the 2 048-pose fixture of SciPy's sparse direct solver (tests/golden/make_posegraph_golden.py: independent
+    assembly, numerical Jacobians): the oracle's linearisation and PCG reproduce its Gauss-Newton step"""
+    import os
+
+    from srrg2_slam_interfaces_amd import posegraph as pgm
+
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posegraph_golden_2k.npz"))
+    g = syn.pose_graph_3d(V=2048, E=8192, seed=12)
+    p = pgm.default_params()
+    p.pcg_tolerance, p.pcg_max_iterations, p.max_iterations = 1e-10, 20000, 1
+    pg = oracle.OraclePoseGraph(abi.SE3_QUAT_RIGHT)
+    pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+    st = pg.solve(p)
+    assert st[0]["solver_status"] == 0 and st[0]["pcg_iterations"] < 20000
+    assert abs(st[0]["chi"] - float(G["chi0"])) / float(G["chi0"]) < 1e-6
+    assert np.max(np.abs(pg.poses() - G["poses_after_1"])) < 2e-5
