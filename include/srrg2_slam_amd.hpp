@@ -11,6 +11,7 @@
 //   AlignerSliceMotionModel         AlignerSliceMotionModel_               aligner_slice_motion_model.hpp:13-92
 //   AlignerSliceOdomPrior           AlignerSliceOdom{2,3}DPrior            aligner_slice_odometry_prior.{h,cpp}
 //   Scene / SceneClipperBall / MergerCorrespondenceHomo                    mapping/scene_clipper.h, merger_correspondence_homo.h
+//   (loop-closure drivers and the pose graph: srrg2_slam_amd_loop_closure.hpp)
 #pragma once
 #include <array>
 #include <cstring>
@@ -154,6 +155,35 @@ public:
     check(srrg2_aligner_get_iteration_stats(_h, nullptr, &n));
     _iteration_stats.resize((size_t) n);
     if (n) check(srrg2_aligner_get_iteration_stats(_h, _iteration_stats.data(), &n));
+  }
+  // K independent alignments against the fixed scene already set: the loop body of
+  // MultiLoopDetectorBruteForce_::compute (multi_loop_detector_brute_force_impl.cpp:64-91) for all candidates at once.
+  // clouds: K pointers to packed Dim-float records with their sizes; normals may be empty (none) or K pointers.
+  std::vector<srrg2_batch_result> computeBatch(const std::vector<const float*>& clouds, const std::vector<int>& sizes,
+                                               const std::vector<const float*>& normals,
+                                               const std::vector<EstimateType>& guesses) {
+    const int K = (int) clouds.size();
+    if ((int) sizes.size() != K || (int) guesses.size() != K || (!normals.empty() && (int) normals.size() != K))
+      throw std::runtime_error("MultiAligner_::computeBatch|inconsistent argument sizes");
+    std::vector<int32_t> offsets((size_t) K + 1, 0);
+    for (int k = 0; k < K; ++k) offsets[(size_t) k + 1] = offsets[(size_t) k] + sizes[(size_t) k];
+    std::vector<float> coords((size_t) offsets[(size_t) K] * Dim), nrm;
+    if (!normals.empty()) nrm.resize(coords.size());
+    std::vector<float> g((size_t) K * EstimateType::N);
+    for (int k = 0; k < K; ++k) {
+      std::memcpy(coords.data() + (size_t) offsets[(size_t) k] * Dim, clouds[(size_t) k], sizeof(float) * (size_t) sizes[(size_t) k] * Dim);
+      if (!normals.empty())
+        std::memcpy(nrm.data() + (size_t) offsets[(size_t) k] * Dim, normals[(size_t) k], sizeof(float) * (size_t) sizes[(size_t) k] * Dim);
+      std::memcpy(g.data() + (size_t) k * EstimateType::N, guesses[(size_t) k].data(), sizeof(float) * EstimateType::N);
+    }
+    srrg2_aligner_params p{param_max_iterations, param_min_num_inliers, param_enable_inlier_only_runs ? 1 : 0,
+                           param_keep_only_inlier_correspondences ? 1 : 0};
+    check(srrg2_aligner_set_params(_h, &p));
+    std::vector<srrg2_batch_result> results((size_t) K);
+    if (K)
+      check(srrg2_aligner_compute_batch(_h, K, coords.data(), Dim * 4, normals.empty() ? nullptr : nrm.data(), Dim * 4,
+                                        offsets.data(), SRRG2_MEM_HOST, g.data(), results.data()));
+    return results;
   }
   Status status() const { return _status; }
   const IterationStatsVector& iterationStats() const { return _iteration_stats; }

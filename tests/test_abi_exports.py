@@ -54,3 +54,20 @@ def test_no_cpu_fallback_without_device():
 
     with pytest.raises(RuntimeError, match="no HIP device"):
         pkg.MultiAligner()
+
+
+def test_headers_compile_with_plain_gxx(tmp_path):
+    """the C++ mirrors compile with g++ alone (no HIP headers for a caller); the reference-side adapter
+    (srrg2_slam_amd_adapter.hpp) needs srrg2_core / srrg2_solver, which this image does not have: it must compile to
+    nothing instead of failing"""
+    import subprocess
+
+    src = tmp_path / "tu.cpp"
+    src.write_text('#include "srrg2_slam_amd.h"\n#include "srrg2_slam_amd.hpp"\n#include "srrg2_slam_amd_loop_closure.hpp"\n'
+                   '#include "srrg2_slam_amd_adapter.hpp"\n'
+                   '#ifdef SRRG2_SLAM_AMD_HAVE_SRRG2_CORE\n#error "unexpected: srrg2_core found"\n#endif\n'
+                   'int main() { srrg2_slam_amd::LoopClosure<3> c; return c.source_graph_id + 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    c_src = tmp_path / "tu.c"  # the C ABI header is C
+    c_src.write_text('#include "srrg2_slam_amd.h"\nint main(void) { return SRRG2_AMD_ABI_VERSION == 2 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(c_src)])

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPP = os.path.join(ROOT, "tests", "cpp")
 BIN = os.path.join(CPP, "bin", "test_motion_model_slice")
 BIN_CYCLE = os.path.join(CPP, "bin", "test_tracker_cycle")
+BIN_LOOP = os.path.join(CPP, "bin", "test_loop_closure")
 
 
 def _build():
@@ -18,7 +19,7 @@ def _build():
 
 def test_cpp_mirror_compiles_and_links():
     _build()
-    assert os.path.exists(BIN) and os.path.exists(BIN_CYCLE)
+    assert os.path.exists(BIN) and os.path.exists(BIN_CYCLE) and os.path.exists(BIN_LOOP)
 
 
 @pytest.mark.gpu
@@ -36,5 +37,16 @@ def test_cpp_tracker_cycle_on_gpu():
     if not os.path.exists(BIN_CYCLE):
         _build()
     out = subprocess.run([BIN_CYCLE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASSED" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_loop_closure_on_gpu():
+    """select candidates -> batched alignment + accept gates -> relocalize -> validate -> optimize, all through the C++
+    mirror (srrg2_slam_amd_loop_closure.hpp): the host drivers of SURVEY.md section 8f rows 1 and 3 in C++."""
+    if not os.path.exists(BIN_LOOP):
+        _build()
+    out = subprocess.run([BIN_LOOP], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASSED" in out.stdout
