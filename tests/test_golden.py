@@ -63,3 +63,51 @@ def test_one_iteration_c1_se2(backend, oracle):
         H, b, dx = al.last_system()
         assert np.max(np.abs(H - GOLD["c_H"])) / np.max(np.abs(GOLD["c_H"])) < 1e-5
         assert np.max(np.abs(dx - GOLD["c_dx"])) < 1e-5
+
+
+# ---- second derivation: finite-difference Jacobians on the golden side (tests/golden/make_golden_fd.py) --------------------
+GOLD_FD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icp_golden_fd.npz"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_reprojection_factor_against_finite_differences(backend, oracle):
+    """projective finder + pinhole reprojection factor (the second slice of BASELINE config C3): correspondences and
+    responses bit-exact against the restated finder, H / b / dx / X against a Gauss-Newton step whose Jacobians are
+    central finite differences of the residual function"""
+    from helpers import projective_config
+
+    d = syn.rgbd_pair(rows=60, cols=80, seed=3100)
+    al = _aligner(backend, oracle, abi.SE3_QUAT_RIGHT)
+    al.set_params(max_iterations=1, min_num_inliers=10)
+    setup_pair(al, d, projective_config(abi.SE3_QUAT_RIGHT, abi.SLICE_REPROJECTION, d, gate=0.05), GOLD_FD["r_guess"])
+    assert al.compute() == abi.SUCCESS
+    c = al.correspondences(0)
+    match = GOLD_FD["r_match"]
+    sel = match >= 0
+    assert np.array_equal(c["moving_idx"], np.nonzero(sel)[0].astype(np.int32))
+    assert np.array_equal(c["fixed_idx"], match[sel])
+    assert c["response"].tobytes() == GOLD_FD["r_resp"][sel].tobytes()
+    assert al.iteration_stats()[0]["num_inliers"] == int(GOLD_FD["r_n"])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD_FD["r_X"])) <= 1e-5
+    if backend == "oracle":
+        H, b, dx = al.last_system()
+        assert np.max(np.abs(H - GOLD_FD["r_H"])) / np.max(np.abs(GOLD_FD["r_H"])) < 1e-4
+        assert np.max(np.abs(b - GOLD_FD["r_b"])) / np.max(np.abs(GOLD_FD["r_b"])) < 1e-3
+        assert np.max(np.abs(dx - GOLD_FD["r_dx"])) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("gi", [0, 1])
+def test_se3_euler_box_plus_against_finite_differences(backend, oracle, gi):
+    """MultiAligner3D (VariableSE3EulerRightAD): X <- X * [Rx Ry Rz | t] with a finite-difference Jacobian"""
+    d = syn.cloud_pair_3d(n=1500, seed=321)
+    al = _aligner(backend, oracle, abi.SE3_EULER_RIGHT)
+    al.set_params(max_iterations=1)
+    setup_pair(al, d, cue_config(abi.SE3_EULER_RIGHT, abi.SLICE_P2P, 0.25), GOLD_FD["e%d_guess" % gi])
+    assert al.compute() == abi.SUCCESS
+    _check_corr(al.correspondences(0), GOLD_FD["e%d_idx" % gi], GOLD_FD["e%d_d2" % gi])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD_FD["e%d_X" % gi])) <= 1e-5
+    if backend == "oracle":
+        H, b, dx = al.last_system()
+        assert np.max(np.abs(H - GOLD_FD["e%d_H" % gi])) / np.max(np.abs(GOLD_FD["e%d_H" % gi])) < 1e-5
+        assert np.max(np.abs(dx - GOLD_FD["e%d_dx" % gi])) < 1e-5
