@@ -537,6 +537,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   const int fast_ppt  = std::getenv("SRRG2_AMD_FAST_PPT") ? std::atoi(std::getenv("SRRG2_AMD_FAST_PPT")) : 1;
   // batches gather the kept neighbour from the cache-resident fixed cloud (36 -> 8 streamed bytes per point); single
   // alignments read it from per-point arrays (no dependent load on the chain of a latency-bound launch)
+  // (smallest moving cloud that uses the converged-pass kernel.  Sparse clouds of a few thousand points leave a larger
+  // share of their certificates behind; since those searches run four at a time with 16 lanes each the kernel is ahead
+  // at every size -- 2 000 points: 0.26 ms per compute() either way, 0.42 ms with one search per wave at a time,
+  // profiles/r2m_bench_small.json / r2n_bench_small*.json -- so the threshold is 0; kept as a switch)
+  const int fast_min = std::getenv("SRRG2_AMD_FAST_MIN") ? std::atoi(std::getenv("SRRG2_AMD_FAST_MIN")) : 0;
   const bool fast_gather = std::getenv("SRRG2_AMD_FAST_GATHER") ? std::atoi(std::getenv("SRRG2_AMD_FAST_GATHER")) != 0 : K > 4;
   const bool fast_batch_queue = std::getenv("SRRG2_AMD_FAST_QUEUE") ? std::atoi(std::getenv("SRRG2_AMD_FAST_QUEUE")) != 0 : false;
   std::vector<SliceDev> sdev((size_t) nslices);
@@ -808,7 +813,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           // The deferred-search kernel pays off while many points are open; once the searches are mostly skipped
           // its launch costs more than finishing a few near points inside the step kernel (queue_on, decided below).
           SliceDev sd = sdev[si];
-          const bool fast = (slot0 > 0 || it >= fast_from) && !(C.tune & 4);
+          const bool fast = (slot0 > 0 || it >= fast_from) && !(C.tune & 4) && nm_max >= fast_min;
           if (!queue_on[si] || (s->fast_queue_only && !fast)) {
             sd.queue  = nullptr;
             sd.qcount = nullptr;

@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   const bool cert_a  = !(S.tune & 4096), cert_c = !(S.tune & (4096 | 65536));
   const int lane     = threadIdx.x & 63;
   const int wid      = threadIdx.x >> 6;
-  __shared__ int coop_lds[4][264];
+  __shared__ int coop_lds[4][288];  // (64-lane scans need 264 ints, four 16-lane teams 4 x 72)
 
   // gates, rows and factor terms of a point whose nearest neighbour {fk, nk} is known (valid); straight-line
   auto linearize = [&](auto first, long long (&acc)[ACC_N], bool valid, const float4 pk, const float4 fk, const float4 nk,
@@ -1331,11 +1331,41 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   for (int k = 0; k < PPT; ++k) {
     sbest[k] = INFINITY; sexcl[k] = 0.f; sidx[k] = NO_MATCH; spos[k] = 0;
     const bool open = open_ball2[k] >= 0.f;
-    unsigned long long todo = __ballot(open);
-    if (!todo) continue;
+    if (!__ballot(open)) continue;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (open) transform_point<DIM>(T, p[k], qx, qy, qz);
     const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
+    // small balls (the usual case: the ball of the previous neighbour): four searches per pass, 16 lanes each
+    unsigned long long near = __ballot(open && r2 == 2);
+    while (near) {
+      int src[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        src[t] = near ? __ffsll((long long) near) - 1 : -1;
+        near &= near - 1;
+      }
+      const int team = lane >> 4;
+      const int mine = team == 0 ? src[0] : (team == 1 ? src[1] : (team == 2 ? src[2] : src[3]));
+      const int from = mine >= 0 ? mine : lane;
+      const float sqx = __shfl(qx, from), sqy = __shfl(qy, from), sqz = __shfl(qz, from), sball = __shfl(open_ball2[k], from);
+      const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
+      const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
+      float wbest, wexcl2;
+      int widx, wpos;
+      coop_scan<DIM, 16>(g, lane, coop_lds[wid], sqx, sqy, sqz, scx, scy, scz, mine >= 0 ? 2 : -1, sball, wbest, widx, wpos, wexcl2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // the result of team t goes to the lane that owns the point
+        const float rb = __shfl(wbest, 16 * t), re = __shfl(wexcl2, 16 * t);
+        const int ri = __shfl(widx, 16 * t), rp = __shfl(wpos, 16 * t);
+        if (lane == src[t]) {
+          sbest[k] = rb;
+          sidx[k]  = ri;
+          spos[k]  = rp;
+          sexcl[k] = sqrtf(re) * 0.99999f;
+        }
+      }
+    }
+    unsigned long long todo = __ballot(open && r2 != 2);
     while (todo) {
       const int src = __ffsll((long long) todo) - 1;
       todo &= todo - 1;

@@ -32,6 +32,7 @@ def search_path(request, monkeypatch):
     on all of these paths: they must give the same bits."""
     qmin, fast_from, ppt, fq, gather = _PATHS[request.param]
     monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", qmin)
+    monkeypatch.setenv("SRRG2_AMD_FAST_MIN", "0")  # (the converged-pass kernel also on this module's small clouds)
     for name, val in (("SRRG2_AMD_FAST_FROM", fast_from), ("SRRG2_AMD_FAST_PPT", ppt), ("SRRG2_AMD_FAST_QUEUE", fq),
                       ("SRRG2_AMD_FAST_GATHER", gather)):
         if val is None:

@@ -9,7 +9,7 @@ import json
 import sqlite3
 import sys
 
-KERNELS = ("k_icp_step<", "k_icp_step_queue<", "k_icp_step_proj<", "k_proj_zbuf")
+KERNELS = ("k_icp_step<", "k_icp_step_fast<", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")
 
 
 def per_kernel(db, counter):
@@ -24,6 +24,7 @@ def per_kernel(db, counter):
 
 def main():
     out, workload, fdb, wdb = sys.argv[1:5]
+    per_launch = int(sys.argv[5]) if len(sys.argv) > 5 else None  # C4: alignments per launch of the profiled command
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     kernels = {}
     total = 0.0
@@ -35,9 +36,10 @@ def main():
         kernels[k] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "dispatches": n}
         total += (fb + wb) * n
         if "queue" not in k and "zbuf" not in k:
-            passes = max(passes, n)  # one step-kernel dispatch per slice pass; the deferred-search kernel runs in some
+            passes += n  # one step-kernel dispatch (k_icp_step or k_icp_step_fast) per slice pass; the deferred-search kernel runs in some
     total = total / max(passes, 1)
     json.dump({"workload": workload, "bytes_per_slice_pass": total, "slice_passes": passes, "kernels": kernels,
+               **({"alignments_per_launch": per_launch} if per_launch else {}),
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, averaged per dispatch; KiB -> bytes; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes); includes Infinity-Cache hits"},
               open(out, "w"), indent=1)
