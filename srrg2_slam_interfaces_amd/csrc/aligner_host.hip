@@ -37,7 +37,7 @@ struct Slice {
   // fixed cloud + search grid
   DevBuf<float4> fixed_raw, fixed_nrm_raw;   // ingest order
   DevBuf<float4> fixed_sorted, fixed_nrm_sorted;
-  DevBuf<int> cell_start, cursor, scan_sums;
+  DevBuf<int> cell_start, cursor, scan_sums, pos_of;
   DevBuf<unsigned> scalars;  // [0..2] bbox min keys, [3..5] bbox max keys, [6] nvalid, [7] ninf bits, [8] scan total
   GridDev grid{};
   int nf          = 0;
@@ -89,7 +89,7 @@ struct Slice {
     ms_probs_host     = nullptr;
     ms_probs_host_cap = 0;
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
-    cell_start.release(); cursor.release(); scan_sums.release(); scalars.release();
+    cell_start.release(); cursor.release(); scan_sums.release(); scalars.release(); pos_of.release();
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
@@ -327,15 +327,17 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   if ((rc = s->scan_sums.reserve((size_t) srrg2amd::scan_num_blocks(ncell) + 1))) return rc;
   if ((rc = s->fixed_sorted.reserve((size_t) std::max(n, 1) + 8))) return rc;  // scan_range over-reads <= 3 entries
   if (s->fixed_has_normals && (rc = s->fixed_nrm_sorted.reserve((size_t) std::max(n, 1)))) return rc;
+  if ((rc = s->pos_of.reserve((size_t) std::max(n, 1)))) return rc;
   HIP_TRY(hipMemsetAsync(s->cell_start.p, 0, ((size_t) ncell + 1) * sizeof(int), a->stream));
   srrg2amd::launch_grid_count(g, s->fixed_raw.p, n, s->cell_start.p, a->stream);
   srrg2amd::launch_exclusive_scan(s->cell_start.p, ncell, s->scan_sums.p, (int*) (s->scalars.p + 8), a->stream);
   HIP_TRY(hipMemcpyAsync(s->cursor.p, s->cell_start.p, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, a->stream));
   srrg2amd::launch_grid_scatter(g, s->fixed_raw.p, s->fixed_has_normals ? s->fixed_nrm_raw.p : nullptr, n, s->cursor.p,
-                                s->fixed_sorted.p, s->fixed_has_normals ? s->fixed_nrm_sorted.p : nullptr, a->stream);
+                                s->fixed_sorted.p, s->fixed_has_normals ? s->fixed_nrm_sorted.p : nullptr, s->pos_of.p, a->stream);
   g.cell_start = s->cell_start.p;
   g.pts        = s->fixed_sorted.p;
   g.nrm        = s->fixed_has_normals ? s->fixed_nrm_sorted.p : nullptr;
+  g.pos_of     = s->pos_of.p;
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -36,6 +36,7 @@ struct GridDev {
   const int* cell_start;  // ncell + 1
   const float4* pts;
   const float4* nrm;      // sorted like pts (w unused); null when the cloud has no normals
+  const int* pos_of;      // [n] original index -> position in pts (the searches track keys, not positions)
 };
 
 // One cue slice (AlignerSliceProcessor_) as the step kernel sees it.

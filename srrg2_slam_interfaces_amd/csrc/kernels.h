@@ -14,7 +14,7 @@ void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s);
 int scan_num_blocks(int n);
 void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s);
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
-                         float4* out_nrm, hipStream_t s);
+                         float4* out_nrm, int* pos_of, hipStream_t s);
 // Morton sort of K moving clouds (counts/cursor: (K << 3*bits) + 1 ints; bb: K*6 keys initialised to
 // {0xffffffff x3, 0 x3}; counts zeroed)
 bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int bits,

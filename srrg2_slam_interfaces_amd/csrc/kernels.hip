@@ -14,6 +14,7 @@
 // order without FMA contraction (-ffp-contract=off), products widened to double, sums carried as
 // exact 64-bit fixed point so that the reduction order (lanes, waves, blocks, GPUs) cannot change
 // a single bit of H, b or the statistics.
+#include <cstdlib>
 #include "kernels.h"
 
 #include <type_traits>
@@ -44,42 +45,47 @@ namespace {
 #define FX_MAGIC_BITS 0x4338000000000000ll        // its bit pattern
 __device__ __forceinline__ long long fx_bits(double biased) { return __double_as_longlong(biased) - FX_MAGIC_BITS; }
 
-// One candidate: squared distance in the specified float32 operation order, then ONE 64-bit unsigned compare of the
-// key (d2 bits << 32 | fixed index) -- d2 >= 0, so the bit pattern orders like the value and the low word breaks ties
-// towards the smaller index.  Written with selects only: the branchy form compiles to exec-mask juggling and dozens of
-// register moves per candidate.
-template <int DIM>
-__device__ __forceinline__ void test_candidate(const float4 f, float qx, float qy, float qz, int j, bool valid,
-                                               unsigned long long& bkey, int& bpos) {
-  const float dx = f.x - qx, dy = f.y - qy;
-  float d2       = dx * dx + dy * dy;
-  if (DIM == 3) {
-    const float dz = f.z - qz;
-    d2             = d2 + dz * dz;
-  }
-  const unsigned long long key = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned) __float_as_int(f.w);
-  const bool better            = valid && key < bkey;
-  bkey                         = better ? key : bkey;
-  bpos                         = better ? j : bpos;
+// One candidate.  Squared distance in the specified float32 operation order, then the running minimum of the 64-bit key
+// (d2 bits << 32 | fixed index) -- d2 >= 0, so the bit pattern orders like the value and the low word breaks ties
+// towards the smaller index -- taken with ONE v_min_f64: read as a double the key is a positive finite number (the
+// exponent field of a float never reaches 0x7ff in the top 11 bits of the pair; denormals are enabled for float64 and
+// compare exactly), and positive doubles order like their bit patterns.  No branch, no compare + selects.
+// The position of the winner in the sorted array is not tracked (two selects per candidate): finish_point looks it up
+// once through GridDev::pos_of.  An invalid candidate (the masked tail of a four-wide group) becomes the neutral key.
+__device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsigned long long b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long) a)), "v"(__longlong_as_double((long long) b)));
+  return (unsigned long long) __double_as_longlong(r);
 }
 
-// ... and the squared distance of the runner-up (b2 = second smallest d2 over the candidates seen): the loser of every
-// comparison is a runner-up candidate.  Used by the first search phase to leave an exclusion radius behind.
 template <int DIM>
-__device__ __forceinline__ void test_candidate2(const float4 f, float qx, float qy, float qz, int j, bool valid,
-                                                unsigned long long& bkey, int& bpos, float& b2) {
+__device__ __forceinline__ float cand_d2(const float4 f, float qx, float qy, float qz) {
   const float dx = f.x - qx, dy = f.y - qy;
   float d2       = dx * dx + dy * dy;
   if (DIM == 3) {
     const float dz = f.z - qz;
     d2             = d2 + dz * dz;
   }
-  const unsigned long long key = ((unsigned long long) __float_as_uint(d2) << 32) | (unsigned) __float_as_int(f.w);
-  const bool better            = valid && key < bkey;
-  const float loser            = better ? __uint_as_float((unsigned) (bkey >> 32)) : d2;
-  b2                           = valid ? fminf(b2, loser) : b2;
-  bkey                         = better ? key : bkey;
-  bpos                         = better ? j : bpos;
+  return d2;
+}
+
+template <int DIM>
+__device__ __forceinline__ void test_candidate(const float4 f, float qx, float qy, float qz, bool valid,
+                                               unsigned long long& bkey) {
+  const float d2 = valid ? cand_d2<DIM>(f, qx, qy, qz) : INFINITY;
+  const unsigned idx = valid ? (unsigned) __float_as_int(f.w) : (unsigned) NO_MATCH;
+  bkey = key_min(bkey, ((unsigned long long) __float_as_uint(d2) << 32) | idx);
+}
+
+// ... and the squared distance of the runner-up (b2 = second smallest d2 over the candidates seen), for the exclusion
+// radius: with best <= b2 the new runner-up is the median of (best, b2, d2) -- one v_med3_f32.
+template <int DIM>
+__device__ __forceinline__ void test_candidate2(const float4 f, float qx, float qy, float qz, bool valid,
+                                                unsigned long long& bkey, float& b2) {
+  const float d2 = valid ? cand_d2<DIM>(f, qx, qy, qz) : INFINITY;
+  const unsigned idx = valid ? (unsigned) __float_as_int(f.w) : (unsigned) NO_MATCH;
+  b2   = __builtin_amdgcn_fmed3f(__uint_as_float((unsigned) (bkey >> 32)), b2, d2);
+  bkey = key_min(bkey, ((unsigned long long) __float_as_uint(d2) << 32) | idx);
 }
 
 // -DSRRG2_TIMELINE: per-wave timeline of the step kernel (tools/timeline.py); compiled out of the product build
@@ -110,35 +116,28 @@ __device__ __forceinline__ unsigned long long make_key(float best, int bidx) {
 __device__ __forceinline__ float key_best(unsigned long long k) { return __uint_as_float((unsigned) (k >> 32)); }
 __device__ __forceinline__ int key_idx(unsigned long long k) { return (int) (unsigned) k; }
 
-// scan the contiguous candidates [j, e) with four independent 16-byte loads in flight.  Reads up to 3 entries
-// past e (masked out): the sorted arrays are allocated with >= 4 entries of slack.
+// scan the contiguous candidates [j, e): full groups of four independent 16-byte loads without masks, then the tail
+// (1-3 candidates; reads up to 2 entries past e, masked out: the sorted arrays are allocated with slack).
 template <int DIM>
 __device__ __forceinline__ void scan_range2(const float4* __restrict__ pts, int j, int e, float qx, float qy, float qz,
-                                            unsigned long long& bkey, int& bpos, float& b2) {
-  for (; j < e; j += 4) {
+                                            unsigned long long& bkey, float& b2) {
+  for (; j + 4 <= e; j += 4) {
     const float4 f0 = pts[j];
     const float4 f1 = pts[j + 1];
     const float4 f2 = pts[j + 2];
     const float4 f3 = pts[j + 3];
-    test_candidate2<DIM>(f0, qx, qy, qz, j, true, bkey, bpos, b2);
-    test_candidate2<DIM>(f1, qx, qy, qz, j + 1, j + 1 < e, bkey, bpos, b2);
-    test_candidate2<DIM>(f2, qx, qy, qz, j + 2, j + 2 < e, bkey, bpos, b2);
-    test_candidate2<DIM>(f3, qx, qy, qz, j + 3, j + 3 < e, bkey, bpos, b2);
+    test_candidate2<DIM>(f0, qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(f1, qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(f2, qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(f3, qx, qy, qz, true, bkey, b2);
   }
-}
-
-template <int DIM>
-__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int j, int e, float qx, float qy, float qz,
-                                           unsigned long long& bkey, int& bpos) {
-  for (; j < e; j += 4) {
+  if (j < e) {
     const float4 f0 = pts[j];
     const float4 f1 = pts[j + 1];
     const float4 f2 = pts[j + 2];
-    const float4 f3 = pts[j + 3];
-    test_candidate<DIM>(f0, qx, qy, qz, j, true, bkey, bpos);
-    test_candidate<DIM>(f1, qx, qy, qz, j + 1, j + 1 < e, bkey, bpos);
-    test_candidate<DIM>(f2, qx, qy, qz, j + 2, j + 2 < e, bkey, bpos);
-    test_candidate<DIM>(f3, qx, qy, qz, j + 3, j + 3 < e, bkey, bpos);
+    test_candidate2<DIM>(f0, qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(f1, qx, qy, qz, j + 1 < e, bkey, b2);
+    test_candidate2<DIM>(f2, qx, qy, qz, j + 2 < e, bkey, b2);
   }
 }
 
@@ -160,7 +159,7 @@ __device__ __forceinline__ void axis_range(float q, float rr, float o, float inv
 // (independent loads), then the candidates of each row are streamed four at a time.
 template <int DIM>
 __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             float r2box, unsigned long long& bkey, int& bpos, float& b2,
+                                             float r2box, unsigned long long& bkey, float& b2,
                                              float& complete2, unsigned long long* tl = nullptr) {
   constexpr int NROWS = DIM == 3 ? 9 : 3;
   complete2 = r2box;
@@ -190,7 +189,7 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
   // its distance (+ a pad, so that the scan still proves an exclusion margin) prunes the other rows by their distance
   // to the query.  complete2 = squared radius inside which this scan has seen every fixed point of the block.
   constexpr int RC = DIM == 3 ? 4 : 1;
-  scan_range2<DIM>(g.pts, rs[RC], re[RC], qx, qy, qz, bkey, bpos, b2);
+  scan_range2<DIM>(g.pts, rs[RC], re[RC], qx, qy, qz, bkey, b2);
   rs[RC] = re[RC] = 0;
   complete2 = r2box;
   if (key_idx(bkey) != NO_MATCH) {
@@ -234,13 +233,13 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
     if (__any(rs[r] < re[r])) {
 #pragma unroll
       for (int k = 0; k < W0; ++k)
-        test_candidate2<DIM>(c[r][k], qx, qy, qz, rs[r] + k, rs[r] + k < re[r], bkey, bpos, b2);
+        test_candidate2<DIM>(c[r][k], qx, qy, qz, rs[r] + k < re[r], bkey, b2);
     }
   }
   STAMP(tl, 3);  // first W0 candidates of every row tested
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
-    scan_range2<DIM>(g.pts, rs[r] + W0, re[r], qx, qy, qz, bkey, bpos, b2);
+    scan_range2<DIM>(g.pts, rs[r] + W0, re[r], qx, qy, qz, bkey, b2);
   }
 }
 
@@ -249,7 +248,7 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
 // the radius-1 block (harmless: the minimum is idempotent).
 template <int DIM>
 __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
-                                             float r2box, unsigned long long& bkey, int& bpos, float& b2) {
+                                             float r2box, unsigned long long& bkey, float& b2) {
   const float rr = ball_radius(r2box);
   int x0, x1, y0, y1, z0 = 0, z1 = 0;
   axis_range(qx, rr, g.ox, g.inv_h, cx - 2, cx + 2, g.nx, x0, x1);
@@ -268,8 +267,48 @@ __device__ __forceinline__ void scan_radius2(const GridDev& g, float qx, float q
     }
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-      scan_range2<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, bpos, b2);
+      scan_range2<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, b2);
     }
+  }
+}
+
+// The SHELL of the radius-2 cube: the cells of the 5^DIM cube that are not in the 3^DIM block (which scan_radius1 has
+// seen, trimmed to its own ball), trimmed to the ball of squared radius r2box.  Continues the running (key, runner-up)
+// pair of the first phase: every fixed point of cube ∩ ball is met exactly once over both phases.  A lane that found a
+// candidate in the block but could not settle on it (the usual case of a misaligned first pass: ~40 % of the lanes)
+// only has to look at the few shell cells its candidate's ball reaches, instead of re-reading the whole block.
+template <int DIM>
+__device__ __forceinline__ void scan_shell2(const GridDev& g, float qx, float qy, float qz, int cx, int cy, int cz,
+                                            float r2box, unsigned long long& bkey, float& b2) {
+  const float rr = ball_radius(r2box);
+  int x0, x1, y0, y1, z0 = 0, z1 = 0;
+  axis_range(qx, rr, g.ox, g.inv_h, cx - 2, cx + 2, g.nx, x0, x1);
+  axis_range(qy, rr, g.oy, g.inv_h, cy - 2, cy + 2, g.ny, y0, y1);
+  if (DIM == 3) axis_range(qz, rr, g.oz, g.inv_h, cz - 2, cz + 2, g.nz, z0, z1);
+  if (x0 > x1) return;
+  // inner rows (|y - cy| <= 1 and |z - cz| <= 1) keep only the cells cx - 2 and cx + 2; the x-extent of the block itself
+  // is [cx - 1, cx + 1] clipped to the grid exactly as scan_radius1 clipped it
+  const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, g.nx - 1);
+  for (int z = z0; z <= z1; ++z) {
+    const bool zin = DIM == 3 ? (z >= cz - 1 && z <= cz + 1) : true;
+    int rs[10], re[10];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int y     = cy + r - 2;
+      const bool ok   = y >= y0 && y <= y1;
+      const bool inner = zin && r >= 1 && r <= 3;
+      const int row   = ok ? (z * g.ny + y) * g.nx : 0;
+      // left part: [x0, min(x1, bx0 - 1)] for inner rows, the whole [x0, x1] otherwise; right part: inner rows only
+      const int la = x0, lb = inner ? min(x1, bx0 - 1) : x1;
+      const int ra = max(x0, bx1 + 1), rb = x1;
+      const bool lok = ok && la <= lb, rok = ok && inner && ra <= rb;
+      rs[2 * r]     = lok ? g.cell_start[row + la] : 0;
+      re[2 * r]     = lok ? g.cell_start[row + lb + 1] : 0;
+      rs[2 * r + 1] = rok ? g.cell_start[row + ra] : 0;
+      re[2 * r + 1] = rok ? g.cell_start[row + rb + 1] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) scan_range2<DIM>(g.pts, rs[r], re[r], qx, qy, qz, bkey, b2);
   }
 }
 
@@ -511,7 +550,6 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
     }
   };
   unsigned long long key = NO_KEY;
-  int lpos               = 0;
   float lb2              = INFINITY;
   const bool any = sr >= 0 && x0 <= x1 && y0 <= y1 && z0 <= z1;
   const int ny_r = any ? y1 - y0 + 1 : 1;
@@ -567,7 +605,7 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
         }
         const int j   = first[r] + (t - flat[r]);
         const int run = min(next, tend) - t;  // candidates of this row in my share: consecutive in memory
-        scan_range2<DIM>(g.pts, j, j + run, sqx, sqy, sqz, key, lpos, lb2);
+        scan_range2<DIM>(g.pts, j, j + run, sqx, sqy, sqz, key, lb2);
         t += run;
       }
     }
@@ -580,11 +618,7 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
     const unsigned long long o = __shfl_xor(kmin, off);
     kmin = o < kmin ? o : kmin;
   }
-  // position of the winner: the first lane of the team holding the minimum key
-  unsigned long long who = __ballot(key == kmin);
-  if (TW < 64) who = (who >> (team * TW)) & ((1ull << TW) - 1ull);
-  const int wl = team * TW + __ffsll((long long) who) - 1;
-  wpos  = __shfl(lpos, wl);
+  wpos  = 0;  // (not tracked: GridDev::pos_of gives the winner's position when it is needed)
   wbest = __uint_as_float((unsigned) (kmin >> 32));
   widx  = (int) (unsigned) kmin;
   // squared exclusion radius: the runner-up of the team (a lane that does not hold the winner contributes its own
@@ -616,6 +650,7 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       if (KNOB(S.tune, 8)) found = false;
       // (a kept neighbour comes with its normal, loaded together with the prior: one round trip less on the chain; the
       // normal of a neighbour beyond the gate is fetched too: it is stored with the neighbour for the next iteration)
+      if (!kept && bidx != NO_MATCH) bpos = g.pos_of[bidx];  // (searches do not track positions: one 4-byte gather here)
       if (bidx != NO_MATCH && (PLANE || S.use_normal_gate))
         nf = KNOB(S.tune, 32) ? make_float4(0.f, 0.f, 1.f, 0.f) : (kept ? kept_n : g.nrm[bpos]);
       // (with nf: one round trip, not one after the normal gate; a kept neighbour comes with its coordinates)
@@ -783,7 +818,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
   bool skipped = false;     // the previous nearest neighbour is provably still the nearest
   float excl_wide = 0.f;
   float pad       = 0.02f * g.h;  // margin of the scans beyond the nearest neighbour (grows with the motion)
-  __shared__ int coop_lds[NW][264];
+  __shared__ int coop_lds[NW][288];  // (64-lane scans need 264 ints, four 16-lane teams 4 x 72)
   STAMP(tl, 1);  // moving point + prior loaded
   if (active && !KNOB(S.tune, 16)) {
     transform_point<DIM>(T, p, qx, qy, qz);
@@ -797,8 +832,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
     // factors 1.00001 / 0.99999 keep every inequality on the safe side.  The oracle searches from scratch.
     if (use_prior && has_prev) {
       unsigned long long k1 = NO_KEY;
-      int pos1              = 0;
-      test_candidate<DIM>(pf, qx, qy, qz, 0, true, k1, pos1);
+      test_candidate<DIM>(pf, qx, qy, qz, true, k1);
       float px, py, pz;
       transform_point<DIM>(Tprev, p, px, py, pz);
       const float ex = qx - px, ey = qy - py, ez = qz - pz;
@@ -833,6 +867,10 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
   }
   // Converged iterations: a handful of lanes per wave still need a search (near-ties, lost exclusion radius) and would
   // make the whole wave pay the search latency.  Hand them to the deferred-search kernel, which is launched anyway.
+  // running (key, runner-up) pair and completeness radius of the first search phase (continued by the shell scan)
+  unsigned long long bkey = NO_KEY;
+  float b2                = INFINITY;
+  float complete2         = INFINITY;
   bool straggler = false;
   if (use_q && use_prior && rfar > 1 && !KNOB(S.tune, 16) && !(S.tune & 8192)) {
     const bool need  = active && !skipped;
@@ -843,15 +881,81 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
       r2        = ball2 <= bound2_of(2, g.h) ? 2 : rfar;
     }
   }
-  if (active && !KNOB(S.tune, 16)) {
-    if (!skipped && !straggler) {
+  // Workgroup-level compaction of the per-lane scans (batch mode): a wave pays for its slowest lane, and on the passes
+  // before convergence only a fraction of the lanes still needs the first phase (the rest hold a certificate), and ~40 %
+  // of those the second.  The lanes that need a scan leave their query in LDS; the first n threads of the workgroup each
+  // take one and hand the (key, runner-up, completeness) triple back through LDS: whole waves skip the phase.
+  // (everything here is uniform over the workgroup: use_q and the tune word are per problem)
+  const bool compact = !use_q && !(S.tune & 2097152);
+  constexpr int COMPACT_MAX = NW * 48;  // above this the scan runs in place (nothing to win, two barriers to lose)
+  __shared__ float4 s_q[NW * 64];
+  __shared__ unsigned long long s_key[NW * 64];
+  __shared__ float s_b2[NW * 64], s_c2[NW * 64];
+  __shared__ int s_wq[NW * 64], s_cnt1[NW], s_cnt2[NW];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const bool need1 = active && !KNOB(S.tune, 16) && !skipped && !straggler;
+  {
+    bool in_lds = false;
+    int n1 = 0;
+    if (compact) {
+      const unsigned long long m = __ballot(need1);
+      if (lane == 0) s_cnt1[wid] = __popcll(m);
+      __syncthreads();
+      int base = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int c = s_cnt1[w];
+        if (w < wid) base += c;
+        n1 += c;
+      }
+      in_lds = n1 > 0 && n1 <= COMPACT_MAX;
+      if (in_lds) {
+        if (need1) {
+          s_wq[base + __popcll(m & below)] = threadIdx.x;
+          s_q[threadIdx.x]                 = make_float4(qx, qy, qz, r2box);
+        }
+        __syncthreads();
+      }
+    }
+    bool wvalid = need1;
+    float wqx = qx, wqy = qy, wqz = qz, wr2 = r2box;
+    int owner = threadIdx.x;
+    if (in_lds) {
+      wvalid = (int) threadIdx.x < n1;
+      if (wvalid) {
+        owner          = s_wq[threadIdx.x];
+        const float4 v = s_q[owner];
+        wqx = v.x; wqy = v.y; wqz = v.z; wr2 = v.w;
+      }
+    }
+    unsigned long long rkey = NO_KEY;
+    float rb2 = INFINITY, rc2 = INFINITY;
+    if (wvalid) {
+      const int wcx = cell_coord(wqx, g.ox, g.inv_h);
+      const int wcy = cell_coord(wqy, g.oy, g.inv_h);
+      const int wcz = DIM == 3 ? cell_coord(wqz, g.oz, g.inv_h) : 0;
+      scan_radius1<DIM>(g, wqx, wqy, wqz, wcx, wcy, wcz, wr2, rkey, rb2, rc2, tl);
+    }
+    if (in_lds) {
+      if (wvalid) {
+        s_key[owner] = rkey;
+        s_b2[owner]  = rb2;
+        s_c2[owner]  = rc2;
+      }
+      __syncthreads();
+      if (need1) {
+        rkey = s_key[threadIdx.x];
+        rb2  = s_b2[threadIdx.x];
+        rc2  = s_c2[threadIdx.x];
+      }
+    }
+    if (need1) {
+      bkey      = rkey;
+      b2        = rb2;
+      complete2 = rc2;
       cx = cell_coord(qx, g.ox, g.inv_h);
       cy = cell_coord(qy, g.oy, g.inv_h);
       cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
-      unsigned long long bkey = NO_KEY;
-      float b2                = INFINITY;
-      float complete2         = INFINITY;
-      scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, bpos, b2, complete2, tl);
       best = key_best(bkey);
       bidx = key_idx(bkey);
       const bool found1 = bidx != NO_MATCH && best <= gfar;  // a candidate that can bound the wider scan
@@ -912,7 +1016,6 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
         base_far += q_cnt[1][w];
       }
       if (r2 > 1) {
-        const unsigned long long below = (1ull << lane) - 1ull;
         QEntry e;
         e.i = i; e.r2 = r2; e.best = best; e.bidx = bidx; e.bpos = bpos;
         e.qx = qx; e.qy = qy; e.qz = qz;
@@ -927,44 +1030,143 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
     }
   } else {
     // radius-2 cube per lane, then the cooperative scan for what is still open
-    if (r2 > 1 && rfar >= 2 && !KNOB(S.tune, 2)) {
-      // (starts from scratch: the cube contains the 3^DIM block again, and the runner-up tracking must meet every
-      // fixed point exactly once)
-      unsigned long long bkey = NO_KEY;
-      float b2                = INFINITY;
-      scan_radius2<DIM>(g, qx, qy, qz, cx, cy, cz, ball2, bkey, bpos, b2);
-      best = key_best(bkey);
-      bidx = key_idx(bkey);
-      const bool found2 = bidx != NO_MATCH && best <= gfar;
-      if ((found2 && best <= bound2_of(2, g.h)) || rfar == 2) {
-        r2        = 0;
-        excl_wide = sqrtf(fminf(fminf(b2, ball2), bound2_of(2, g.h))) * 0.99999f;
-      } else {
-        r2    = rfar;
-        ball2 = gfar;
-        if (found2) {
-          const float rr = (sqrtf(best) + pad) * 1.00001f;
-          ball2          = fminf(rr * rr, gfar);
-          r2             = 2;
-          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+    // the shell of the radius-2 cube, continuing the first phase's (key, runner-up) pair: both phases together have met
+    // every fixed point of cube(2) within min(ball, first phase's completeness radius) exactly once
+    // (SRRG2_AMD_TUNE bit 1048576: the whole cube from scratch, as round 1 did)
+    const bool need2 = r2 > 1 && rfar >= 2 && !KNOB(S.tune, 2);
+    {
+      bool in_lds = false;
+      int n2 = 0;
+      if (compact) {
+        const unsigned long long m = __ballot(need2);
+        if (lane == 0) s_cnt2[wid] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const int c = s_cnt2[w];
+          if (w < wid) base += c;
+          n2 += c;
+        }
+        in_lds = n2 > 0 && n2 <= COMPACT_MAX;
+        if (in_lds) {
+          if (need2) {
+            s_wq[base + __popcll(m & below)] = threadIdx.x;
+            s_q[threadIdx.x]                 = make_float4(qx, qy, qz, ball2);
+            s_key[threadIdx.x]               = bkey;
+            s_b2[threadIdx.x]                = b2;
+          }
+          __syncthreads();
+        }
+      }
+      bool wvalid = need2;
+      float wqx = qx, wqy = qy, wqz = qz, wball = ball2;
+      unsigned long long rkey = bkey;
+      float rb2 = b2;
+      int owner = threadIdx.x;
+      if (in_lds) {
+        wvalid = (int) threadIdx.x < n2;
+        if (wvalid) {
+          owner          = s_wq[threadIdx.x];
+          const float4 v = s_q[owner];
+          wqx = v.x; wqy = v.y; wqz = v.z; wball = v.w;
+          rkey = s_key[owner];
+          rb2  = s_b2[owner];
+        }
+      }
+      if (wvalid) {
+        const int wcx = cell_coord(wqx, g.ox, g.inv_h);
+        const int wcy = cell_coord(wqy, g.oy, g.inv_h);
+        const int wcz = DIM == 3 ? cell_coord(wqz, g.oz, g.inv_h) : 0;
+        if (S.tune & 1048576) {
+          rkey = NO_KEY;
+          rb2  = INFINITY;
+          scan_radius2<DIM>(g, wqx, wqy, wqz, wcx, wcy, wcz, wball, rkey, rb2);
+        } else {
+          scan_shell2<DIM>(g, wqx, wqy, wqz, wcx, wcy, wcz, wball, rkey, rb2);
+        }
+      }
+      if (in_lds) {
+        __syncthreads();  // (every worker has read its item: the slots may be overwritten)
+        if (wvalid) {
+          s_key[owner] = rkey;
+          s_b2[owner]  = rb2;
+        }
+        __syncthreads();
+        if (need2) {
+          rkey = s_key[threadIdx.x];
+          rb2  = s_b2[threadIdx.x];
+        }
+      }
+      if (need2) {
+        bkey = rkey;
+        b2   = rb2;
+        if (S.tune & 1048576) complete2 = INFINITY;
+        best = key_best(bkey);
+        bidx = key_idx(bkey);
+        const bool found2 = bidx != NO_MATCH && best <= gfar;
+        if ((found2 && best <= bound2_of(2, g.h)) || rfar == 2) {
+          r2        = 0;
+          excl_wide = sqrtf(fminf(fminf(fminf(b2, ball2), complete2), bound2_of(2, g.h))) * 0.99999f;
+        } else {
+          r2    = rfar;
+          ball2 = gfar;
+          if (found2) {
+            const float rr = (sqrtf(best) + pad) * 1.00001f;
+            ball2          = fminf(rr * rr, gfar);
+            r2             = 2;
+            while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+          }
         }
       }
     }
     unsigned long long need = __ballot(r2 > 1);
     if (KNOB(S.tune, 1)) need = 0;
+    // Four open points per pass, a team of 16 lanes each (the cost of a cooperative scan is its fixed part -- row ranges,
+    // prefix sum, two LDS round trips -- not its candidates: on the misaligned first pass of a batch a wave has a dozen
+    // such points, most of them with nothing inside the gate); one 64-lane scan at a time when a single point is left.
     while (need) {
-      const int src = __ffsll((long long) need) - 1;
-      need &= need - 1;
+      if (__popcll(need) == 1 || (S.tune & 524288)) {
+        const int src = __ffsll((long long) need) - 1;
+        need &= need - 1;
+        float wbest, wexcl2;
+        int widx, wpos;
+        coop_scan<DIM, 64>(g, lane, coop_lds[wid], __shfl(qx, src), __shfl(qy, src), __shfl(qz, src), __shfl(cx, src),
+                           __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), __shfl(ball2, src), wbest, widx, wpos, wexcl2);
+        if (lane == src) excl_wide = sqrtf(wexcl2) * 0.99999f;
+        if (lane == src && (wbest < best || (wbest == best && widx < bidx))) {
+          best = wbest;
+          bidx = widx;
+        }
+        continue;
+      }
+      int src[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        src[t] = need ? __ffsll((long long) need) - 1 : -1;
+        need &= need - 1;
+      }
+      const int team = lane >> 4;
+      const int mine = team == 0 ? src[0] : (team == 1 ? src[1] : (team == 2 ? src[2] : src[3]));
+      const int from = mine >= 0 ? mine : lane;
       float wbest, wexcl2;
       int widx, wpos;
-      coop_scan<DIM, 64>(g, lane, coop_lds[wid], __shfl(qx, src), __shfl(qy, src), __shfl(qz, src), __shfl(cx, src),
-                     __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), __shfl(ball2, src), wbest, widx, wpos,
-                     wexcl2);
-      if (lane == src) excl_wide = sqrtf(wexcl2) * 0.99999f;
-      if (lane == src && (wbest < best || (wbest == best && widx < bidx))) {
-        best = wbest;
-        bidx = widx;
-        bpos = wpos;
+      // (every shuffle outside the select: the owner of a point may sit in a team that has nothing to do this pass)
+      const int sr_from = __shfl(r2, from);
+      coop_scan<DIM, 16>(g, lane, coop_lds[wid], __shfl(qx, from), __shfl(qy, from), __shfl(qz, from), __shfl(cx, from),
+                         __shfl(cy, from), __shfl(cz, from), mine >= 0 ? sr_from : -1, __shfl(ball2, from), wbest, widx,
+                         wpos, wexcl2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {  // the result of team t goes to the lane that owns the point
+        const float rb = __shfl(wbest, 16 * t), re = __shfl(wexcl2, 16 * t);
+        const int ri = __shfl(widx, 16 * t);
+        if (lane == src[t]) {
+          excl_wide = sqrtf(re) * 0.99999f;
+          if (rb < best || (rb == best && ri < bidx)) {
+            best = rb;
+            bidx = ri;
+          }
+        }
       }
     }
   }
@@ -1264,8 +1466,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
     const float dl   = __builtin_amdgcn_sqrtf((ex * ex + ey * ey) + ez * ez);
     const bool hasp  = __float_as_int(pf[k].w) != NO_MATCH;
     unsigned long long k1 = NO_KEY;
-    int pos1              = 0;
-    test_candidate<DIM>(pf[k], qx, qy, qz, 0, true, k1, pos1);
+    test_candidate<DIM>(pf[k], qx, qy, qz, true, k1);
     const float best = key_best(k1);
     const float d1   = __builtin_amdgcn_sqrtf(best);
     const float rhs  = pm[k] * 0.99999f;
@@ -1390,7 +1591,8 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
     const bool open = open_ball2[k] >= 0.f;
     float4 fk = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH)), nk = make_float4(0.f, 0.f, 0.f, 0.f);
     if (open && sidx[k] != NO_MATCH) {  // the new neighbour and its normal
-      fk = g.pts[spos[k]];
+      spos[k] = g.pos_of[sidx[k]];
+      fk      = g.pts[spos[k]];
       if (PLANE || ngate) nk = g.nrm[spos[k]];
     }
     float qx, qy, qz;
@@ -1436,8 +1638,7 @@ __global__ __launch_bounds__(256) void k_icp_outputs(SliceDev S, const ProblemDe
       float qx, qy, qz;
       transform_point<DIM>(T, p, qx, qy, qz);
       unsigned long long k1 = NO_KEY;
-      int pos1              = 0;
-      test_candidate<DIM>(f, qx, qy, qz, 0, true, k1, pos1);
+      test_candidate<DIM>(f, qx, qy, qz, true, k1);
       const float best = key_best(k1);
       bool found       = best <= S.grid.gate2;
       float4 nf        = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2151,8 +2352,18 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   cur.num_correspondences = num_correspondences(C, st);
   cur.chi_inliers         = (float) chi_in;
   cur.chi_outliers        = (float) chi_out;
+  if (KNOB(C.tune, 8388608)) {  // (timing: without the solve and everything behind it)
+    st->nstats++;
+    st->last_H[0] = H[0] + b[0];
+    return;
+  }
   int bad                 = dm::solve<D>(H, b, dx);
   cur.solver_status       = bad ? 1 : 0;
+  if (KNOB(C.tune, 16777216)) {  // (timing: up to and including the solve)
+    st->nstats++;
+    st->last_dx[0] = dx[0] + dx[D - 1];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < D * D; ++i) st->last_H[i] = H[i];
 #pragma unroll
@@ -2172,6 +2383,7 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
       st->kexp[s] = slice_exponent(C, C.slices[s], prob, 0, st->X);
   if (st->nstats < C.max_stats) stats[(size_t) prob * C.max_stats + st->nstats] = cur;
   st->nstats++;
+  if (KNOB(C.tune, 33554432)) return;  // (timing: without the termination criterion and the queue bookkeeping)
   if (C.has_term && has_to_stop(C, st, cur)) st->done = 1;  // :124-126
   for (int s = 0; s < C.nslices; ++s)
     if (C.slices[s].qcount) {
@@ -2241,6 +2453,17 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   }
 }
 
+constexpr int STATE_WORDS = (int) (sizeof(ProblemState) / sizeof(int));
+static_assert(sizeof(ProblemState) % sizeof(int) == 0, "the state is copied word-wise");
+__device__ __forceinline__ void state_to_lds(ProblemState* lds, const ProblemState* st) {
+  for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
+    reinterpret_cast<int*>(lds)[k] = reinterpret_cast<const int*>(st)[k];
+}
+__device__ __forceinline__ void state_from_lds(ProblemState* st, const ProblemState* lds) {
+  for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
+    reinterpret_cast<int*>(st)[k] = reinterpret_cast<const int*>(lds)[k];
+}
+
 // one 256-thread block per problem: sum the per-block partials of every cue slice (exact integer sums, any
 // order), then thread 0 runs the sequential part of the iteration
 __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob) {
@@ -2271,6 +2494,10 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
+  if (KNOB(C.tune, 4194304)) {  // (timing: everything but the sequential part; the iteration counter must still advance)
+    st->nstats++;
+    return;
+  }
   if (C.variable_kind == SRRG2_SE2_RIGHT)
     control_body<3>(C, st, stats, prob, sums, scaled);
   else
@@ -2282,7 +2509,15 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
   const int prob   = blockIdx.x;
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
-  icp_control_block(C, st, stats, prob);
+  // The sequential part reads and writes ~100 words of the state, with stores to other arrays in between that the
+  // compiler must assume to alias: in global memory that is a chain of exposed L2 round trips.  The workgroup stages the
+  // record in LDS (one coalesced load), thread 0 works there, the workgroup writes it back.
+  __shared__ ProblemState sst;
+  state_to_lds(&sst, st);
+  __syncthreads();
+  icp_control_block(C, &sst, stats, prob);
+  __syncthreads();
+  state_from_lds(st, &sst);
 }
 
 // after the main _runSolver: multi_aligner_impl.cpp:75-85 and the start of _postCompute (:165-171)
@@ -2365,12 +2600,16 @@ __global__ __launch_bounds__(256) void k_icp_control_final(CtlParams C, ProblemS
                                                            srrg2_iteration_stats* __restrict__ stats,
                                                            ProblemOut* __restrict__ outs_host,
                                                            srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
-  const int prob   = blockIdx.x;
-  ProblemState* st = &states[prob];
-  if (!st->done && !st->finished) icp_control_block(C, st, stats, prob);
-  __threadfence();  // (thread 0's state and statistics, read by the whole block below)
+  const int prob = blockIdx.x;
+  __shared__ ProblemState sst;  // (see k_icp_control)
+  state_to_lds(&sst, &states[prob]);
   __syncthreads();
-  icp_finalize_block(C, st, stats, outs_host, stats_host, prob, with_post != 0);
+  if (!sst.done && !sst.finished) icp_control_block(C, &sst, stats, prob);  // (uniform: LDS)
+  __threadfence();  // (thread 0's statistics, read by the whole block below)
+  __syncthreads();
+  icp_finalize_block(C, &sst, stats, outs_host, stats_host, prob, with_post != 0);
+  __syncthreads();
+  state_from_lds(&states[prob], &sst);
 }
 
 // ============================================================================================
@@ -2391,10 +2630,7 @@ __global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, cons
   __shared__ ProblemState sst;
   __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
   __shared__ double scaled[SRRG2_MAX_SLICES][ACC_N];
-  constexpr int STATE_WORDS = (int) (sizeof(ProblemState) / sizeof(int));
-  static_assert(sizeof(ProblemState) % sizeof(int) == 0, "the state is copied word-wise");
-  for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
-    reinterpret_cast<int*>(&sst)[k] = reinterpret_cast<const int*>(&states[prob])[k];
+  state_to_lds(&sst, &states[prob]);
   __syncthreads();
   const ProblemDev pd = probs[prob];
   const int ntiles    = (pd.nm + NW * 64 - 1) / (NW * 64);
@@ -2423,8 +2659,7 @@ __global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, cons
   __syncthreads();
   icp_finalize_block(C, &sst, stats, outs_host, stats_host, prob, nrun == 1);
   __syncthreads();
-  for (int k = threadIdx.x; k < STATE_WORDS; k += blockDim.x)
-    reinterpret_cast<int*>(&states[prob])[k] = reinterpret_cast<const int*>(&sst)[k];
+  state_from_lds(&states[prob], &sst);
 }
 
 // ============================================================================================
@@ -2465,16 +2700,18 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
   if (K <= 0 || max_nm <= 0) return;
   int bx = (max_nm + 255) / 256;  // one moving point per thread
   dim3 grid(bx, K);
+  // (experiment: SRRG2_AMD_STEP_LDS = bytes of unused dynamic LDS per workgroup, to lower the occupancy on purpose)
+  static const unsigned dyn = getenv("SRRG2_AMD_STEP_LDS") ? (unsigned) atoi(getenv("SRRG2_AMD_STEP_LDS")) : 0u;
   if (dim == 3) {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step<3, true>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step<3, true>), grid, dim3(256), dyn, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step<3, false>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step<3, false>), grid, dim3(256), dyn, s, S, probs, states);
   } else {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step<2, true>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step<2, true>), grid, dim3(256), dyn, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), dyn, s, S, probs, states);
   }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }

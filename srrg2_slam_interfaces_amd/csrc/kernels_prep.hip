@@ -233,14 +233,19 @@ __global__ void k_scan_add(int* __restrict__ data, int n, const int* __restrict_
 }
 
 __global__ void k_grid_scatter(GridDev g, const float4* __restrict__ pts, const float4* __restrict__ nrm, int n,
-                               int* __restrict__ cursor, float4* __restrict__ out_pts, float4* __restrict__ out_nrm) {
+                               int* __restrict__ cursor, float4* __restrict__ out_pts, float4* __restrict__ out_nrm,
+                               int* __restrict__ pos_of) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  if (!finite3(p.x, p.y, p.z)) return;
+  if (!finite3(p.x, p.y, p.z)) {
+    pos_of[i] = 0;
+    return;
+  }
   int pos      = atomicAdd(&cursor[grid_cell_of(g, p)], 1);
   p.w          = __int_as_float(i);
   out_pts[pos] = p;
+  pos_of[i]    = pos;
   if (nrm) out_nrm[pos] = nrm[i];
 }
 
@@ -553,9 +558,9 @@ void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, 
 }
 
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
-                         float4* out_nrm, hipStream_t s) {
+                         float4* out_nrm, int* pos_of, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_grid_scatter, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, nrm, n, cursor, out_pts, out_nrm);
+  hipLaunchKernelGGL(k_grid_scatter, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, nrm, n, cursor, out_pts, out_nrm, pos_of);
 }
 
 void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
