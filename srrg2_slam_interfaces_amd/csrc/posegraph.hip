@@ -18,10 +18,12 @@
 // float64 throughout (the float32 poses are the only float32 state).  Results agree with the CPU oracle to PCG
 // tolerance, not bit for bit (dot-product order differs); tests bound the pose difference.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "det_math.h"
@@ -224,54 +226,87 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
 }
 
 // =====================================================================================================================
-// Linear solver: conjugate gradients preconditioned by an aggregation multigrid V-cycle.
+// Linear solver: conjugate gradients preconditioned by a smoothed-aggregation multigrid V-cycle.
 //
 // Block-Jacobi PCG needs ~2700 iterations on BASELINE's C5 graph (50 000 poses on a 112 x 112 x 4 lattice of loop
 // closures, one gauge vertex: the accumulated odometry drift is the slowest mode of a grounded lattice Laplacian) and
 // was cut at 200 per Gauss-Newton iteration in round 1 without converging.  The hierarchy:
 //   * aggregates by greedy pairwise matching (three passes per level: <= 8 poses per aggregate), a pose is matched with
 //     its nearest unmatched graph neighbour; built on the host when the graph's structure changes;
-//   * interpolation = the rigid-body motion of the aggregate: dx_i = P_i eta_I with P_i = Ad(X_i^-1 X_I) in the
-//     (translation, quaternion-vector) coordinates of the right perturbation -- the near-null space of H (global
+//   * tentative interpolation T = the rigid-body motion of the aggregate: dx_i = T_i eta_I with T_i = Ad(X_i^-1 X_I) in
+//     the (translation, quaternion-vector) coordinates of the right perturbation -- the near-null space of H (global
 //     rigid motions) is represented exactly on every level;
-//   * coarse operators by the Galerkin product P^T H P, assembled per coarse block from fixed lists (no atomics:
-//     deterministic), float64; recomputed every Gauss-Newton iteration on the device;
-//   * V(1,1) cycle with damped block-Jacobi smoothing (omega = 0.6); the coarsest level (<= 64 nodes) is solved by its
-//     dense inverse; levels of <= MG_FUSE_NODES nodes run inside ONE single-workgroup launch (they are launch floors
-//     otherwise).
+//   * the interpolation is smoothed by one damped block-Jacobi sweep, Ps = (I - 0.66 Dinv H) T.  With T alone the
+//     cycle's convergence degrades with the number of levels (C5, plain aggregation: 151-415 CG iterations per
+//     Gauss-Newton iteration, profiles/r2k); with Ps: 30-79.  The price is fill: a row of Ps holds the aggregates of a
+//     pose and of its neighbours (C5: 4 blocks per row), the coarse operators have 40-120 blocks per row, so rows and
+//     columns of the coarse levels are shared by 2-32 adjacent lanes (MgLevel::row_parts / col_parts / prow_parts);
+//   * coarse operators by the Galerkin product Ps^T (H Ps) in two sparse products over patterns fixed on the host; every
+//     output block is one lane group's fixed-order sum (no atomics: deterministic), float64; recomputed every
+//     Gauss-Newton iteration on the device;
+//   * V(1,1) cycle with damped block-Jacobi smoothing (omega = 0.7); the coarsest level (<= 32 nodes) is solved by its
+//     dense inverse; small sparse levels run inside ONE single-workgroup launch (they are launch floors otherwise).
 // The cycle is symmetric and positive definite, so PCG applies.  Off-diagonal blocks are stored once per factor
 // (H_ij; the `to` end reads it transposed): (E + V) x 288 bytes per SpMV instead of (2E + V) x 288.  They stay float64:
 // the smallest eigenvalue of a 50 000-pose graph with one gauge vertex is ~1e-9 of the largest, float32 blocks
 // (relative error 6e-8) make the operator indefinite in exactly the drift modes the solve is about -- measured: with
 // float32 blocks PCG needed 151 / 175 / 200 iterations on C5 and the coarsest Cholesky failed in the fourth
 // Gauss-Newton iteration (profiles/r2k_bench_c5_float32_blocks.json).
-// Measured with the numpy prototype of this scheme on the C5 generator at 12.5 k poses: 62 PCG iterations / 220
-// fine-SpMV equivalents against 1373 / 1373 for block-Jacobi.
 // =====================================================================================================================
-#define MG_OMEGA 0.6
+#define MG_OMEGA 0.7
+#define MG_OMEGA_P 0.66  // damping of the interpolation smoother
 #define MG_MAX_LEVELS 16
 #define MG_FUSE_NODES 170   // levels of at most this many nodes run inside the single-workgroup launch (one row per thread)
 #define MG_COARSEST_NODES 32
+#define MG_FUSE_BLOCKS 1200   // ... and at most this many off-diagonal blocks
 
 struct MgLevel {  // device view of one level (level 0 = the pose graph without its Fixed variables' couplings)
-  int n, ne, nc, nce;
+  int n, ne, nc, nce, np, nq;
+  double omega;                 // damping of the block-Jacobi smoother
+  int row_parts, col_parts, prow_parts;  // lanes sharing one row of H / one column of Ps / one row of Ps: powers of two <= 32
   const int2* eij;              // [ne] endpoints of the off-diagonal blocks (this level's node ids)
   const int* inc_start;         // [n + 1]
   const int2* inc_adj;          // incidences: {other node, (edge << 1) | side (1: this node is the edge's second endpoint)}
   const int* agg;               // [n] aggregate of the next level, or -1 (Fixed variables)
-  const int* mem_start;         // [nc + 1] members of every aggregate
-  const int* mem_list;
   const int* rep0;              // [n] graph vertex whose pose represents this node
-  const int* cd_start;          // [nc + 1] edges of this level inside an aggregate
-  const int* cd_list;
-  const int* ce_start;          // [nce + 1] edges of this level that make up a coarse edge: (edge << 1) | flipped
-  const int* ce_list;
+  // smoothed interpolation Ps (n x nc blocks): rows = this level's nodes (CSR, columns ascending), and by column (CSC)
+  const int* prow_start;        // [n + 1]
+  const int* pcol;              // [np]
+  const int* prow_of;           // [np] row of every entry
+  const int* pcsc_start;        // [nc + 1]
+  const int* pcsc_ent;          // [np] entries of every column, rows ascending
+  // Q = H Ps (n x nc blocks, CSR, columns ascending): the first half of the Galerkin product
+  const int* qrow_start;        // [n + 1]
+  const int* qcol;              // [nq]
+  const int* qrow_of;           // [nq]
   double* Hd;                   // [n][D*D] diagonal blocks
   double* Ho;                   // [ne][D*D] off-diagonal blocks H_ij (i = eij.x, j = eij.y), stored once per edge
-  float* P;                     // [n][D*D] interpolation blocks
+  float* P;                     // [n][D*D] tentative interpolation blocks (the aggregate's rigid motion)
+  double* Ps;                   // [np][D*D] smoothed interpolation
+  double* Q;                    // [nq][D*D]
   double* Dinv;                 // [n][D*D] inverse diagonal blocks (smoother)
   double *x, *r, *res;          // [n][D] work vectors of the cycle
 };
+
+// sum of w over the `parts` adjacent lanes that share an output (fixed butterfly: deterministic; every lane gets the sum)
+template <int D>
+__device__ __forceinline__ void mg_group_sum(double (&w)[D], int parts) {
+  for (int off = parts >> 1; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int r = 0; r < D; ++r) w[r] = w[r] + __shfl_xor(w[r], off);
+  }
+}
+
+// position of `key` in the ascending list cols[lo, hi), or -1
+__device__ __forceinline__ int mg_find(const int* __restrict__ cols, int lo, int hi, int key) {
+  while (hi - lo > 4) {
+    const int mid = (lo + hi) >> 1;
+    if (cols[mid] <= key) lo = mid; else hi = mid;
+  }
+  for (int k = lo; k < hi; ++k)
+    if (cols[k] == key) return k;
+  return -1;
+}
 
 // ---- device pieces of the cycle; (tid, nth) = this thread / number of threads sharing the loop --------------------
 template <int D>
@@ -281,7 +316,7 @@ __device__ __forceinline__ void mg_smooth0(const MgLevel& L, int tid, int nth) {
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < D; ++c) s = s + L.Dinv[((size_t) v * D + row) * D + c] * L.r[(size_t) v * D + c];
-    L.x[t] = MG_OMEGA * s;
+    L.x[t] = L.omega * s;
   }
 }
 
@@ -318,40 +353,96 @@ __device__ __forceinline__ double mg_row(const MgLevel& L, const double* __restr
   return y;
 }
 
+// the share of lane `part` (of `parts`) in (H x)_t: the diagonal block (part 0) and every parts-th group of four incidences
+template <int D>
+__device__ __forceinline__ double mg_row_part(const MgLevel& L, const double* __restrict__ x, int v, int row, int part, int parts) {
+  double y = 0.0;
+  if (part == 0) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) y = y + L.Hd[((size_t) v * D + row) * D + c] * x[(size_t) v * D + c];
+  }
+  const int q1 = L.inc_start[v + 1];
+  for (int q0 = L.inc_start[v] + 4 * part; q0 < q1; q0 += 4 * parts) {
+    int2 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = q0 + k < q1 ? L.inc_adj[q0 + k] : make_int2(-1, 0);
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] = 0.0;
+      if (a[k].x >= 0) {
+        const double* B  = L.Ho + (size_t) (a[k].y >> 1) * D * D;
+        const double* xo = x + (size_t) a[k].x * D;
+        if (a[k].y & 1) {
+#pragma unroll
+          for (int c = 0; c < D; ++c) s[k] = s[k] + B[c * D + row] * xo[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < D; ++c) s[k] = s[k] + B[row * D + c] * xo[c];
+        }
+      }
+    }
+    y = y + ((s[0] + s[1]) + (s[2] + s[3]));
+  }
+  return y;
+}
+
+// res = r - H x.  Coarse levels of a smoothed-aggregation hierarchy have long rows (C5: 40-120 blocks) and few of them:
+// `row_parts` adjacent lanes share a row and add their shares with a fixed shuffle tree (deterministic).
 template <int D>
 __device__ __forceinline__ void mg_residual(const MgLevel& L, int tid, int nth) {
-  for (int t = tid; t < L.n * D; t += nth) {
-    const int v = t / D, row = t - v * D;
-    L.res[t]    = L.r[t] - mg_row<D>(L, L.x, v, row);
+  const int parts = L.row_parts;
+  if (parts == 1) {
+    for (int t = tid; t < L.n * D; t += nth) {
+      const int v = t / D, row = t - v * D;
+      L.res[t]    = L.r[t] - mg_row<D>(L, L.x, v, row);
+    }
+    return;
+  }
+  for (int t = tid; t < L.n * D * parts; t += nth) {  // (nth and the bound are multiples of `parts`: whole groups run)
+    const int part = t & (parts - 1), u = t / parts;
+    const int v = u / D, row = u - v * D;
+    double y = mg_row_part<D>(L, L.x, v, row, part, parts);
+    for (int off = parts >> 1; off >= 1; off >>= 1) y = y + __shfl_xor(y, off);
+    if (part == 0) L.res[u] = L.r[u] - y;
   }
 }
 
-// r_coarse = P^T res
+// r_coarse = Ps^T res   (`col_parts` adjacent lanes share a column of Ps: a coarse node interpolates to 30-250 fine ones)
 template <int D>
 __device__ __forceinline__ void mg_restrict(const MgLevel& L, double* __restrict__ rc, int tid, int nth) {
-  for (int t = tid; t < L.nc * D; t += nth) {
-    const int I = t / D, a = t - I * D;
+  const int parts = L.col_parts;
+  for (int t = tid; t < L.nc * D * parts; t += nth) {
+    const int part = t & (parts - 1), u = t / parts;
+    const int I = u / D, a = u - I * D;
     double s = 0.0;
-    for (int m = L.mem_start[I]; m < L.mem_start[I + 1]; ++m) {
-      const int i = L.mem_list[m];
+    for (int m = L.pcsc_start[I] + part; m < L.pcsc_start[I + 1]; m += parts) {
+      const int e = L.pcsc_ent[m], i = L.prow_of[e];
+      const double* B = L.Ps + (size_t) e * D * D;
 #pragma unroll
-      for (int b = 0; b < D; ++b) s = s + (double) L.P[((size_t) i * D + b) * D + a] * L.res[(size_t) i * D + b];
+      for (int b = 0; b < D; ++b) s = s + B[b * D + a] * L.res[(size_t) i * D + b];
     }
-    rc[t] = s;
+    for (int off = parts >> 1; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
+    if (part == 0) rc[u] = s;
   }
 }
 
-// x += P x_coarse
+// x += Ps x_coarse   (`prow_parts` adjacent lanes share a row of Ps)
 template <int D>
 __device__ __forceinline__ void mg_prolong(const MgLevel& L, const double* __restrict__ xc, int tid, int nth) {
-  for (int t = tid; t < L.n * D; t += nth) {
-    const int v = t / D, row = t - v * D;
-    const int I = L.agg[v];
-    if (I < 0) continue;
+  const int parts = L.prow_parts;
+  for (int t = tid; t < L.n * D * parts; t += nth) {
+    const int part = t & (parts - 1), u = t / parts;
+    const int v = u / D, row = u - v * D;
     double s = 0.0;
+    for (int e = L.prow_start[v] + part; e < L.prow_start[v + 1]; e += parts) {
+      const double* B  = L.Ps + (size_t) e * D * D;
+      const double* xo = xc + (size_t) L.pcol[e] * D;
 #pragma unroll
-    for (int a = 0; a < D; ++a) s = s + (double) L.P[((size_t) v * D + row) * D + a] * xc[(size_t) I * D + a];
-    L.x[t] = L.x[t] + s;
+      for (int a = 0; a < D; ++a) s = s + B[row * D + a] * xo[a];
+    }
+    for (int off = parts >> 1; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
+    if (part == 0) L.x[u] = L.x[u] + s;
   }
 }
 
@@ -363,7 +454,7 @@ __device__ __forceinline__ void mg_update(const MgLevel& L, int tid, int nth) {
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < D; ++c) s = s + L.Dinv[((size_t) v * D + row) * D + c] * L.res[(size_t) v * D + c];
-    L.x[t] = L.x[t] + MG_OMEGA * s;
+    L.x[t] = L.x[t] + L.omega * s;
   }
 }
 
@@ -463,7 +554,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_interp(const MgLevel* __restr
   for (int k = 0; k < D * D; ++k) P[k] = 0.f;
   if (I < 0) return;
   const float* Xi = poses + (size_t) L.rep0[i] * T;
-  const float* XI = poses + (size_t) L.rep0[L.mem_list[L.mem_start[I]]] * T;
+  const float* XI = poses + (size_t) levels[l + 1].rep0[I] * T;  // (the pose of the aggregate's first member)
   float Xi_inv[12], A[12];
   if (D == 6) {
     dm::se3_inverse(Xi, Xi_inv);
@@ -490,96 +581,148 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_interp(const MgLevel* __restr
   }
 }
 
-// row `r` of  Pi^T B Pj  (B, Pi, Pj: D x D)
+// Smoothed aggregation: Ps = (I - omega_p Dinv H) T with T the tentative (rigid-motion) interpolation.  Entry (i, A) of Ps:
+//   [agg(i) = A] T_i  -  omega_p Dinv_i  sum_{j in N(i) + i, agg(j) = A} H_ij T_j.          One thread per (entry, column).
+// Piecewise-rigid interpolation alone leaves the V-cycle's convergence dependent on the number of levels (C5: 151-415 CG
+// iterations per solve); one Jacobi sweep on the interpolation removes its high-energy part (C5: ~30 iterations).
 template <int D>
-__device__ __forceinline__ void mg_ptbp_row(const float* Pi, const double* B, const float* Pj, int r, double* out) {
+__global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(const MgLevel* __restrict__ levels, int l, double omega_p) {
+  const MgLevel L = levels[l];
+  const int parts = L.row_parts;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.np * D * parts) return;  // (whole groups: the bound is a multiple of `parts`)
+  const int part = t & (parts - 1), u = t / parts;
+  const int e = u / D, c = u - e * D;
+  const int i = L.prow_of[e], A = L.pcol[e];
   double w[D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) {
-    double s = 0.0;
+  for (int r = 0; r < D; ++r) w[r] = 0.0;
+  const bool own = L.agg[i] == A;
+  if (own && part == 0) {
+    const float* Ti = L.P + (size_t) i * D * D;
+    const double* H = L.Hd + (size_t) i * D * D;
 #pragma unroll
-    for (int a = 0; a < D; ++a) s = s + (double) Pi[a * D + r] * (double) B[a * D + c];
-    w[c] = s;
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int a = 0; a < D; ++a) w[r] = w[r] + H[r * D + a] * (double) Ti[a * D + c];
   }
+  for (int q = L.inc_start[i] + part; q < L.inc_start[i + 1]; q += parts) {
+    const int2 adj = L.inc_adj[q];
+    if (L.agg[adj.x] != A) continue;
+    const float* Tj = L.P + (size_t) adj.x * D * D;
+    const double* B = L.Ho + (size_t) (adj.y >> 1) * D * D;
+    if (adj.y & 1) {
 #pragma unroll
-  for (int c = 0; c < D; ++c) {
-    double s = 0.0;
+      for (int r = 0; r < D; ++r)
 #pragma unroll
-    for (int a = 0; a < D; ++a) s = s + w[a] * (double) Pj[a * D + c];
-    out[c] = s;
+        for (int a = 0; a < D; ++a) w[r] = w[r] + B[a * D + r] * (double) Tj[a * D + c];
+    } else {
+#pragma unroll
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int a = 0; a < D; ++a) w[r] = w[r] + B[r * D + a] * (double) Tj[a * D + c];
+    }
   }
-}
-// row `r` of (Pi^T B Pj)^T = Pj^T B^T Pi
-template <int D>
-__device__ __forceinline__ void mg_ptbp_row_t(const float* Pi, const double* B, const float* Pj, int r, double* out) {
-  double w[D];  // w = B Pj[:, r]
+  mg_group_sum<D>(w, parts);
+  if (part != 0) return;
+  const double* Di = L.Dinv + (size_t) i * D * D;
+  double* out      = L.Ps + (size_t) e * D * D;
 #pragma unroll
-  for (int a = 0; a < D; ++a) {
+  for (int r = 0; r < D; ++r) {
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) s = s + (double) B[a * D + c] * (double) Pj[c * D + r];
-    w[a] = s;
-  }
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    double s = 0.0;
-#pragma unroll
-    for (int a = 0; a < D; ++a) s = s + (double) Pi[a * D + c] * w[a];
-    out[c] = s;
+    for (int a = 0; a < D; ++a) s = s + Di[r * D + a] * w[a];
+    out[r * D + c] = (own ? (double) L.P[((size_t) i * D + r) * D + c] : 0.0) - omega_p * s;
   }
 }
 
-// Galerkin product of level l into level l + 1: one thread per (coarse block, row); fixed lists, fixed order
+// w (D x D, row-major) += A B  or  A^T B, as D rank-1 updates (12 operand values live at a time)
+template <int D, bool TRANSPOSE_A>
+__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* __restrict__ A, const double* __restrict__ B) {
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double col[D], row[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) col[r] = TRANSPOSE_A ? A[a * D + r] : A[r * D + a];
+#pragma unroll
+    for (int c = 0; c < D; ++c) row[c] = B[a * D + c];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c < D; ++c) w[r * D + c] = w[r * D + c] + col[r] * row[c];
+  }
+}
+
+// Q = H Ps.  One thread per (entry of Q, part): the look-ups of Ps[j, B] over the incidences j of row i are the
+// expensive part (a binary search each), so a thread does them once for the whole D x D block; `row_parts` adjacent
+// lanes share the incidences and add their blocks with the fixed butterfly.
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_hp(const MgLevel* __restrict__ levels, int l) {
+  const MgLevel L = levels[l];
+  const int parts = L.row_parts;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.nq * parts) return;  // (whole groups: the bound is a multiple of `parts`)
+  const int part = t & (parts - 1), q = t / parts;
+  const int i = L.qrow_of[q], Bc = L.qcol[q];
+  double w[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) w[k] = 0.0;
+  if (part == 0) {
+    const int e = mg_find(L.pcol, L.prow_start[i], L.prow_start[i + 1], Bc);
+    if (e >= 0) mg_block_mac<D, false>(w, L.Hd + (size_t) i * D * D, L.Ps + (size_t) e * D * D);
+  }
+  for (int k = L.inc_start[i] + part; k < L.inc_start[i + 1]; k += parts) {
+    const int2 adj = L.inc_adj[k];
+    const int e    = mg_find(L.pcol, L.prow_start[adj.x], L.prow_start[adj.x + 1], Bc);
+    if (e < 0) continue;
+    const double* Pe = L.Ps + (size_t) e * D * D;
+    const double* B  = L.Ho + (size_t) (adj.y >> 1) * D * D;
+    if (adj.y & 1)
+      mg_block_mac<D, true>(w, B, Pe);
+    else
+      mg_block_mac<D, false>(w, B, Pe);
+  }
+  mg_group_sum<D * D>(w, parts);
+  if (part != 0) return;
+  double* out = L.Q + (size_t) q * D * D;
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) out[k] = w[k];
+}
+
+// Galerkin product, second half: Hc[A, B] = sum_i Ps[i, A]^T Q[i, B] over the rows of column A; the diagonal blocks
+// and the blocks of the coarse edges (A < B).  One thread per (coarse block, part); fixed lists, fixed order: deterministic.
 template <int D>
 __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(const MgLevel* __restrict__ levels, int l) {
   const MgLevel L = levels[l];
   const MgLevel C = levels[l + 1];
+  const int parts = L.col_parts;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < L.nc * D) {  // diagonal block of aggregate I
-    const int I = t / D, r = t - I * D;
-    double acc[D], tmp[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (int m = L.mem_start[I]; m < L.mem_start[I + 1]; ++m) {
-      const int i = L.mem_list[m];
-      mg_ptbp_row<D>(L.P + (size_t) i * D * D, L.Hd + (size_t) i * D * D, L.P + (size_t) i * D * D, r, tmp);
-#pragma unroll
-      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
-    }
-    for (int q = L.cd_start[I]; q < L.cd_start[I + 1]; ++q) {
-      const int e   = L.cd_list[q];
-      const int2 vv = L.eij[e];
-      const float *Pi = L.P + (size_t) vv.x * D * D, *Pj = L.P + (size_t) vv.y * D * D;
-      const double* B = L.Ho + (size_t) e * D * D;
-      mg_ptbp_row<D>(Pi, B, Pj, r, tmp);
-#pragma unroll
-      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
-      mg_ptbp_row_t<D>(Pi, B, Pj, r, tmp);
-#pragma unroll
-      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
-    }
-#pragma unroll
-    for (int c = 0; c < D; ++c) C.Hd[((size_t) I * D + r) * D + c] = acc[c];
-  } else if (t < (L.nc + L.nce) * D) {  // off-diagonal block of a coarse edge
-    const int ce = (t - L.nc * D) / D, r = (t - L.nc * D) - ce * D;
-    double acc[D], tmp[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (int q = L.ce_start[ce]; q < L.ce_start[ce + 1]; ++q) {
-      const int code = L.ce_list[q], e = code >> 1;
-      const int2 vv  = L.eij[e];
-      const float *Pi = L.P + (size_t) vv.x * D * D, *Pj = L.P + (size_t) vv.y * D * D;
-      const double* B = L.Ho + (size_t) e * D * D;
-      if (code & 1)
-        mg_ptbp_row_t<D>(Pi, B, Pj, r, tmp);
-      else
-        mg_ptbp_row<D>(Pi, B, Pj, r, tmp);
-#pragma unroll
-      for (int c = 0; c < D; ++c) acc[c] = acc[c] + tmp[c];
-    }
-#pragma unroll
-    for (int c = 0; c < D; ++c) C.Ho[((size_t) ce * D + r) * D + c] = acc[c];
+  if (t >= (L.nc + L.nce) * parts) return;
+  const int part = t & (parts - 1), blk = t / parts;
+  int A, B;
+  double* out;
+  if (blk < L.nc) {
+    A = B = blk;
+    out = C.Hd + (size_t) blk * D * D;
+  } else {
+    const int2 ab = C.eij[blk - L.nc];
+    A = ab.x;
+    B = ab.y;
+    out = C.Ho + (size_t) (blk - L.nc) * D * D;
   }
+  double acc[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) acc[k] = 0.0;
+  for (int m = L.pcsc_start[A] + part; m < L.pcsc_start[A + 1]; m += parts) {
+    const int e = L.pcsc_ent[m], i = L.prow_of[e];
+    const int q = mg_find(L.qcol, L.qrow_start[i], L.qrow_start[i + 1], B);
+    if (q < 0) continue;
+    mg_block_mac<D, true>(acc, L.Ps + (size_t) e * D * D, L.Q + (size_t) q * D * D);
+  }
+  mg_group_sum<D * D>(acc, parts);
+  if (part != 0) return;
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) out[k] = acc[k];
 }
 
 // inverse diagonal blocks of level l (the smoother)
@@ -845,16 +988,17 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int T, int varia
 
 // host side of one level: structure (built when the graph changes) + device buffers
 struct MgLevelBufs {
-  int n = 0, ne = 0, nc = 0, nce = 0;
+  int n = 0, ne = 0, nc = 0, nce = 0, np = 0, nq = 0, row_parts = 1, col_parts = 1, prow_parts = 1;
   DevBuf<int2> eij;
-  DevBuf<int> inc_start, agg, mem_start, mem_list, rep0, cd_start, cd_list, ce_start, ce_list;
+  DevBuf<int> inc_start, agg, rep0, prow_start, pcol, prow_of, pcsc_start, pcsc_ent, qrow_start, qcol, qrow_of;
   DevBuf<int2> inc_adj;
   DevBuf<float> P;
-  DevBuf<double> Hd, Ho, Dinv, x, r, res;
+  DevBuf<double> Hd, Ho, Ps, Q, Dinv, x, r, res;
   void release() {
-    eij.release(); inc_start.release(); inc_adj.release(); agg.release(); mem_start.release(); mem_list.release();
-    rep0.release(); cd_start.release(); cd_list.release(); ce_start.release(); ce_list.release(); Hd.release();
-    Ho.release(); P.release(); Dinv.release(); x.release(); r.release(); res.release();
+    eij.release(); inc_start.release(); inc_adj.release(); agg.release(); rep0.release(); prow_start.release();
+    pcol.release(); prow_of.release(); pcsc_start.release(); pcsc_ent.release(); qrow_start.release(); qcol.release();
+    qrow_of.release(); Hd.release(); Ho.release(); P.release(); Ps.release(); Q.release(); Dinv.release(); x.release();
+    r.release(); res.release();
   }
 };
 
@@ -870,7 +1014,8 @@ struct srrg2_posegraph_s {
   DevBuf<int> part_n, inc_start, inc_edge, act_edge;
   DevBuf<PgScalars> sc;
   // multigrid hierarchy
-  std::vector<MgLevelBufs*> levels;
+  std::vector<MgLevelBufs*> levels;      // the current hierarchy: the first levels of the pool
+  std::vector<MgLevelBufs*> level_pool;  // level objects with their device buffers, kept across rebuilds
   DevBuf<MgLevel> levels_dev;
   DevBuf<double> coarse_A, coarse_inv;
   int coarsest_dense = 1;
@@ -891,14 +1036,65 @@ int upload(DevBuf<T>& b, const std::vector<T>& v) {
   return 0;
 }
 
+// Rows of a sparse pattern, each the sorted set of distinct columns that `row_fn(row, stamp, out)` pushes (it marks a column
+// in `stamp` -- one int per column, initialised to -1 -- with the row's id to see it once).  The rows are independent: a
+// few host threads take contiguous chunks of them, the chunks are concatenated in order (the result does not depend on
+// the number of threads).
+template <typename RowFn>
+void pattern_rows(int nrows, int ncols, std::vector<int>& start, std::vector<int>& cols, std::vector<int>* row_of, RowFn row_fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nthreads = (int) std::max(1u, std::min({hw ? hw : 1u, 16u, (unsigned) (nrows / 512 + 1)}));
+  std::vector<std::vector<int>> chunk_cols((size_t) nthreads), chunk_len((size_t) nthreads);
+  auto work = [&](int t) {
+    const int r0 = (int) ((long long) nrows * t / nthreads), r1 = (int) ((long long) nrows * (t + 1) / nthreads);
+    std::vector<int> stamp((size_t) std::max(ncols, 1), -1), out;
+    std::vector<int>& cc = chunk_cols[(size_t) t];
+    std::vector<int>& ll = chunk_len[(size_t) t];
+    ll.reserve((size_t) (r1 - r0));
+    for (int r = r0; r < r1; ++r) {
+      out.clear();
+      row_fn(r, stamp, out);
+      std::sort(out.begin(), out.end());
+      cc.insert(cc.end(), out.begin(), out.end());
+      ll.push_back((int) out.size());
+    }
+  };
+  if (nthreads == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
+    for (std::thread& th : pool) th.join();
+  }
+  start.assign((size_t) nrows + 1, 0);
+  size_t total = 0;
+  for (int t = 0; t < nthreads; ++t) total += chunk_cols[(size_t) t].size();
+  cols.clear();
+  cols.reserve(total);
+  if (row_of) {
+    row_of->clear();
+    row_of->reserve(total);
+  }
+  int r = 0;
+  for (int t = 0; t < nthreads; ++t) {
+    cols.insert(cols.end(), chunk_cols[(size_t) t].begin(), chunk_cols[(size_t) t].end());
+    for (int len : chunk_len[(size_t) t]) {
+      if (row_of) row_of->insert(row_of->end(), (size_t) len, r);
+      start[(size_t) r + 1] = start[(size_t) r] + len;
+      ++r;
+    }
+  }
+}
+
 // Aggregation hierarchy from the graph's structure and the current poses (host; only when the structure changed).
 int build_hierarchy(srrg2_posegraph_s* g) {
   const int V = g->V, E = g->E, D = g->D, T = g->T;
-  for (MgLevelBufs* L : g->levels) {
-    L->release();
-    delete L;
-  }
-  g->levels.clear();
+  const auto t_begin = std::chrono::steady_clock::now();
+  double ms_match = 0.0, ms_pattern = 0.0;
+  auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  g->levels.clear();  // (the levels' device buffers stay in g->level_pool: a rebuild reuses them, they only ever grow)
   std::vector<float> poses((size_t) std::max(V, 1) * T);
   HIP_TRY(hipMemcpy(poses.data(), g->poses.p, sizeof(float) * (size_t) V * T, hipMemcpyDeviceToHost));
   auto position = [&](int v, float* out) {
@@ -925,13 +1121,22 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   g->coarsest_dense = 1;
   // matching passes per level: 2 -> aggregates of <= 4 poses, 3 -> <= 8 (fewer levels, slower convergence; measured in
   // DESIGN.md section 6)
-  const int match_passes = std::getenv("SRRG2_AMD_PG_PASSES") ? std::max(1, std::atoi(std::getenv("SRRG2_AMD_PG_PASSES"))) : 2;
+  const int match_passes = std::getenv("SRRG2_AMD_PG_PASSES") ? std::max(1, std::atoi(std::getenv("SRRG2_AMD_PG_PASSES"))) : 3;
   for (int level = 0; level < MG_MAX_LEVELS; ++level) {
     const int ne = (int) (eij.size() / 2);
-    MgLevelBufs* L = new MgLevelBufs();
+    if ((size_t) level >= g->level_pool.size()) g->level_pool.push_back(new MgLevelBufs());
+    MgLevelBufs* L = g->level_pool[(size_t) level];
     g->levels.push_back(L);
+    L->nc = L->nce = L->np = L->nq = 0;
+    L->row_parts = L->col_parts = L->prow_parts = 1;
     L->n  = n;
     L->ne = ne;
+    {  // lanes per row of H: ~8 incidences each
+      const double avg = n > 0 ? 2.0 * ne / n : 0.0;
+      int parts = 1;
+      while (parts < 16 && 8.0 * parts < avg) parts *= 2;
+      L->row_parts = parts;
+    }
     // incidence lists in (node, edge) order
     std::vector<int> inc_start((size_t) n + 1, 0);
     std::vector<int2> inc_adj((size_t) std::max(2 * ne, 1), make_int2(-1, 0));
@@ -964,6 +1169,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     if (free_nodes <= MG_COARSEST_NODES && level > 0) break;  // this is the coarsest level
     if (level == 0 && free_nodes <= MG_COARSEST_NODES && n <= MG_COARSEST_NODES) break;
     // two passes of greedy pairwise matching with the nearest unmatched neighbour: aggregates of <= 4 nodes
+    const auto t_match = std::chrono::steady_clock::now();
     std::vector<int> agg((size_t) n);
     for (int v = 0; v < n; ++v) agg[(size_t) v] = excluded[(size_t) v] ? -1 : v;  // singletons first
     int nagg = n;
@@ -976,12 +1182,23 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         for (int v = 0; v < n; ++v)
           if (cur[(size_t) v] >= 0 && first[(size_t) cur[(size_t) v]] < 0) first[(size_t) cur[(size_t) v]] = v;
         // neighbours of every current aggregate
-        std::vector<std::vector<int>> nb((size_t) n);
+        std::vector<int> nb_start((size_t) n + 1, 0), nb_list;  // (CSR, in edge order)
         for (int e = 0; e < ne; ++e) {
           const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
           if (a < 0 || b < 0 || a == b) continue;
-          nb[(size_t) a].push_back(b);
-          nb[(size_t) b].push_back(a);
+          nb_start[(size_t) a + 1]++;
+          nb_start[(size_t) b + 1]++;
+        }
+        for (int a = 0; a < n; ++a) nb_start[(size_t) a + 1] += nb_start[(size_t) a];
+        nb_list.resize((size_t) std::max(nb_start[(size_t) n], 1));
+        {
+          std::vector<int> fill(nb_start.begin(), nb_start.end() - 1);
+          for (int e = 0; e < ne; ++e) {
+            const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
+            if (a < 0 || b < 0 || a == b) continue;
+            nb_list[(size_t) fill[(size_t) a]++] = b;
+            nb_list[(size_t) fill[(size_t) b]++] = a;
+          }
         }
         std::vector<int> match((size_t) n, -1);
         for (int a = 0; a < n; ++a) {
@@ -990,7 +1207,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
           position(rep0[(size_t) first[(size_t) a]], pa);
           int best = -1;
           float bd = 3.0e38f;
-          for (int b : nb[(size_t) a]) {
+          for (int k = nb_start[(size_t) a]; k < nb_start[(size_t) a + 1]; ++k) {
+            const int b = nb_list[(size_t) k];
             if (match[(size_t) b] >= 0 || b == a) continue;
             float pb[3];
             position(rep0[(size_t) first[(size_t) b]], pb);
@@ -1016,53 +1234,92 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       if (free_nodes > 256) g->coarsest_dense = 0;
       break;
     }
+    ms_match += ms_since(t_match);
+    const auto t_pattern = std::chrono::steady_clock::now();
     const int nc = nagg;
-    std::vector<int> mem_start((size_t) nc + 1, 0), mem_list((size_t) std::max(free_nodes, 1), 0), crep0((size_t) nc, 0);
-    for (int v = 0; v < n; ++v)
-      if (agg[(size_t) v] >= 0) mem_start[(size_t) agg[(size_t) v] + 1]++;
-    for (int I = 0; I < nc; ++I) mem_start[(size_t) I + 1] += mem_start[(size_t) I];
+    std::vector<int> crep0((size_t) nc, -1);
+    for (int v = 0; v < n; ++v)  // representative of an aggregate = its first member
+      if (agg[(size_t) v] >= 0 && crep0[(size_t) agg[(size_t) v]] < 0) crep0[(size_t) agg[(size_t) v]] = rep0[(size_t) v];
+    // pattern of the smoothed interpolation: row i = the aggregates of i and of its neighbours
+    std::vector<int> prow_start, pcol, prow_of;
+    pattern_rows(n, nc, prow_start, pcol, &prow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
+      if (agg[(size_t) v] < 0) return;
+      stamp[(size_t) agg[(size_t) v]] = v;
+      out.push_back(agg[(size_t) v]);
+      for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) {
+        const int a = agg[(size_t) inc_adj[(size_t) q].x];
+        if (a >= 0 && stamp[(size_t) a] != v) {
+          stamp[(size_t) a] = v;
+          out.push_back(a);
+        }
+      }
+    });
+    const int np = (int) pcol.size();
+    std::vector<int> pcsc_start((size_t) nc + 1, 0), pcsc_ent((size_t) std::max(np, 1), 0);
+    for (int e = 0; e < np; ++e) pcsc_start[(size_t) pcol[(size_t) e] + 1]++;
+    for (int I = 0; I < nc; ++I) pcsc_start[(size_t) I + 1] += pcsc_start[(size_t) I];
     {
-      std::vector<int> cur(mem_start.begin(), mem_start.end() - 1);
-      for (int v = 0; v < n; ++v)
-        if (agg[(size_t) v] >= 0) mem_list[(size_t) cur[(size_t) agg[(size_t) v]]++] = v;
+      std::vector<int> cur(pcsc_start.begin(), pcsc_start.end() - 1);
+      for (int e = 0; e < np; ++e) pcsc_ent[(size_t) cur[(size_t) pcol[(size_t) e]]++] = e;  // (rows ascending)
     }
-    for (int I = 0; I < nc; ++I) crep0[(size_t) I] = rep0[(size_t) mem_list[(size_t) mem_start[(size_t) I]]];
-    // coarse edges: unique unordered pairs of aggregates, in order of first appearance; internal edges per aggregate
-    std::vector<std::pair<long long, int>> keyed;  // (key, fine edge code)
-    std::vector<std::vector<int>> internal((size_t) nc);
-    for (int e = 0; e < ne; ++e) {
-      const int I = agg[(size_t) eij[2 * (size_t) e]], J = agg[(size_t) eij[2 * (size_t) e + 1]];
-      if (I < 0 || J < 0) continue;
-      if (I == J) {
-        internal[(size_t) I].push_back(e);
-        continue;
+    // pattern of Q = H Ps: row i = union of the rows of Ps over i and its neighbours
+    std::vector<int> qrow_start, qcol, qrow_of;
+    pattern_rows(n, nc, qrow_start, qcol, &qrow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
+      if (agg[(size_t) v] < 0) return;
+      auto add_row = [&](int j) {
+        for (int e = prow_start[(size_t) j]; e < prow_start[(size_t) j + 1]; ++e) {
+          const int a = pcol[(size_t) e];
+          if (stamp[(size_t) a] != v) {
+            stamp[(size_t) a] = v;
+            out.push_back(a);
+          }
+        }
+      };
+      add_row(v);
+      for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) add_row(inc_adj[(size_t) q].x);
+    });
+    const int nq = (int) qcol.size();
+    // coarse edges (A < B): B in the row of Q of some row of column A of Ps
+    std::vector<int> ce_start, ce_col, ceij;
+    pattern_rows(nc, nc, ce_start, ce_col, nullptr, [&](int A, std::vector<int>& stamp, std::vector<int>& out) {
+      for (int m = pcsc_start[(size_t) A]; m < pcsc_start[(size_t) A + 1]; ++m) {
+        const int i = prow_of[(size_t) pcsc_ent[(size_t) m]];
+        // (the row is ascending: skip to the first column behind A)
+        const int* end = qcol.data() + qrow_start[(size_t) i + 1];
+        const int* first = qcol.data() + qrow_start[(size_t) i];
+        for (const int* q = std::upper_bound(first, end, A); q < end; ++q)
+          if (stamp[(size_t) *q] != A) {
+            stamp[(size_t) *q] = A;
+            out.push_back(*q);
+          }
       }
-      const int lo = std::min(I, J), hi = std::max(I, J);
-      keyed.emplace_back((long long) lo * nc + hi, (e << 1) | (I > J ? 1 : 0));
-    }
-    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first < b.first; });
-    std::vector<int> ceij, ce_start(1, 0), ce_list;
-    for (size_t k = 0; k < keyed.size(); ++k) {
-      if (k == 0 || keyed[k].first != keyed[k - 1].first) {
-        if (k) ce_start.push_back((int) ce_list.size());
-        ceij.push_back((int) (keyed[k].first / nc));
-        ceij.push_back((int) (keyed[k].first % nc));
+    });
+    ceij.resize(2 * ce_col.size());
+    for (int A = 0; A < nc; ++A)
+      for (int k = ce_start[(size_t) A]; k < ce_start[(size_t) A + 1]; ++k) {
+        ceij[2 * (size_t) k]     = A;
+        ceij[2 * (size_t) k + 1] = ce_col[(size_t) k];
       }
-      ce_list.push_back(keyed[k].second);
-    }
-    ce_start.push_back((int) ce_list.size());
     const int nce = (int) (ceij.size() / 2);
-    if (nce == 0) ce_start.assign(1, 0);
-    std::vector<int> cd_start((size_t) nc + 1, 0), cd_list;
-    for (int I = 0; I < nc; ++I) {
-      for (int e : internal[(size_t) I]) cd_list.push_back(e);
-      cd_start[(size_t) I + 1] = (int) cd_list.size();
-    }
+    ms_pattern += ms_since(t_pattern);
     L->nc  = nc;
     L->nce = nce;
-    if ((rc = upload(L->agg, agg)) || (rc = upload(L->mem_start, mem_start)) || (rc = upload(L->mem_list, mem_list)) ||
-        (rc = upload(L->cd_start, cd_start)) || (rc = upload(L->cd_list, cd_list)) || (rc = upload(L->ce_start, ce_start)) ||
-        (rc = upload(L->ce_list, ce_list)))
+    L->np  = np;
+    L->nq  = nq;
+    {  // lanes per column of Ps: ~8 entries each
+      const double avg = nc > 0 ? (double) np / nc : 0.0;
+      int parts = 1;
+      while (parts < 32 && 8.0 * parts < avg) parts *= 2;
+      L->col_parts = parts;
+      const double avg_row = n > 0 ? (double) np / n : 0.0;  // lanes per row of Ps: ~4 entries each
+      parts = 1;
+      while (parts < 8 && 4.0 * parts < avg_row) parts *= 2;
+      L->prow_parts = parts;
+    }
+    if ((rc = upload(L->agg, agg)) || (rc = upload(L->prow_start, prow_start)) || (rc = upload(L->pcol, pcol)) ||
+        (rc = upload(L->prow_of, prow_of)) || (rc = upload(L->pcsc_start, pcsc_start)) || (rc = upload(L->pcsc_ent, pcsc_ent)) ||
+        (rc = upload(L->qrow_start, qrow_start)) || (rc = upload(L->qcol, qcol)) || (rc = upload(L->qrow_of, qrow_of)) ||
+        (rc = L->Ps.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Q.reserve((size_t) std::max(nq, 1) * D * D)))
       return rc;
     // next level
     n = nc;
@@ -1072,8 +1329,9 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   }
   if (std::getenv("SRRG2_AMD_PG_DEBUG")) {
     std::fprintf(stderr, "posegraph hierarchy:");
-    for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks ->", L->n, L->ne);
-    std::fprintf(stderr, " coarsest %s\n", g->coarsest_dense ? "dense" : "smoothed");
+    for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d) ->", L->n, L->ne, L->np, L->nq);
+    std::fprintf(stderr, " coarsest %s; built in %.1f ms on the host (matching %.1f, patterns %.1f)\n",
+                 g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, ms_pattern);
   }
   // device views
   const int nl = (int) g->levels.size();
@@ -1081,11 +1339,14 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   for (int l = 0; l < nl; ++l) {
     MgLevelBufs* L = g->levels[(size_t) l];
     MgLevel& v     = views[(size_t) l];
-    v.n = L->n; v.ne = L->ne; v.nc = L->nc; v.nce = L->nce;
-    v.eij = L->eij.p; v.inc_start = L->inc_start.p; v.inc_adj = L->inc_adj.p; v.agg = L->agg.p;
-    v.mem_start = L->mem_start.p; v.mem_list = L->mem_list.p; v.rep0 = L->rep0.p; v.cd_start = L->cd_start.p;
-    v.cd_list = L->cd_list.p; v.ce_start = L->ce_start.p; v.ce_list = L->ce_list.p;
-    v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Dinv = L->Dinv.p; v.x = L->x.p; v.r = L->r.p; v.res = L->res.p;
+    v.n = L->n; v.ne = L->ne; v.nc = L->nc; v.nce = L->nce; v.np = L->np; v.nq = L->nq;
+    v.omega = std::getenv("SRRG2_AMD_PG_OMEGA") ? std::atof(std::getenv("SRRG2_AMD_PG_OMEGA")) : MG_OMEGA;
+    v.row_parts = L->row_parts; v.col_parts = L->col_parts; v.prow_parts = L->prow_parts;
+    v.eij = L->eij.p; v.inc_start = L->inc_start.p; v.inc_adj = L->inc_adj.p; v.agg = L->agg.p; v.rep0 = L->rep0.p;
+    v.prow_start = L->prow_start.p; v.pcol = L->pcol.p; v.prow_of = L->prow_of.p; v.pcsc_start = L->pcsc_start.p;
+    v.pcsc_ent = L->pcsc_ent.p; v.qrow_start = L->qrow_start.p; v.qcol = L->qcol.p; v.qrow_of = L->qrow_of.p;
+    v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Ps = L->Ps.p; v.Q = L->Q.p; v.Dinv = L->Dinv.p; v.x = L->x.p;
+    v.r = L->r.p; v.res = L->res.p;
   }
   if ((rc = g->levels_dev.reserve((size_t) nl))) return rc;
   HIP_TRY(hipMemcpy(g->levels_dev.p, views.data(), sizeof(MgLevel) * (size_t) nl, hipMemcpyHostToDevice));
@@ -1125,27 +1386,39 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   MgLevelBufs* L0 = g->levels[0];
   // first level that runs inside the single-workgroup launch
   int lf = nl;
-  for (int l = 0; l < nl; ++l)
-    if (g->levels[(size_t) l]->n <= MG_FUSE_NODES) { lf = l; break; }
+  for (int l = 0; l < nl; ++l)  // (a small but dense level -- C5: 100 nodes, 4950 blocks -- is 1.4 MB of blocks: not for one workgroup)
+    if (g->levels[(size_t) l]->n <= MG_FUSE_NODES && g->levels[(size_t) l]->ne <= MG_FUSE_BLOCKS) { lf = l; break; }
   auto blocks_for = [](int items) { return std::max(std::min((items + PG_THREADS - 1) / PG_THREADS, 2048), 1); };
+  // damping of the Jacobi sweep that smooths the interpolation (0: plain aggregation)
+  const double omega_p = std::getenv("SRRG2_AMD_PG_OMEGA_P") ? std::atof(std::getenv("SRRG2_AMD_PG_OMEGA_P")) : MG_OMEGA_P;
   // z = V-cycle(r): input levels[0].r (= g->r aliased below), output levels[0].x
   auto vcycle = [&]() {
     for (int l = 0; l < lf; ++l) {
-      const int bl = blocks_for(g->levels[(size_t) l]->n * D), bc = blocks_for(g->levels[(size_t) l]->nc * D);
+      const MgLevelBufs* Lb = g->levels[(size_t) l];
+      const int bl = blocks_for(Lb->n * D), bc = blocks_for(Lb->nc * D * Lb->col_parts), br = blocks_for(Lb->n * D * Lb->row_parts);
       hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, g->levels_dev.p, l, g->sc.p);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(br), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
       hipLaunchKernelGGL(k_mg_op<D>, dim3(bc), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, g->levels_dev.p, l, g->sc.p);
     }
     hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
                        g->coarsest_dense, g->sc.p);
     for (int l = lf - 1; l >= 0; --l) {
-      const int bl = blocks_for(g->levels[(size_t) l]->n * D);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, g->levels_dev.p, l, g->sc.p);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
+      const int bl = blocks_for(g->levels[(size_t) l]->n * D), br = blocks_for(g->levels[(size_t) l]->n * D * g->levels[(size_t) l]->row_parts);
+      const int bp = blocks_for(g->levels[(size_t) l]->n * D * g->levels[(size_t) l]->prow_parts);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bp), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(br), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
       hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, g->levels_dev.p, l, g->sc.p);
     }
   };
   int nstats = 0;
+  constexpr int PCG_CHUNK = 10;  // CG iterations between two looks at the convergence flag
+  static const bool use_graph = !(std::getenv("SRRG2_AMD_PG_GRAPH") && std::atoi(std::getenv("SRRG2_AMD_PG_GRAPH")) == 0);
+  hipGraphExec_t chunk_exec = nullptr;
+  bool graph_failed = false;
+  struct ExecGuard {  // (every return path below releases the instantiated graph)
+    hipGraphExec_t& e;
+    ~ExecGuard() { if (e) (void) hipGraphExecDestroy(e); }
+  } exec_guard{chunk_exec};
   for (int it = 0; it < p->max_iterations; ++it) {
     HIP_TRY(hipMemsetAsync(g->sc.p, 0, sizeof(PgScalars), g->stream));
     if (E > 0)
@@ -1163,10 +1436,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       HIP_TRY(hipMemcpyAsync(L0->Dinv.p, g->Minv.p, sizeof(double) * (size_t) V * D * D, hipMemcpyDeviceToDevice, g->stream));
       for (int l = 0; l < nl; ++l) {
         MgLevelBufs* L = g->levels[(size_t) l];
+        auto grid_of = [](size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); };
         hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l, T, g->poses.p);
-        if (L->nc + L->nce > 0)
-          hipLaunchKernelGGL(k_mg_galerkin<D>, dim3((unsigned) (((size_t) (L->nc + L->nce) * D + PG_THREADS - 1) / PG_THREADS)),
-                             dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
+        hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * D * L->row_parts), dim3(PG_THREADS), 0, g->stream,
+                           g->levels_dev.p, l, omega_p);
+        hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * L->row_parts), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
+        hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
+                           g->levels_dev.p, l);
         hipLaunchKernelGGL(k_mg_dinv<D>, dim3((unsigned) ((L->nc + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
                            g->levels_dev.p, l + 1, g->sc.p);
       }
@@ -1184,11 +1460,10 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, 1, z, g->p.p, g->part_rz.p, g->part_rz.p, g->sc.p);
     PgScalars h{};
     int launched = 0;
-    while (launched < p->pcg_max_iterations) {
-      const int chunk = std::min(10, p->pcg_max_iterations - launched);
-      for (int k = 0; k < chunk; ++k) {
-        double* rz_cur = ((launched + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
-        double* rz_nxt = ((launched + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
+    auto launch_iterations = [&](int first, int count) {
+      for (int k = 0; k < count; ++k) {
+        double* rz_cur = ((first + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
+        double* rz_nxt = ((first + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
         hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_update_xr, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance, g->p.p,
                            g->Ap.p, g->x.p, r, rz_cur, g->part_pAp.p, g->part_rr.p, g->part_bb.p, g->sc.p);
@@ -1197,6 +1472,31 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         vcycle();
         hipLaunchKernelGGL(k_pg_dot_rz, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, r, z, rz_nxt, g->sc.p);
         hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, 0, z, g->p.p, rz_cur, rz_nxt, g->sc.p);
+      }
+    };
+    while (launched < p->pcg_max_iterations) {
+      const int chunk = std::min(PCG_CHUNK, p->pcg_max_iterations - launched);
+      // A CG iteration is ~30 small launches: issued one by one the host's launch rate (not the kernels) sets the pace.
+      // A chunk of PCG_CHUNK iterations (an even number: the ping-pong of the rz partials repeats) is captured once per
+      // solve() into a HIP graph and replayed; every pointer and scalar it carries is fixed for the whole call.
+      if (chunk == PCG_CHUNK && use_graph && !chunk_exec && !graph_failed) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          launch_iterations(0, PCG_CHUNK);
+          if (hipStreamEndCapture(g->stream, &graph) != hipSuccess || !graph ||
+              hipGraphInstantiate(&chunk_exec, graph, nullptr, nullptr, 0) != hipSuccess)
+            chunk_exec = nullptr;
+          if (graph) (void) hipGraphDestroy(graph);
+        }
+        if (!chunk_exec) {
+          graph_failed = true;
+          (void) hipGetLastError();
+        }
+      }
+      if (chunk == PCG_CHUNK && chunk_exec) {
+        HIP_TRY(hipGraphLaunch(chunk_exec, g->stream));
+      } else {
+        launch_iterations(launched, chunk);
       }
       launched += chunk;
       HIP_TRY(hipMemcpyAsync(&h, g->sc.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
@@ -1311,10 +1611,11 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   g->part_pAp.release(); g->part_rr.release(); g->part_bb.release(); g->part_chi.release(); g->part_n.release();
   g->inc_start.release(); g->inc_edge.release(); g->sc.release(); g->act_edge.release(); g->levels_dev.release();
   g->coarse_A.release(); g->coarse_inv.release();
-  for (MgLevelBufs* L : g->levels) {
+  for (MgLevelBufs* L : g->level_pool) {
     L->release();
     delete L;
   }
+  g->level_pool.clear();
   g->levels.clear();
   if (g->stream) (void) hipStreamDestroy(g->stream);
   delete g;

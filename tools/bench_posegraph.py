@@ -14,8 +14,9 @@ from srrg2_slam_interfaces_amd import _abi as abi
 from srrg2_slam_interfaces_amd import posegraph as pgm
 from srrg2_slam_interfaces_amd import synthetic as syn
 
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-E = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+V = int(_pos[0]) if len(_pos) > 0 else 50000
+E = int(_pos[1]) if len(_pos) > 1 else 200000
 t0 = time.time()
 g = syn.pose_graph_3d(V=V, E=E, seed=5000)
 gen_s = time.time() - t0
