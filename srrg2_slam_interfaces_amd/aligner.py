@@ -42,6 +42,77 @@ def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+_BATCH_DTYPE = np.dtype(abi.BatchResult)
+
+
+class BatchResults:
+    """The K result records of one compute_batch*() call: a read-only sequence of dicts (``res[k]["status"]`` ...)
+    over the array of ``srrg2_batch_result`` the library filled, plus whole-batch views of it (``res.status``,
+    ``res.moving_in_fixed`` ...).  Nothing is copied or converted until it is asked for: a loop-closure detector
+    that only reads the statuses of 256 candidates does not pay for 256 dicts."""
+
+    def __init__(self, raw, K, dim, tsize):
+        self._raw = raw  # (keeps the ctypes array alive)
+        self._K = K
+        self._dim = dim
+        self._tsize = tsize
+        self._arr = np.frombuffer(raw, dtype=_BATCH_DTYPE, count=max(K, 1))[:K]
+
+    def __len__(self):
+        return self._K
+
+    @property
+    def status(self):
+        return self._arr["status"]
+
+    @property
+    def num_iterations(self):
+        return self._arr["num_iterations"]
+
+    @property
+    def num_correspondences(self):
+        return self._arr["num_correspondences"]
+
+    @property
+    def moving_in_fixed(self):
+        T = self._arr["moving_in_fixed"][:, :self._tsize]
+        return T.reshape(self._K, 3, 3) if self._dim == 2 else T.reshape(self._K, 3, 4)
+
+    @property
+    def information(self):
+        D = 3 if self._dim == 2 else 6
+        return self._arr["information"][:, :D * D].reshape(self._K, D, D)
+
+    @property
+    def last(self):
+        """structured array of the last IterationStats of every alignment"""
+        return self._arr["last"]
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(self._K))]
+        if k < 0:
+            k += self._K
+        if not 0 <= k < self._K:
+            raise IndexError(k)
+        row = self._arr[k]
+        D = 3 if self._dim == 2 else 6
+        T = np.array(row["moving_in_fixed"][:self._tsize], dtype=np.float32)
+        last = row["last"]
+        return {
+            "moving_in_fixed": T.reshape(3, 3) if self._dim == 2 else T.reshape(3, 4),
+            "status": int(row["status"]),
+            "num_iterations": int(row["num_iterations"]),
+            "last": {name: last[name].item() for name in last.dtype.names},
+            # numCorrespondences() after compute() (after pruning) and H of the last Gauss-Newton iteration
+            "num_correspondences": int(row["num_correspondences"]),
+            "information": np.array(row["information"][:D * D], dtype=np.float32).reshape(D, D),
+        }
+
+    def __iter__(self):
+        return (self[k] for k in range(self._K))
+
+
 class MultiAligner:
     """One ``MultiAlignerBase_<Variable>``: one estimate, N slices, one Gauss-Newton solver."""
 
@@ -265,20 +336,7 @@ class MultiAligner:
         return self._unpack_batch(res, K)
 
     def _unpack_batch(self, res, K):
-        out = []
-        D = 3 if self.dim == 2 else 6
-        for k in range(K):
-            T = np.array(res[k].moving_in_fixed[:self.tsize], dtype=np.float32)
-            out.append({
-                "moving_in_fixed": T.reshape(3, 3) if self.dim == 2 else T.reshape(3, 4),
-                "status": res[k].status,
-                "num_iterations": res[k].num_iterations,
-                "last": res[k].last.as_dict(),
-                # numCorrespondences() after compute() (after pruning) and H of the last Gauss-Newton iteration
-                "num_correspondences": res[k].num_correspondences,
-                "information": np.array(res[k].information[:D * D], dtype=np.float32).reshape(D, D),
-            })
-        return out
+        return BatchResults(res, K, self.dim, self.tsize)
 
     def compute_batch(self, moving_clouds, guesses, moving_normals=None):
         """K independent alignments against the fixed scene (multi_loop_detector_brute_force_impl.cpp:63-91)."""

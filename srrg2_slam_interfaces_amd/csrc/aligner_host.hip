@@ -349,8 +349,11 @@ int check_slice(srrg2_aligner* a, int si, const char* what) {
 }
 
 // upload the moving clouds of K problems (concatenated, offsets[K+1]) into slice `si`
+// `wait`: return only when the ingest has finished reading the caller's buffer (set_moving: the caller may reuse it on
+// return).  compute_batch passes false: it returns after the compute() that follows on the same stream has delivered
+// its results, and the launches of that compute() overlap the sort instead of waiting behind it.
 int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const float* normals, int ns,
-                  const int32_t* offsets, int K, int mem) {
+                  const int32_t* offsets, int K, int mem, bool wait = true) {
   Slice* s    = a->slices[si];
   if (a->records_state == 1) a->records_state = 2;  // (the records of the last compute() can no longer be derived)
   const int n = offsets[K] - offsets[0];
@@ -401,7 +404,8 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
                                      normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
       HIP_TRY(hipGetLastError());
       // the caller may reuse its buffer on return (host or device memory: the ingest has finished reading it)
-      HIP_TRY(hipStreamSynchronize(a->stream));
+      if (wait) HIP_TRY(hipStreamSynchronize(a->stream));
+      s->ms_pending         = !wait;  // (the sort reads the pinned problem table: the compute() that follows drains the stream)
       s->nm_total           = n;
       s->has_moving         = true;
       s->moving_has_normals = normals != nullptr;
@@ -435,7 +439,7 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
                          s->ms_bb.p, s->ms_counts.p, s->ms_cursor.p, s->ms_sums.p, s->ms_sums.p + s->ms_sums.cap - 1,
                          s->moving.p, normals ? s->moving_nrm.p : nullptr, a->stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(a->stream));  // the caller may reuse its buffer on return (host or device memory)
+  if (wait) HIP_TRY(hipStreamSynchronize(a->stream));  // the caller may reuse its buffer on return (host or device memory)
   s->nm_total           = n;
   s->has_moving         = true;
   s->moving_has_normals = normals != nullptr;
@@ -1384,7 +1388,7 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
   if (offsets[K] > offsets[0] && !coords) return fail(SRRG2_E_INVALID, "compute_batch: null cloud");
   int rc;
   if ((rc = set_device(a))) return rc;
-  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem))) return rc;
+  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false))) return rc;
   if ((rc = run_compute(a, K, offsets, guesses))) return rc;
   const int slots = a->max_stats;
   for (int k = 0; k < K; ++k) {

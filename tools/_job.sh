@@ -1,7 +1,12 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r2ze; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
-SRRG2_AMD_PG_DEBUG=1 timeout 600 python tools/bench_posegraph.py --cpu > $O/bench_c5.json 2>$O/bench_c5.err; cut -c1-330 $O/bench_c5.json; tail -1 $O/bench_c5.err | cut -c250-
-SRRG2_AMD_PG_PASSES=4 timeout 600 python tools/bench_posegraph.py > $O/bench_c5_passes4.json 2>/dev/null; cut -c100-230 $O/bench_c5_passes4.json
-python bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>$O/bench_c2.err; cut -c1-200 $O/bench_c2.json
+O=$GRAFT_REPO_ROOT/gpurun_out/r2zi; mkdir -p $O
+L=srrg2_slam_interfaces_amd/lib
+cp $L/libsrrg2_slam_amd.so /tmp/new.so; cp $L/libsrrg2_old.so /tmp/old.so
+for rep in 1 2; do for v in old new; do
+  cp /tmp/$v.so $L/libsrrg2_slam_amd.so
+  echo "$v c2 $(python bench.py --workload c2 --no-cpu-baseline 2>/dev/null | cut -c40-160)"
+  echo "$v c4 $(python bench.py --workload c4 --no-cpu-baseline 2>/dev/null | cut -c40-160)"
+  echo "$v c4-256 $(python bench.py --workload c4 --batch 256 --no-cpu-baseline 2>/dev/null | cut -c40-160)"
+done; done | tee $O/ab_nowait.txt
+cp /tmp/new.so $L/libsrrg2_slam_amd.so
