@@ -2352,14 +2352,14 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   cur.num_correspondences = num_correspondences(C, st);
   cur.chi_inliers         = (float) chi_in;
   cur.chi_outliers        = (float) chi_out;
-  if (KNOB(C.tune, 8388608)) {  // (timing: without the solve and everything behind it)
+  if (KNOB(C.tune, 134217728)) {  // (timing: without the solve and everything behind it)
     st->nstats++;
     st->last_H[0] = H[0] + b[0];
     return;
   }
   int bad                 = dm::solve<D>(H, b, dx);
   cur.solver_status       = bad ? 1 : 0;
-  if (KNOB(C.tune, 16777216)) {  // (timing: up to and including the solve)
+  if (KNOB(C.tune, 268435456)) {  // (timing: up to and including the solve)
     st->nstats++;
     st->last_dx[0] = dx[0] + dx[D - 1];
     return;
@@ -2383,7 +2383,7 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
       st->kexp[s] = slice_exponent(C, C.slices[s], prob, 0, st->X);
   if (st->nstats < C.max_stats) stats[(size_t) prob * C.max_stats + st->nstats] = cur;
   st->nstats++;
-  if (KNOB(C.tune, 33554432)) return;  // (timing: without the termination criterion and the queue bookkeeping)
+  if (KNOB(C.tune, 536870912)) return;  // (timing: without the termination criterion and the queue bookkeeping)
   if (C.has_term && has_to_stop(C, st, cur)) st->done = 1;  // :124-126
   for (int s = 0; s < C.nslices; ++s)
     if (C.slices[s].qcount) {
@@ -2494,7 +2494,7 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
-  if (KNOB(C.tune, 4194304)) {  // (timing: everything but the sequential part; the iteration counter must still advance)
+  if (KNOB(C.tune, 67108864)) {  // (timing: everything but the sequential part; the iteration counter must still advance)
     st->nstats++;
     return;
   }
