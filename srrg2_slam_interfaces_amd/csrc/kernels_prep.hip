@@ -2,6 +2,7 @@
 // bounding boxes, the dense voxel grid over the fixed cloud (counting sort: CorrespondenceFinder_ search-structure
 // construction, S/registration/correspondence_finder.h:80-91), prefix scans, and the Morton sort of the moving clouds.
 // Pure data movement and integer work: HBM-bound, nothing here touches the arithmetic specification of the ICP passes.
+#include <cstdlib>
 #include "kernels.h"
 
 #include "device_util.h"
@@ -368,7 +369,14 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
   __shared__ unsigned bbs[6];
   __shared__ float kmn[3], kscale[3];  // cell coordinate = (v - kmn) * kscale (one reciprocal per axis, not a division per point)
   __shared__ int wsum[16];
-  const ProblemDev pd = probs[blockIdx.x];
+  // gridDim.x workgroups per problem (blockIdx.y): each sorts ITS contiguous share of the problem's points on its own --
+  // own bounding box, own histogram -- into the same share of the output.  The cloud then is gridDim.x sorted segments
+  // instead of one: the sort only serves the coherence of neighbouring lanes, the results do not depend on the order.
+  // (a batch of 32 clouds is 32 workgroups otherwise: 118 us on an eighth of the chip)
+  const ProblemDev whole = probs[blockIdx.y];
+  const int seg0 = (int) ((long long) whole.nm * blockIdx.x / gridDim.x);
+  const int seg1 = (int) ((long long) whole.nm * (blockIdx.x + 1) / gridDim.x);
+  const ProblemDev pd = ProblemDev{whole.moff + seg0, seg1 - seg0};
   const int ncell     = 1 << (3 * bits);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* base = src + (size_t) pd.moff * sf;
@@ -426,7 +434,11 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
         amax             = fmaxf(amax, fabsf(__uint_as_float(b)));
       }
     }
-    maxabs_bits[blockIdx.x] = __float_as_uint(amax);
+    // (non-negative floats order like their bit patterns; the host zeroes the word when segments share it)
+    if (gridDim.x == 1)
+      maxabs_bits[blockIdx.y] = __float_as_uint(amax);
+    else
+      atomicMax(&maxabs_bits[blockIdx.y], __float_as_uint(amax));
   }
   if (tid < 3) {
     const unsigned a = bbs[tid], z = bbs[3 + tid];
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
       const int i = i0 + j * 1024;
       if (i >= pd.nm) continue;
       const int pos = atomicAdd(&hist[key_of(q[j])], 1);
-      q[j].w        = __int_as_float(i);
+      q[j].w        = __int_as_float(seg0 + i);  // the caller's index within its problem
       out_pts[pd.moff + pos] = q[j];
       if (nbase) out_nrm[pd.moff + pos] = nq[j];
     }
@@ -584,6 +596,17 @@ bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, co
                         float4* out_pts, float4* out_nrm, unsigned* maxabs_bits, hipStream_t s) {
   if (bits > 5) return false;
   if (K <= 0) return true;
+  // segments per problem: fill about half the chip's CUs (one 1024-thread workgroup each); segments get the coarser key
+  // space of the big batches (16^3 cells for ~6-12 k points)
+  static const int seg_env = getenv("SRRG2_AMD_MSORT_SEGMENTS") ? atoi(getenv("SRRG2_AMD_MSORT_SEGMENTS")) : 0;
+  // (measured on C4, profiles/r2zk_ab_msort_segments.txt: 32 alignments 287 -> 305 k it/s with 4 segments, 8 alignments
+  // 146 -> 161 k, 64 alignments 331 -> 345 k with 2; the passes lose 1.4 % of coherence, the sort goes from 118 to ~35 us)
+  int G = seg_env > 0 ? seg_env : (K >= 128 ? 1 : (128 / K < 8 ? 128 / K : 8));
+  if (G < 1) G = 1;
+  if (G > 1) {
+    bits = bits < 4 ? bits : 4;
+    (void) hipMemsetAsync(maxabs_bits, 0, (size_t) K * sizeof(unsigned), s);
+  }
   const size_t lds = sizeof(int) << (3 * bits);
   static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msort_local),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) (sizeof(int) << 15)) == hipSuccess;
@@ -591,7 +614,7 @@ bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, co
     (void) hipGetLastError();
     return false;
   }
-  hipLaunchKernelGGL(k_msort_local, dim3(K), dim3(1024), lds, s, src, sf, nsrc, nsf, probs, dim, bits, out_pts, out_nrm,
+  hipLaunchKernelGGL(k_msort_local, dim3(G, K), dim3(1024), lds, s, src, sf, nsrc, nsf, probs, dim, bits, out_pts, out_nrm,
                      maxabs_bits);
   return true;
 }

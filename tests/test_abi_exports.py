@@ -71,3 +71,47 @@ def test_headers_compile_with_plain_gxx(tmp_path):
     c_src = tmp_path / "tu.c"  # the C ABI header is C
     c_src.write_text('#include "srrg2_slam_amd.h"\nint main(void) { return SRRG2_AMD_ABI_VERSION == 2 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(c_src)])
+
+
+def test_batch_results_view_is_lazy_and_matches_the_struct():
+    """BatchResults (the Python view of srrg2_batch_result[K]) reads the library's array in place: whole-batch columns,
+    per-result dicts on demand, negative indices, slices, iteration"""
+    import ctypes as C
+
+    import numpy as np
+
+    from srrg2_slam_interfaces_amd import _abi as abi
+    from srrg2_slam_interfaces_amd.aligner import BatchResults
+
+    K = 5
+    raw = (abi.BatchResult * K)()
+    for k in range(K):
+        raw[k].status = k % 3
+        raw[k].num_iterations = 10 + k
+        raw[k].num_correspondences = 1000 * k
+        for i in range(12):
+            raw[k].moving_in_fixed[i] = 100.0 * k + i
+        for i in range(36):
+            raw[k].information[i] = 0.5 * k + i
+        raw[k].last.num_inliers = 7 * k
+        raw[k].last.chi_inliers = 0.25 * k
+    res = BatchResults(raw, K, 3, 12)
+    assert len(res) == K and len(list(res)) == K
+    assert np.array_equal(res.status, [0, 1, 2, 0, 1])
+    assert np.array_equal(res.num_iterations, 10 + np.arange(K))
+    assert res.moving_in_fixed.shape == (K, 3, 4) and res.information.shape == (K, 6, 6)
+    assert res.moving_in_fixed[3, 1, 2] == 306.0 and res.information[2, 1, 0] == 7.0
+    r = res[-1]
+    assert r["status"] == 1 and r["num_iterations"] == 14 and r["num_correspondences"] == 4000
+    assert r["moving_in_fixed"].shape == (3, 4) and r["moving_in_fixed"][2, 3] == 411.0
+    assert r["information"].shape == (6, 6) and r["information"][5, 5] == 37.0
+    assert r["last"]["num_inliers"] == 28 and r["last"]["chi_inliers"] == 1.0
+    assert [x["status"] for x in res[1:3]] == [1, 2]
+    raw[0].status = 2  # a view, not a copy
+    assert res[0]["status"] == 2
+    # SE(2): 3x3 transforms, 3x3 information
+    res2 = BatchResults(raw, K, 2, 9)
+    assert res2[1]["moving_in_fixed"].shape == (3, 3) and res2.information.shape == (K, 3, 3)
+    with __import__("pytest").raises(IndexError):
+        res[K]
+    assert C.sizeof(abi.BatchResult) == res._arr.dtype.itemsize
