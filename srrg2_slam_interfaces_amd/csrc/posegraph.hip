@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int T, int varia
 
 // host side of one level: structure (built when the graph changes) + device buffers
 struct MgLevelBufs {
-  int n = 0, ne = 0, nc = 0, nce = 0, np = 0, nq = 0, row_parts = 1, col_parts = 1, prow_parts = 1;
+  int n = 0, ne = 0, nc = 0, nce = 0, np = 0, nq = 0, row_parts = 1, col_parts = 1, prow_parts = 1, smoothed = 1;
   DevBuf<int2> eij;
   DevBuf<int> inc_start, agg, rep0, prow_start, pcol, prow_of, pcsc_start, pcsc_ent, qrow_start, qcol, qrow_of;
   DevBuf<int2> inc_adj;
@@ -1015,6 +1016,7 @@ struct srrg2_posegraph_s {
   DevBuf<PgScalars> sc;
   // multigrid hierarchy
   std::vector<MgLevelBufs*> levels;      // the current hierarchy: the first levels of the pool
+  std::set<int> pg_force_tentative;      // levels whose smoothed interpolation exceeded the fill limit (this build)
   std::vector<MgLevelBufs*> level_pool;  // level objects with their device buffers, kept across rebuilds
   DevBuf<MgLevel> levels_dev;
   DevBuf<double> coarse_A, coarse_inv;
@@ -1094,6 +1096,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
+  g->pg_force_tentative.clear();
   g->levels.clear();  // (the levels' device buffers stay in g->level_pool: a rebuild reuses them, they only ever grow)
   std::vector<float> poses((size_t) std::max(V, 1) * T);
   HIP_TRY(hipMemcpy(poses.data(), g->poses.p, sizeof(float) * (size_t) V * T, hipMemcpyDeviceToHost));
@@ -1129,6 +1132,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     g->levels.push_back(L);
     L->nc = L->nce = L->np = L->nq = 0;
     L->row_parts = L->col_parts = L->prow_parts = 1;
+    L->smoothed = 1;
     L->n  = n;
     L->ne = ne;
     {  // lanes per row of H: ~8 incidences each
@@ -1240,20 +1244,42 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     std::vector<int> crep0((size_t) nc, -1);
     for (int v = 0; v < n; ++v)  // representative of an aggregate = its first member
       if (agg[(size_t) v] >= 0 && crep0[(size_t) agg[(size_t) v]] < 0) crep0[(size_t) agg[(size_t) v]] = rep0[(size_t) v];
-    // pattern of the smoothed interpolation: row i = the aggregates of i and of its neighbours
+    // pattern of the smoothed interpolation: row i = the aggregates of i and of its neighbours.  Fill guard: a hub (a
+    // pose with thousands of factors) puts its whole row into the rows of Q = H Ps of all its neighbours -- quadratic in
+    // its degree.  When the pattern of Q would exceed 64 blocks per node (C5: 11 / 43 / 77 on its three levels) this
+    // level falls back to the tentative interpolation (row = the node's own aggregate, no smoothing).
     std::vector<int> prow_start, pcol, prow_of;
-    pattern_rows(n, nc, prow_start, pcol, &prow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
-      if (agg[(size_t) v] < 0) return;
-      stamp[(size_t) agg[(size_t) v]] = v;
-      out.push_back(agg[(size_t) v]);
-      for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) {
-        const int a = agg[(size_t) inc_adj[(size_t) q].x];
-        if (a >= 0 && stamp[(size_t) a] != v) {
-          stamp[(size_t) a] = v;
-          out.push_back(a);
+    bool smoothed = !(std::getenv("SRRG2_AMD_PG_OMEGA_P") && std::atof(std::getenv("SRRG2_AMD_PG_OMEGA_P")) == 0.0) &&
+                    !g->pg_force_tentative.count(level);
+    const long long q_limit = 64LL * std::max(n, 4096);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      pattern_rows(n, nc, prow_start, pcol, &prow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
+        if (agg[(size_t) v] < 0) return;
+        stamp[(size_t) agg[(size_t) v]] = v;
+        out.push_back(agg[(size_t) v]);
+        if (!smoothed) return;
+        for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) {
+          const int a = agg[(size_t) inc_adj[(size_t) q].x];
+          if (a >= 0 && stamp[(size_t) a] != v) {
+            stamp[(size_t) a] = v;
+            out.push_back(a);
+          }
+        }
+      });
+      if (!smoothed) break;
+      // upper bound of the size of Q's pattern (before duplicates are merged): cheap, and enough to stop a blow-up
+      // before it is computed; the exact size is checked again below
+      long long bound = 0;
+      for (int v = 0; v < n; ++v) {
+        bound += prow_start[(size_t) v + 1] - prow_start[(size_t) v];
+        for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) {
+          const int j = inc_adj[(size_t) q].x;
+          bound += prow_start[(size_t) j + 1] - prow_start[(size_t) j];
         }
       }
-    });
+      if (bound <= 16 * q_limit) break;
+      smoothed = false;
+    }
     const int np = (int) pcol.size();
     std::vector<int> pcsc_start((size_t) nc + 1, 0), pcsc_ent((size_t) std::max(np, 1), 0);
     for (int e = 0; e < np; ++e) pcsc_start[(size_t) pcol[(size_t) e] + 1]++;
@@ -1278,6 +1304,13 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       add_row(v);
       for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) add_row(inc_adj[(size_t) q].x);
     });
+    if (smoothed && (long long) qcol.size() > q_limit) {
+      // (exact size over the limit: this level again, without smoothing)
+      g->pg_force_tentative.insert(level);
+      --level;
+      g->levels.pop_back();
+      continue;
+    }
     const int nq = (int) qcol.size();
     // coarse edges (A < B): B in the row of Q of some row of column A of Ps
     std::vector<int> ce_start, ce_col, ceij;
@@ -1306,6 +1339,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     L->nce = nce;
     L->np  = np;
     L->nq  = nq;
+    L->smoothed = smoothed ? 1 : 0;
     {  // lanes per column of Ps: ~8 entries each
       const double avg = nc > 0 ? (double) np / nc : 0.0;
       int parts = 1;
@@ -1329,7 +1363,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   }
   if (std::getenv("SRRG2_AMD_PG_DEBUG")) {
     std::fprintf(stderr, "posegraph hierarchy:");
-    for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d) ->", L->n, L->ne, L->np, L->nq);
+    for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative");
     std::fprintf(stderr, " coarsest %s; built in %.1f ms on the host (matching %.1f, patterns %.1f)\n",
                  g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, ms_pattern);
   }
@@ -1439,7 +1473,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         auto grid_of = [](size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); };
         hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l, T, g->poses.p);
         hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * D * L->row_parts), dim3(PG_THREADS), 0, g->stream,
-                           g->levels_dev.p, l, omega_p);
+                           g->levels_dev.p, l, L->smoothed ? omega_p : 0.0);
         hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * L->row_parts), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
         hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
                            g->levels_dev.p, l);
