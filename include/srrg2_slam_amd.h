@@ -31,6 +31,7 @@
 #ifndef SRRG2_SLAM_AMD_H
 #define SRRG2_SLAM_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -306,6 +307,27 @@ int srrg2_multi_gpu_shard_count(int K, int world, int rank);
 int srrg2_multi_gpu_shard_indices(int K, int world, int rank, int32_t* indices_out);
 int srrg2_multi_gpu_pack_record(int k, int variable_kind, const srrg2_batch_result* r, double* record_out);
 int srrg2_multi_gpu_unpack_record(const double* record, int variable_kind, int* k_out, srrg2_batch_result* r_out);
+
+/* ---- one alignment sharded by moving points (second mode; no reference counterpart) ---------
+ * For clouds of millions of points one alignment can be spread over G GPUs: the fixed cloud is set on every rank, rank g
+ * sets ITS share of the moving points, and every Gauss-Newton iteration adds the ranks' partial sums before the control
+ * step -- solver->compute() over all factors (multi_aligner_impl.cpp:112) as an all-reduce(sum) of the per-slice
+ * fixed-point sums (int64, exact: the result is bit-identical to the one-GPU alignment of the whole cloud, whatever G
+ * is and however the points are dealt).  The library does not own a communicator: it calls `fn` on the aligner's stream
+ * order, the host side (torch.distributed / RCCL) performs the reduction IN PLACE on the device buffer:
+ *   op SRRG2_REDUCE_SUM_I64  `count` int64 values  (before every control step: the slot sets of the cue slice)
+ *   op SRRG2_REDUCE_MAX_U32  `count` uint32 values (once per compute(): the bit pattern of max |coordinate|, which sizes
+ *                            the fixed-point exponent and must be the same on every rank)
+ * `stream` is the hipStream_t the buffer's producers and consumers are ordered on; fn returns 0 on success.
+ * total_moving_points = the number of moving points over all ranks (the other input of the exponent).
+ * fn == NULL switches the mode off.  compute() only (K = 1), one nearest-neighbour cue slice plus prior slices. */
+#define SRRG2_REDUCE_SUM_I64 0
+#define SRRG2_REDUCE_MAX_U32 1
+typedef int (*srrg2_reduce_fn)(void* user, int op, void* device_buffer, size_t count, void* stream);
+int srrg2_aligner_set_point_shard(srrg2_aligner_h h, srrg2_reduce_fn fn, void* user, int64_t total_moving_points);
+/* plain copies for bindings that cannot touch device memory themselves (kind 0: device -> host, 1: host -> device,
+ * 2: device -> device; stream == NULL: synchronous, else asynchronous on that hipStream_t) */
+int srrg2_amd_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream);
 
 /* ---- pose graph: the global Solver of MultiGraphSLAM_ ---------------------- */
 /* MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317): graph->bindFactors();

@@ -137,6 +137,12 @@ public:
   // (aligner_slice_processor_impl.cpp:20-36): call it whenever the sensor pose changed
   void setSensorInRobot(int slice, const EstimateType& T) { check(srrg2_aligner_set_sensor_in_robot(_h, slice, T.data())); }
   void setPriorMeasurement(int slice, const EstimateType& Z) { check(srrg2_aligner_set_prior_measurement(_h, slice, Z.data())); }
+  // ONE alignment over the ranks of a communicator, sharded by moving points (srrg2_aligner_set_point_shard):
+  // `reduce` adds / maximises the device buffer in place over all ranks on the given stream (e.g. ncclAllReduce);
+  // total_moving_points counts the moving points of all ranks.  reduce == nullptr switches the mode off.
+  void setPointShard(srrg2_reduce_fn reduce, void* user, int64_t total_moving_points) {
+    check(srrg2_aligner_set_point_shard(_h, reduce, user, total_moving_points));
+  }
 
   void setMovingInFixed(const EstimateType& X) { check(srrg2_aligner_set_moving_in_fixed(_h, X.data())); }
   const EstimateType& movingInFixed() const {

@@ -206,6 +206,34 @@ class MultiAligner:
         assert T.size == self.tsize
         self._check(self._b.fn("set_sensor_in_robot")(self._h, C.c_int(slice_idx), _fptr(T)))
 
+    REDUCE_SUM_I64, REDUCE_MAX_U32 = 0, 1
+    _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+    def set_point_shard(self, reduce, total_moving_points):
+        """ONE alignment sharded by moving points over the ranks of a process group (srrg2_aligner_set_point_shard):
+        this rank sets its share of the moving cloud, every compute() calls ``reduce(op, device_ptr, count, stream)``
+        -- in place, on all ranks alike -- for the max |coordinate| word (op REDUCE_MAX_U32, once) and for the int64
+        partial sums before every control step (op REDUCE_SUM_I64).  The estimate, the statistics and H are then those of
+        the one-GPU alignment of the whole cloud, bit for bit.  ``reduce=None`` switches the mode off.
+        (distributed.point_shard_reducer builds ``reduce`` on torch.distributed)"""
+        if reduce is None:
+            self._shard_cb = None
+            self._check(self._b.fn("set_point_shard")(self._h, None, None, C.c_int64(0)))
+            return
+
+        def _cb(_user, op, ptr, count, stream):
+            try:
+                reduce(int(op), int(ptr), int(count), int(stream) if stream else 0)
+                return 0
+            except Exception:  # (an exception must not unwind through the C frames)
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._shard_cb = self._REDUCE_FN(_cb)  # (kept alive with the handle)
+        self._check(self._b.fn("set_point_shard")(self._h, self._shard_cb, None, C.c_int64(int(total_moving_points))))
+
     def set_prior_measurement(self, slice_idx, T):
         T = _as_f32(T).reshape(-1)
         assert T.size == self.tsize

@@ -103,6 +103,10 @@ struct srrg2_aligner_s {
   int kind = 0, dim = 3, dof = 6, tsize = 12, device = 0;
   hipStream_t stream = nullptr;
   srrg2_aligner_params params{10, 10, 0, 0};
+  // point-sharded alignment (srrg2_aligner_set_point_shard): the host side's reduction and the global point count
+  srrg2_reduce_fn reduce_fn = nullptr;
+  void* reduce_user         = nullptr;
+  long long shard_total     = 0;
   bool has_term = false;
   srrg2_termination_params term{5, 20, 20, 20, 0.2f};
   std::vector<Slice*> slices;
@@ -532,7 +536,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // 360 beams 0.18 -> 0.12 ms, 500 3-D points 0.34 -> 0.25 ms -- and behind it from ~2000 points on)
     static const int small_max = std::getenv("SRRG2_AMD_SMALL_MAX") ? std::atoi(std::getenv("SRRG2_AMD_SMALL_MAX")) : 1024;
     small = ncue == 1 && a->slices[fc]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm <= small_max &&
-            !std::getenv("SRRG2_AMD_TIMELINE");
+            !std::getenv("SRRG2_AMD_TIMELINE") && !a->reduce_fn;  // (the one-workgroup kernel has no place for the reduction)
   }
   // The converged pass kernel takes over from iteration `fast_from` of the first run (all of the inlier-only run): by
   // then nearly every point keeps its neighbour.  Batches give it `fast_ppt` points per thread and a queue.
@@ -610,6 +614,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     sc.ninf_bits = s->scalars.p + 7;
     sc.finf_bits = s->scalars.p + 10;
     sc.gcorr_off = nullptr;
+    sc.nm_global = (a->reduce_fn && s->cfg.kind != SRRG2_SLICE_PRIOR) ? (int) a->shard_total : 0;
     SliceDev& d       = sdev[si];
     d.grid            = s->grid;
     d.mpts            = s->moving.p;
@@ -696,6 +701,21 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR && si != first_cue)
         return fail(SRRG2_E_UNSUPPORTED, "compute_batch supports one cue slice (plus prior slices)");
   }
+  bool hook_failed = false;
+  if (a->reduce_fn) {
+    // point-sharded alignment: one nearest-neighbour cue slice, K = 1; max |coordinate| over all ranks before the
+    // exponent is sized
+    int ncue_nn = 0, ncue = 0;
+    for (int si = 0; si < nslices; ++si) {
+      if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+      ++ncue;
+      if (a->slices[si]->cfg.finder == SRRG2_FINDER_NN_GATED) ++ncue_nn;
+    }
+    if (K != 1 || ncue != 1 || ncue_nn != 1)
+      return fail(SRRG2_E_UNSUPPORTED, "point-sharded alignments: compute() with one nearest-neighbour cue slice");
+    if (a->reduce_fn(a->reduce_user, SRRG2_REDUCE_MAX_U32, a->slices[first_cue]->pinf.p, (size_t) K, (void*) a->stream))
+      return fail(SRRG2_E_INVALID, "the reduction hook of the point-sharded alignment failed");
+  }
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
   auto t_prep = std::chrono::steady_clock::now();
   srrg2amd::launch_icp_init(C, a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, a->stream);
@@ -730,6 +750,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   bool probed = false;
   bool final_launched = false;  // the last control step of compute() carried the post / finalize steps
   auto control = [&](int it, bool last_phase) {
+    if (a->reduce_fn && !hook_failed) {  // the ranks' partial sums, added in place, before anybody looks at them
+      Slice* s = a->slices[first_cue];
+      if (a->reduce_fn(a->reduce_user, SRRG2_REDUCE_SUM_I64, s->partials.p, (size_t) K * PARTIAL_SLOTS * ACC_N, (void*) a->stream))
+        hook_failed = true;
+    }
     if (last_phase && it == a->params.max_iterations - 1) {
       srrg2amd::launch_icp_control_final(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                          !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
@@ -868,6 +893,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       }
   }
   if (!seen || a->profile || std::getenv("SRRG2_AMD_TIMELINE")) HIP_TRY(hipStreamSynchronize(a->stream));
+  if (hook_failed) return fail(SRRG2_E_INVALID, "the reduction hook of the point-sharded alignment failed");
   if (hosttime) {
     auto t_end = std::chrono::steady_clock::now();
     std::fprintf(stderr, "compute: prep %.1f us, first launch %.1f us, enqueue %.1f us, wait %.1f us\n",
@@ -1143,6 +1169,27 @@ int srrg2_aligner_set_moving(srrg2_aligner_h a, int si, const float* coords, int
   if ((rc = set_device(a))) return rc;
   const int32_t offsets[2] = {0, n};
   return upload_moving(a, si, coords, cs, normals, ns, offsets, 1, mem);
+}
+
+int srrg2_aligner_set_point_shard(srrg2_aligner_h a, srrg2_reduce_fn fn, void* user, int64_t total_moving_points) {
+  if (!a) return fail(SRRG2_E_INVALID, "null handle");
+  if (fn && (total_moving_points <= 0 || total_moving_points > 0x7fffffffLL))
+    return fail(SRRG2_E_INVALID, "total_moving_points must be in [1, 2^31)");
+  a->reduce_fn   = fn;
+  a->reduce_user = fn ? user : nullptr;
+  a->shard_total = fn ? (long long) total_moving_points : 0;
+  return 0;
+}
+
+int srrg2_amd_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream) {
+  if (!dst || !src || kind < 0 || kind > 2) return fail(SRRG2_E_INVALID, "srrg2_amd_memcpy: bad arguments");
+  const hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToHost : (kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
+  if (stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t) stream));
+  } else {
+    HIP_TRY(hipMemcpy(dst, src, bytes, k));
+  }
+  return 0;
 }
 
 int srrg2_aligner_set_sensor_in_robot(srrg2_aligner_h a, int si, const float* T) {

@@ -142,6 +142,7 @@ struct SliceCtl {
   int* qcount;              // deferred-search queue counters of the slice (reset by the control kernel), or null
   int* qprobe_host;         // pinned host copy of the counters of iteration probe_it ([problem][near, far]), or null
   const ProblemDev* probs;  // [problem] table of the slice (device): point counts for the decision threshold
+  int nm_global;            // > 0: moving points of the alignment over ALL ranks (point-sharded alignment: sizes the exponent)
   const long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N] (null for priors)
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals

@@ -2442,7 +2442,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
         for (int i = 0; i < tsize; ++i) st->X[i] = sc.prior_Z[i];
       }
     } else {
-      nm_of[s] = pd.nm;
+      nm_of[s] = sc.nm_global > 0 ? sc.nm_global : pd.nm;
     }
   }
   for (int s = 0; s < C.nslices; ++s) {  // (after the loop: a prior slice may have replaced the initial guess)

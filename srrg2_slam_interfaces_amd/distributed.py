@@ -97,3 +97,46 @@ def all_gather_records(local_records, K, device=None):
 
 def exchange_records(local_records, K, device=None, mode="all_reduce"):
     return (all_reduce_records if mode == "all_reduce" else all_gather_records)(local_records, K, device=device)
+
+
+def point_shard_reducer(lib, group=None, through_host=None):
+    """The ``reduce`` callable of MultiAligner.set_point_shard on torch.distributed: sums (int64) / maxima (uint32 bit
+    patterns of non-negative floats, reduced as int32: same order) over the ranks of ``group``, in place on the
+    aligner's device buffer.  With an RCCL (``nccl``) group the buffer is copied into a torch tensor on the aligner's
+    stream, all-reduced under that stream (torch orders the collective after the copy and the copy back after the
+    collective: no host wait), and copied back; with a host-side group (``gloo``: the CPU tests, two ranks on one GPU) it
+    goes through pinned-size host arrays, synchronously.  ``lib`` = the loaded C library (``_capi.lib()``):
+    srrg2_amd_memcpy does the raw copies."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    if through_host is None:
+        through_host = backend != "nccl"
+    lib.srrg2_amd_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def reduce(op, ptr, count, stream):
+        dtype, nbytes, red = (torch.int64, 8 * count, dist.ReduceOp.SUM) if op == 0 else (torch.int32, 4 * count, dist.ReduceOp.MAX)
+        if through_host:
+            if stream:
+                torch.cuda.ExternalStream(stream).synchronize()
+            host = torch.empty(count, dtype=dtype)
+            if lib.srrg2_amd_memcpy(C.c_void_p(host.data_ptr()), C.c_void_p(ptr), nbytes, 0, None):
+                raise RuntimeError("srrg2_amd_memcpy (device -> host) failed")
+            dist.all_reduce(host, op=red, group=group)
+            if lib.srrg2_amd_memcpy(C.c_void_p(ptr), C.c_void_p(host.data_ptr()), nbytes, 1, None):
+                raise RuntimeError("srrg2_amd_memcpy (host -> device) failed")
+            return
+        ext = torch.cuda.ExternalStream(stream)
+        with torch.cuda.stream(ext):
+            buf = torch.empty(count, dtype=dtype, device="cuda")
+            if lib.srrg2_amd_memcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(ptr), nbytes, 2, C.c_void_p(stream)):
+                raise RuntimeError("srrg2_amd_memcpy (device -> device) failed")
+            dist.all_reduce(buf, op=red, group=group)  # (ordered on `ext`: c10d waits for and signals the current stream)
+            if lib.srrg2_amd_memcpy(C.c_void_p(ptr), C.c_void_p(buf.data_ptr()), nbytes, 2, C.c_void_p(stream)):
+                raise RuntimeError("srrg2_amd_memcpy (device -> device) failed")
+            buf.record_stream(ext)
+
+    return reduce

@@ -30,7 +30,7 @@ def test_oracle_mirrors_the_call_surface(oracle):
     lib = oracle.lib()
     for n in _declared_functions():
         if n.startswith("srrg2_aligner_") and not n.startswith("srrg2_aligner_profile") and \
-                n not in ("srrg2_aligner_default_params",):
+                n not in ("srrg2_aligner_default_params", "srrg2_aligner_set_point_shard"):  # (defined as = the one-rank result)
             assert hasattr(lib, "oracle_" + n[len("srrg2_"):]), n
 
 

@@ -179,3 +179,83 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert rec["config"]["alignments_total"] == 16 and rec["config"]["alignments_per_step_per_gpu"] == 8
     assert rec["alignments_per_sec"] > 0 and rec["config"]["all_success"] is True
     assert "cpu_baseline" not in rec  # rank 0 at N = 1 only
+
+
+# ---- ONE alignment sharded by moving points (second mode; include/srrg2_slam_amd.h: set_point_shard) ---------
+def _point_shard_problem():
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    return syn.cloud_pair_3d(n=30_000, seed=4400)
+
+
+def _point_shard_aligner(robust):
+    import srrg2_slam_interfaces_amd as pkg
+    from helpers import cue_config
+    from srrg2_slam_interfaces_amd import _abi as abi
+
+    al = pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=0)
+    al.set_params(max_iterations=10, min_num_inliers=10, enable_inlier_only_runs=1 if robust else 0)
+    cfg = cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY if robust else abi.ROBUST_NONE, 0.05, 0.8)
+    return al, al.add_slice(cfg)
+
+
+def _point_shard_run(al, moving, normals):
+    """one alignment through the batch entry point (K = 1: it also returns H of the last Gauss-Newton iteration)"""
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    r = al.compute_batch([moving], [syn.identity(3)], [normals])[0]
+    st = al.iteration_stats()
+    return {"X": np.array(r["moving_in_fixed"], np.float32), "status": r["status"],
+            "stats": np.array([[s[k] for k in ("num_inliers", "num_outliers", "num_suppressed", "num_correspondences",
+                                               "solver_status", "chi_inliers", "chi_outliers")] for s in st], np.float64),
+            "H": np.array(r["information"], np.float32)}
+
+
+def _point_shard_worker(rank, world, port, out_dir, robust):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from srrg2_slam_interfaces_amd import _capi
+    from srrg2_slam_interfaces_amd import distributed as D
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    d = _point_shard_problem()
+    al, si = _point_shard_aligner(robust)
+    al.set_fixed(si, d["fixed"], d["fixed_normals"])
+    # an uneven, interleaved deal: rank 0 takes two of every three points
+    n = d["moving"].shape[0]
+    sel = (np.arange(n) % 3 != 2) if rank == 0 else (np.arange(n) % 3 == 2)
+    al.set_point_shard(D.point_shard_reducer(_capi.lib()), n)
+    out = _point_shard_run(al, d["moving"][sel], d["moving_normals"][sel])
+    assert out["status"] == 0
+    np.savez(os.path.join(out_dir, "shard_%d.npz" % rank), **out)
+    # the mode can be switched off again: the same handle then aligns its own share only (a different result)
+    al.set_point_shard(None, 0)
+    np.save(os.path.join(out_dir, "alone_%d.npy" % rank), _point_shard_run(al, d["moving"][sel], d["moving_normals"][sel])["X"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robust", [False, True])
+def test_point_sharded_alignment_equals_the_one_gpu_alignment(tmp_path, robust):
+    """two ranks (device 0, gloo) each hold a share of the moving cloud; their partial fixed-point sums are added before
+    every control step (exact integers): estimate, per-iteration statistics and H equal the alignment of the whole cloud
+    on one GPU bit for bit -- with the inlier-only second run and the Cauchy kernel as well"""
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    world = 2
+    mp.spawn(_point_shard_worker, args=(world, _free_port(), str(tmp_path), robust), nprocs=world, join=True)
+    d = _point_shard_problem()
+    al, si = _point_shard_aligner(robust)
+    al.set_fixed(si, d["fixed"], d["fixed_normals"])
+    ref = _point_shard_run(al, d["moving"], d["moving_normals"])
+    assert ref["status"] == 0 and ref["stats"].shape[0] == (20 if robust else 10)
+    for rank in range(world):
+        got = np.load(tmp_path / ("shard_%d.npz" % rank))
+        assert int(got["status"]) == ref["status"]
+        assert got["X"].tobytes() == ref["X"].tobytes()
+        assert got["stats"].tobytes() == ref["stats"].tobytes()
+        assert got["H"].tobytes() == ref["H"].tobytes()
+        alone = np.load(tmp_path / ("alone_%d.npy" % rank))
+        assert alone.tobytes() != ref["X"].tobytes()  # (a share alone is a different problem)
