@@ -1244,11 +1244,12 @@ __device__ __forceinline__ void block_reduce_store_biased(long long (&acc)[ACC_N
 // FIRST: the accumulators are written, not added to (one point per thread: no adds at all).
 template <int D, int ROWS, bool FIRST>
 __device__ __forceinline__ uint8_t factor_accumulate_flat(float (&J)[ROWS][D], float (&e)[ROWS], bool found, int rk, float thr,
-                                                          double scale, long long (&acc)[ACC_N]) {
+                                                          double scale, long long (&acc)[ACC_N], bool valid = true) {
+  // (valid == false: a correspondence whose factor is suppressed -- counted, not linearised: factor_accumulate's `invalid`)
   float chi = e[0] * e[0];
 #pragma unroll
   for (int r = 1; r < ROWS; ++r) chi = chi + e[r] * e[r];
-  const bool ok         = found && isfinite(chi);
+  const bool ok         = found && valid && isfinite(chi);
   const bool kernelized = ok && rk != SRRG2_ROBUST_NONE && !(chi < thr);
   float w               = 1.f;
   if (__any(kernelized)) {  // (wave-uniform branch around the divisions; one value merges)
@@ -2005,102 +2006,90 @@ __device__ __forceinline__ void step_proj_body(const SliceDev& S, const ProblemD
   const double scale = dm::pow2(kexp);
   const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
   const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  // Straight-line like the converged pass of the nearest-neighbour slices (k_icp_step_fast): the match, the gates and the
+  // validity of the factor are predicates, every lane produces all 32 values (weight 0 adds the bias alone), so that no
+  // control flow surrounds the accumulators -- with branches the compiler re-materialises them on every path.
   long long acc[ACC_N];
+  const int i    = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inr = i < pd.nm;
+  const int gi   = pd.moff + (inr ? i : 0);
+  float4 p       = make_float4(NAN, 0.f, 0.f, 0.f);
+  if (inr) p = S.mpts[gi];
+  const int ci      = __float_as_int(p.w);  // caller's index within the problem
+  const bool active = inr && finite3(p.x, p.y, p.z);
+  const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+  const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+  const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+  float u, v;
+  int pix = -1;
+  if (active) pix = project_point(S, qx, qy, qz, u, v);
+  const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) ci;
+  bool found = false;
+  float4 f   = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pix >= 0 && zcur[pix] == key) {
+    f     = S.fixed_org[pix];
+    found = finite3(f.x, f.y, f.z);
+  }
+  const float dd = fabsf(f.z - qz);
+  {
+    const float dx = f.x - qx, dy = f.y - qy, dz = f.z - qz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    const float g2 = (2.f * S.gate) * (2.f * S.gate);
+    found          = found && dd <= S.gate && d2 <= g2;
+  }
+  float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (found && (!REPRO || S.use_normal_gate) && S.fixed_org_nrm) nf = S.fixed_org_nrm[pix];
+  if (S.use_normal_gate) {  // (uniform)
+    float4 nm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (found) nm = S.mnrm[gi];
+    const float rx  = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
+    const float ry  = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
+    const float rz  = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
+    const float dot = (nf.x * rx + nf.y * ry) + nf.z * rz;
+    found           = found && dot > S.normal_cos;
+  }
+  float J[ROWS][D];
+  float e[ROWS];
+  float m[ROWS][3];
+  bool valid = true;
+  if (REPRO) {
+    // (lanes without a match compute on zeros: their rows are forced to 0 by factor_accumulate_flat)
+    valid          = f.z > 0.f;
+    const float uq = (S.K[0] * qx) / qz + S.K[2], vq = (S.K[4] * qy) / qz + S.K[5];
+    const float uf = (S.K[0] * f.x) / f.z + S.K[2], vf = (S.K[4] * f.y) / f.z + S.K[5];
+    e[0]           = valid ? uq - uf : 0.f;
+    e[ROWS - 1]    = valid ? vq - vf : 0.f;
+    if (!(fabsf(e[0]) <= PIX_BOUND) || !(fabsf(e[ROWS - 1]) <= PIX_BOUND)) valid = false;
+    const float iz = 1.0f / qz;
+    const float g[2][3] = {{S.K[0] * iz, 0.f, -(((S.K[0] * qx) * iz) * iz)},
+                           {0.f, S.K[4] * iz, -(((S.K[4] * qy) * iz) * iz)}};
 #pragma unroll
-  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < pd.nm) {
-    const int gi   = pd.moff + i;
-    const float4 p = S.mpts[gi];
-    const int ci   = __float_as_int(p.w);  // caller's index within the problem
-    int match      = -1;
-    float resp     = 0.f;
-    uint8_t fstat  = SRRG2_FACTOR_SUPPRESSED;
-    if (finite3(p.x, p.y, p.z)) {
-      const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
-      const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
-      const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
-      float u, v;
-      const int pix = project_point(S, qx, qy, qz, u, v);
-      bool found    = false;
-      float4 f      = make_float4(0.f, 0.f, 0.f, 0.f);
-      float dd      = 0.f;
-      if (pix >= 0) {
-        const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) ci;
-        if (zcur[pix] == key) {
-          f = S.fixed_org[pix];
-          if (finite3(f.x, f.y, f.z)) {
-            dd             = fabsf(f.z - qz);
-            const float dx = f.x - qx, dy = f.y - qy, dz = f.z - qz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            const float g2 = (2.f * S.gate) * (2.f * S.gate);
-            found          = dd <= S.gate && d2 <= g2;
-          }
-        }
-      }
-      float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (found && (!REPRO || S.use_normal_gate) && S.fixed_org_nrm) nf = S.fixed_org_nrm[pix];
-      if (found && S.use_normal_gate) {
-        const float4 nm = S.mnrm[gi];
-        const float rx  = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
-        const float ry  = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
-        const float rz  = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
-        const float dot = (nf.x * rx + nf.y * ry) + nf.z * rz;
-        if (!(dot > S.normal_cos)) found = false;
-      }
-      if (found) {
-        match = pix;
-        resp  = dd;
-        float J[ROWS][D];
-        float e[ROWS];
-        float m[ROWS][3];
-        bool invalid = false;
-        if (REPRO) {
-          if (!(f.z > 0.f)) {
-            invalid = true;
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-              e[r] = 0.f;
-              m[r][0] = m[r][1] = m[r][2] = 0.f;
-            }
-          } else {
-            const float uq = (S.K[0] * qx) / qz + S.K[2], vq = (S.K[4] * qy) / qz + S.K[5];
-            const float uf = (S.K[0] * f.x) / f.z + S.K[2], vf = (S.K[4] * f.y) / f.z + S.K[5];
-            e[0]           = uq - uf;
-            e[ROWS - 1]    = vq - vf;
-            if (!(fabsf(e[0]) <= PIX_BOUND) || !(fabsf(e[ROWS - 1]) <= PIX_BOUND)) invalid = true;
-            const float iz = 1.0f / qz;
-            const float g[2][3] = {{S.K[0] * iz, 0.f, -(((S.K[0] * qx) * iz) * iz)},
-                                   {0.f, S.K[4] * iz, -(((S.K[4] * qy) * iz) * iz)}};
+      for (int k = 0; k < 3; ++k) m[r][k] = (T[0 * 4 + k] * g[r][0] + T[1 * 4 + k] * g[r][1]) + T[2 * 4 + k] * g[r][2];
+  } else {
+    e[0]    = (nf.x * (qx - f.x) + nf.y * (qy - f.y)) + nf.z * (qz - f.z);
+    m[0][0] = (T[0] * nf.x + T[4] * nf.y) + T[8] * nf.z;
+    m[0][1] = (T[1] * nf.x + T[5] * nf.y) + T[9] * nf.z;
+    m[0][2] = (T[2] * nf.x + T[6] * nf.y) + T[10] * nf.z;
+  }
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-              for (int k = 0; k < 3; ++k) m[r][k] = (T[0 * 4 + k] * g[r][0] + T[1 * 4 + k] * g[r][1]) + T[2 * 4 + k] * g[r][2];
-          }
-        } else {
-          e[0]    = (nf.x * (qx - f.x) + nf.y * (qy - f.y)) + nf.z * (qz - f.z);
-          m[0][0] = (T[0] * nf.x + T[4] * nf.y) + T[8] * nf.z;
-          m[0][1] = (T[1] * nf.x + T[5] * nf.y) + T[9] * nf.z;
-          m[0][2] = (T[2] * nf.x + T[6] * nf.y) + T[10] * nf.z;
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          J[r][0] = m[r][0];
-          J[r][1] = m[r][1];
-          J[r][2] = m[r][2];
-          J[r][3] = kk * (p.y * m[r][2] - p.z * m[r][1]);
-          J[r][4] = kk * (p.z * m[r][0] - p.x * m[r][2]);
-          J[r][5] = kk * (p.x * m[r][1] - p.y * m[r][0]);
-        }
-        fstat = factor_accumulate<D, ROWS>(J, e, invalid, rk, S.robust_thr, scale, false, acc);
-      }
-    }
+  for (int r = 0; r < ROWS; ++r) {
+    J[r][0] = m[r][0];
+    J[r][1] = m[r][1];
+    J[r][2] = m[r][2];
+    J[r][3] = kk * (p.y * m[r][2] - p.z * m[r][1]);
+    J[r][4] = kk * (p.z * m[r][0] - p.x * m[r][2]);
+    J[r][5] = kk * (p.x * m[r][1] - p.y * m[r][0]);
+  }
+  const uint8_t fstat = factor_accumulate_flat<D, ROWS, true>(J, e, found, rk, S.robust_thr, scale, acc, valid);
+  if (inr) {
     // (stored in the sorted order of the moving cloud: coalesced; the host API maps back to the caller's order)
-    S.corr_fixed[gi] = match;
-    S.corr_resp[gi]  = resp;
+    S.corr_fixed[gi] = found ? pix : -1;
+    S.corr_resp[gi]  = found ? dd : 0.f;
     S.corr_stat[gi]  = fstat;
   }
-  block_reduce_store<4>(acc, S.partials, prob, blockIdx.x);
+  block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, 1);
 }
 
 template <bool REPRO>
