@@ -11,9 +11,10 @@
 //   - a scene point hit by ONE correspondence is independent of all others (the common case: the tracker's
 //     correspondences come through an injective local->global map),
 //   - scene points hit by several correspondences are replayed in correspondence order by one thread per scene point
-//     (k_merge_dups walks the ordered list of such correspondences),
+//     (k_merge_dups: the duplicates are grouped by a radix sort),
 //   - appends keep measurement order (stable compaction by exclusive scan).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -41,6 +42,8 @@ struct srrg2_scene {
   DevBuf<int> flags, scan_sums, counts, dup_list;
   DevBuf<unsigned char> merged;
   DevBuf<srrg2_correspondence> corr;
+  DevBuf<unsigned long long> dup_keys;  // (scene index << 32 | correspondence index) of the duplicates: unsorted, sorted
+  DevBuf<char> sort_tmp;
   DevBuf<char> staging;
   int* scalars = nullptr;  // pinned host mirror of dscalars
   DevBuf<int> dscalars;    // device: [0] scan total, [1] num_merged, [2] error flag, [3] duplicates seen, [4] ncorr
@@ -185,18 +188,30 @@ __global__ void k_compact_dups(const int* __restrict__ dup_flags_scanned, const 
     if (counts[corr[c].fixed_idx] > 1) dup_list[dup_flags_scanned[c]] = c;
 }
 
-// scene points hit several times: replay their correspondences in order (:51 "for all correspondences"); the list is
-// ordered, and different scene points do not interact, so one thread walks it
+// scene points hit several times: replay their correspondences in order (:51 "for all correspondences").  Different
+// scene points do not interact, so the duplicates are grouped by scene point -- a radix sort of the keys
+// (scene index << 32 | correspondence index): groups come out contiguous, each in correspondence order -- and ONE THREAD
+// PER DISTINCT SCENE POINT replays its group (a single thread walking the whole list paid one memory latency per entry).
+__global__ void k_dup_keys(const srrg2_correspondence* __restrict__ corr, const int* __restrict__ dup_list, int ndup,
+                           unsigned long long* __restrict__ keys) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ndup; t += gridDim.x * blockDim.x) {
+    const int c = dup_list[t];
+    keys[t]     = ((unsigned long long) (unsigned) corr[c].fixed_idx << 32) | (unsigned) c;
+  }
+}
+
 __global__ void k_merge_dups(int dim, Xf M, float max_response, float max_d2, const srrg2_correspondence* __restrict__ corr,
-                             const int* __restrict__ dup_list, int ndup, float4* scene_pts, float4* scene_nrm,
+                             const unsigned long long* __restrict__ keys, int ndup, float4* scene_pts, float4* scene_nrm,
                              const float4* __restrict__ meas_pts, const float4* __restrict__ meas_nrm,
                              unsigned char* __restrict__ merged) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  for (int t = 0; t < ndup; ++t) {
-    const srrg2_correspondence k = corr[dup_list[t]];
-    if (merge_one(dim, M, max_response, max_d2, scene_pts, scene_nrm, meas_pts, meas_nrm, k.fixed_idx, k.moving_idx, k.response))
-      merged[k.moving_idx] = 1;
-    __threadfence();
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ndup; t += gridDim.x * blockDim.x) {
+    const unsigned s = (unsigned) (keys[t] >> 32);
+    if (t > 0 && (unsigned) (keys[t - 1] >> 32) == s) continue;  // not the first of its group
+    for (int j = t; j < ndup && (unsigned) (keys[j] >> 32) == s; ++j) {
+      const srrg2_correspondence k = corr[(unsigned) keys[j]];
+      if (merge_one(dim, M, max_response, max_d2, scene_pts, scene_nrm, meas_pts, meas_nrm, k.fixed_idx, k.moving_idx, k.response))
+        merged[k.moving_idx] = 1;
+    }
   }
 }
 
@@ -380,7 +395,7 @@ int srrg2_scene_destroy(srrg2_scene_h s) {
   (void) hipSetDevice(s->device);
   if (s->stream) (void) hipStreamSynchronize(s->stream);
   s->pts.release(); s->nrm.release(); s->gidx.release(); s->flags.release(); s->scan_sums.release();
-  s->counts.release(); s->dup_list.release(); s->merged.release(); s->corr.release(); s->staging.release(); s->dscalars.release();
+  s->counts.release(); s->dup_list.release(); s->dup_keys.release(); s->sort_tmp.release(); s->merged.release(); s->corr.release(); s->staging.release(); s->dscalars.release();
   if (s->scalars) (void) hipHostFree(s->scalars);
   if (s->stream) (void) hipStreamDestroy(s->stream);
   delete s;
@@ -553,9 +568,19 @@ int srrg2_scene_merge(srrg2_scene_h scene, srrg2_scene_h meas, const float* meas
         if ((rc = scene->dup_list.reserve((size_t) ndup + 1))) return rc;
         hipLaunchKernelGGL(k_compact_dups, dim3(blocks_for(ncorr)), dim3(256), 0, st, scene->flags.p, scene->corr.p, ncorr,
                            scene->counts.p, scene->dup_list.p);
-        hipLaunchKernelGGL(k_merge_dups, dim3(1), dim3(64), 0, st, scene->dim, M, p->maximum_response,
-                           p->maximum_distance_geometry_squared, scene->corr.p, scene->dup_list.p, ndup, scene->pts.p, snrm,
-                           meas->pts.p, mnrm, scene->merged.p);
+        if (ndup > 0) {
+          if ((rc = scene->dup_keys.reserve(2 * (size_t) ndup))) return rc;
+          unsigned long long* kin  = scene->dup_keys.p;
+          unsigned long long* kout = scene->dup_keys.p + ndup;
+          hipLaunchKernelGGL(k_dup_keys, dim3(blocks_for(ndup)), dim3(256), 0, st, scene->corr.p, scene->dup_list.p, ndup, kin);
+          size_t tmp_bytes = 0;
+          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, kin, kout, ndup, 0, 64, st));
+          if ((rc = scene->sort_tmp.reserve(std::max<size_t>(tmp_bytes, 1)))) return rc;
+          HIP_TRY(hipcub::DeviceRadixSort::SortKeys(scene->sort_tmp.p, tmp_bytes, kin, kout, ndup, 0, 64, st));
+          hipLaunchKernelGGL(k_merge_dups, dim3(blocks_for(ndup)), dim3(256), 0, st, scene->dim, M, p->maximum_response,
+                             p->maximum_distance_geometry_squared, scene->corr.p, kout, ndup, scene->pts.p, snrm, meas->pts.p,
+                             mnrm, scene->merged.p);
+        }
       }
     }
   }
