@@ -182,10 +182,10 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
 
 
 # ---- ONE alignment sharded by moving points (second mode; include/srrg2_slam_amd.h: set_point_shard) ---------
-def _point_shard_problem():
+def _point_shard_problem(n=30_000):
     from srrg2_slam_interfaces_amd import synthetic as syn
 
-    return syn.cloud_pair_3d(n=30_000, seed=4400)
+    return syn.cloud_pair_3d(n=n, seed=4400)
 
 
 def _point_shard_aligner(robust):
@@ -211,7 +211,7 @@ def _point_shard_run(al, moving, normals):
             "H": np.array(r["information"], np.float32)}
 
 
-def _point_shard_worker(rank, world, port, out_dir, robust):
+def _point_shard_worker(rank, world, port, out_dir, robust, npts):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -219,7 +219,7 @@ def _point_shard_worker(rank, world, port, out_dir, robust):
     from srrg2_slam_interfaces_amd import distributed as D
     from srrg2_slam_interfaces_amd import synthetic as syn
 
-    d = _point_shard_problem()
+    d = _point_shard_problem(npts)
     al, si = _point_shard_aligner(robust)
     al.set_fixed(si, d["fixed"], d["fixed_normals"])
     # an uneven, interleaved deal: rank 0 takes two of every three points
@@ -237,16 +237,18 @@ def _point_shard_worker(rank, world, port, out_dir, robust):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robust", [False, True])
-def test_point_sharded_alignment_equals_the_one_gpu_alignment(tmp_path, robust):
+@pytest.mark.parametrize("robust,npts", [(False, 30_000), (True, 30_000), (False, 240_000)])
+def test_point_sharded_alignment_equals_the_one_gpu_alignment(tmp_path, robust, npts):
     """two ranks (device 0, gloo) each hold a share of the moving cloud; their partial fixed-point sums are added before
     every control step (exact integers): estimate, per-iteration statistics and H equal the alignment of the whole cloud
     on one GPU bit for bit -- with the inlier-only second run and the Cauchy kernel as well"""
     from srrg2_slam_interfaces_amd import synthetic as syn
 
     world = 2
-    mp.spawn(_point_shard_worker, args=(world, _free_port(), str(tmp_path), robust), nprocs=world, join=True)
-    d = _point_shard_problem()
+    # (240 000 points: rank 0 holds 160 000 and runs with the deferred-search kernel, rank 1 holds 80 000 and runs
+    # without it -- the ranks may take different kernel paths, the sums do not care)
+    mp.spawn(_point_shard_worker, args=(world, _free_port(), str(tmp_path), robust, npts), nprocs=world, join=True)
+    d = _point_shard_problem(npts)
     al, si = _point_shard_aligner(robust)
     al.set_fixed(si, d["fixed"], d["fixed_normals"])
     ref = _point_shard_run(al, d["moving"], d["moving_normals"])
