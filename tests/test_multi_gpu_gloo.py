@@ -261,3 +261,38 @@ def test_point_sharded_alignment_equals_the_one_gpu_alignment(tmp_path, robust, 
         assert got["H"].tobytes() == ref["H"].tobytes()
         alone = np.load(tmp_path / ("alone_%d.npy" % rank))
         assert alone.tobytes() != ref["X"].tobytes()  # (a share alone is a different problem)
+
+
+def _point_shard_rccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from srrg2_slam_interfaces_amd import _capi
+    from srrg2_slam_interfaces_amd import distributed as D
+
+    d = _point_shard_problem()
+    al, si = _point_shard_aligner(False)
+    al.set_fixed(si, d["fixed"], d["fixed_normals"])
+    al.set_point_shard(D.point_shard_reducer(_capi.lib()), d["moving"].shape[0])  # (RCCL group: the on-stream path)
+    out = _point_shard_run(al, d["moving"], d["moving_normals"])
+    np.savez(os.path.join(out_dir, "rccl.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_point_shard_reducer_on_the_aligners_stream_with_rccl(tmp_path):
+    """the RCCL form of the reduction hook (device buffer -> torch tensor -> all_reduce under the aligner's own stream ->
+    back, no host wait): a one-rank RCCL group is all a one-GPU box can run -- the sums come back unchanged, so the
+    alignment must equal the plain one bit for bit; what it checks is the stream ordering of hook and kernels"""
+    mp.spawn(_point_shard_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    d = _point_shard_problem()
+    al, si = _point_shard_aligner(False)
+    al.set_fixed(si, d["fixed"], d["fixed_normals"])
+    ref = _point_shard_run(al, d["moving"], d["moving_normals"])
+    got = np.load(tmp_path / "rccl.npz")
+    assert int(got["status"]) == ref["status"] == 0
+    assert got["X"].tobytes() == ref["X"].tobytes()
+    assert got["stats"].tobytes() == ref["stats"].tobytes()
+    assert got["H"].tobytes() == ref["H"].tobytes()
