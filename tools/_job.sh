@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r2zx; mkdir -p $O
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 tools/bench_point_shard.py --points 2000000 --steps 10 2>$O/e1.txt | tee $O/point_shard_1rank_rccl.json | cut -c1-600; tail -3 $O/e1.txt
-SRRG2_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 tools/bench_point_shard.py --points 2000000 --steps 10 2>$O/e2.txt | tee $O/point_shard_2ranks_shared.json | cut -c1-600; tail -3 $O/e2.txt
+O=$GRAFT_REPO_ROOT/gpurun_out/r2zz2; mkdir -p $O
+for n in 100000 200000 500000 1000000 2000000 5000000; do for g in 0 -1; do
+  if [ $g = 0 ]; then export SRRG2_AMD_GRID2=0; else unset SRRG2_AMD_GRID2; fi
+  echo "points $n grid2 $g $(python bench.py --workload c2 --points $n --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | cut -c40-160)"
+done; done | tee $O/grid2_dense.txt
+unset SRRG2_AMD_GRID2
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_big -o t -- python $GRAFT_REPO_ROOT/bench.py --workload c2 --points 2000000 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $GRAFT_REPO_ROOT/tools/trace_steps.py $(find /tmp/tr_big -name '*.db' | head -1) | cut -c1-400 | tee $O/trace_2M.txt
