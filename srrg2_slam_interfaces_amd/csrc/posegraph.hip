@@ -582,76 +582,60 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_interp(const MgLevel* __restr
   }
 }
 
-// Smoothed aggregation: Ps = (I - omega_p Dinv H) T with T the tentative (rigid-motion) interpolation.  Entry (i, A) of Ps:
-//   [agg(i) = A] T_i  -  omega_p Dinv_i  sum_{j in N(i) + i, agg(j) = A} H_ij T_j.          One thread per (entry, column).
-// Piecewise-rigid interpolation alone leaves the V-cycle's convergence dependent on the number of levels (C5: 151-415 CG
-// iterations per solve); one Jacobi sweep on the interpolation removes its high-energy part (C5: ~30 iterations).
-template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(const MgLevel* __restrict__ levels, int l, double omega_p) {
-  const MgLevel L = levels[l];
-  const int parts = L.row_parts;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= L.np * D * parts) return;  // (whole groups: the bound is a multiple of `parts`)
-  const int part = t & (parts - 1), u = t / parts;
-  const int e = u / D, c = u - e * D;
-  const int i = L.prow_of[e], A = L.pcol[e];
-  double w[D];
-#pragma unroll
-  for (int r = 0; r < D; ++r) w[r] = 0.0;
-  const bool own = L.agg[i] == A;
-  if (own && part == 0) {
-    const float* Ti = L.P + (size_t) i * D * D;
-    const double* H = L.Hd + (size_t) i * D * D;
-#pragma unroll
-    for (int r = 0; r < D; ++r)
-#pragma unroll
-      for (int a = 0; a < D; ++a) w[r] = w[r] + H[r * D + a] * (double) Ti[a * D + c];
-  }
-  for (int q = L.inc_start[i] + part; q < L.inc_start[i + 1]; q += parts) {
-    const int2 adj = L.inc_adj[q];
-    if (L.agg[adj.x] != A) continue;
-    const float* Tj = L.P + (size_t) adj.x * D * D;
-    const double* B = L.Ho + (size_t) (adj.y >> 1) * D * D;
-    if (adj.y & 1) {
-#pragma unroll
-      for (int r = 0; r < D; ++r)
-#pragma unroll
-        for (int a = 0; a < D; ++a) w[r] = w[r] + B[a * D + r] * (double) Tj[a * D + c];
-    } else {
-#pragma unroll
-      for (int r = 0; r < D; ++r)
-#pragma unroll
-        for (int a = 0; a < D; ++a) w[r] = w[r] + B[r * D + a] * (double) Tj[a * D + c];
-    }
-  }
-  mg_group_sum<D>(w, parts);
-  if (part != 0) return;
-  const double* Di = L.Dinv + (size_t) i * D * D;
-  double* out      = L.Ps + (size_t) e * D * D;
-#pragma unroll
-  for (int r = 0; r < D; ++r) {
-    double s = 0.0;
-#pragma unroll
-    for (int a = 0; a < D; ++a) s = s + Di[r * D + a] * w[a];
-    out[r * D + c] = (own ? (double) L.P[((size_t) i * D + r) * D + c] : 0.0) - omega_p * s;
-  }
-}
-
 // w (D x D, row-major) += A B  or  A^T B, as D rank-1 updates (12 operand values live at a time)
-template <int D, bool TRANSPOSE_A>
-__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* __restrict__ A, const double* __restrict__ B) {
+template <int D, bool TRANSPOSE_A, typename TB>
+__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* __restrict__ A, const TB* __restrict__ B) {
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double col[D], row[D];
 #pragma unroll
     for (int r = 0; r < D; ++r) col[r] = TRANSPOSE_A ? A[a * D + r] : A[r * D + a];
 #pragma unroll
-    for (int c = 0; c < D; ++c) row[c] = B[a * D + c];
+    for (int c = 0; c < D; ++c) row[c] = (double) B[a * D + c];
 #pragma unroll
     for (int r = 0; r < D; ++r)
 #pragma unroll
       for (int c = 0; c < D; ++c) w[r * D + c] = w[r * D + c] + col[r] * row[c];
   }
+}
+
+// Smoothed aggregation: Ps = (I - omega_p Dinv H) T with T the tentative (rigid-motion) interpolation.  Entry (i, A) of Ps:
+//   [agg(i) = A] T_i  -  omega_p Dinv_i  sum_{j in N(i) + i, agg(j) = A} H_ij T_j.
+// Piecewise-rigid interpolation alone leaves the V-cycle's convergence dependent on the number of levels (C5: 151-415 CG
+// iterations per solve); one Jacobi sweep on the interpolation removes its high-energy part (C5: ~30 iterations).
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(const MgLevel* __restrict__ levels, int l, double omega_p) {
+  // one thread per (entry of Ps, part): every H block of the row is read once for the whole D x D block of the entry
+  const MgLevel L = levels[l];
+  const int parts = L.row_parts;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.np * parts) return;  // (whole groups: the bound is a multiple of `parts`)
+  const int part = t & (parts - 1), e = t / parts;
+  const int i = L.prow_of[e], A = L.pcol[e];
+  double w[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) w[k] = 0.0;
+  const bool own = L.agg[i] == A;
+  if (own && part == 0) mg_block_mac<D, false>(w, L.Hd + (size_t) i * D * D, L.P + (size_t) i * D * D);
+  for (int q = L.inc_start[i] + part; q < L.inc_start[i + 1]; q += parts) {
+    const int2 adj = L.inc_adj[q];
+    if (L.agg[adj.x] != A) continue;
+    const float* Tj = L.P + (size_t) adj.x * D * D;
+    const double* B = L.Ho + (size_t) (adj.y >> 1) * D * D;
+    if (adj.y & 1)
+      mg_block_mac<D, true>(w, B, Tj);
+    else
+      mg_block_mac<D, false>(w, B, Tj);
+  }
+  mg_group_sum<D * D>(w, parts);
+  if (part != 0) return;
+  double o[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) o[k] = 0.0;
+  mg_block_mac<D, false>(o, L.Dinv + (size_t) i * D * D, w);
+  double* out = L.Ps + (size_t) e * D * D;
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) out[k] = (own ? (double) L.P[(size_t) i * D * D + k] : 0.0) - omega_p * o[k];
 }
 
 // Q = H Ps.  One thread per (entry of Q, part): the look-ups of Ps[j, B] over the incidences j of row i are the
@@ -1472,7 +1456,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         MgLevelBufs* L = g->levels[(size_t) l];
         auto grid_of = [](size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); };
         hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l, T, g->poses.p);
-        hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * D * L->row_parts), dim3(PG_THREADS), 0, g->stream,
+        hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * L->row_parts), dim3(PG_THREADS), 0, g->stream,
                            g->levels_dev.p, l, L->smoothed ? omega_p : 0.0);
         hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * L->row_parts), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
         hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
