@@ -741,8 +741,12 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(const MgLevel* __restric
 
 // dense inverse of the coarsest operator: assemble, Cholesky in place, then one thread per column solves for the inverse
 template <int D>
-__global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(const MgLevel* __restrict__ levels, int l, double* __restrict__ A,
-                                                              double* __restrict__ Cinv, PgScalars* __restrict__ sc) {
+__global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(const MgLevel* __restrict__ levels, int l, double* __restrict__ Aglobal,
+                                                              double* __restrict__ Cinv, PgScalars* __restrict__ sc, int in_lds) {
+  // (the factorisation is a chain of N column steps with three barriers each: with the matrix in LDS a step costs
+  // ~2 us instead of ~12; the host asks for it when N x N doubles fit)
+  extern __shared__ double A_lds[];
+  double* __restrict__ A = in_lds ? A_lds : Aglobal;
   const MgLevel L = levels[l];
   const int N = L.n * D, tid = threadIdx.x, nth = blockDim.x;
   for (int k = tid; k < N * N; k += nth) A[k] = 0.0;
@@ -788,6 +792,32 @@ __global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(const MgLevel* __r
     }
   }
   __syncthreads();
+  if (in_lds == 2) {
+    // Y = L^-1 by a right-looking sweep over the rows (all columns at once: no thread walks a dependent chain of N^2
+    // terms), in LDS behind the factor; then Cinv = Y^T Y, every entry on its own.  The pivot of a switched-off
+    // coordinate is 1e150: its row and column of the inverse come out as ~0, like the column solves below.
+    double* __restrict__ Y = A_lds + (size_t) N * N;
+    for (int k = tid; k < N * N; k += nth) Y[k] = (k / N == k % N) ? 1.0 : 0.0;
+    for (int i = 0; i < N; ++i) {
+      __syncthreads();
+      const double piv = A[(size_t) i * N + i];
+      for (int c = tid; c <= i; c += nth) Y[(size_t) i * N + c] = Y[(size_t) i * N + c] / piv;
+      __syncthreads();
+      const int rows = N - i - 1, cols = i + 1;
+      for (int idx = tid; idx < rows * cols; idx += nth) {
+        const int j = i + 1 + idx / cols, c = idx - (idx / cols) * cols;
+        Y[(size_t) j * N + c] -= A[(size_t) j * N + i] * Y[(size_t) i * N + c];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < N * N; idx += nth) {
+      const int a = idx / N, b = idx - a * N;
+      double sum = 0.0;
+      for (int k = (a > b ? a : b); k < N; ++k) sum += Y[(size_t) k * N + a] * Y[(size_t) k * N + b];
+      Cinv[idx] = sum;
+    }
+    return;
+  }
   // column c of the inverse: L y = e_c, L^T x = y   (Cinv is symmetric: stored row = column)
   for (int c = tid; c < N; c += nth) {
     double* x = Cinv + (size_t) c * N;
@@ -1464,9 +1494,17 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         hipLaunchKernelGGL(k_mg_dinv<D>, dim3((unsigned) ((L->nc + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
                            g->levels_dev.p, l + 1, g->sc.p);
       }
-      if (g->coarsest_dense)
-        hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, nl, g->coarse_A.p,
-                           g->coarse_inv.p, g->sc.p);
+      if (g->coarsest_dense) {
+        const size_t Nc       = (size_t) g->levels[(size_t) nl]->n * D;
+        const size_t lds_need = Nc * Nc * sizeof(double);
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mg_coarsest_inverse<D>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        // 2: factor and L^-1 in LDS (row-sweep inverse); 1: factor in LDS; 0: everything in global memory
+        const int in_lds = !lds_ok ? 0 : (2 * lds_need <= 150 * 1024 ? 2 : (lds_need <= 150 * 1024 ? 1 : 0));
+        if (!lds_ok) (void) hipGetLastError();
+        hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), (size_t) in_lds * lds_need, g->stream, g->levels_dev.p,
+                           nl, g->coarse_A.p, g->coarse_inv.p, g->sc.p, in_lds);
+      }
     }
     // PCG: r lives in level 0's r (the cycle's input), z = level 0's x (its output)
     double* r = L0->r.p;
