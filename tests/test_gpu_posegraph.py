@@ -108,6 +108,18 @@ def test_larger_graph_properties(product):
         np.abs(g["poses_init"][:, :, 3] - g["poses_gt"][:, :, 3]))
 
 
+def test_larger_se2_graph_properties(product):
+    """the same size-independent properties for SE(2): 20 000 poses / 60 000 factors, every linear solve on tolerance
+    within a few dozen multigrid-preconditioned CG iterations, chi monotone down to the noise floor"""
+    g = syn.pose_graph_2d(V=20000, E=60000)
+    pg = product.PoseGraph(abi.SE2_RIGHT)
+    pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+    st = pg.solve()
+    chis = [s["chi"] for s in st]
+    assert all(s["solver_status"] == 0 and s["pcg_iterations"] < 150 and s["pcg_residual"] <= 1.01e-6 for s in st)
+    assert all(b <= a * 1.0001 for a, b in zip(chis, chis[1:])) and chis[-1] < 0.02 * chis[0]
+
+
 def test_hub_vertex_fill_guard(oracle, product, capfd, monkeypatch):
     """a pose with factors to every other pose (a place revisited all the time): the smoothed interpolation of that
     level would fill the Galerkin product quadratically in the hub's degree -- the hierarchy falls back to the tentative
