@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SRRG2_AMD_ABI_VERSION 2
+#define SRRG2_AMD_ABI_VERSION 3
 #define SRRG2_MAX_SLICES 8
 
 /* ---- enums -------------------------------------------------------------- */
@@ -460,6 +460,42 @@ int srrg2_scene_merge(srrg2_scene_h scene, srrg2_scene_h measurement, const floa
 int srrg2_scene_merge_from_aligner(srrg2_scene_h scene, srrg2_scene_h measurement, const float* measurement_in_scene,
                                    srrg2_aligner_h aligner, int slice_idx, srrg2_scene_h clipped,
                                    const srrg2_merger_params* p, srrg2_merge_result* out);
+
+/* ---- strategy knobs (no reference counterpart) ----------------------------------------------------------------
+ * Every setting gives the SAME results (indices, estimates, statistics bit for bit): the knobs choose between exact
+ * strategies of the finder / reduction / control step.  A handle starts from srrg2_aligner_default_tuning() overridden
+ * by the SRRG2_AMD_* environment variables, which are read ONCE, in srrg2_aligner_create (never inside compute()).
+ * Negative values of the `int32_t` switches mean "automatic" (the library picks by problem size). */
+typedef struct srrg2_aligner_tuning {
+  int32_t strategy_mask;        /* SRRG2_AMD_TUNE bit mask (DESIGN.md "Strategy knobs"); 0 = defaults                 */
+  int32_t queue_probe_iteration;/* SRRG2_AMD_QPROBE: iteration whose deferred-search counters decide whether the
+                                   deferred-search launch is kept (default 1; -1 = never drop it)                      */
+  int32_t small_max_points;     /* SRRG2_AMD_SMALL_MAX: largest moving cloud run by the one-workgroup kernel (1024)    */
+  int32_t fast_from_iteration;  /* SRRG2_AMD_FAST_FROM: first iteration the converged-pass kernel takes (3)           */
+  int32_t fast_points_per_thread; /* SRRG2_AMD_FAST_PPT: 1, 2 or 4 (1)                                                */
+  int32_t fast_min_points;      /* SRRG2_AMD_FAST_MIN: smallest moving cloud using the converged-pass kernel (0)       */
+  int32_t fast_gather;          /* SRRG2_AMD_FAST_GATHER: kept neighbours gathered from the fixed cloud (1) or streamed
+                                   from per-point arrays (0); -1 = batches of more than 4 alignments gather            */
+  int32_t fast_batch_queue;     /* SRRG2_AMD_FAST_QUEUE: batches hand failed certificates to the deferred-search kernel (0) */
+  int32_t queue_min_points;     /* SRRG2_AMD_QUEUE_MIN: smallest moving cloud that uses the deferred-search kernel (90000) */
+  int32_t msort_segments;       /* SRRG2_AMD_MSORT_SEGMENTS: workgroups per cloud of the batch Morton sort; 0 = automatic */
+  int32_t msort_key_bits;       /* SRRG2_AMD_MSORT_BITS: total bits of the (anisotropic) Morton key of the moving-cloud
+                                   sort; 0 = automatic (15 for batches sorted in LDS, 18 for single clouds); -1 = the
+                                   round-2 isotropic keys (4 / 5 / 6 bits per axis by batch size)                      */
+  int32_t fused_control;        /* SRRG2_AMD_FUSED_CONTROL: the control step of an iteration runs in the epilogue of the
+                                   last-arriving workgroup of its step kernel (1) or as its own launch (0); -1 = automatic */
+  int32_t lds_tile;             /* SRRG2_AMD_LDS_TILE: search passes of batches stage each wave's neighbourhood of the
+                                   fixed cloud in LDS (1) or gather it per lane (0); -1 = automatic                     */
+  float   cell_target;          /* SRRG2_AMD_CELL_TARGET: points per occupied grid cell the automatic cell size aims at (8) */
+  float   rmax_cap;             /* SRRG2_AMD_RMAX_CAP: largest cube radius (cells) needed to cover the gate; 0 = default
+                                   (3 for 2-D clouds, none for 3-D)                                                    */
+  int32_t reserved_[9];
+} srrg2_aligner_tuning;
+/* built-in defaults (the environment is NOT consulted) */
+void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t);
+/* the handle's current knobs / replace them (takes effect from the next set_fixed / set_moving / compute) */
+int srrg2_aligner_get_tuning(srrg2_aligner_h h, srrg2_aligner_tuning* t_out);
+int srrg2_aligner_set_tuning(srrg2_aligner_h h, const srrg2_aligner_tuning* t);
 
 /* ---- measurement hooks (no reference counterpart: the reference profiles with
  * PROFILE_TIME scopes outside the aligner) ------------- */

@@ -5,7 +5,7 @@ Shared by the product binding (``_capi.py``) and by the test-side oracle binding
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SLICES = 8
 
 # enum srrg2_variable_kind  (S/registration/aligners/multi_aligner.h:152-158)
@@ -93,6 +93,28 @@ class BatchResult(C.Structure):
         ("num_correspondences", C.c_int32),
         ("reserved_", C.c_int32),
         ("information", C.c_float * 36),
+    ]
+
+
+class AlignerTuning(C.Structure):
+    """srrg2_aligner_tuning: strategy knobs, every setting gives the same results (include/srrg2_slam_amd.h)"""
+    _fields_ = [
+        ("strategy_mask", C.c_int32),
+        ("queue_probe_iteration", C.c_int32),
+        ("small_max_points", C.c_int32),
+        ("fast_from_iteration", C.c_int32),
+        ("fast_points_per_thread", C.c_int32),
+        ("fast_min_points", C.c_int32),
+        ("fast_gather", C.c_int32),
+        ("fast_batch_queue", C.c_int32),
+        ("queue_min_points", C.c_int32),
+        ("msort_segments", C.c_int32),
+        ("msort_key_bits", C.c_int32),
+        ("fused_control", C.c_int32),
+        ("lds_tile", C.c_int32),
+        ("cell_target", C.c_float),
+        ("rmax_cap", C.c_float),
+        ("reserved_", C.c_int32 * 9),
     ]
 
 

@@ -10,7 +10,8 @@ import os
 from .aligner import Backend
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrrg2_slam_amd.so")
+# (SRRG2_AMD_LIB: an instrumented build of the same sources for profiling -- make OUT=... EXTRA=-DSRRG2_TILE_STATS; never a fallback)
+LIB_PATH = os.environ.get("SRRG2_AMD_LIB") or os.path.join(_HERE, "lib", "libsrrg2_slam_amd.so")
 _LIB = None
 
 

@@ -159,6 +159,21 @@ class MultiAligner:
         else:
             self._check(self._b.fn("set_termination")(self._h, C.byref(params)))
 
+    def tuning(self):
+        """the handle's strategy knobs (abi.AlignerTuning): defaults overridden by the SRRG2_AMD_* environment at creation"""
+        t = abi.AlignerTuning()
+        self._check(self._b.fn("get_tuning")(self._h, C.byref(t)))
+        return t
+
+    def set_tuning(self, **knobs):
+        """change strategy knobs by name (fields of srrg2_aligner_tuning); results do not depend on them"""
+        t = self.tuning()
+        for k, v in knobs.items():
+            if k not in dict(abi.AlignerTuning._fields_) or k == "reserved_":
+                raise KeyError(k)
+            setattr(t, k, v)
+        self._check(self._b.fn("set_tuning")(self._h, C.byref(t)))
+
     def add_slice(self, config):
         idx = C.c_int(-1)
         self._check(self._b.fn("add_slice")(self._h, C.byref(config), C.byref(idx)))

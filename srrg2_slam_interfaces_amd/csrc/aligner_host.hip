@@ -41,7 +41,7 @@ struct Slice {
   DevBuf<unsigned> scalars;  // [0..2] bbox min keys, [3..5] bbox max keys, [6] nvalid, [7] ninf bits, [8] scan total
   GridDev grid{};
   int nf          = 0;
-  float probe_h = 0.f, probe_ext = 0.f, probe_gate = 0.f;  // last automatic cell size and the cloud it was probed on
+  float probe_h = 0.f, probe_ext = 0.f, probe_gate = 0.f, probe_target = 0.f;  // last automatic cell size and the cloud it was probed on
   int probe_n   = 0;
   bool has_fixed  = false;
   bool fixed_has_normals = false;
@@ -54,6 +54,7 @@ struct Slice {
   DevBuf<unsigned> pinf;  // per problem
   int nm_total            = 0;
   bool has_moving         = false;
+  bool moving_is_batch    = false;  // the bound moving cloud is the concatenation of a compute_batch with K > 1
   bool moving_has_normals = false;
   // outputs
   DevBuf<int> corr_fixed;
@@ -135,6 +136,10 @@ struct srrg2_aligner_s {
   int records_state = 0;
   std::vector<SliceDev> last_sdev;
   std::vector<int> last_nm_max;
+  // strategy knobs: defaults overridden by the SRRG2_AMD_* environment ONCE, at create; srrg2_aligner_set_tuning replaces them
+  srrg2_aligner_tuning tuning{};
+  std::string timeline_path;  // SRRG2_AMD_TIMELINE (-DSRRG2_TIMELINE builds), read at create
+  bool hosttime = false;      // SRRG2_AMD_HOSTTIME, read at create
   // profiling
   bool profile = false;
   double prof_ms = 0.0;
@@ -280,7 +285,7 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     float ext = 0.f;
     for (int d = 0; d < dim; ++d) ext = std::fmax(ext, mx[d] - mn[d]);
     const bool similar = s->probe_h > 0.f && s->probe_gate == gate && std::fabs((float) nvalid - (float) s->probe_n) <= 0.1f * (float) s->probe_n &&
-                         std::fabs(ext - s->probe_ext) <= 0.1f * s->probe_ext && !std::getenv("SRRG2_AMD_CELL_TARGET");
+                         std::fabs(ext - s->probe_ext) <= 0.1f * s->probe_ext && s->probe_target == a->tuning.cell_target;
     if (similar) {
       h = fit_cell(s->probe_h);
     } else {
@@ -297,7 +302,7 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     HIP_TRY(hipStreamSynchronize(a->stream));
     if (nocc > 0) {
       const float occupancy = (float) nvalid / (float) nocc;
-      const float target    = std::getenv("SRRG2_AMD_CELL_TARGET") ? (float) std::atof(std::getenv("SRRG2_AMD_CELL_TARGET")) : 8.0f;
+      const float target    = a->tuning.cell_target > 0.f ? a->tuning.cell_target : 8.0f;
       float scale           = std::sqrt(target / occupancy);
       scale                 = std::fmin(std::fmax(scale, 0.5f), 4.0f);
       h                     = std::fmin(h * scale, gate);
@@ -307,10 +312,10 @@ int build_grid(srrg2_aligner* a, Slice* s) {
       // 2000 beams 0.48 -> 0.26 ms, 4000 beams 0.67 -> 0.39 ms per compute(); 3-D clouds are better off with the
       // density rule: 1 M points 4.5 k it/s without a cap, 4.0 / 3.0 / 2.8 k with radius <= 3 / 4 / 6).
       float rcap = dim == 2 ? 3.f : 0.f;
-      if (const char* cap = std::getenv("SRRG2_AMD_RMAX_CAP")) rcap = (float) std::atof(cap);
+      if (a->tuning.rmax_cap > 0.f) rcap = a->tuning.rmax_cap;
       if (rcap > 1.f) h = std::fmax(h, gate * 1.25f / (rcap - 0.011f));
       h                     = fit_cell(h);
-      s->probe_h = h; s->probe_n = nvalid; s->probe_ext = ext; s->probe_gate = gate;
+      s->probe_h = h; s->probe_n = nvalid; s->probe_ext = ext; s->probe_gate = gate; s->probe_target = a->tuning.cell_target;
     }
     }
   }
@@ -344,6 +349,34 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   g.pos_of     = s->pos_of.p;
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// defaults overridden by the SRRG2_AMD_* variables; called once per handle, from srrg2_aligner_create
+void tuning_from_environment(srrg2_aligner_tuning* t) {
+  srrg2_aligner_default_tuning(t);
+  auto geti = [](const char* name, int32_t& v) {
+    if (const char* e = std::getenv(name)) v = (int32_t) std::atoi(e);
+  };
+  auto getf = [](const char* name, float& v) {
+    if (const char* e = std::getenv(name)) v = (float) std::atof(e);
+  };
+  geti("SRRG2_AMD_TUNE", t->strategy_mask);
+  geti("SRRG2_AMD_QPROBE", t->queue_probe_iteration);
+  geti("SRRG2_AMD_SMALL_MAX", t->small_max_points);
+  geti("SRRG2_AMD_FAST_FROM", t->fast_from_iteration);
+  geti("SRRG2_AMD_FAST_PPT", t->fast_points_per_thread);
+  geti("SRRG2_AMD_FAST_MIN", t->fast_min_points);
+  geti("SRRG2_AMD_FAST_GATHER", t->fast_gather);
+  geti("SRRG2_AMD_FAST_QUEUE", t->fast_batch_queue);
+  geti("SRRG2_AMD_QUEUE_MIN", t->queue_min_points);
+  geti("SRRG2_AMD_MSORT_SEGMENTS", t->msort_segments);
+  geti("SRRG2_AMD_MSORT_BITS", t->msort_key_bits);
+  geti("SRRG2_AMD_FUSED_CONTROL", t->fused_control);
+  geti("SRRG2_AMD_LDS_TILE", t->lds_tile);
+  getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
+  getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
+  if (t->fast_points_per_thread < 1) t->fast_points_per_thread = 1;
+  if (!(t->cell_target > 0.f)) t->cell_target = 8.0f;
 }
 
 int check_slice(srrg2_aligner* a, int si, const char* what) {
@@ -393,31 +426,36 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     pd[k]  = ProblemDev{off, cnt};
     max_nm = std::max(max_nm, cnt);
   }
-  // Morton sort per problem: 64^3 cells for one cloud, fewer per problem for big batches
-  const int bits = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
+  // Morton sort per problem.  Key space: 2^18 cells for one cloud (global histogram), 2^15 / 2^12 for batches (histogram
+  // in LDS), dealt to the axes by extent (tuning.msort_key_bits: -1 = the isotropic keys of round 2, 6 / 5 / 4 bits per axis)
+  const int mk    = a->tuning.msort_key_bits;
+  const int aniso = mk >= 0 ? 1 : 0;
+  const int bits  = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
+  const int kbits = aniso ? (mk > 0 ? mk : (K <= 4 ? 18 : 15)) : 3 * bits;
   // small key spaces: one workgroup per problem sorts straight from the caller's (staged) layout, with the problem
   // table read from pinned host memory (no copies, memsets or waits on the stream); the ingest-order copy of the
   // clouds, which this path does not produce, is only read by given-correspondences slices
-  static const bool local_sort = !(std::getenv("SRRG2_AMD_TUNE") && (std::atoi(std::getenv("SRRG2_AMD_TUNE")) & (1 << 22)));
-  if (local_sort && bits <= 5 && s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES) {
+  const bool local_sort = !(a->tuning.strategy_mask & (1 << 22));
+  if (local_sort && kbits <= 15 && s->cfg.finder != SRRG2_FINDER_CORRESPONDENCES) {
     if ((rc = ensure_pinned(s->ms_probs_host, s->ms_probs_host_cap, (size_t) K))) return rc;
     if (s->ms_pending) HIP_TRY(hipStreamSynchronize(a->stream));  // (set_moving twice without a compute() in between)
     s->ms_pending = false;
     std::memcpy(s->ms_probs_host, pd.data(), (size_t) K * sizeof(ProblemDev));
-    if (srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, bits, s->moving.p,
-                                     normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
+    if (srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, kbits, aniso, a->tuning.msort_segments,
+                                     max_nm, s->moving.p, normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
       HIP_TRY(hipGetLastError());
       // the caller may reuse its buffer on return (host or device memory: the ingest has finished reading it)
       if (wait) HIP_TRY(hipStreamSynchronize(a->stream));
       s->ms_pending         = !wait;  // (the sort reads the pinned problem table: the compute() that follows drains the stream)
       s->nm_total           = n;
       s->has_moving         = true;
+      s->moving_is_batch    = K > 1;
       s->moving_has_normals = normals != nullptr;
       return 0;
     }
   }
   HIP_TRY(hipMemsetAsync(s->pinf.p, 0, (size_t) K * sizeof(unsigned), a->stream));
-  const size_t ncell = (size_t) K << (3 * bits);
+  const size_t ncell = (size_t) K << kbits;
   if ((rc = s->ms_counts.reserve(ncell + 1))) return rc;
   if ((rc = s->ms_cursor.reserve(ncell + 1))) return rc;
   if ((rc = s->ms_sums.reserve((size_t) srrg2amd::scan_num_blocks((int) ncell) + 2))) return rc;
@@ -439,13 +477,14 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   srrg2amd::launch_ingest_batch(dsrc, sf, s->ms_probs.p, K, max_nm, a->dim, s->moving_raw.p, s->pinf.p, 1, a->stream);
   if (normals)
     srrg2amd::launch_ingest_batch(nsrc, nsf, s->ms_probs.p, K, max_nm, a->dim, s->moving_nrm_raw.p, nullptr, 0, a->stream);
-  srrg2amd::launch_msort(s->moving_raw.p, normals ? s->moving_nrm_raw.p : nullptr, s->ms_probs.p, K, max_nm, bits,
+  srrg2amd::launch_msort(s->moving_raw.p, normals ? s->moving_nrm_raw.p : nullptr, s->ms_probs.p, K, max_nm, kbits, aniso,
                          s->ms_bb.p, s->ms_counts.p, s->ms_cursor.p, s->ms_sums.p, s->ms_sums.p + s->ms_sums.cap - 1,
                          s->moving.p, normals ? s->moving_nrm.p : nullptr, a->stream);
   HIP_TRY(hipGetLastError());
   if (wait) HIP_TRY(hipStreamSynchronize(a->stream));  // the caller may reuse its buffer on return (host or device memory)
   s->nm_total           = n;
   s->has_moving         = true;
+  s->moving_is_batch    = K > 1;
   s->moving_has_normals = normals != nullptr;
   return 0;
 }
@@ -467,6 +506,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     if (!s->has_fixed) return fail(SRRG2_E_STATE, "compute: cue slice| no fixed");
     if (!s->has_moving) return fail(SRRG2_E_STATE, "compute: cue slice| no moving");
+    if (K == 1 && s->moving_is_batch)
+      return fail(SRRG2_E_STATE, "compute: the moving cloud bound to the cue slice is the concatenation of the last "
+                                 "compute_batch (K > 1); bind one with set_moving first");
     if (s->cfg.kind == SRRG2_SLICE_P2PLANE && !s->fixed_has_normals)
       return fail(SRRG2_E_STATE, "compute: point-to-plane slice needs fixed normals");
     if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE && s->nf != s->cfg.image_rows * s->cfg.image_cols)
@@ -519,8 +561,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   C.seq           = ++a->seq;
   if (C.seq <= 0) C.seq = a->seq = 1;
   for (int k = 0; k < K; ++k) a->outs_host[k].seq = 0;  // (never a sequence number: fresh pinned memory is not zeroed)
-  C.tune          = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
-  C.probe_it      = std::getenv("SRRG2_AMD_QPROBE") ? std::atoi(std::getenv("SRRG2_AMD_QPROBE")) : 1;
+  const srrg2_aligner_tuning& tn = a->tuning;  // (read once at create / set_tuning: no environment look-ups in compute())
+  C.tune          = tn.strategy_mask;
+  C.probe_it      = tn.queue_probe_iteration;
   if (a->params.max_iterations <= C.probe_it + 3 || K > 4) C.probe_it = -1;
   // Small problems (laser scans, landmark maps) with one nearest-neighbour cue slice (plus priors): one workgroup per
   // problem runs the whole compute() (k_icp_small) instead of ~24 launches of a few microseconds of work each.
@@ -534,26 +577,29 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       }
     // (measured, tools/bench_small.py: ahead of one launch per pass up to ~1000 points -- 1000-beam scan 0.33 -> 0.23 ms,
     // 360 beams 0.18 -> 0.12 ms, 500 3-D points 0.34 -> 0.25 ms -- and behind it from ~2000 points on)
-    static const int small_max = std::getenv("SRRG2_AMD_SMALL_MAX") ? std::atoi(std::getenv("SRRG2_AMD_SMALL_MAX")) : 1024;
+    const int small_max = tn.small_max_points;
     small = ncue == 1 && a->slices[fc]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm <= small_max &&
-            !std::getenv("SRRG2_AMD_TIMELINE") && !a->reduce_fn;  // (the one-workgroup kernel has no place for the reduction)
+            a->timeline_path.empty() && !a->reduce_fn;  // (the one-workgroup kernel has no place for the reduction)
   }
   // The converged pass kernel takes over from iteration `fast_from` of the first run (all of the inlier-only run): by
   // then nearly every point keeps its neighbour.  Batches give it `fast_ppt` points per thread and a queue.
-  const int fast_from = std::getenv("SRRG2_AMD_FAST_FROM") ? std::atoi(std::getenv("SRRG2_AMD_FAST_FROM")) : 3;
+  const int fast_from = tn.fast_from_iteration;
   // (measured on C4, 32 x 50k, profiles/r2c: one point per thread with the failed certificates searched by their own wave
   // 37.7 us per pass / 268.8 k it/s; two points per thread 45 us -- the accumulators stay live across the search, 181
   // registers -- ; with a queue the nearly idle deferred-search launch costs 15 us per iteration: 31 + 15 us, 254 k it/s)
-  const int fast_ppt  = std::getenv("SRRG2_AMD_FAST_PPT") ? std::atoi(std::getenv("SRRG2_AMD_FAST_PPT")) : 1;
+  const int fast_ppt  = tn.fast_points_per_thread;
   // batches gather the kept neighbour from the cache-resident fixed cloud (36 -> 8 streamed bytes per point); single
   // alignments read it from per-point arrays (no dependent load on the chain of a latency-bound launch)
   // (smallest moving cloud that uses the converged-pass kernel.  Sparse clouds of a few thousand points leave a larger
   // share of their certificates behind; since those searches run four at a time with 16 lanes each the kernel is ahead
   // at every size -- 2 000 points: 0.26 ms per compute() either way, 0.42 ms with one search per wave at a time,
   // profiles/r2m_bench_small.json / r2n_bench_small*.json -- so the threshold is 0; kept as a switch)
-  const int fast_min = std::getenv("SRRG2_AMD_FAST_MIN") ? std::atoi(std::getenv("SRRG2_AMD_FAST_MIN")) : 0;
-  const bool fast_gather = std::getenv("SRRG2_AMD_FAST_GATHER") ? std::atoi(std::getenv("SRRG2_AMD_FAST_GATHER")) != 0 : K > 4;
-  const bool fast_batch_queue = std::getenv("SRRG2_AMD_FAST_QUEUE") ? std::atoi(std::getenv("SRRG2_AMD_FAST_QUEUE")) != 0 : false;
+  const int fast_min = tn.fast_min_points;
+  const bool fast_gather = tn.fast_gather >= 0 ? tn.fast_gather != 0 : K > 4;
+  const bool fast_batch_queue = tn.fast_batch_queue != 0;
+  // search passes of batches: every wave's neighbourhood of the fixed cloud staged in LDS (k_icp_step_tile; 1: tiles of
+  // 336 candidates, four workgroups per CU; 2: 512 candidates, three workgroups per CU)
+  const int lds_tile = tn.lds_tile >= 0 ? tn.lds_tile : 0;
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {
@@ -586,8 +632,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // ... and with few points per launch the extra launches cost more than they save (measured, tools/loop_compute.py:
     // without the queue 3 k / 10 k / 30 k / 60 k points take 0.286 / 0.249 / 0.254 / 0.272 ms per compute() instead of
     // 0.307 / 0.271 / 0.264 / 0.277 ms; equal at 80-100 k; 150 k: 0.356 ms with the queue, 0.462 ms without)
-    // (read on every compute(): the tests run every scenario on both paths)
-    const int queue_min = std::getenv("SRRG2_AMD_QUEUE_MIN") ? std::atoi(std::getenv("SRRG2_AMD_QUEUE_MIN")) : 90000;
+    const int queue_min = tn.queue_min_points;
     const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small;
     // batches: the converged pass (k_icp_step_fast) hands the points whose certificate failed to the deferred-search
     // kernel; the first iterations (k_icp_step) finish their open points themselves
@@ -627,7 +672,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     d.prev_f          = s->prev_f.p;
     d.prev_m          = s->prev_m.p;
     d.dbg             = nullptr;
-    if (std::getenv("SRRG2_AMD_TIMELINE")) {
+    if (!a->timeline_path.empty()) {
       const size_t nw = (size_t) K * ((nm_max_s + 255) / 256) * 4;
       if ((rc = s->dbg.reserve(32 * nw * 16))) return rc;
       HIP_TRY(hipMemsetAsync(s->dbg.p, 0, 32 * nw * 16 * sizeof(unsigned long long), a->stream));
@@ -689,7 +734,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       // both z-buffers start clean; afterwards every pass resets the buffer of the next one
       HIP_TRY(hipMemsetAsync(s->zbuf.p, 0xff, (size_t) 2 * K * d.rows * d.cols * sizeof(unsigned long long), a->stream));
     }
-    d.tune            = std::getenv("SRRG2_AMD_TUNE") ? std::atoi(std::getenv("SRRG2_AMD_TUNE")) : 0;
+    d.tune            = tn.strategy_mask;
     if (a->dim == 3)
       dm::se3_inverse(s->cfg.sensor_in_robot, d.Sinv);
     else
@@ -750,7 +795,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   bool probed = false;
   bool final_launched = false;  // the last control step of compute() carried the post / finalize steps
   auto control = [&](int it, bool last_phase) {
-    if (a->reduce_fn && !hook_failed) {  // the ranks' partial sums, added in place, before anybody looks at them
+    if (a->reduce_fn) {  // the ranks' partial sums, added in place, before anybody looks at them
+      // (after a failure the hook is still called for the remaining control steps: the collectives of the ranks stay
+      // matched -- a rank that stopped calling would leave its healthy peers hanging in theirs -- and the error is
+      // reported when compute() returns)
       Slice* s = a->slices[first_cue];
       if (a->reduce_fn(a->reduce_user, SRRG2_REDUCE_SUM_I64, s->partials.p, (size_t) K * PARTIAL_SLOTS * ACC_N, (void*) a->stream))
         hook_failed = true;
@@ -852,6 +900,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           if (fast)
             srrg2amd::launch_icp_step_fast(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, fast_ppt,
                                            fast_gather, a->stream);
+          else if (!sd.queue && lds_tile > 0 && !small)
+            srrg2amd::launch_icp_step_tile(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
+                                           lds_tile == 2 ? 512 : 336, a->stream);
           else
             srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
         }
@@ -876,7 +927,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     srrg2amd::launch_icp_finalize(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                   !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
   HIP_TRY(hipGetLastError());
-  static const bool hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
+  const bool hosttime = a->hosttime;
   auto t_enq = std::chrono::steady_clock::now();
   // The last kernel of compute() writes every result into pinned host memory and, behind a system-scope fence, the
   // sequence number of this compute() into ProblemOut::seq: the host polls those words instead of waiting for the
@@ -892,7 +943,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         break;
       }
   }
-  if (!seen || a->profile || std::getenv("SRRG2_AMD_TIMELINE")) HIP_TRY(hipStreamSynchronize(a->stream));
+  if (!seen || a->profile || !a->timeline_path.empty()) HIP_TRY(hipStreamSynchronize(a->stream));
   if (hook_failed) return fail(SRRG2_E_INVALID, "the reduction hook of the point-sharded alignment failed");
   if (hosttime) {
     auto t_end = std::chrono::steady_clock::now();
@@ -902,7 +953,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
                  std::chrono::duration<double, std::micro>(t_enq - t_begin).count(),
                  std::chrono::duration<double, std::micro>(t_end - t_enq).count());
   }
-  if (const char* tl_path = std::getenv("SRRG2_AMD_TIMELINE")) {  // dump of the last compute(): u64 nwaves, then stamps
+  if (const char* tl_path = a->timeline_path.empty() ? nullptr : a->timeline_path.c_str()) {  // dump of the last compute(): u64 nwaves, then stamps
     for (int si = 0; si < nslices; ++si) {
       Slice* s = a->slices[si];
       if (!sdev[si].dbg) continue;
@@ -992,6 +1043,40 @@ void srrg2_aligner_default_params(srrg2_aligner_params* p) {
   p->keep_only_inlier_correspondences = 0;
 }
 
+void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t) {
+  if (!t) return;
+  std::memset(t, 0, sizeof(*t));
+  t->strategy_mask          = 0;
+  t->queue_probe_iteration  = 1;
+  t->small_max_points       = 1024;
+  t->fast_from_iteration    = 3;
+  t->fast_points_per_thread = 1;
+  t->fast_min_points        = 0;
+  t->fast_gather            = -1;
+  t->fast_batch_queue       = 0;
+  t->queue_min_points       = 90000;
+  t->msort_segments         = 0;
+  t->msort_key_bits         = 0;
+  t->fused_control          = -1;
+  t->lds_tile               = -1;
+  t->cell_target            = 8.0f;
+  t->rmax_cap               = 0.f;
+}
+
+int srrg2_aligner_get_tuning(srrg2_aligner_h a, srrg2_aligner_tuning* t) {
+  if (!a || !t) return fail(SRRG2_E_INVALID, "get_tuning: null argument");
+  *t = a->tuning;
+  return 0;
+}
+
+int srrg2_aligner_set_tuning(srrg2_aligner_h a, const srrg2_aligner_tuning* t) {
+  if (!a || !t) return fail(SRRG2_E_INVALID, "set_tuning: null argument");
+  if (t->fast_points_per_thread < 1 || t->fast_from_iteration < 0 || !(t->cell_target > 0.f) || t->msort_key_bits > 18)
+    return fail(SRRG2_E_INVALID, "set_tuning: value out of range");
+  a->tuning = *t;
+  return 0;
+}
+
 void srrg2_termination_default_params(srrg2_termination_params* p) {
   if (!p) return;
   p->window_size = 5;  // aligner_termination_criteria.h:40-56
@@ -1031,6 +1116,9 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
   a->tsize  = variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
   a->device = device;
   identity(variable_kind, a->X);
+  tuning_from_environment(&a->tuning);
+  if (const char* tl = std::getenv("SRRG2_AMD_TIMELINE")) a->timeline_path = tl;
+  a->hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
     delete a;
     return fail(SRRG2_E_HIP, "create: cannot create stream");
@@ -1436,7 +1524,13 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
   int rc;
   if ((rc = set_device(a))) return rc;
   if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false))) return rc;
-  if ((rc = run_compute(a, K, offsets, guesses))) return rc;
+  if ((rc = run_compute(a, K, offsets, guesses))) {
+    // (run_compute may have failed before anything drained the stream: the ingest must have finished reading the
+    // caller's buffer before this call returns, error or not)
+    (void) hipStreamSynchronize(a->stream);
+    for (Slice* sl : a->slices) sl->ms_pending = false;
+    return rc;
+  }
   const int slots = a->max_stats;
   for (int k = 0; k < K; ++k) {
     const ProblemOut& o = a->outs_host[k];
@@ -1453,8 +1547,10 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
     results[k].num_correspondences = tot;
     std::memcpy(results[k].information, o.H, sizeof(o.H));
   }
-  // the handle's moving cloud is now the concatenation of the batch: a later compute() must bind its own
-  if (K > 1) a->slices[0]->has_moving = false;
+  // The handle's observable state is that of the LAST alignment (K x {set_moving; set_moving_in_fixed; compute()}):
+  // status, estimate, statistics, correspondences and factor status of problem K - 1 stay readable.  The bound moving
+  // cloud, however, is the concatenation of the batch (Slice::moving_is_batch): a later plain compute() must bind its
+  // own cloud first and says so (SRRG2_E_STATE) instead of aligning K clouds as one.
   return 0;
 }
 

@@ -15,15 +15,21 @@ int scan_num_blocks(int n);
 void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s);
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
                          float4* out_nrm, int* pos_of, hipStream_t s);
-// Morton sort of K moving clouds (counts/cursor: (K << 3*bits) + 1 ints; bb: K*6 keys initialised to
+// Morton sort of K moving clouds (counts/cursor: (K << kbits) + 1 ints; bb: K*6 keys initialised to
 // {0xffffffff x3, 0 x3}; counts zeroed)
-bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int bits,
-                        float4* out_pts, float4* out_nrm, unsigned* maxabs_bits, hipStream_t s);
-void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
+// kbits = total key bits (2^kbits cells per cloud); aniso != 0: bits dealt to the axes by extent (kernels_prep.hip: KeySpec);
+// segments = workgroups per cloud (0: automatic)
+bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int kbits,
+                        int aniso, int segments, int max_nm, float4* out_pts, float4* out_nrm, unsigned* maxabs_bits,
+                        hipStream_t s);
+void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int kbits, int aniso,
                   unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
                   float4* out_nrm, hipStream_t s);
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s);
+// search pass of a batch (no deferred-search queue) with every wave's neighbourhood of the fixed cloud staged in LDS
+void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                          int max_nm, int cap, hipStream_t s);
 // iterations >= 1 of a compute(): the converged pass, ppt moving points per thread, + the deferred-search kernel if S.queue
 void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                           int max_nm, int ppt, bool gather, hipStream_t s);

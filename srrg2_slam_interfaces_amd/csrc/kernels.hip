@@ -1190,6 +1190,476 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 }
 
 // ============================================================================================
+// Search passes of batches with the neighbourhood of every WAVE staged in LDS (k_icp_step_tile).
+//
+// What bounds k_icp_step in the throughput regime (profiles/r2u_*, r3a_*): the texture path is busy ~70 % of a search
+// pass -- it moves 64 bytes per clock of REQUESTED lane data, so a 16-byte candidate gather costs a wave 16 of its cycles
+// however well its lanes coalesce (a finer Morton order of the moving cloud changes nothing: profiles/r3a_ab_msort.txt) --
+// the vector ALUs ~65 %, at four waves per SIMD.  Here every wave fetches the candidates it needs ONCE, coalesced, into
+// LDS: the lanes of a wave are neighbours in space (Morton order), their 3^DIM blocks overlap, the union is a box of a
+// few dozen rows of cells.  The lanes then scan their own rows with ds_read_b128 (LDS: 128 bytes per clock, its own
+// pipe, ~100 cycles of latency instead of ~500-2000), without the prefetch registers the global path needs to hide
+// that latency, without the workgroup-level compaction and its barriers.  Same candidates, same arithmetic, same exact
+// minimum of the key: bit-identical results.  A wave whose box does not fit (TILE_CAP candidates, TILE_ROWS rows,
+// TILE_NX cells per row: Morton-curve jumps, very dense spots) takes the global path for that phase.
+// ============================================================================================
+namespace {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_ROWS = 48;   // rows of cells (y, z) of a wave's box
+constexpr int TILE_NX   = 12;   // cells per row
+constexpr int TILE_CSW  = TILE_NX + 1;
+
+template <int CAP>
+struct WaveTile {             // per wave, in LDS
+  f4v pts[CAP + 4];           // the candidates of the box, row after row (scan_range2 over-reads <= 2 entries: masked)
+  int rowbase[TILE_ROWS];     // index of cell (X0, y, z) in the grid
+  int rowA[TILE_ROWS];        // position of the row's first candidate in grid.pts
+  int rowoff[TILE_ROWS + 1];  // ... and in pts[] (exclusive prefix sum of the row sizes; [nrows] = total)
+  unsigned short cs[TILE_ROWS * TILE_CSW];  // cs[r][k]: offset in pts[] at which cell X0 + k of row r starts
+};
+
+// candidates of a contiguous range, from LDS: the arithmetic of scan_range2
+template <int DIM>
+__device__ __forceinline__ void scan_range_lds(const f4v* pts, int j, int e, float qx, float qy, float qz,
+                                               unsigned long long& bkey, float& b2) {
+  for (; j + 4 <= e; j += 4) {
+    const f4v a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
+    test_candidate2<DIM>(make_float4(a0.x, a0.y, a0.z, a0.w), qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(make_float4(a1.x, a1.y, a1.z, a1.w), qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(make_float4(a2.x, a2.y, a2.z, a2.w), qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(make_float4(a3.x, a3.y, a3.z, a3.w), qx, qy, qz, true, bkey, b2);
+  }
+  if (j < e) {
+    const f4v a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2];
+    test_candidate2<DIM>(make_float4(a0.x, a0.y, a0.z, a0.w), qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(make_float4(a1.x, a1.y, a1.z, a1.w), qx, qy, qz, j + 1 < e, bkey, b2);
+    test_candidate2<DIM>(make_float4(a2.x, a2.y, a2.z, a2.w), qx, qy, qz, j + 2 < e, bkey, b2);
+  }
+}
+
+// wave-wide minimum / maximum of a per-lane int, as a wave-uniform value (invalid lanes pass the neutral element)
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+struct TileBox {
+  int X0, Y0, Z0, nxb, nyb, nzb;
+  bool ok;
+  int why;  // 0 = staged, 1 = too many cells per row, 2 = too many rows, 3 = too many candidates (statistics builds)
+  int total;
+};
+
+// -DSRRG2_TILE_STATS: census of the wave tiles per iteration (tools/tile_stats.py); compiled out of the product build
+#ifdef SRRG2_TILE_STATS
+__device__ unsigned long long g_tile_stats[4 * 16];
+#define TILE_STAT(it, k, v)                                                                             \
+  do {                                                                                                  \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_tile_stats[((it) < 3 ? (it) : 3) * 16 + (k)], (unsigned long long) (v)); \
+  } while (0)
+#else
+#define TILE_STAT(it, k, v) do { } while (0)
+#endif
+
+// Stage the box [x0, x1] x [y0, y1] x [z0, z1] (union over the lanes with `want`) of the grid into the wave's tile.
+// Wave-uniform control flow; returns ok = false (nothing staged) when the box does not fit.
+template <int CAP>
+__device__ __forceinline__ TileBox stage_tile(const GridDev& g, WaveTile<CAP>& t, int lane, bool want, int x0, int x1, int y0,
+                                              int y1, int z0, int z1) {
+  TileBox b;
+  b.ok = false;
+  b.why = 1;
+  b.total = 0;
+  b.X0 = wave_min_i(want ? x0 : 0x7fffffff);
+  b.Y0 = wave_min_i(want ? y0 : 0x7fffffff);
+  b.Z0 = wave_min_i(want ? z0 : 0x7fffffff);
+  const int X1 = wave_max_i(want ? x1 : -0x7fffffff), Y1 = wave_max_i(want ? y1 : -0x7fffffff),
+            Z1 = wave_max_i(want ? z1 : -0x7fffffff);
+  b.nxb = X1 - b.X0 + 1;
+  b.nyb = Y1 - b.Y0 + 1;
+  b.nzb = Z1 - b.Z0 + 1;
+  if (X1 < b.X0 || b.nxb > TILE_NX) return b;
+  b.why = 2;
+  if (b.nyb > TILE_ROWS || b.nzb > TILE_ROWS || b.nyb * b.nzb > TILE_ROWS) return b;
+  const int nrows = b.nyb * b.nzb;
+  // one lane per row: where the row starts in the grid and in the sorted cloud, how many candidates it holds
+  int rbase = 0, A = 0, cnt = 0;
+  if (lane < nrows) {
+    const int rz = (int) (((float) lane + 0.5f) * (1.0f / (float) b.nyb));  // lane / nyb (exact: lane < 64)
+    const int ry = lane - rz * b.nyb;
+    rbase        = ((b.Z0 + rz) * g.ny + (b.Y0 + ry)) * g.nx + b.X0;
+    A            = g.cell_start[rbase];
+    cnt          = g.cell_start[rbase + b.nxb] - A;
+  }
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(incl, off);
+    if (lane >= off) incl += u;
+  }
+  const int total = __shfl(incl, 63);
+  b.why   = 3;
+  b.total = total;
+  if (total > CAP) return b;
+  if (lane < nrows) {
+    t.rowbase[lane] = rbase;
+    t.rowA[lane]    = A;
+    t.rowoff[lane]  = incl - cnt;
+  }
+  if (lane == 0) t.rowoff[nrows] = total;
+  wave_lds_sync();
+  // the cell table: four rows per step, 16 lanes each (TILE_CSW <= 16 entries per row, contiguous in the grid)
+  {
+    const int k = lane & 15;
+    for (int r = lane >> 4; r < nrows; r += 4)
+      if (k <= b.nxb) t.cs[r * TILE_CSW + k] = (unsigned short) (g.cell_start[t.rowbase[r] + k] - t.rowA[r] + t.rowoff[r]);
+  }
+  // the candidates: the flattened list, 64 at a time (coalesced within a row); the row of a slot by bisection
+  for (int s0 = 0; s0 < total; s0 += 64) {
+    const int s = s0 + lane;
+    if (s < total) {
+      int lo = 0, hi = nrows - 1;  // last row whose offset is <= s
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.rowoff[mid] <= s) lo = mid; else hi = mid - 1;
+      }
+      const float4 c = g.pts[t.rowA[lo] + (s - t.rowoff[lo])];
+      f4v v;
+      v.x = c.x; v.y = c.y; v.z = c.z; v.w = c.w;
+      t.pts[s] = v;
+    }
+  }
+  wave_lds_sync();
+  b.ok  = true;
+  b.why = 0;
+  return b;
+}
+
+// The first search phase (scan_radius1) on a staged tile: the 3^DIM cells around the query trimmed to the ball of squared
+// radius r2box, the row through the query's own cell first, the other rows pruned by the distance of that row's best.
+// (x0 .. z1: the lane's cell ranges, as computed for the staging; same candidates as scan_radius1 in the same order of
+// rows, hence the same key minimum, runner-up and completeness radius)
+template <int DIM, int CAP>
+__device__ __forceinline__ void scan_radius1_tile(const GridDev& g, const WaveTile<CAP>& t, const TileBox& b, float qx, float qy,
+                                                  float qz, int cx, int cy, int cz, float r2box, int x0, int x1, int y0, int y1,
+                                                  int z0, int z1, unsigned long long& bkey, float& b2, float& complete2) {
+  constexpr int NROWS = DIM == 3 ? 9 : 3;
+  constexpr int RC    = DIM == 3 ? 4 : 1;
+  complete2 = r2box;
+  if (x0 > x1) return;
+  const int kx0 = x0 - b.X0, kx1 = x1 + 1 - b.X0;
+  auto row_range = [&](int r, int& rs, int& re) {
+    const int y = cy + (r % 3) - 1;
+    const int z = DIM == 3 ? cz + (r / 3) - 1 : 0;
+    rs = re = 0;
+    if (y >= y0 && y <= y1 && z >= z0 && z <= z1) {
+      const int tr = (z - b.Z0) * b.nyb + (y - b.Y0);
+      rs = t.cs[tr * TILE_CSW + kx0];
+      re = t.cs[tr * TILE_CSW + kx1];
+    }
+  };
+  {
+    int rs, re;
+    row_range(RC, rs, re);
+    scan_range_lds<DIM>(t.pts, rs, re, qx, qy, qz, bkey, b2);
+  }
+  if (key_idx(bkey) != NO_MATCH) {
+    const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+    complete2      = fminf(complete2, rb * rb);
+  }
+  const bool prune = complete2 < 3.0e38f;
+  const float rb   = prune ? sqrtf(complete2) : 0.f;
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+    if (r == RC) continue;
+    bool keep = true;
+    if (prune) {
+      const int y     = cy + (r % 3) - 1;
+      const float ylo = g.oy + (float) y * g.h;
+      float dy        = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)), 0.f);
+      dy              = fmaxf(dy - (0.01f * g.h + (fabsf(qy) + rb) * 2e-6f), 0.f);
+      float rem       = complete2 * 1.00002f - dy * dy;
+      if (DIM == 3) {
+        const int z     = cz + (r / 3) - 1;
+        const float zlo = g.oz + (float) z * g.h;
+        float dz        = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)), 0.f);
+        dz              = fmaxf(dz - (0.01f * g.h + (fabsf(qz) + rb) * 2e-6f), 0.f);
+        rem             = rem - dz * dz;
+      }
+      keep = !(rem < 0.f);
+    }
+    int rs = 0, re = 0;
+    if (keep) row_range(r, rs, re);
+    scan_range_lds<DIM>(t.pts, rs, re, qx, qy, qz, bkey, b2);
+  }
+}
+
+// The shell of the radius-2 cube (scan_shell2) on a staged tile; x0 .. z1: the lane's ranges of the 5^DIM cube trimmed to
+// the ball (as computed for the staging).
+template <int DIM, int CAP>
+__device__ __forceinline__ void scan_shell2_tile(const GridDev& g, const WaveTile<CAP>& t, const TileBox& b, float qx, float qy,
+                                                 float qz, int cx, int cy, int cz, int x0, int x1, int y0, int y1, int z0, int z1,
+                                                 unsigned long long& bkey, float& b2) {
+  if (x0 > x1) return;
+  const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, g.nx - 1);
+  for (int z = z0; z <= z1; ++z) {
+    const bool zin = DIM == 3 ? (z >= cz - 1 && z <= cz + 1) : true;
+    for (int y = y0; y <= y1; ++y) {
+      const bool inner = zin && y >= cy - 1 && y <= cy + 1;
+      const int tr     = (z - b.Z0) * b.nyb + (y - b.Y0);
+      const unsigned short* row = t.cs + tr * TILE_CSW - b.X0;  // row[x] = offset of cell x
+      const int la = x0, lb = inner ? min(x1, bx0 - 1) : x1;
+      const int ra = max(x0, bx1 + 1), rb = x1;
+      if (la <= lb) scan_range_lds<DIM>(t.pts, row[la], row[lb + 1], qx, qy, qz, bkey, b2);
+      if (inner && ra <= rb) scan_range_lds<DIM>(t.pts, row[ra], row[rb + 1], qx, qy, qz, bkey, b2);
+    }
+  }
+}
+
+}  // namespace
+
+// One moving point per thread, one alignment per blockIdx.y; no deferred-search queue (the throughput regime).
+template <int DIM, bool PLANE, int CAP>
+__global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                       ProblemState* __restrict__ states) {
+  constexpr int NW = 4;
+  const int prob   = blockIdx.y;
+  const ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  const int tile      = blockIdx.x;
+  float T[12];
+  load_T(st->Tf[S.slice_idx], T);
+  const double scale = dm::pow2(st->kexp[S.slice_idx]);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float thr    = S.robust_thr;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  const GridDev& g   = S.grid;
+  const float b2_1   = bound2_of(1, g.h);
+  const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
+  const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
+  const int rfar   = (use_prior && !(S.tune & 65536)) ? g.rmax : g.rfar_gate;
+  float Tprev[12];
+  load_T(st->Tfprev[S.slice_idx], Tprev);
+
+  // the tile of a wave and the row tables of its cooperative scans are never live together
+  union WaveLds {
+    WaveTile<CAP> tile;
+    int coop[288];
+  };
+  __shared__ WaveLds wlds[NW];
+
+  const int i        = tile * (NW * 64) + threadIdx.x;
+  const int lane     = threadIdx.x & 63;
+  const int wid      = threadIdx.x >> 6;
+  const bool inrange = i < pd.nm;
+  const int gi       = pd.moff + (inrange ? i : 0);
+  float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pf          = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
+  float4 pn          = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pnm         = make_float4(0.f, 0.f, 0.f, 0.f);
+  float pm           = 0.f;
+  if (inrange) {
+    p = S.mpts[gi];
+    if (use_prior) {
+      pf = S.prev_f[gi];
+      pm = S.prev_m[gi];
+      if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
+      if (S.use_normal_gate) pnm = S.mnrm[gi];
+    }
+  }
+  const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
+  const int oi        = pd.moff + __float_as_int(p.w);
+  const bool active   = inrange && finite3(p.x, p.y, p.z);
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  float best = INFINITY;
+  int bidx = NO_MATCH, bpos = 0;
+  int r2 = 0;
+  float excl = 0.f, r2box = INFINITY, ball2 = INFINITY, excl_wide = 0.f;
+  bool skipped = false;
+  float pad    = 0.02f * g.h;
+  if (active) {
+    transform_point<DIM>(T, p, qx, qy, qz);
+    // temporal coherence, exactly as in icp_step_body: (a) the previous neighbour is provably still the nearest,
+    // (b) the search is trimmed to its ball, (c) still nothing within the gate
+    if (use_prior && has_prev) {
+      unsigned long long k1 = NO_KEY;
+      test_candidate<DIM>(pf, qx, qy, qz, true, k1);
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p, px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      const float d1 = sqrtf(key_best(k1));
+      if (d1 * 1.00001f + dl * 1.00001f < pm * 0.99999f && !(S.tune & 4096)) {
+        skipped = true;
+        best    = key_best(k1);
+        bidx    = key_idx(k1);
+        excl    = pm * 0.9999999f - dl * 1.00001f;
+      } else {
+        pad            = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+        const float rr = (d1 + pad) * 1.00001f;
+        r2box          = fminf(rr * rr, gfar);
+      }
+    } else if (use_prior && !has_prev && pm > 0.f && !(S.tune & (4096 | 65536))) {
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p, px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      if (sqrtf(g.gate2) * 1.00001f + dl * 1.00001f < pm * 0.99999f) {
+        skipped = true;
+        excl    = pm * 0.9999999f - dl * 1.00001f;
+      }
+    }
+  }
+  const int cx = cell_coord(qx, g.ox, g.inv_h);
+  const int cy = cell_coord(qy, g.oy, g.inv_h);
+  const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+  unsigned long long bkey = NO_KEY;
+  float b2 = INFINITY, complete2 = INFINITY;
+  // ---- first phase: the 3^DIM block, trimmed to the ball
+  const bool need1 = active && !skipped;
+  if (__any(need1)) {
+    const float rr = ball_radius(r2box);
+    int x0, x1, y0, y1, z0 = 0, z1 = 0;
+    axis_range(qx, rr, g.ox, g.inv_h, cx - 1, cx + 1, g.nx, x0, x1);
+    axis_range(qy, rr, g.oy, g.inv_h, cy - 1, cy + 1, g.ny, y0, y1);
+    if (DIM == 3) axis_range(qz, rr, g.oz, g.inv_h, cz - 1, cz + 1, g.nz, z0, z1);
+    const bool want = need1 && x0 <= x1 && y0 <= y1 && z0 <= z1;
+    const TileBox tb = stage_tile<CAP>(g, wlds[wid].tile, lane, want, x0, x1, y0, y1, z0, z1);
+    TILE_STAT(st->nstats, 0, 1);
+    TILE_STAT(st->nstats, 1 + tb.why, 1);
+    TILE_STAT(st->nstats, 5, tb.total);
+    TILE_STAT(st->nstats, 6, tb.nyb * tb.nzb);
+    TILE_STAT(st->nstats, 7, __popcll(__ballot(need1)));
+    if (need1) {
+      if (tb.ok) {
+        complete2 = r2box;
+        if (want) scan_radius1_tile<DIM, CAP>(g, wlds[wid].tile, tb, qx, qy, qz, cx, cy, cz, r2box, x0, x1, y0, y1, z0, z1, bkey, b2, complete2);
+      } else {
+        scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, b2, complete2);
+      }
+      best = key_best(bkey);
+      bidx = key_idx(bkey);
+      const bool found1 = bidx != NO_MATCH && best <= gfar;
+      ball2             = gfar;
+      if (!(found1 && best <= b2_1) && rfar > 1) {
+        r2 = rfar;
+        if (found1) {
+          const float rr2 = (sqrtf(best) + pad) * 1.00001f;
+          ball2           = fminf(rr2 * rr2, gfar);
+          r2              = 1;
+          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+        }
+      } else {
+        excl = sqrtf(fminf(fminf(b2, complete2), b2_1)) * 0.99999f;
+      }
+    }
+  }
+  // ---- second phase: the shell of the radius-2 cube, continuing the (key, runner-up) pair of the first
+  const bool need2 = r2 > 1 && rfar >= 2;
+  if (__any(need2)) {
+    wave_lds_sync();  // (the first phase's tile is dead)
+    const float rr = ball_radius(ball2);
+    int x0, x1, y0, y1, z0 = 0, z1 = 0;
+    axis_range(qx, rr, g.ox, g.inv_h, cx - 2, cx + 2, g.nx, x0, x1);
+    axis_range(qy, rr, g.oy, g.inv_h, cy - 2, cy + 2, g.ny, y0, y1);
+    if (DIM == 3) axis_range(qz, rr, g.oz, g.inv_h, cz - 2, cz + 2, g.nz, z0, z1);
+    const bool want = need2 && x0 <= x1 && y0 <= y1 && z0 <= z1;
+    const TileBox tb = stage_tile<CAP>(g, wlds[wid].tile, lane, want, x0, x1, y0, y1, z0, z1);
+    TILE_STAT(st->nstats, 8, 1);
+    TILE_STAT(st->nstats, 9 + tb.why, 1);
+    TILE_STAT(st->nstats, 13, tb.total);
+    TILE_STAT(st->nstats, 14, __popcll(__ballot(need2)));
+    if (need2) {
+      if (tb.ok) {
+        if (want) scan_shell2_tile<DIM, CAP>(g, wlds[wid].tile, tb, qx, qy, qz, cx, cy, cz, x0, x1, y0, y1, z0, z1, bkey, b2);
+      } else {
+        scan_shell2<DIM>(g, qx, qy, qz, cx, cy, cz, ball2, bkey, b2);
+      }
+      best = key_best(bkey);
+      bidx = key_idx(bkey);
+      const bool found2 = bidx != NO_MATCH && best <= gfar;
+      if ((found2 && best <= bound2_of(2, g.h)) || rfar == 2) {
+        r2        = 0;
+        excl_wide = sqrtf(fminf(fminf(fminf(b2, ball2), complete2), bound2_of(2, g.h))) * 0.99999f;
+      } else {
+        r2    = rfar;
+        ball2 = gfar;
+        if (found2) {
+          const float rr2 = (sqrtf(best) + pad) * 1.00001f;
+          ball2           = fminf(rr2 * rr2, gfar);
+          r2              = 2;
+          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+        }
+      }
+    }
+  }
+  // ---- what is still open: cooperative scans (teams of 16 lanes, four points per pass), as in icp_step_body
+  unsigned long long need = __ballot(r2 > 1);
+  TILE_STAT(st->nstats, 15, __popcll(need));
+  if (need) wave_lds_sync();  // (the tile is dead: its memory now holds the row tables of the scans)
+  while (need) {
+    if (__popcll(need) == 1) {
+      const int src = __ffsll((long long) need) - 1;
+      need &= need - 1;
+      float wbest, wexcl2;
+      int widx, wpos;
+      coop_scan<DIM, 64>(g, lane, wlds[wid].coop, __shfl(qx, src), __shfl(qy, src), __shfl(qz, src), __shfl(cx, src),
+                         __shfl(cy, src), __shfl(cz, src), __shfl(r2, src), __shfl(ball2, src), wbest, widx, wpos, wexcl2);
+      if (lane == src) excl_wide = sqrtf(wexcl2) * 0.99999f;
+      if (lane == src && (wbest < best || (wbest == best && widx < bidx))) {
+        best = wbest;
+        bidx = widx;
+      }
+      continue;
+    }
+    int src[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      src[t] = need ? __ffsll((long long) need) - 1 : -1;
+      need &= need - 1;
+    }
+    const int team = lane >> 4;
+    const int mine = team == 0 ? src[0] : (team == 1 ? src[1] : (team == 2 ? src[2] : src[3]));
+    const int from = mine >= 0 ? mine : lane;
+    float wbest, wexcl2;
+    int widx, wpos;
+    const int sr_from = __shfl(r2, from);
+    coop_scan<DIM, 16>(g, lane, wlds[wid].coop, __shfl(qx, from), __shfl(qy, from), __shfl(qz, from), __shfl(cx, from),
+                       __shfl(cy, from), __shfl(cz, from), mine >= 0 ? sr_from : -1, __shfl(ball2, from), wbest, widx, wpos,
+                       wexcl2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float rb = __shfl(wbest, 16 * t), re = __shfl(wexcl2, 16 * t);
+      const int ri = __shfl(widx, 16 * t);
+      if (lane == src[t]) {
+        excl_wide = sqrtf(re) * 0.99999f;
+        if (rb < best || (rb == best && ri < bidx)) {
+          best = rb;
+          bidx = ri;
+        }
+      }
+    }
+  }
+  if (excl_wide != 0.f || r2 != 0) excl = excl_wide;
+  long long acc[ACC_N];
+#pragma unroll
+  for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
+  finish_point<DIM, PLANE>(S, T, rk, thr, kk, scale, inrange, active, gi, oi, p, qx, qy, qz, best, bidx, bpos, excl, skipped,
+                           pf, pn, pnm, use_prior && S.use_normal_gate, acc);
+  block_reduce_store<NW>(acc, S.partials, prob, tile, nullptr);
+}
+
+// ============================================================================================
 // The converged pass.  From the second iteration of a compute() on, nearly every moving point keeps its nearest
 // neighbour (exclusion-radius certificate, see icp_step_body): such a pass is a streaming kernel -- load the point, its
 // previous neighbour and the neighbour's normal, prove that the neighbour is unchanged, linearise, reduce -- and in
@@ -2703,6 +3173,37 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
       hipLaunchKernelGGL((k_icp_step<2, false>), grid, dim3(256), dyn, s, S, probs, states);
   }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
+}
+
+#ifdef SRRG2_TILE_STATS
+extern "C" int srrg2_amd_debug_tile_stats(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stats), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long zero[64];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stats), zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
+// the search pass of a batch with wave tiles in LDS (cap: candidates per wave tile, 336: four workgroups per CU, 512: three)
+void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                          int max_nm, int cap, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  dim3 grid((max_nm + 255) / 256, K);
+#define TILE_LAUNCH(D, P)                                                                            \
+  do {                                                                                               \
+    if (cap > 400)                                                                                   \
+      hipLaunchKernelGGL((k_icp_step_tile<D, P, 512>), grid, dim3(256), 0, s, S, probs, states);      \
+    else                                                                                             \
+      hipLaunchKernelGGL((k_icp_step_tile<D, P, 336>), grid, dim3(256), 0, s, S, probs, states);      \
+  } while (0)
+  if (dim == 3) {
+    if (plane) TILE_LAUNCH(3, true); else TILE_LAUNCH(3, false);
+  } else {
+    if (plane) TILE_LAUNCH(2, true); else TILE_LAUNCH(2, false);
+  }
+#undef TILE_LAUNCH
 }
 
 template <int PPT, bool GATHER>

@@ -263,25 +263,95 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {  // v < 64: insert two
   return v;
 }
 
-__device__ __forceinline__ unsigned morton_key(const float4 p, const unsigned* bb, int bits) {
-  const unsigned ncell = 1u << (3 * bits);
-  if (!finite3(p.x, p.y, p.z)) return ncell - 1;
-  const float res = (float) (1 << bits);
-  unsigned c[3];
-  const float v[3] = {p.x, p.y, p.z};
+__device__ __forceinline__ unsigned spread2(unsigned v) {  // v < 65536: insert one zero bit between bits
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// Key layout of the moving-cloud sort.  The key has `kbits` bits in all; each axis gets as many of them as it takes to
+// make the cells roughly cubic (a 10 m x 10 m x 1 m scene sorted with the same number of bits per axis has cells that
+// are ten times flatter than wide: the 64 consecutive points of a wave then spread over a 0.6 m patch instead of 0.15 m).
+// Bits are dealt one at a time to the axis whose cells are currently the longest (aniso == 0: kbits / 3 per axis, the
+// layout of round 2).  The key interleaves the axes like a Morton code, the longer axes contributing their extra top
+// bits first:  [ top bits of the longest axis | 2-way interleave of the two longest | 3-way interleave of all three ].
+// Any monotone cell assignment gives a valid sort; the order only serves the coherence of neighbouring lanes.
+struct KeySpec {
+  float mn[3], scale[3];  // cell coordinate of axis d = (v - mn[d]) * scale[d], clamped to [0, 2^b[d])
+  int b[3];               // bits per axis
+  int ia, ib, ic;         // the axes by bits, descending
+};
+
+__device__ __forceinline__ void key_spec_from_bbox(const float* mn, const float* mx, bool any, int kbits, int aniso, KeySpec& k) {
+  float ext[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    unsigned kmn = bb[d], kmx = bb[3 + d];
-    unsigned bmn = (kmn & 0x80000000u) ? (kmn & 0x7fffffffu) : ~kmn;
-    unsigned bmx = (kmx & 0x80000000u) ? (kmx & 0x7fffffffu) : ~kmx;
-    float mn = __uint_as_float(bmn), mx = __uint_as_float(bmx);
-    float ext = mx - mn;
-    float u   = ext > 0.f ? (v[d] - mn) / ext * res : 0.f;
-    int ci    = (int) u;
-    ci        = min(max(ci, 0), (1 << bits) - 1);
-    c[d]      = (unsigned) ci;
+    k.mn[d] = mn[d];
+    ext[d]  = any ? mx[d] - mn[d] : 0.f;
+    k.b[d]  = 0;
   }
-  return spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+  if (aniso) {
+    float cell[3] = {ext[0], ext[1], ext[2]};
+    for (int t = 0; t < kbits; ++t) {
+      int best = -1;
+      float bv = 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (cell[d] > bv) { bv = cell[d]; best = d; }
+      if (best < 0) break;  // (a single point: every extent is zero)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (d == best) { k.b[d]++; cell[d] *= 0.5f; }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) k.b[d] = kbits / 3;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) k.scale[d] = (ext[d] > 0.f) ? (float) (1 << k.b[d]) / ext[d] : 0.f;
+  // axes by bits, descending (ties keep x, y, z order: equal bits give the plain Morton code)
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (k.b[i1] > k.b[i0]) { int t = i0; i0 = i1; i1 = t; }
+  if (k.b[i2] > k.b[i1]) { int t = i1; i1 = i2; i2 = t; }
+  if (k.b[i1] > k.b[i0]) { int t = i0; i0 = i1; i1 = t; }
+  k.ia = i0; k.ib = i1; k.ic = i2;
+}
+
+__device__ __forceinline__ unsigned key_of_point(const float4 p, const KeySpec& k, int kbits) {
+  if (!finite3(p.x, p.y, p.z)) return (1u << kbits) - 1u;
+  const float v[3] = {p.x, p.y, p.z};
+  unsigned c[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int ci = (int) ((v[d] - k.mn[d]) * k.scale[d]);
+    c[d]         = (unsigned) min(max(ci, 0), (1 << k.b[d]) - 1);
+  }
+  auto pick = [&](int i) { return i == 0 ? c[0] : (i == 1 ? c[1] : c[2]); };
+  auto bits_of = [&](int i) { return i == 0 ? k.b[0] : (i == 1 ? k.b[1] : k.b[2]); };
+  const unsigned ca = pick(k.ia), cb = pick(k.ib), cc = pick(k.ic);
+  const int ba = bits_of(k.ia), bb = bits_of(k.ib), bc = bits_of(k.ic);
+  (void) ba;
+  const unsigned mc = (1u << bc) - 1u, mm = (1u << (bb - bc)) - 1u;
+  const unsigned lo  = spread3(ca & mc) | (spread3(cb & mc) << 1) | (spread3(cc & mc) << 2);
+  const unsigned mid = spread2((ca >> bc) & mm) | (spread2((cb >> bc) & mm) << 1);
+  const unsigned hi  = ca >> bb;
+  return (hi << (3 * bc + 2 * (bb - bc))) | (mid << (3 * bc)) | lo;
+}
+
+// (global-histogram path: the key layout is re-derived from the problem's bounding box by every thread -- uniform values)
+__device__ __forceinline__ unsigned morton_key(const float4 p, const unsigned* bb, int kbits, int aniso) {
+  float mn[3], mx[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const unsigned kmn = bb[d], kmx = bb[3 + d];
+    mn[d] = __uint_as_float((kmn & 0x80000000u) ? (kmn & 0x7fffffffu) : ~kmn);
+    mx[d] = __uint_as_float((kmx & 0x80000000u) ? (kmx & 0x7fffffffu) : ~kmx);
+  }
+  KeySpec k;
+  key_spec_from_bbox(mn, mx, bb[0] != 0xffffffffu, kbits, aniso, k);
+  return key_of_point(p, k, kbits);
 }
 
 __global__ void k_msort_bbox(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
@@ -332,22 +402,22 @@ __global__ void k_msort_bbox(const float4* __restrict__ pts, const ProblemDev* _
 }
 
 __global__ void k_msort_count(const float4* __restrict__ pts, const ProblemDev* __restrict__ probs,
-                              const unsigned* __restrict__ bb, int bits, int* __restrict__ counts) {
+                              const unsigned* __restrict__ bb, int kbits, int aniso, int* __restrict__ counts) {
   const ProblemDev pd = probs[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
-    unsigned key = morton_key(pts[pd.moff + i], bb + blockIdx.y * 6, bits);
-    atomicAdd(&counts[((size_t) blockIdx.y << (3 * bits)) + key], 1);
+    unsigned key = morton_key(pts[pd.moff + i], bb + blockIdx.y * 6, kbits, aniso);
+    atomicAdd(&counts[((size_t) blockIdx.y << kbits) + key], 1);
   }
 }
 
 __global__ void k_msort_scatter(const float4* __restrict__ pts, const float4* __restrict__ nrm,
-                                const ProblemDev* __restrict__ probs, const unsigned* __restrict__ bb, int bits,
+                                const ProblemDev* __restrict__ probs, const unsigned* __restrict__ bb, int kbits, int aniso,
                                 int* __restrict__ cursor, float4* __restrict__ out_pts, float4* __restrict__ out_nrm) {
   const ProblemDev pd = probs[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.nm; i += gridDim.x * blockDim.x) {
     float4 p     = pts[pd.moff + i];
-    unsigned key = morton_key(p, bb + blockIdx.y * 6, bits);
-    int pos      = atomicAdd(&cursor[((size_t) blockIdx.y << (3 * bits)) + key], 1);
+    unsigned key = morton_key(p, bb + blockIdx.y * 6, kbits, aniso);
+    int pos      = atomicAdd(&cursor[((size_t) blockIdx.y << kbits) + key], 1);
     p.w          = __int_as_float(i);
     out_pts[pos] = p;
     if (nrm) out_nrm[pos] = nrm[pd.moff + i];
@@ -360,14 +430,14 @@ __global__ void k_msort_scatter(const float4* __restrict__ pts, const float4* __
 // kernels, the bounding-box / count / scan x 3 / copy / scatter kernels and their 2 x nm global atomics per problem
 // (a 32 x 50k batch: 68 + 188 us -> one kernel).  Each thread keeps eight points in flight per round.
 __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ src, int sf, const float* __restrict__ nsrc,
-                                                      int nsf, const ProblemDev* __restrict__ probs, int dim, int bits,
+                                                      int nsf, const ProblemDev* __restrict__ probs, int dim, int kbits, int aniso,
                                                       float4* __restrict__ out_pts, float4* __restrict__ out_nrm,
                                                       unsigned* __restrict__ maxabs_bits /* [K] */) {
   constexpr int NPT = 8;  // points in flight per thread and round
-  extern __shared__ int hist[];  // 1 << (3 * bits) counters, then cursors
+  extern __shared__ int hist[];  // 1 << kbits counters, then cursors
   __shared__ unsigned red[16][6];
   __shared__ unsigned bbs[6];
-  __shared__ float kmn[3], kscale[3];  // cell coordinate = (v - kmn) * kscale (one reciprocal per axis, not a division per point)
+  __shared__ KeySpec kspec;  // cell coordinate = (v - mn) * scale (one reciprocal per axis, not a division per point)
   __shared__ int wsum[16];
   // gridDim.x workgroups per problem (blockIdx.y): each sorts ITS contiguous share of the problem's points on its own --
   // own bounding box, own histogram -- into the same share of the output.  The cloud then is gridDim.x sorted segments
@@ -377,7 +447,7 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
   const int seg0 = (int) ((long long) whole.nm * blockIdx.x / gridDim.x);
   const int seg1 = (int) ((long long) whole.nm * (blockIdx.x + 1) / gridDim.x);
   const ProblemDev pd = ProblemDev{whole.moff + seg0, seg1 - seg0};
-  const int ncell     = 1 << (3 * bits);
+  const int ncell     = 1 << kbits;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const float* base = src + (size_t) pd.moff * sf;
   auto load = [&](int i) {
@@ -440,24 +510,22 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
     else
       atomicMax(&maxabs_bits[blockIdx.y], __float_as_uint(amax));
   }
-  if (tid < 3) {
-    const unsigned a = bbs[tid], z = bbs[3 + tid];
-    const float mnf  = __uint_as_float((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
-    const float mxf  = __uint_as_float((z & 0x80000000u) ? (z & 0x7fffffffu) : ~z);
-    const float ext  = mxf - mnf;
-    kmn[tid]         = mnf;
-    kscale[tid]      = (bbs[0] != 0xffffffffu && ext > 0.f) ? (float) (1 << bits) / ext : 0.f;
+  if (tid == 0) {
+    float mnf[3], mxf[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const unsigned a = bbs[d], z = bbs[3 + d];
+      mnf[d] = __uint_as_float((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
+      mxf[d] = __uint_as_float((z & 0x80000000u) ? (z & 0x7fffffffu) : ~z);
+    }
+    KeySpec k;
+    key_spec_from_bbox(mnf, mxf, bbs[0] != 0xffffffffu, kbits, aniso, k);
+    kspec = k;
   }
   __syncthreads();
   // (any monotone cell assignment gives a valid sort: the keys only order the points)
-  auto key_of = [&](const float4 p) -> unsigned {
-    if (!finite3(p.x, p.y, p.z)) return (unsigned) ncell - 1u;
-    const int hi = (1 << bits) - 1;
-    const int cx = min(max((int) ((p.x - kmn[0]) * kscale[0]), 0), hi);
-    const int cy = min(max((int) ((p.y - kmn[1]) * kscale[1]), 0), hi);
-    const int cz = min(max((int) ((p.z - kmn[2]) * kscale[2]), 0), hi);
-    return spread3((unsigned) cx) | (spread3((unsigned) cy) << 1) | (spread3((unsigned) cz) << 2);
-  };
+  const KeySpec ks = kspec;
+  auto key_of = [&](const float4 p) -> unsigned { return key_of_point(p, ks, kbits); };
   // ---- pass 2: histogram
   for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
     float4 q[NPT];
@@ -575,47 +643,51 @@ void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm,
   hipLaunchKernelGGL(k_grid_scatter, dim3((n + 255) / 256), dim3(256), 0, s, g, pts, nrm, n, cursor, out_pts, out_nrm, pos_of);
 }
 
-void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int bits,
+void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs, int K, int max_nm, int kbits, int aniso,
                   unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
                   float4* out_nrm, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
   int bx = (max_nm + 255) / 256;
   if (bx > 1024) bx = 1024;
   dim3 grid(bx, K);
-  const int ncell = K << (3 * bits);
+  const int ncell = K << kbits;
   // (few, grid-striding blocks per problem for the bounding box: its cost is the atomics, not the reads)
   hipLaunchKernelGGL(k_msort_bbox, dim3(bx < 32 ? bx : 32, K), dim3(256), 0, s, pts, probs, bb);
-  hipLaunchKernelGGL(k_msort_count, grid, dim3(256), 0, s, pts, probs, bb, bits, counts);
+  hipLaunchKernelGGL(k_msort_count, grid, dim3(256), 0, s, pts, probs, bb, kbits, aniso, counts);
   launch_exclusive_scan(counts, ncell, scan_sums, scan_total, s);
   (void) hipMemcpyAsync(cursor, counts, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, s);
-  hipLaunchKernelGGL(k_msort_scatter, grid, dim3(256), 0, s, pts, nrm, probs, bb, bits, cursor, out_pts, out_nrm);
+  hipLaunchKernelGGL(k_msort_scatter, grid, dim3(256), 0, s, pts, nrm, probs, bb, kbits, aniso, cursor, out_pts, out_nrm);
 }
 
 // false: the key space does not fit in LDS (the caller takes the ingest + global-histogram path)
-bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int bits,
-                        float4* out_pts, float4* out_nrm, unsigned* maxabs_bits, hipStream_t s) {
-  if (bits > 5) return false;
+bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, const ProblemDev* probs, int K, int dim, int kbits,
+                        int aniso, int segments, int max_nm, float4* out_pts, float4* out_nrm, unsigned* maxabs_bits,
+                        hipStream_t s) {
+  if (kbits > 15) return false;
   if (K <= 0) return true;
   // segments per problem: fill about half the chip's CUs (one 1024-thread workgroup each); segments get the coarser key
   // space of the big batches (16^3 cells for ~6-12 k points)
-  static const int seg_env = getenv("SRRG2_AMD_MSORT_SEGMENTS") ? atoi(getenv("SRRG2_AMD_MSORT_SEGMENTS")) : 0;
+  const int seg_env = segments;
   // (measured on C4, profiles/r2zk_ab_msort_segments.txt: 32 alignments 287 -> 305 k it/s with 4 segments, 8 alignments
   // 146 -> 161 k, 64 alignments 331 -> 345 k with 2; the passes lose 1.4 % of coherence, the sort goes from 118 to ~35 us;
   // 128 alignments 362 -> 372 k with 2 (profiles/r2zs_env_tests.txt); 256: within noise, one workgroup per cloud)
   int G = seg_env > 0 ? seg_env : (K >= 256 ? 1 : (K >= 64 ? 2 : (128 / K < 8 ? 128 / K : 8)));
   if (G < 1) G = 1;
   if (G > 1) {
-    bits = bits < 4 ? bits : 4;
+    if (!aniso) kbits = kbits < 12 ? kbits : 12;
     (void) hipMemsetAsync(maxabs_bits, 0, (size_t) K * sizeof(unsigned), s);
   }
-  const size_t lds = sizeof(int) << (3 * bits);
+  // (anisotropic keys: 2^15 cells when a workgroup sorts >= 8 Ki points -- clearing and scanning the histogram is then
+  // no more than the points themselves -- else 2^12)
+  if (aniso && kbits > 12 && max_nm / G < 8192) kbits = 12;
+  const size_t lds = sizeof(int) << kbits;
   static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msort_local),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) (sizeof(int) << 15)) == hipSuccess;
   if (!attr_ok) {
     (void) hipGetLastError();
     return false;
   }
-  hipLaunchKernelGGL(k_msort_local, dim3(G, K), dim3(1024), lds, s, src, sf, nsrc, nsf, probs, dim, bits, out_pts, out_nrm,
+  hipLaunchKernelGGL(k_msort_local, dim3(G, K), dim3(1024), lds, s, src, sf, nsrc, nsf, probs, dim, kbits, aniso, out_pts, out_nrm,
                      maxabs_bits);
   return true;
 }

@@ -9,7 +9,8 @@ information matrix.  Two equivalent forms (same table on every rank, bit for bit
   * all-gather of the ranks' own rows;
   * all-reduce(sum) of a K-row table in which every rank fills its own rows and leaves the others zero -- the
     "all-reduce of the final Hessian" of BASELINE.json's north_star: the rows carry H (upper triangle) next to X and the
-    statistics, x + 0 = x is exact, so the sum reproduces every row unchanged.
+    statistics; the sum runs over the rows' int64 bit patterns (x + 0 = x for every bit pattern, -0.0 included), so it
+    reproduces every row unchanged.
 Backend: torch.distributed ("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  The record layout is the
 C ABI's (srrg2_multi_gpu_pack_record, include/srrg2_slam_amd.h); tests/test_multi_gpu_gloo.py checks both agree.
 """
@@ -67,9 +68,14 @@ def all_reduce_records(local_records, K, device=None):
     table = _local_table(local_records, K)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return table
-    t = torch.from_numpy(table).to(device if device is not None else "cpu")
+    if device is None:  # (NCCL / RCCL reduces device tensors only)
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+    # The sum runs over the int64 BIT PATTERNS of the float64 rows: every row is non-zero on exactly one rank, so the
+    # integer sum reproduces its bits exactly -- a float sum would turn -0.0 into +0.0 (-0.0 + 0.0 = +0.0) and could
+    # differ from the all-gather form in the sign of a zero.
+    t = torch.from_numpy(table.view(np.int64).copy()).to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy()
+    return t.cpu().numpy().view(np.float64)
 
 
 def all_gather_records(local_records, K, device=None):

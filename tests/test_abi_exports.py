@@ -23,14 +23,16 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
-    assert lib.srrg2_amd_abi_version() == 2
+    assert lib.srrg2_amd_abi_version() == 3
 
 
 def test_oracle_mirrors_the_call_surface(oracle):
     lib = oracle.lib()
     for n in _declared_functions():
         if n.startswith("srrg2_aligner_") and not n.startswith("srrg2_aligner_profile") and \
-                n not in ("srrg2_aligner_default_params", "srrg2_aligner_set_point_shard"):  # (defined as = the one-rank result)
+                n not in ("srrg2_aligner_default_params", "srrg2_aligner_set_point_shard",  # (defined as = the one-rank result)
+                          # (strategy knobs choose between exact device strategies: the oracle searches from scratch)
+                          "srrg2_aligner_default_tuning", "srrg2_aligner_get_tuning", "srrg2_aligner_set_tuning"):
             assert hasattr(lib, "oracle_" + n[len("srrg2_"):]), n
 
 
@@ -43,6 +45,7 @@ def test_pod_layouts_match_ctypes():
     assert C.sizeof(abi.TerminationParams) == 20
     assert C.sizeof(abi.SliceConfig) == 8 * 4 + 12 * 4 + 9 * 4 + 4 * 4 + 6 * 4 + 4
     assert C.sizeof(abi.BatchResult) == 48 + 8 + 32 + 8 + 144
+    assert C.sizeof(abi.AlignerTuning) == 4 * 24
 
 
 def test_no_cpu_fallback_without_device():
@@ -69,7 +72,7 @@ def test_headers_compile_with_plain_gxx(tmp_path):
                    'int main() { srrg2_slam_amd::LoopClosure<3> c; return c.source_graph_id + 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
     c_src = tmp_path / "tu.c"  # the C ABI header is C
-    c_src.write_text('#include "srrg2_slam_amd.h"\nint main(void) { return SRRG2_AMD_ABI_VERSION == 2 ? 0 : 1; }\n')
+    c_src.write_text('#include "srrg2_slam_amd.h"\nint main(void) { return SRRG2_AMD_ABI_VERSION == 3 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(c_src)])
 
 
