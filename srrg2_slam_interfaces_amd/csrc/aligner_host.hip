@@ -598,8 +598,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   const bool fast_gather = tn.fast_gather >= 0 ? tn.fast_gather != 0 : K > 4;
   const bool fast_batch_queue = tn.fast_batch_queue != 0;
   // search passes of batches: every wave's neighbourhood of the fixed cloud staged in LDS (k_icp_step_tile; 1: tiles of
-  // 336 candidates, four workgroups per CU; 2: 512 candidates, three workgroups per CU)
-  const int lds_tile = tn.lds_tile >= 0 ? tn.lds_tile : 0;
+  // 416 candidates, four workgroups per CU; 2: 504 candidates, three workgroups per CU)
+  // (automatic: batches of more than four alignments -- C4-256 374 -> 406 k it/s, C4-32 305 -> 322 k, C4-8 167 -> 171 k;
+  // single alignments are launch / latency bound and neutral to 1.5 % slower with it: 30 k points 41.7 -> 41.1 k it/s,
+  // profiles/r3i_ab_tile_default.txt)
+  const int lds_tile = tn.lds_tile >= 0 ? tn.lds_tile : (K > 4 ? 1 : 0);
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {
@@ -902,7 +905,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
                                            fast_gather, a->stream);
           else if (!sd.queue && lds_tile > 0 && !small)
             srrg2amd::launch_icp_step_tile(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
-                                           lds_tile == 2 ? 512 : 336, a->stream);
+                                           lds_tile == 2 ? 504 : 416, a->stream);
           else
             srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
         }

@@ -968,7 +968,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
           const float rr = (sqrtf(best) + pad) * 1.00001f;
           ball2          = fminf(rr * rr, gfar);
           r2             = 1;
-          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+          _Pragma("clang loop vectorize(disable) unroll(disable)") while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
         }
       } else {
         // settled: the scan was complete inside min(ball, block); nothing but the winner is closer than this
@@ -1115,7 +1115,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
             const float rr = (sqrtf(best) + pad) * 1.00001f;
             ball2          = fminf(rr * rr, gfar);
             r2             = 2;
-            while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+            _Pragma("clang loop vectorize(disable) unroll(disable)") while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
           }
         }
       }
@@ -1207,35 +1207,86 @@ namespace {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-constexpr int TILE_ROWS = 48;   // rows of cells (y, z) of a wave's box
+constexpr int TILE_ROWS = 64;   // rows of cells (y, z) of a wave's box (one lane per row)
 constexpr int TILE_NX   = 12;   // cells per row
 constexpr int TILE_CSW  = TILE_NX + 1;
+constexpr int TILE_LIST = 12;   // ranges a lane can queue before it scans them
 
 template <int CAP>
 struct WaveTile {             // per wave, in LDS
-  f4v pts[CAP + 4];           // the candidates of the box, row after row (scan_range2 over-reads <= 2 entries: masked)
-  int rowbase[TILE_ROWS];     // index of cell (X0, y, z) in the grid
-  int rowA[TILE_ROWS];        // position of the row's first candidate in grid.pts
-  int rowoff[TILE_ROWS + 1];  // ... and in pts[] (exclusive prefix sum of the row sizes; [nrows] = total)
+  static_assert(CAP + 4 <= 512, "range starts are packed in 9 bits");
+  f4v pts[CAP + 4];           // the candidates of the box, row after row (+ slack: groups of four read past the end, masked)
   unsigned short cs[TILE_ROWS * TILE_CSW];  // cs[r][k]: offset in pts[] at which cell X0 + k of row r starts
+  union {
+    struct {                     // while the tile is staged:
+      int rowbase[TILE_ROWS];     //   index of cell (X0, y, z) in the grid
+      int rowA[TILE_ROWS];        //   position of the row's first candidate in grid.pts
+      int rowoff[TILE_ROWS + 1];  //   ... and in pts[] (exclusive prefix sum of the row sizes; [nrows] = total)
+    } st;
+    unsigned short list[TILE_LIST * 64];  // while it is scanned: list[k][lane] = start | count << 9 of the lane's k-th range
+  } u;
 };
 
-// candidates of a contiguous range, from LDS: the arithmetic of scan_range2
+// One group of four candidates from LDS, the first `cnt` of them valid (cnt >= 4: all).  (Measured without the masks --
+// a group that runs past its range then tests a few more real fixed points, which cannot change the minimum: 2 % fewer
+// vector instructions, but the candidates seen early shrink the ball the rest of the scan is pruned to, and with it the
+// exclusion radius left behind: the first converged pass went from 34 to 52 us.  profiles/r3h_*)
+template <int DIM>
+__device__ __forceinline__ void test_group_lds(const f4v* pts, int j, int cnt, float qx, float qy, float qz,
+                                               unsigned long long& bkey, float& b2) {
+  const f4v a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
+  test_candidate2<DIM>(make_float4(a0.x, a0.y, a0.z, a0.w), qx, qy, qz, cnt > 0, bkey, b2);
+  test_candidate2<DIM>(make_float4(a1.x, a1.y, a1.z, a1.w), qx, qy, qz, cnt > 1, bkey, b2);
+  test_candidate2<DIM>(make_float4(a2.x, a2.y, a2.z, a2.w), qx, qy, qz, cnt > 2, bkey, b2);
+  test_candidate2<DIM>(make_float4(a3.x, a3.y, a3.z, a3.w), qx, qy, qz, cnt > 3, bkey, b2);
+}
+
+// candidates [j, e) of the tile, four at a time, the last group masked (no separate tail code: with the rows of 64 lanes
+// of different lengths the tail block ran for nearly every row)
 template <int DIM>
 __device__ __forceinline__ void scan_range_lds(const f4v* pts, int j, int e, float qx, float qy, float qz,
                                                unsigned long long& bkey, float& b2) {
-  for (; j + 4 <= e; j += 4) {
-    const f4v a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
-    test_candidate2<DIM>(make_float4(a0.x, a0.y, a0.z, a0.w), qx, qy, qz, true, bkey, b2);
-    test_candidate2<DIM>(make_float4(a1.x, a1.y, a1.z, a1.w), qx, qy, qz, true, bkey, b2);
-    test_candidate2<DIM>(make_float4(a2.x, a2.y, a2.z, a2.w), qx, qy, qz, true, bkey, b2);
-    test_candidate2<DIM>(make_float4(a3.x, a3.y, a3.z, a3.w), qx, qy, qz, true, bkey, b2);
+  for (; j < e; j += 4) test_group_lds<DIM>(pts, j, e - j, qx, qy, qz, bkey, b2);
+}
+
+// Every lane walks ITS OWN list of n ranges as one flattened sequence of groups of four: the wave iterates as often as
+// its busiest lane has groups -- not, as with one loop per row, the sum over the rows of the busiest lane of each row
+// (measured on C4, tools/tile_stats.py: 10.7 instead of 19.4 group iterations per wave and search pass).
+template <int DIM>
+__device__ __forceinline__ void scan_list_lds(const f4v* pts, const unsigned short* list, int lane, int n, float qx, float qy,
+                                              float qz, unsigned long long& bkey, float& b2) {
+  int cur = 0, j = 0, cnt = 0;
+  if (n > 0) {
+    const unsigned u = list[lane];
+    j   = (int) (u & 511u);
+    cnt = (int) (u >> 9);
   }
-  if (j < e) {
-    const f4v a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2];
-    test_candidate2<DIM>(make_float4(a0.x, a0.y, a0.z, a0.w), qx, qy, qz, true, bkey, b2);
-    test_candidate2<DIM>(make_float4(a1.x, a1.y, a1.z, a1.w), qx, qy, qz, j + 1 < e, bkey, b2);
-    test_candidate2<DIM>(make_float4(a2.x, a2.y, a2.z, a2.w), qx, qy, qz, j + 2 < e, bkey, b2);
+  while (__any(cnt > 0)) {
+    test_group_lds<DIM>(pts, j, cnt, qx, qy, qz, bkey, b2);  // (a lane that has finished: group 0, all masked)
+    j += 4;
+    cnt -= 4;
+    if (cnt <= 0) {
+      cnt = 0;
+      j   = 0;
+      if (++cur < n) {
+        const unsigned u = list[cur * 64 + lane];
+        j   = (int) (u & 511u);
+        cnt = (int) (u >> 9);
+      }
+    }
+  }
+}
+
+// Queue the range [rs, re) of the tile on the lane's list.  An entry holds up to 127 candidates; the (rare: a very dense
+// spot) longer range is scanned on the spot instead.  The caller leaves room for the entry (n < TILE_LIST).
+template <int DIM>
+__device__ __forceinline__ void list_push(const f4v* pts, unsigned short* list, int lane, int& n, int rs, int re, float qx,
+                                          float qy, float qz, unsigned long long& bkey, float& b2) {
+  if (re - rs > 127) {
+    scan_range_lds<DIM>(pts, rs, re, qx, qy, qz, bkey, b2);
+  } else if (rs < re) {
+    list[n * 64 + lane] = (unsigned short) (rs | ((re - rs) << 9));
+    ++n;
   }
 }
 
@@ -1278,15 +1329,28 @@ __device__ __forceinline__ TileBox stage_tile(const GridDev& g, WaveTile<CAP>& t
   b.ok = false;
   b.why = 1;
   b.total = 0;
-  b.X0 = wave_min_i(want ? x0 : 0x7fffffff);
-  b.Y0 = wave_min_i(want ? y0 : 0x7fffffff);
-  b.Z0 = wave_min_i(want ? z0 : 0x7fffffff);
-  const int X1 = wave_max_i(want ? x1 : -0x7fffffff), Y1 = wave_max_i(want ? y1 : -0x7fffffff),
-            Z1 = wave_max_i(want ? z1 : -0x7fffffff);
+  // the box: six wave reductions, two per step (min of v and of -v packed in one 64-bit value would need a 64-bit min:
+  // the lower corner is reduced as it is, the upper corner negated -- one min chain of three values each)
+  int lo0 = want ? x0 : 0x7fffffff, lo1 = want ? y0 : 0x7fffffff, lo2 = want ? z0 : 0x7fffffff;
+  int hi0 = want ? -x1 : 0x7fffffff, hi1 = want ? -y1 : 0x7fffffff, hi2 = want ? -z1 : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo0 = min(lo0, __shfl_xor(lo0, off));
+    lo1 = min(lo1, __shfl_xor(lo1, off));
+    lo2 = min(lo2, __shfl_xor(lo2, off));
+    hi0 = min(hi0, __shfl_xor(hi0, off));
+    hi1 = min(hi1, __shfl_xor(hi1, off));
+    hi2 = min(hi2, __shfl_xor(hi2, off));
+  }
+  b.X0 = __builtin_amdgcn_readfirstlane(lo0);
+  b.Y0 = __builtin_amdgcn_readfirstlane(lo1);
+  b.Z0 = __builtin_amdgcn_readfirstlane(lo2);
+  const int X1 = -__builtin_amdgcn_readfirstlane(hi0), Y1 = -__builtin_amdgcn_readfirstlane(hi1),
+            Z1 = -__builtin_amdgcn_readfirstlane(hi2);
   b.nxb = X1 - b.X0 + 1;
   b.nyb = Y1 - b.Y0 + 1;
   b.nzb = Z1 - b.Z0 + 1;
-  if (X1 < b.X0 || b.nxb > TILE_NX) return b;
+  if (b.X0 == 0x7fffffff || b.nxb > TILE_NX) return b;
   b.why = 2;
   if (b.nyb > TILE_ROWS || b.nzb > TILE_ROWS || b.nyb * b.nzb > TILE_ROWS) return b;
   const int nrows = b.nyb * b.nzb;
@@ -1310,17 +1374,18 @@ __device__ __forceinline__ TileBox stage_tile(const GridDev& g, WaveTile<CAP>& t
   b.total = total;
   if (total > CAP) return b;
   if (lane < nrows) {
-    t.rowbase[lane] = rbase;
-    t.rowA[lane]    = A;
-    t.rowoff[lane]  = incl - cnt;
+    t.u.st.rowbase[lane] = rbase;
+    t.u.st.rowA[lane]    = A;
+    t.u.st.rowoff[lane]  = incl - cnt;
   }
-  if (lane == 0) t.rowoff[nrows] = total;
+  if (lane == 0) t.u.st.rowoff[nrows] = total;
   wave_lds_sync();
   // the cell table: four rows per step, 16 lanes each (TILE_CSW <= 16 entries per row, contiguous in the grid)
   {
     const int k = lane & 15;
     for (int r = lane >> 4; r < nrows; r += 4)
-      if (k <= b.nxb) t.cs[r * TILE_CSW + k] = (unsigned short) (g.cell_start[t.rowbase[r] + k] - t.rowA[r] + t.rowoff[r]);
+      if (k <= b.nxb)
+        t.cs[r * TILE_CSW + k] = (unsigned short) (g.cell_start[t.u.st.rowbase[r] + k] - t.u.st.rowA[r] + t.u.st.rowoff[r]);
   }
   // the candidates: the flattened list, 64 at a time (coalesced within a row); the row of a slot by bisection
   for (int s0 = 0; s0 < total; s0 += 64) {
@@ -1330,98 +1395,131 @@ __device__ __forceinline__ TileBox stage_tile(const GridDev& g, WaveTile<CAP>& t
 #pragma unroll
       for (int it = 0; it < 6; ++it) {
         const int mid = (lo + hi + 1) >> 1;
-        if (t.rowoff[mid] <= s) lo = mid; else hi = mid - 1;
+        if (t.u.st.rowoff[mid] <= s) lo = mid; else hi = mid - 1;
       }
-      const float4 c = g.pts[t.rowA[lo] + (s - t.rowoff[lo])];
+      const float4 c = g.pts[t.u.st.rowA[lo] + (s - t.u.st.rowoff[lo])];
       f4v v;
       v.x = c.x; v.y = c.y; v.z = c.z; v.w = c.w;
       t.pts[s] = v;
     }
   }
-  wave_lds_sync();
+  wave_lds_sync();  // (from here on the row tables are dead: their memory becomes the lanes' range lists)
   b.ok  = true;
   b.why = 0;
   return b;
 }
 
+// squared distance of q to the slab of cells with coordinate c along one axis, shrunk by the rounding of the cell
+// boundaries (1 % of a cell + 2e-6 of the coordinate magnitude: a point's cell is floor(fl(fl(x - o) * inv_h)))
+__device__ __forceinline__ float slab_dist2(float q, int c, float o, float h, float rb) {
+  const float lo = o + (float) c * h;
+  float d        = fmaxf(fmaxf(lo - q, q - (lo + h)), 0.f);
+  d              = fmaxf(d - (0.01f * h + (fabsf(q) + rb) * 2e-6f), 0.f);
+  return d * d;
+}
+
 // The first search phase (scan_radius1) on a staged tile: the 3^DIM cells around the query trimmed to the ball of squared
-// radius r2box, the row through the query's own cell first, the other rows pruned by the distance of that row's best.
-// (x0 .. z1: the lane's cell ranges, as computed for the staging; same candidates as scan_radius1 in the same order of
-// rows, hence the same key minimum, runner-up and completeness radius)
+// radius r2box, the row through the query's own cell first, the other rows pruned by the distance of that row's best and
+// then walked as ONE flattened list.  (x0 .. z1: the lane's cell ranges, as computed for the staging; the same candidates
+// as scan_radius1, hence the same key minimum; runner-up and completeness radius are as valid.)  Called by every lane
+// of the wave: lanes without a search (want == false) walk empty ranges.
 template <int DIM, int CAP>
-__device__ __forceinline__ void scan_radius1_tile(const GridDev& g, const WaveTile<CAP>& t, const TileBox& b, float qx, float qy,
-                                                  float qz, int cx, int cy, int cz, float r2box, int x0, int x1, int y0, int y1,
-                                                  int z0, int z1, unsigned long long& bkey, float& b2, float& complete2) {
+__device__ __forceinline__ void scan_radius1_tile(const GridDev& g, WaveTile<CAP>& t, const TileBox& b, int lane, float qx,
+                                                  float qy, float qz, int cx, int cy, int cz, float r2box, bool want, int x0,
+                                                  int x1, int y0, int y1, int z0, int z1, unsigned long long& bkey, float& b2,
+                                                  float& complete2, bool centre_only = false) {
   constexpr int NROWS = DIM == 3 ? 9 : 3;
   constexpr int RC    = DIM == 3 ? 4 : 1;
   complete2 = r2box;
-  if (x0 > x1) return;
   const int kx0 = x0 - b.X0, kx1 = x1 + 1 - b.X0;
   auto row_range = [&](int r, int& rs, int& re) {
     const int y = cy + (r % 3) - 1;
     const int z = DIM == 3 ? cz + (r / 3) - 1 : 0;
     rs = re = 0;
-    if (y >= y0 && y <= y1 && z >= z0 && z <= z1) {
+    if (want && y >= y0 && y <= y1 && z >= z0 && z <= z1) {
       const int tr = (z - b.Z0) * b.nyb + (y - b.Y0);
       rs = t.cs[tr * TILE_CSW + kx0];
       re = t.cs[tr * TILE_CSW + kx1];
     }
   };
+  // the row through the query's own cell first: its best candidate (+ a pad, so that the scan still proves an exclusion
+  // margin) prunes the other rows.  (With the ball of the previous neighbour as bound all nine rows could be pruned
+  // against that ball and walked as one list: measured 5 % MORE vector instructions on the passes with a prior.)
   {
     int rs, re;
     row_range(RC, rs, re);
     scan_range_lds<DIM>(t.pts, rs, re, qx, qy, qz, bkey, b2);
+    if (key_idx(bkey) != NO_MATCH) {
+      const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+      complete2      = fminf(complete2, rb * rb);
+    }
   }
-  if (key_idx(bkey) != NO_MATCH) {
-    const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
-    complete2      = fminf(complete2, rb * rb);
-  }
+  if (centre_only) return;  // (timing knob)
+  // the other rows: every point of a row is at least (dy, dz) away -- three slab distances per axis instead of one
+  // rectangle distance per row
   const bool prune = complete2 < 3.0e38f;
   const float rb   = prune ? sqrtf(complete2) : 0.f;
+  const float c2   = complete2 * 1.00002f;
+  float dy2[3], dz2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dy2[k] = slab_dist2(qy, cy + k - 1, g.oy, g.h, rb);
+    if (DIM == 3) dz2[k] = slab_dist2(qz, cz + k - 1, g.oz, g.h, rb);
+  }
+  int n = 0;
 #pragma unroll
   for (int r = 0; r < NROWS; ++r) {
     if (r == RC) continue;
-    bool keep = true;
-    if (prune) {
-      const int y     = cy + (r % 3) - 1;
-      const float ylo = g.oy + (float) y * g.h;
-      float dy        = fmaxf(fmaxf(ylo - qy, qy - (ylo + g.h)), 0.f);
-      dy              = fmaxf(dy - (0.01f * g.h + (fabsf(qy) + rb) * 2e-6f), 0.f);
-      float rem       = complete2 * 1.00002f - dy * dy;
-      if (DIM == 3) {
-        const int z     = cz + (r / 3) - 1;
-        const float zlo = g.oz + (float) z * g.h;
-        float dz        = fmaxf(fmaxf(zlo - qz, qz - (zlo + g.h)), 0.f);
-        dz              = fmaxf(dz - (0.01f * g.h + (fabsf(qz) + rb) * 2e-6f), 0.f);
-        rem             = rem - dz * dz;
-      }
-      keep = !(rem < 0.f);
-    }
+    const float rem = (c2 - dy2[r % 3]) - dz2[DIM == 3 ? r / 3 : 0];
     int rs = 0, re = 0;
-    if (keep) row_range(r, rs, re);
-    scan_range_lds<DIM>(t.pts, rs, re, qx, qy, qz, bkey, b2);
+    if (!(prune && rem < 0.f)) row_range(r, rs, re);
+    list_push<DIM>(t.pts, t.u.list, lane, n, rs, re, qx, qy, qz, bkey, b2);  // (<= 8 entries)
   }
+  static_assert(TILE_LIST >= 8, "the first phase queues up to eight rows");
+  wave_lds_sync();
+  scan_list_lds<DIM>(t.pts, t.u.list, lane, n, qx, qy, qz, bkey, b2);
 }
 
 // The shell of the radius-2 cube (scan_shell2) on a staged tile; x0 .. z1: the lane's ranges of the 5^DIM cube trimmed to
-// the ball (as computed for the staging).
+// the ball (as computed for the staging).  The lane's ranges are queued TILE_LIST at a time and walked as flattened lists;
+// rows farther from the query than the ball are skipped (the chord test of coop_scan: scan_shell2 only trims to the box
+// of the ball).  Called by every lane of the wave.
 template <int DIM, int CAP>
-__device__ __forceinline__ void scan_shell2_tile(const GridDev& g, const WaveTile<CAP>& t, const TileBox& b, float qx, float qy,
-                                                 float qz, int cx, int cy, int cz, int x0, int x1, int y0, int y1, int z0, int z1,
-                                                 unsigned long long& bkey, float& b2) {
-  if (x0 > x1) return;
+__device__ __forceinline__ void scan_shell2_tile(const GridDev& g, WaveTile<CAP>& t, const TileBox& b, int lane, float qx,
+                                                 float qy, float qz, int cx, int cy, int cz, float ball2, bool want, int x0,
+                                                 int x1, int y0, int y1, int z0, int z1, unsigned long long& bkey, float& b2) {
   const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, g.nx - 1);
-  for (int z = z0; z <= z1; ++z) {
-    const bool zin = DIM == 3 ? (z >= cz - 1 && z <= cz + 1) : true;
-    for (int y = y0; y <= y1; ++y) {
+  const float rr = ball_radius(ball2);
+  const float r2 = rr * rr;
+  // walk the rows (y, z) of the lane's box in a fixed order; `pos` = the next row to queue
+  const int ny_r = want ? y1 - y0 + 1 : 0, nz_r = want ? z1 - z0 + 1 : 0;
+  const int nrow = ny_r * nz_r;
+  int pos = 0;
+  int y = y0, z = z0;
+  while (__any(pos < nrow)) {
+    int n = 0;
+    while (pos < nrow && n + 2 <= TILE_LIST) {  // (a row queues at most two ranges)
+      const bool zin   = DIM == 3 ? (z >= cz - 1 && z <= cz + 1) : true;
       const bool inner = zin && y >= cy - 1 && y <= cy + 1;
-      const int tr     = (z - b.Z0) * b.nyb + (y - b.Y0);
-      const unsigned short* row = t.cs + tr * TILE_CSW - b.X0;  // row[x] = offset of cell x
-      const int la = x0, lb = inner ? min(x1, bx0 - 1) : x1;
-      const int ra = max(x0, bx1 + 1), rb = x1;
-      if (la <= lb) scan_range_lds<DIM>(t.pts, row[la], row[lb + 1], qx, qy, qz, bkey, b2);
-      if (inner && ra <= rb) scan_range_lds<DIM>(t.pts, row[ra], row[rb + 1], qx, qy, qz, bkey, b2);
+      float rem        = r2 - slab_dist2(qy, y, g.oy, g.h, rr);
+      if (DIM == 3) rem -= slab_dist2(qz, z, g.oz, g.h, rr);
+      if (!(rem < 0.f)) {
+        const int tr = (z - b.Z0) * b.nyb + (y - b.Y0);
+        const unsigned short* row = t.cs + tr * TILE_CSW - b.X0;  // row[x] = offset of cell x
+        const int la = x0, lb = inner ? min(x1, bx0 - 1) : x1;
+        const int ra = max(x0, bx1 + 1), rbx = x1;
+        if (la <= lb) list_push<DIM>(t.pts, t.u.list, lane, n, row[la], row[lb + 1], qx, qy, qz, bkey, b2);
+        if (inner && ra <= rbx) list_push<DIM>(t.pts, t.u.list, lane, n, row[ra], row[rbx + 1], qx, qy, qz, bkey, b2);
+      }
+      ++pos;
+      if (++y > y1) {
+        y = y0;
+        ++z;
+      }
     }
+    wave_lds_sync();
+    scan_list_lds<DIM>(t.pts, t.u.list, lane, n, qx, qy, qz, bkey, b2);
+    wave_lds_sync();  // (the list is rewritten by the next round)
   }
 }
 
@@ -1526,7 +1624,9 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
   unsigned long long bkey = NO_KEY;
   float b2 = INFINITY, complete2 = INFINITY;
   // ---- first phase: the 3^DIM block, trimmed to the ball
-  const bool need1 = active && !skipped;
+  // (timing knobs, profiling builds only: 16 = no search, 33554432 = stage the tiles without scanning them,
+  // 67108864 = the row through the query's cell only, 2 = no shell phase, 8 = no linearisation)
+  const bool need1 = active && !skipped && !KNOB(S.tune, 16);
   if (__any(need1)) {
     const float rr = ball_radius(r2box);
     int x0, x1, y0, y1, z0 = 0, z1 = 0;
@@ -1540,13 +1640,12 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
     TILE_STAT(st->nstats, 5, tb.total);
     TILE_STAT(st->nstats, 6, tb.nyb * tb.nzb);
     TILE_STAT(st->nstats, 7, __popcll(__ballot(need1)));
+    if (tb.ok && !KNOB(S.tune, 33554432))
+      scan_radius1_tile<DIM, CAP>(g, wlds[wid].tile, tb, lane, qx, qy, qz, cx, cy, cz, r2box, want, x0, x1, y0, y1, z0, z1, bkey,
+                                  b2, complete2, KNOB(S.tune, 67108864));
+    else if (need1)
+      scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, b2, complete2);
     if (need1) {
-      if (tb.ok) {
-        complete2 = r2box;
-        if (want) scan_radius1_tile<DIM, CAP>(g, wlds[wid].tile, tb, qx, qy, qz, cx, cy, cz, r2box, x0, x1, y0, y1, z0, z1, bkey, b2, complete2);
-      } else {
-        scan_radius1<DIM>(g, qx, qy, qz, cx, cy, cz, r2box, bkey, b2, complete2);
-      }
       best = key_best(bkey);
       bidx = key_idx(bkey);
       const bool found1 = bidx != NO_MATCH && best <= gfar;
@@ -1557,7 +1656,7 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
           const float rr2 = (sqrtf(best) + pad) * 1.00001f;
           ball2           = fminf(rr2 * rr2, gfar);
           r2              = 1;
-          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+          _Pragma("clang loop vectorize(disable) unroll(disable)") while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
         }
       } else {
         excl = sqrtf(fminf(fminf(b2, complete2), b2_1)) * 0.99999f;
@@ -1565,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
     }
   }
   // ---- second phase: the shell of the radius-2 cube, continuing the (key, runner-up) pair of the first
-  const bool need2 = r2 > 1 && rfar >= 2;
+  const bool need2 = r2 > 1 && rfar >= 2 && !KNOB(S.tune, 2);
   if (__any(need2)) {
     wave_lds_sync();  // (the first phase's tile is dead)
     const float rr = ball_radius(ball2);
@@ -1579,12 +1678,11 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
     TILE_STAT(st->nstats, 9 + tb.why, 1);
     TILE_STAT(st->nstats, 13, tb.total);
     TILE_STAT(st->nstats, 14, __popcll(__ballot(need2)));
+    if (tb.ok)
+      scan_shell2_tile<DIM, CAP>(g, wlds[wid].tile, tb, lane, qx, qy, qz, cx, cy, cz, ball2, want, x0, x1, y0, y1, z0, z1, bkey, b2);
+    else if (need2)
+      scan_shell2<DIM>(g, qx, qy, qz, cx, cy, cz, ball2, bkey, b2);
     if (need2) {
-      if (tb.ok) {
-        if (want) scan_shell2_tile<DIM, CAP>(g, wlds[wid].tile, tb, qx, qy, qz, cx, cy, cz, x0, x1, y0, y1, z0, z1, bkey, b2);
-      } else {
-        scan_shell2<DIM>(g, qx, qy, qz, cx, cy, cz, ball2, bkey, b2);
-      }
       best = key_best(bkey);
       bidx = key_idx(bkey);
       const bool found2 = bidx != NO_MATCH && best <= gfar;
@@ -1598,7 +1696,7 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
           const float rr2 = (sqrtf(best) + pad) * 1.00001f;
           ball2           = fminf(rr2 * rr2, gfar);
           r2              = 2;
-          while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
+          _Pragma("clang loop vectorize(disable) unroll(disable)") while (r2 < rfar && bound2_of(r2, g.h) < ball2) ++r2;
         }
       }
     }
@@ -3186,17 +3284,17 @@ extern "C" int srrg2_amd_debug_tile_stats(unsigned long long* out, int reset) {
 }
 #endif
 
-// the search pass of a batch with wave tiles in LDS (cap: candidates per wave tile, 336: four workgroups per CU, 512: three)
+// the search pass of a batch with wave tiles in LDS (cap: candidates per wave tile, 416: four workgroups per CU, 504: three)
 void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                           int max_nm, int cap, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
   dim3 grid((max_nm + 255) / 256, K);
 #define TILE_LAUNCH(D, P)                                                                            \
   do {                                                                                               \
-    if (cap > 400)                                                                                   \
-      hipLaunchKernelGGL((k_icp_step_tile<D, P, 512>), grid, dim3(256), 0, s, S, probs, states);      \
+    if (cap > 450)                                                                                   \
+      hipLaunchKernelGGL((k_icp_step_tile<D, P, 504>), grid, dim3(256), 0, s, S, probs, states);      \
     else                                                                                             \
-      hipLaunchKernelGGL((k_icp_step_tile<D, P, 336>), grid, dim3(256), 0, s, S, probs, states);      \
+      hipLaunchKernelGGL((k_icp_step_tile<D, P, 416>), grid, dim3(256), 0, s, S, probs, states);      \
   } while (0)
   if (dim == 3) {
     if (plane) TILE_LAUNCH(3, true); else TILE_LAUNCH(3, false);

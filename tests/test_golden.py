@@ -22,6 +22,17 @@ def _aligner(backend, oracle, kind):
     return pkg.MultiAligner(kind)
 
 
+def _H_of_last_iteration(al, backend, data, guess, with_normals=True):
+    """H = sum w J^T J (+ priors) of the last Gauss-Newton iteration.  The oracle exposes its last system; the product
+    exposes H through the batch result record (srrg2_batch_result::information, float32): the same alignment run once
+    more as a batch of one."""
+    if backend == "oracle":
+        return al.last_system()[0]
+    res = al.compute_batch([data["moving"]], [guess], [data["moving_normals"]] if with_normals else None)
+    assert res[0]["status"] == al.status()
+    return res[0]["information"].astype(np.float64)
+
+
 def _check_corr(c, idx, d2):
     sel = idx >= 0
     assert np.array_equal(c["moving_idx"], np.nonzero(sel)[0].astype(np.int32))
@@ -42,10 +53,13 @@ def test_one_iteration_se3(backend, oracle, gi, name, slice_kind, rob):
     _check_corr(al.correspondences(0), GOLD["a%d_idx" % gi], GOLD["a%d_d2" % gi])
     X_gold = GOLD["a%d_%s_X" % (gi, name)]
     assert np.max(np.abs(al.moving_in_fixed() - X_gold)) <= 1e-5  # increments within 1e-5 (north_star)
+    Hg = GOLD["a%d_%s_H" % (gi, name)]
+    H = _H_of_last_iteration(al, backend, d, GOLD["a%d_guess" % gi])
+    assert np.max(np.abs(H - Hg)) / np.max(np.abs(Hg)) < 1e-5  # float32 J entries vs float64 J (both backends)
+    assert np.max(np.abs(al.moving_in_fixed() - X_gold)) <= 1e-5  # (the batch of one ends on the same estimate)
     if backend == "oracle":
         H, b, dx = al.last_system()
-        Hg, bg, dxg = GOLD["a%d_%s_H" % (gi, name)], GOLD["a%d_%s_b" % (gi, name)], GOLD["a%d_%s_dx" % (gi, name)]
-        assert np.max(np.abs(H - Hg)) / np.max(np.abs(Hg)) < 1e-5  # float32 J entries vs float64 J
+        bg, dxg = GOLD["a%d_%s_b" % (gi, name)], GOLD["a%d_%s_dx" % (gi, name)]
         assert np.max(np.abs(b - bg)) / np.max(np.abs(bg)) < 1e-4
         assert np.max(np.abs(dx - dxg)) < 1e-5
 
@@ -59,9 +73,10 @@ def test_one_iteration_c1_se2(backend, oracle):
     assert al.compute() == abi.SUCCESS
     _check_corr(al.correspondences(0), GOLD["c_idx"], GOLD["c_d2"])
     assert np.max(np.abs(al.moving_in_fixed() - GOLD["c_X"])) <= 1e-5
+    H = _H_of_last_iteration(al, backend, d, syn.identity(2))
+    assert np.max(np.abs(H - GOLD["c_H"])) / np.max(np.abs(GOLD["c_H"])) < 1e-5
     if backend == "oracle":
         H, b, dx = al.last_system()
-        assert np.max(np.abs(H - GOLD["c_H"])) / np.max(np.abs(GOLD["c_H"])) < 1e-5
         assert np.max(np.abs(dx - GOLD["c_dx"])) < 1e-5
 
 
@@ -89,9 +104,10 @@ def test_reprojection_factor_against_finite_differences(backend, oracle):
     assert c["response"].tobytes() == GOLD_FD["r_resp"][sel].tobytes()
     assert al.iteration_stats()[0]["num_inliers"] == int(GOLD_FD["r_n"])
     assert np.max(np.abs(al.moving_in_fixed() - GOLD_FD["r_X"])) <= 1e-5
+    H = _H_of_last_iteration(al, backend, d, GOLD_FD["r_guess"])
+    assert np.max(np.abs(H - GOLD_FD["r_H"])) / np.max(np.abs(GOLD_FD["r_H"])) < 1e-4
     if backend == "oracle":
         H, b, dx = al.last_system()
-        assert np.max(np.abs(H - GOLD_FD["r_H"])) / np.max(np.abs(GOLD_FD["r_H"])) < 1e-4
         assert np.max(np.abs(b - GOLD_FD["r_b"])) / np.max(np.abs(GOLD_FD["r_b"])) < 1e-3
         assert np.max(np.abs(dx - GOLD_FD["r_dx"])) < 1e-5
 
@@ -107,7 +123,94 @@ def test_se3_euler_box_plus_against_finite_differences(backend, oracle, gi):
     assert al.compute() == abi.SUCCESS
     _check_corr(al.correspondences(0), GOLD_FD["e%d_idx" % gi], GOLD_FD["e%d_d2" % gi])
     assert np.max(np.abs(al.moving_in_fixed() - GOLD_FD["e%d_X" % gi])) <= 1e-5
+    H = _H_of_last_iteration(al, backend, d, GOLD_FD["e%d_guess" % gi])
+    assert np.max(np.abs(H - GOLD_FD["e%d_H" % gi])) / np.max(np.abs(GOLD_FD["e%d_H" % gi])) < 1e-5
     if backend == "oracle":
         H, b, dx = al.last_system()
-        assert np.max(np.abs(H - GOLD_FD["e%d_H" % gi])) / np.max(np.abs(GOLD_FD["e%d_H" % gi])) < 1e-5
         assert np.max(np.abs(dx - GOLD_FD["e%d_dx" % gi])) < 1e-5
+
+
+# ---- whole compute() calls (tests/golden/make_golden2.py): robustifier variants, inlier-only run, SE(2) plane, prior + cue
+GOLD2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icp_golden2.npz"))
+
+
+def _check_stats(stats, gold_rows, chi_rtol=2e-4):
+    """IterationStats of every iteration against the golden's [num_inliers, num_outliers, num_correspondences,
+    chi_inliers, chi_outliers]: counts exactly, chi sums to float32 accumulation accuracy"""
+    assert len(stats) == len(gold_rows)
+    for it, (s, gr) in enumerate(zip(stats, gold_rows)):
+        assert s["iteration"] == it and s["solver_status"] == 0
+        assert (s["num_inliers"], s["num_outliers"], s["num_correspondences"]) == (int(gr[0]), int(gr[1]), int(gr[2])), (it, s, gr)
+        assert abs(s["chi_inliers"] - gr[3]) <= chi_rtol * max(gr[3], 1e-6), (it, s, gr)
+        assert abs(s["chi_outliers"] - gr[4]) <= chi_rtol * max(gr[4], 1e-6), (it, s, gr)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_saturated_robustifier_then_inlier_only_clamp_run(backend, oracle):
+    """Saturated kernel for two iterations, then the inlier-only run with Clamp robustifiers
+    (multi_aligner_impl.cpp:163-211): statistics of all four iterations, the final H, estimate and correspondences"""
+    d = syn.cloud_pair_3d(n=2500, seed=777)
+    al = _aligner(backend, oracle, abi.SE3_QUAT_RIGHT)
+    al.set_params(max_iterations=2, min_num_inliers=10, enable_inlier_only_runs=True)
+    setup_pair(al, d, cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_SATURATED, 0.0008))
+    assert al.compute() == abi.SUCCESS
+    _check_stats(al.iteration_stats(), GOLD2["s_stats"])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD2["s_X"])) <= 1e-5
+    # the correspondences of the last iteration: same pairs; the responses differ from the golden's by the float32
+    # rounding of the estimate they were searched with (three Gauss-Newton steps in, the estimates agree to ~1e-7)
+    c, idx, d2 = al.correspondences(0), GOLD2["s_idx"], GOLD2["s_d2"]
+    sel = idx >= 0
+    assert np.array_equal(c["moving_idx"], np.nonzero(sel)[0].astype(np.int32))
+    assert np.array_equal(c["fixed_idx"], idx[sel])
+    assert np.max(np.abs(c["response"] - d2[sel])) <= 1e-6
+    H = _H_of_last_iteration(al, backend, d, syn.identity(3))
+    assert np.max(np.abs(H - GOLD2["s_H"])) / np.max(np.abs(GOLD2["s_H"])) < 1e-4
+    _check_stats(al.iteration_stats(), GOLD2["s_stats"])  # (the batch of one leaves the same statistics behind)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_se2_point_to_plane(backend, oracle):
+    d = syn.scan_pair_2d(beams=1000, seed=1200)
+    al = _aligner(backend, oracle, abi.SE2_RIGHT)
+    al.set_params(max_iterations=1)
+    setup_pair(al, d, cue_config(abi.SE2_RIGHT, abi.SLICE_P2PLANE, 0.5))
+    assert al.compute() == abi.SUCCESS
+    _check_corr(al.correspondences(0), GOLD2["l_idx"], GOLD2["l_d2"])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD2["l_X"])) <= 1e-5
+    st = al.iteration_stats()
+    assert len(st) == 1 and st[0]["num_inliers"] == int(np.sum(GOLD2["l_idx"] >= 0)) and st[0]["num_outliers"] == 0
+    assert abs(st[0]["chi_inliers"] - float(GOLD2["l_chi"])) <= 2e-4 * float(GOLD2["l_chi"])
+    H = _H_of_last_iteration(al, backend, d, syn.identity(2))
+    assert np.max(np.abs(H - GOLD2["l_H"])) / np.max(np.abs(GOLD2["l_H"])) < 1e-5
+    if backend == "oracle":
+        H, b, dx = al.last_system()
+        assert np.max(np.abs(b - GOLD2["l_b"])) / np.max(np.abs(GOLD2["l_b"])) < 1e-4
+        assert np.max(np.abs(dx - GOLD2["l_dx"])) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_prior_slice_next_to_a_cue_slice(backend, oracle):
+    """H and b summed over a point-to-point cue slice and an odometry-prior slice (multi_aligner_impl.cpp:144-160); the
+    golden linearises the prior e = t2v(Z^-1 X) by finite differences"""
+    from helpers import prior_config
+
+    d = syn.cloud_pair_3d(n=1500, seed=888)
+    al = _aligner(backend, oracle, abi.SE3_QUAT_RIGHT)
+    al.set_params(max_iterations=1, min_num_inliers=10)
+    setup_pair(al, d, cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2P, 0.25))
+    pi = al.add_slice(prior_config(abi.SE3_QUAT_RIGHT, info=[float(v) for v in GOLD2["p_info"]], sets_guess=0))
+    al.set_prior_measurement(pi, GOLD2["p_Z"])
+    al.set_moving_in_fixed(syn.identity(3))
+    assert al.compute() == abi.SUCCESS
+    _check_corr(al.correspondences(0), GOLD2["p_idx"], GOLD2["p_d2"])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD2["p_X"])) <= 1e-5
+    st = al.iteration_stats()
+    assert len(st) == 1 and st[0]["num_inliers"] == int(GOLD2["p_num_inliers"]) and st[0]["num_outliers"] == 0
+    assert st[0]["num_correspondences"] == int(np.sum(GOLD2["p_idx"] >= 0)) + 1  # priors count one (:275-285)
+    assert abs(st[0]["chi_inliers"] - float(GOLD2["p_chi_inliers"])) <= 2e-4 * float(GOLD2["p_chi_inliers"])
+    H = _H_of_last_iteration(al, backend, d, syn.identity(3))
+    assert np.max(np.abs(H - GOLD2["p_H"])) / np.max(np.abs(GOLD2["p_H"])) < 1e-5
+    if backend == "oracle":
+        H, b, dx = al.last_system()
+        assert np.max(np.abs(b - GOLD2["p_b"])) / np.max(np.abs(GOLD2["p_b"])) < 1e-4
+        assert np.max(np.abs(dx - GOLD2["p_dx"])) < 1e-5

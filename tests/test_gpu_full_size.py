@@ -91,3 +91,73 @@ def test_c5_full_size_pose_graph_properties(product):
     e0 = np.max(np.abs(g["poses_init"][:, :, 3] - g["poses_gt"][:, :, 3]))
     e1 = np.max(np.abs(poses[:, :, 3] - g["poses_gt"][:, :, 3]))
     assert e1 < 0.05 * e0, (e0, e1)
+
+
+def test_c4_benched_entry_point_device_batch_equals_host_batch_and_oracle(oracle, product):
+    """The path bench.py times for C4: compute_batch_device on 32 x 50 000 points resident in HBM.  Its result records
+    equal those of compute_batch on host clouds byte for byte (status, estimate, statistics, correspondence count, H), and
+    the oracle's batch of the same problems (sampled alignments: the oracle takes ~1 s each)."""
+    import torch
+
+    K, n = 32, 50_000
+    probs = syn.batch_3d(K=K, n=n, seed=4000, shared_fixed_group=1 << 30)
+    ident = syn.identity(3)
+    al = product.MultiAligner(abi.SE3_QUAT_RIGHT)
+    al.add_slice(_c2_cfg())
+    al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
+    host = al.compute_batch([p["moving"] for p in probs], [ident] * K, [p["moving_normals"] for p in probs])
+    host_bytes = bytes(host._raw)
+    coords = torch.from_numpy(np.concatenate([p["moving"] for p in probs], axis=0)).cuda()
+    normals = torch.from_numpy(np.concatenate([p["moving_normals"] for p in probs], axis=0)).cuda()
+    offsets = np.arange(K + 1, dtype=np.int32) * n
+    torch.cuda.synchronize()
+    dev = al.compute_batch_device(coords.data_ptr(), 12, normals.data_ptr(), 12, offsets, np.stack([ident] * K))
+    assert bytes(dev._raw) == host_bytes
+    assert all(r["status"] == abi.SUCCESS and r["num_iterations"] == 10 for r in dev)
+    # the handle's observable state is that of the last alignment of the batch, correspondences included
+    c_last = al.correspondences(0)
+    assert len(c_last) == dev[K - 1]["num_correspondences"] and al.status() == dev[K - 1]["status"]
+    assert al.moving_in_fixed().tobytes() == dev[K - 1]["moving_in_fixed"].tobytes()
+    # ... but the bound moving cloud is the batch: a plain compute() must bind its own first
+    with pytest.raises(RuntimeError, match="compute_batch"):
+        al.compute()
+    # the oracle on the same batch (three alignments of it: first, middle, last)
+    ref = oracle.OracleAligner(abi.SE3_QUAT_RIGHT)
+    ref.add_slice(_c2_cfg())
+    ref.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
+    for k in (0, 17, K - 1):
+        r = ref.compute_batch([probs[k]["moving"]], [ident], [probs[k]["moving_normals"]])[0]
+        g = dev[k]
+        assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes()
+        assert (r["status"], r["num_iterations"], r["num_correspondences"], r["last"]) == \
+               (g["status"], g["num_iterations"], g["num_correspondences"], g["last"])
+        assert np.array_equal(r["information"], g["information"])
+    c_ref = ref.correspondences(0)
+    assert np.array_equal(c_ref["fixed_idx"], c_last["fixed_idx"]) and np.array_equal(c_ref["moving_idx"], c_last["moving_idx"])
+    assert c_ref["response"].tobytes() == c_last["response"].tobytes()
+
+
+def test_device_resident_clouds_through_set_fixed_and_set_moving(oracle, product):
+    """SRRG2_MEM_DEVICE from Python: set_fixed / set_moving on clouds already in HBM (strided float4 records, as the scene
+    slices hand them over) give the run of the same clouds passed from host memory, and the oracle's"""
+    import torch
+
+    d = syn.cloud_pair_3d(n=30_000, seed=2100)
+    ref = oracle.OracleAligner(abi.SE3_QUAT_RIGHT)
+    setup_pair(ref, d, _c2_cfg())
+    assert ref.compute() == abi.SUCCESS
+
+    def padded(a):  # n x 4 float records: stride 16 bytes
+        out = np.zeros((a.shape[0], 4), np.float32)
+        out[:, :3] = a
+        return torch.from_numpy(out).cuda()
+
+    f, fn, m, mn = (padded(d[k]) for k in ("fixed", "fixed_normals", "moving", "moving_normals"))
+    torch.cuda.synchronize()
+    al = product.MultiAligner(abi.SE3_QUAT_RIGHT)
+    al.add_slice(_c2_cfg())
+    al.set_cloud_device("set_fixed", 0, f.data_ptr(), 16, fn.data_ptr(), 16, f.shape[0])
+    al.set_cloud_device("set_moving", 0, m.data_ptr(), 16, mn.data_ptr(), 16, m.shape[0])
+    al.set_moving_in_fixed(syn.identity(3))
+    assert al.compute() == abi.SUCCESS
+    assert_same_run(ref, al)

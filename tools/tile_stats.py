@@ -36,3 +36,7 @@ for it in range(4):
     print("iteration %s: " % (it if it < 3 else "3+") + ", ".join("%s %d" % (nm, x) for nm, x in zip(names, v)))
     print("   phase 1: %.1f%% staged, %.0f candidates / %.1f rows / %.1f lanes per wave; shell: %.1f%% of waves, %.1f%% staged, %.0f candidates, %.1f lanes"
           % (100.0 * v[1] / v[0], v[5] / v[0], v[6] / v[0], v[7] / v[0], 100.0 * v[8] / v[0], 100.0 * v[9] / max(v[8], 1), v[13] / max(v[8], 1), v[14] / max(v[8], 1)))
+v = [buf[48 + k] for k in range(4)]
+if v[0]:
+    print("first phase on staged tiles: %d waves; groups of four candidates executed per wave: %.1f row by row, %.1f if every lane "
+          "walked its own flattened list, %.1f on average per lane" % (v[0], v[1] / v[0], v[2] / v[0], v[3] / v[0] / 64.0))
