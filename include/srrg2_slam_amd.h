@@ -482,14 +482,12 @@ typedef struct srrg2_aligner_tuning {
   int32_t msort_key_bits;       /* SRRG2_AMD_MSORT_BITS: total bits of the (anisotropic) Morton key of the moving-cloud
                                    sort; 0 = automatic (15 for batches sorted in LDS, 18 for single clouds); -1 = the
                                    round-2 isotropic keys (4 / 5 / 6 bits per axis by batch size)                      */
-  int32_t fused_control;        /* SRRG2_AMD_FUSED_CONTROL: the control step of an iteration runs in the epilogue of the
-                                   last-arriving workgroup of its step kernel (1) or as its own launch (0); -1 = automatic */
   int32_t lds_tile;             /* SRRG2_AMD_LDS_TILE: search passes of batches stage each wave's neighbourhood of the
                                    fixed cloud in LDS (1) or gather it per lane (0); -1 = automatic                     */
   float   cell_target;          /* SRRG2_AMD_CELL_TARGET: points per occupied grid cell the automatic cell size aims at (8) */
   float   rmax_cap;             /* SRRG2_AMD_RMAX_CAP: largest cube radius (cells) needed to cover the gate; 0 = default
                                    (3 for 2-D clouds, none for 3-D)                                                    */
-  int32_t reserved_[9];
+  int32_t reserved_[10];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */
 void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t);

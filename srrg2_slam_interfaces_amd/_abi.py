@@ -110,11 +110,10 @@ class AlignerTuning(C.Structure):
         ("queue_min_points", C.c_int32),
         ("msort_segments", C.c_int32),
         ("msort_key_bits", C.c_int32),
-        ("fused_control", C.c_int32),
         ("lds_tile", C.c_int32),
         ("cell_target", C.c_float),
         ("rmax_cap", C.c_float),
-        ("reserved_", C.c_int32 * 9),
+        ("reserved_", C.c_int32 * 10),
     ]
 
 

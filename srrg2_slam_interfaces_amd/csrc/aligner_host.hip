@@ -371,7 +371,6 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   geti("SRRG2_AMD_QUEUE_MIN", t->queue_min_points);
   geti("SRRG2_AMD_MSORT_SEGMENTS", t->msort_segments);
   geti("SRRG2_AMD_MSORT_BITS", t->msort_key_bits);
-  geti("SRRG2_AMD_FUSED_CONTROL", t->fused_control);
   geti("SRRG2_AMD_LDS_TILE", t->lds_tile);
   getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
   getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
@@ -1060,7 +1059,6 @@ void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t) {
   t->queue_min_points       = 90000;
   t->msort_segments         = 0;
   t->msort_key_bits         = 0;
-  t->fused_control          = -1;
   t->lds_tile               = -1;
   t->cell_target            = 8.0f;
   t->rmax_cap               = 0.f;
