@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--points", type=int, default=100_000)
     ap.add_argument("--iterations", type=int, default=10)  # aligner.h:30
-    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default=None, choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--batch", type=int, default=32, help="c4 at N = 1: alignments per step")
     ap.add_argument("--total-alignments", type=int, default=256, help="c4 at N > 1: the job all ranks share")
     ap.add_argument("--batch-points", type=int, default=50_000)
@@ -50,13 +50,18 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    a.explicit_workload = a.workload is not None
     if a.workload is None:
         a.workload = "c2" if world == 1 else "c4"
+    fill_defaults(a, world)
+    return a
+
+
+def fill_defaults(a, world):
     if a.steps is None:
         a.steps = 200 if a.workload == "c2" else (100 if a.workload == "c3" else 20)
     if a.warmup is None:
         a.warmup = 20 if a.workload != "c4" else 3
-    return a
 
 
 def make_aligner(pkg_or_oracle_ctor, abi, iterations, cell_size=0.0):
@@ -74,8 +79,8 @@ def make_aligner(pkg_or_oracle_ctor, abi, iterations, cell_size=0.0):
     return al
 
 
-def main():
-    args = parse()
+def measure(args, init_dist=True):
+    """one workload (args.workload) on this rank's GPU: the bench line of that workload as a dict (rank 0), None elsewhere"""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,10 +100,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if init_dist:
+            if share:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import srrg2_slam_interfaces_amd as pkg
     from srrg2_slam_interfaces_amd import _abi as abi
@@ -192,13 +198,23 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # (a collection of the interpreter inside the timed loop -- the clouds of a 256-alignment batch are hundreds of numpy
+    # arrays -- shows up as a multi-millisecond step: collect before, keep the collector off while the steps are timed)
+    import gc
+
+    gc.collect()
+    gc.disable()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = step()
+        step_s.append(time.perf_counter() - ts)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     table = D.exchange_records(records(res), K_total, device=coll_device, mode=args.exchange)
     assert table.shape[0] == K_total
     all_success = bool(np.all(table[:, 12] == 0)) and bool(np.all(table[:, 13] == args.iterations))
@@ -226,7 +242,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return None
 
     # N > 1: the same job on ONE GPU (rank 0 alone, after the timed region), so that the line carries its own reference
     # for the strong-scaling ratio
@@ -269,6 +285,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "step_ms_min_median_max": [min(step_s) * 1e3, float(np.median(step_s)) * 1e3, max(step_s) * 1e3],
         "higher_is_better": True,
         "scaling": "strong" if (args.workload == "c4" and world > 1) else "weak",
         "vs_baseline": None,
@@ -280,8 +297,10 @@ def main():
                          (args.points, args.iterations)) if args.workload == "c2" else
                         ("C3: MultiAligner with 2 slices (projective + point-to-plane, projective + reprojection), "
                          "640x480 depth pair, %d iterations per compute()" % args.iterations) if args.workload == "c3" else
-                        ("C4: batched loop closure, %d independent %d-pt SE(3) point-to-plane alignments against one "
-                         "query map, sharded k -> k mod %d (%d per GPU per step), %d iterations each" %
+                        ("C4: batched loop closure, %d independent %d-pt SE(3) point-to-plane alignments against ONE query map "
+                         "shared by all alignments of a launch (the brute-force detector's loop: setFixed once, "
+                         "multi_loop_detector_brute_force_impl.cpp:63; SURVEY 8d's 'fixed shared per group of 8' is the "
+                         "8-per-launch line c4_8), sharded k -> k mod %d (%d per GPU per step = per launch), %d iterations each" %
                          (K_total, args.batch_points, world, len(mine), args.iterations)),
             "points": args.points if args.workload == "c2" else (int(data["moving"].shape[0]) if args.workload == "c3" else args.batch_points),
             "iterations_per_step": args.iterations,
@@ -296,7 +315,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("k_icp_step<3,true> [+ k_icp_step_queue<3,true>] / k_icp_step_fast<3,true> (one finder+factor pass of the slice)" if args.workload == "c2" else
-                       "k_icp_step<3,true> / k_icp_step_fast<3,true> (one finder+factor pass over all alignments of the launch)" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
+                       "k_icp_step_tile<3,true,416> (search passes) / k_icp_step_fast<3,true,1,true> (converged passes): one finder+factor pass over all alignments of the launch" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",
@@ -379,9 +398,111 @@ def main():
                 out["speedup_vs_cpu_all_cores"] = out["value"] / allc["value"]
             except Exception as e:  # the all-core figure is informative: never fail the bench line for it
                 out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
-    print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return out
+
+
+def measure_c5(cpu_seconds=30.0, with_cpu=True):
+    """C5: pose-graph Gauss-Newton solve, 50 000 SE(3) poses / 200 000 factors, 10 iterations, PCG tolerance 1e-6
+    (MultiGraphSLAM_::optimize -> global_solver->compute(), S/system/multi_graph_slam_impl.cpp:300-317)"""
+    import srrg2_slam_interfaces_amd as pkg
+    from srrg2_slam_interfaces_amd import _abi as abi
+    from srrg2_slam_interfaces_amd import posegraph as pgm
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    V, E = 50_000, 200_000
+    g = syn.pose_graph_3d(V=V, E=E, seed=5000)
+    E = int(g["ij"].shape[0])
+    pg = pkg.PoseGraph(abi.SE3_QUAT_RIGHT)
+    best, st = None, None
+    for _ in range(3):  # (the first solve also builds the structure of the multigrid hierarchy on the host)
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+        t0 = time.perf_counter()
+        st = pg.solve()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    pcg = sum(s_["pcg_iterations"] for s_ in st)
+    params = pgm.default_params()
+    converged = all(s_["solver_status"] == 0 and s_["pcg_iterations"] < params.pcg_max_iterations and
+                    s_["pcg_residual"] <= 1.01e-6 for s_ in st)
+    # SURVEY.md 8d: 94.8 MB per linearisation, 48.8 MB per PCG iteration (float32 spec; the solver stores float64 blocks)
+    alg = 94.8e6 * len(st) + 48.8e6 * pcg
+    out = {
+        "value": len(st) / best, "unit": "Gauss-Newton iterations/s", "ms_per_step": best * 1e3,
+        "config": {"workload": "C5: pose-graph GN solve, %d SE(3) poses / %d binary factors, %d Gauss-Newton iterations, PCG "
+                               "tolerance 1e-6 (CG preconditioned by a smoothed-aggregation multigrid V-cycle), pose 0 fixed" % (V, E, len(st)),
+                   "pcg_iterations": [s_["pcg_iterations"] for s_ in st], "chi_first_last": [st[0]["chi"], st[-1]["chi"]],
+                   "every_linear_solve_converged": bool(converged)},
+        "roofline": {"bound": "hbm", "kernel": "one PCG iteration = k_pg_spmv + V-cycle (k_mg_op x levels, k_mg_coarse_cycle) + vector kernels; "
+                                               "achieved = algorithmic bytes of the whole solve / its wall time",
+                     "achieved": alg / best / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / best / 1e9 / 8000.0,
+                     "traffic": None, "algorithmic_bytes": alg},
+    }
+    if with_cpu:
+        # CPU baseline = the oracle's solver (block-Jacobi PCG, one thread) run to CONVERGENCE on a bounded sample: the
+        # first Gauss-Newton iteration of the same graph with the iteration cap lifted (the full solve is ten such)
+        try:
+            from oracle import pyoracle
+
+            ref = pyoracle.OraclePoseGraph(abi.SE3_QUAT_RIGHT)
+            ref.set_graph(g["poses_init"], g["ij"], g["Z"])
+            p1 = pgm.default_params()
+            p1.max_iterations, p1.pcg_max_iterations = 1, 100000
+            t0 = time.perf_counter()
+            sr = ref.solve(p1)
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": 1.0 / cdt, "unit": "Gauss-Newton iterations/s", "cores": 1, "kind": "port",
+                "sample": "the first of the ten Gauss-Newton iterations, its linear solve run to the 1e-6 tolerance: %d "
+                          "block-Jacobi PCG iterations, %.1f s (oracle/o_posegraph.c, one thread)" % (sr[0]["pcg_iterations"], cdt),
+                "converged": bool(sr[0]["pcg_residual"] <= 1.01e-6), "pcg_iterations": sr[0]["pcg_iterations"],
+            }
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:  # (informative: never fail the bench line for it)
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    explicit = args.explicit_workload
+    if args.workload == "c5":  # (replicas only: the pose graph does not shard, SURVEY.md 8e)
+        r = measure_c5(with_cpu=not args.no_cpu_baseline)
+        line = {"metric": "posegraph_gauss_newton_iterations_per_sec", "n_gpus": 1, "steps": 3, "warmup": 0,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+        line.update(r)
+        print(json.dumps(line))
+        return
+    out = measure(args)
+    if out is None:
+        return
+    if world == 1 and not explicit:
+        # the default line: C2 is `value`; every other BASELINE configuration rides along as a nested object with its own
+        # value / ms_per_step / roofline, measured in this same process (VERDICT r2 #4)
+        import copy
+
+        def nested(workload, **over):
+            a = copy.copy(args)
+            a.workload, a.no_cpu_baseline = workload, True
+            a.steps, a.warmup = None, None
+            for k, v in over.items():
+                setattr(a, k, v)
+            fill_defaults(a, world)
+            r = measure(a)
+            return {k: r[k] for k in ("value", "unit", "ms_per_step", "step_ms_min_median_max", "steps", "config", "roofline",
+                                      "alignments_per_sec") if k in r}
+
+        try:
+            out["c3"] = nested("c3", steps=50, warmup=5)
+            out["c4_256"] = nested("c4", batch=256, steps=10, warmup=2)
+            out["c4_32"] = nested("c4", batch=32, steps=20, warmup=3)
+            out["c4_8"] = nested("c4", batch=8, steps=20, warmup=3)
+            out["c5"] = measure_c5(with_cpu=not args.no_cpu_baseline)
+        except Exception as e:  # (the headline must survive a failure of a side configuration; it is reported, not hidden)
+            out["nested_error"] = repr(e)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -1524,7 +1524,11 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
   if (offsets[K] > offsets[0] && !coords) return fail(SRRG2_E_INVALID, "compute_batch: null cloud");
   int rc;
   if ((rc = set_device(a))) return rc;
+  const auto t_up0 = std::chrono::steady_clock::now();
   if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false))) return rc;
+  if (a->hosttime)
+    std::fprintf(stderr, "compute_batch: upload_moving (enqueue) %.1f us\n",
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_up0).count());
   if ((rc = run_compute(a, K, offsets, guesses))) {
     // (run_compute may have failed before anything drained the stream: the ingest must have finished reading the
     // caller's buffer before this call returns, error or not)

@@ -286,6 +286,15 @@ struct MgLevel {  // device view of one level (level 0 = the pose graph without 
   double* Ps;                   // [np][D*D] smoothed interpolation
   double* Q;                    // [nq][D*D]
   double* Dinv;                 // [n][D*D] inverse diagonal blocks (smoother)
+  // float32 copies of Hd, Ho, Dinv, read by the V-cycle ONLY (k_mg_to_float, once per Gauss-Newton iteration).  The cycle
+  // is a preconditioner: any fixed symmetric positive definite operator will do, and one built from the blocks rounded to
+  // float32 -- used consistently in the down and the up sweep, accumulated in float64 -- is one (damped Jacobi stays
+  // convergent under a 6e-8 relative perturbation, the coarsest inverse and every Galerkin product stay float64).  CG's
+  // own operator (k_pg_spmv) reads the float64 blocks: THERE float32 loses the drift modes.
+  // Halves the bytes of the six residual passes of a cycle (C5: 2 x 72 + 2 x 78 MB on levels 0 and 1).
+  float* Hdf;
+  float* Hof;
+  float* Dinvf;
   double *x, *r, *res;          // [n][D] work vectors of the cycle
 };
 
@@ -316,18 +325,20 @@ __device__ __forceinline__ void mg_smooth0(const MgLevel& L, int tid, int nth) {
     const int v = t / D, row = t - v * D;
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) s = s + L.Dinv[((size_t) v * D + row) * D + c] * L.r[(size_t) v * D + c];
+    for (int c = 0; c < D; ++c) s = s + (double) L.Dinvf[((size_t) v * D + row) * D + c] * L.r[(size_t) v * D + c];
     L.x[t] = L.omega * s;
   }
 }
 
 // y_t = (H x)_t for row t of this level.  The incidence records carry the neighbour, so the loads of four incidences
 // (record, block row, neighbour's x) are independent and issued together: small levels are pure load latency.
-template <int D>
-__device__ __forceinline__ double mg_row(const MgLevel& L, const double* __restrict__ x, int v, int row) {
+// (BT: float64 blocks for CG's operator, the float32 copies inside the V-cycle)
+template <int D, typename BT>
+__device__ __forceinline__ double mg_row(const MgLevel& L, const BT* __restrict__ Hd, const BT* __restrict__ Ho,
+                                         const double* __restrict__ x, int v, int row) {
   double y = 0.0;
 #pragma unroll
-  for (int c = 0; c < D; ++c) y = y + L.Hd[((size_t) v * D + row) * D + c] * x[(size_t) v * D + c];
+  for (int c = 0; c < D; ++c) y = y + (double) Hd[((size_t) v * D + row) * D + c] * x[(size_t) v * D + c];
   const int q1 = L.inc_start[v + 1];
   for (int q0 = L.inc_start[v]; q0 < q1; q0 += 4) {
     int2 a[4];
@@ -338,14 +349,14 @@ __device__ __forceinline__ double mg_row(const MgLevel& L, const double* __restr
     for (int k = 0; k < 4; ++k) {
       s[k] = 0.0;
       if (a[k].x >= 0) {
-        const double* B  = L.Ho + (size_t) (a[k].y >> 1) * D * D;
+        const BT* B      = Ho + (size_t) (a[k].y >> 1) * D * D;
         const double* xo = x + (size_t) a[k].x * D;
         if (a[k].y & 1) {  // this node is j: H_ji = H_ij^T
 #pragma unroll
-          for (int c = 0; c < D; ++c) s[k] = s[k] + B[c * D + row] * xo[c];
+          for (int c = 0; c < D; ++c) s[k] = s[k] + (double) B[c * D + row] * xo[c];
         } else {
 #pragma unroll
-          for (int c = 0; c < D; ++c) s[k] = s[k] + B[row * D + c] * xo[c];
+          for (int c = 0; c < D; ++c) s[k] = s[k] + (double) B[row * D + c] * xo[c];
         }
       }
     }
@@ -355,12 +366,13 @@ __device__ __forceinline__ double mg_row(const MgLevel& L, const double* __restr
 }
 
 // the share of lane `part` (of `parts`) in (H x)_t: the diagonal block (part 0) and every parts-th group of four incidences
-template <int D>
-__device__ __forceinline__ double mg_row_part(const MgLevel& L, const double* __restrict__ x, int v, int row, int part, int parts) {
+template <int D, typename BT>
+__device__ __forceinline__ double mg_row_part(const MgLevel& L, const BT* __restrict__ Hd, const BT* __restrict__ Ho,
+                                              const double* __restrict__ x, int v, int row, int part, int parts) {
   double y = 0.0;
   if (part == 0) {
 #pragma unroll
-    for (int c = 0; c < D; ++c) y = y + L.Hd[((size_t) v * D + row) * D + c] * x[(size_t) v * D + c];
+    for (int c = 0; c < D; ++c) y = y + (double) Hd[((size_t) v * D + row) * D + c] * x[(size_t) v * D + c];
   }
   const int q1 = L.inc_start[v + 1];
   for (int q0 = L.inc_start[v] + 4 * part; q0 < q1; q0 += 4 * parts) {
@@ -372,14 +384,14 @@ __device__ __forceinline__ double mg_row_part(const MgLevel& L, const double* __
     for (int k = 0; k < 4; ++k) {
       s[k] = 0.0;
       if (a[k].x >= 0) {
-        const double* B  = L.Ho + (size_t) (a[k].y >> 1) * D * D;
+        const BT* B      = Ho + (size_t) (a[k].y >> 1) * D * D;
         const double* xo = x + (size_t) a[k].x * D;
         if (a[k].y & 1) {
 #pragma unroll
-          for (int c = 0; c < D; ++c) s[k] = s[k] + B[c * D + row] * xo[c];
+          for (int c = 0; c < D; ++c) s[k] = s[k] + (double) B[c * D + row] * xo[c];
         } else {
 #pragma unroll
-          for (int c = 0; c < D; ++c) s[k] = s[k] + B[row * D + c] * xo[c];
+          for (int c = 0; c < D; ++c) s[k] = s[k] + (double) B[row * D + c] * xo[c];
         }
       }
     }
@@ -396,14 +408,14 @@ __device__ __forceinline__ void mg_residual(const MgLevel& L, int tid, int nth) 
   if (parts == 1) {
     for (int t = tid; t < L.n * D; t += nth) {
       const int v = t / D, row = t - v * D;
-      L.res[t]    = L.r[t] - mg_row<D>(L, L.x, v, row);
+      L.res[t]    = L.r[t] - mg_row<D, float>(L, L.Hdf, L.Hof, L.x, v, row);
     }
     return;
   }
   for (int t = tid; t < L.n * D * parts; t += nth) {  // (nth and the bound are multiples of `parts`: whole groups run)
     const int part = t & (parts - 1), u = t / parts;
     const int v = u / D, row = u - v * D;
-    double y = mg_row_part<D>(L, L.x, v, row, part, parts);
+    double y = mg_row_part<D, float>(L, L.Hdf, L.Hof, L.x, v, row, part, parts);
     for (int off = parts >> 1; off >= 1; off >>= 1) y = y + __shfl_xor(y, off);
     if (part == 0) L.res[u] = L.r[u] - y;
   }
@@ -454,7 +466,7 @@ __device__ __forceinline__ void mg_update(const MgLevel& L, int tid, int nth) {
     const int v = t / D, row = t - v * D;
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) s = s + L.Dinv[((size_t) v * D + row) * D + c] * L.res[(size_t) v * D + c];
+    for (int c = 0; c < D; ++c) s = s + (double) L.Dinvf[((size_t) v * D + row) * D + c] * L.res[(size_t) v * D + c];
     L.x[t] = L.x[t] + L.omega * s;
   }
 }
@@ -739,6 +751,20 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(const MgLevel* __restric
   for (int k = 0; k < D * D; ++k) L.Dinv[(size_t) v * D * D + k] = bad ? 0.0 : Mi[k];
 }
 
+// the V-cycle's float32 copies of one level's blocks (see MgLevel)
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_to_float(const MgLevel* __restrict__ levels, int l) {
+  const MgLevel L = levels[l];
+  const size_t nd = (size_t) L.n * D * D, no = (size_t) L.ne * D * D;
+  for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < nd || k < no; k += (size_t) gridDim.x * blockDim.x) {
+    if (k < nd) {
+      L.Hdf[k]   = (float) L.Hd[k];
+      L.Dinvf[k] = (float) L.Dinv[k];
+    }
+    if (k < no) L.Hof[k] = (float) L.Ho[k];
+  }
+}
+
 // dense inverse of the coarsest operator: assemble, Cholesky in place, then one thread per column solves for the inverse
 template <int D>
 __global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(const MgLevel* __restrict__ levels, int l, double* __restrict__ Aglobal,
@@ -941,7 +967,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(const MgLevel* __restric
   double pap = 0.0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < L.n * D; t += gridDim.x * blockDim.x) {
     const int v = t / D, row = t - v * D;
-    const double y = mg_row<D>(L, p, v, row);
+    const double y = mg_row<D, double>(L, L.Hd, L.Ho, p, v, row);
     Ap[t] = y;
     pap   = pap + y * p[t];
   }
@@ -1007,13 +1033,13 @@ struct MgLevelBufs {
   DevBuf<int2> eij;
   DevBuf<int> inc_start, agg, rep0, prow_start, pcol, prow_of, pcsc_start, pcsc_ent, qrow_start, qcol, qrow_of;
   DevBuf<int2> inc_adj;
-  DevBuf<float> P;
+  DevBuf<float> P, Hdf, Hof, Dinvf;
   DevBuf<double> Hd, Ho, Ps, Q, Dinv, x, r, res;
   void release() {
     eij.release(); inc_start.release(); inc_adj.release(); agg.release(); rep0.release(); prow_start.release();
     pcol.release(); prow_of.release(); pcsc_start.release(); pcsc_ent.release(); qrow_start.release(); qcol.release();
     qrow_of.release(); Hd.release(); Ho.release(); P.release(); Ps.release(); Q.release(); Dinv.release(); x.release();
-    r.release(); res.release();
+    r.release(); res.release(); Hdf.release(); Hof.release(); Dinvf.release();
   }
 };
 
@@ -1180,7 +1206,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     if ((rc = L->Hd.reserve((size_t) std::max(n, 1) * D * D)) || (rc = L->Ho.reserve((size_t) std::max(ne, 1) * D * D)) ||
         (rc = L->P.reserve((size_t) std::max(n, 1) * D * D)) || (rc = L->Dinv.reserve((size_t) std::max(n, 1) * D * D)) ||
         (rc = L->x.reserve((size_t) std::max(n, 1) * D)) || (rc = L->r.reserve((size_t) std::max(n, 1) * D)) ||
-        (rc = L->res.reserve((size_t) std::max(n, 1) * D)))
+        (rc = L->res.reserve((size_t) std::max(n, 1) * D)) || (rc = L->Hdf.reserve((size_t) std::max(n, 1) * D * D)) ||
+        (rc = L->Hof.reserve((size_t) std::max(ne, 1) * D * D)) || (rc = L->Dinvf.reserve((size_t) std::max(n, 1) * D * D)))
       return rc;
     int free_nodes = 0;
     for (int v = 0; v < n; ++v) free_nodes += excluded[(size_t) v] ? 0 : 1;
@@ -1393,6 +1420,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     v.eij = L->eij.p; v.inc_start = L->inc_start.p; v.inc_adj = L->inc_adj.p; v.agg = L->agg.p; v.rep0 = L->rep0.p;
     v.prow_start = L->prow_start.p; v.pcol = L->pcol.p; v.prow_of = L->prow_of.p; v.pcsc_start = L->pcsc_start.p;
     v.pcsc_ent = L->pcsc_ent.p; v.qrow_start = L->qrow_start.p; v.qcol = L->qcol.p; v.qrow_of = L->qrow_of.p;
+    v.Hdf = L->Hdf.p; v.Hof = L->Hof.p; v.Dinvf = L->Dinvf.p;
     v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Ps = L->Ps.p; v.Q = L->Q.p; v.Dinv = L->Dinv.p; v.x = L->x.p;
     v.r = L->r.p; v.res = L->res.p;
   }
@@ -1504,6 +1532,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         if (!lds_ok) (void) hipGetLastError();
         hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), (size_t) in_lds * lds_need, g->stream, g->levels_dev.p,
                            nl, g->coarse_A.p, g->coarse_inv.p, g->sc.p, in_lds);
+      }
+      // the V-cycle's float32 copies of every level's blocks (the coarsest level is inverted, not cycled through)
+      for (int l = 0; l <= nl; ++l) {
+        const MgLevelBufs* L = g->levels[(size_t) l];
+        const size_t items   = std::max((size_t) L->n, (size_t) L->ne) * D * D;
+        hipLaunchKernelGGL(k_mg_to_float<D>, dim3((unsigned) std::min<size_t>(std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1), 4096)),
+                           dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
       }
     }
     // PCG: r lives in level 0's r (the cycle's input), z = level 0's x (its output)

@@ -1,11 +1,9 @@
-cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r3j; mkdir -p $O; R=$GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $O/pytest_parity.txt 2>&1; tail -3 $O/pytest_parity.txt
-timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
-A=$O/ab_fused.txt; rm -f $A
-bash tools/ab_env.sh $A "--workload c2" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1"
-bash tools/ab_env.sh $A "--workload c3" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1"
-bash tools/ab_env.sh $A "--workload c4 --batch 32" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1"
-bash tools/ab_env.sh $A "--workload c4 --batch 8" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1"
-bash tools/ab_env.sh $A "--workload c4 --batch 256 --steps 10" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1"
-bash tools/ab_env.sh $A "--workload c2 --points 10000" "SRRG2_AMD_FUSED_CONTROL=0" "SRRG2_AMD_FUSED_CONTROL=1"
-cat $A
+cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r3l; mkdir -p $O
+python bench.py --no-cpu-baseline > $O/b3.json 2>/dev/null
+python - $O/b3.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("c2", d["ms_per_step"], d["step_ms_min_median_max"])
+for k in ("c3","c4_256","c4_32","c4_8"):
+    r=d.get(k); print(k, round(r["value"],1), round(r["ms_per_step"],4), r["step_ms_min_median_max"])
+PY
