@@ -328,6 +328,8 @@ int srrg2_aligner_set_point_shard(srrg2_aligner_h h, srrg2_reduce_fn fn, void* u
 /* plain copies for bindings that cannot touch device memory themselves (kind 0: device -> host, 1: host -> device,
  * 2: device -> device; stream == NULL: synchronous, else asynchronous on that hipStream_t) */
 int srrg2_amd_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream);
+/* wait for everything queued on `stream` (the hipStream_t a reduction hook was handed) to finish */
+int srrg2_amd_stream_synchronize(void* stream);
 
 /* ---- pose graph: the global Solver of MultiGraphSLAM_ ---------------------- */
 /* MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317): graph->bindFactors();

@@ -14,15 +14,18 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <map>
 #include <queue>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "srrg2_slam_amd.hpp"
+#include "srrg2_slam_amd_multi_device.hpp"
 
 namespace srrg2_slam_amd {
 
@@ -147,6 +150,10 @@ public:
   using LoopClosureType    = LoopClosure<DIM>;
   // PARAMs, multi_loop_detector_brute_force.h:20-41
   AlignerType* param_relocalize_aligner    = nullptr;
+  // not in the reference (one process, one aligner): more handles with the same slices and PARAMs, one per device.  The
+  // candidates are then spread k -> handle k mod G over host threads (srrg2_slam_amd_multi_device.hpp); closures, drops and
+  // their order are those of the one-handle run.
+  std::vector<AlignerType*> param_relocalize_aligners;
   unsigned param_relocalize_min_inliers    = 500;
   float param_relocalize_max_chi_inliers   = 0.005f;
   float param_relocalize_min_inliers_ratio = 0.7f;
@@ -178,10 +185,16 @@ public:
       guesses.push_back(h.initial_guess);
     }
     if (clouds.empty()) return _detected_closures;
-    AlignerType& al = *param_relocalize_aligner;
-    al.setFixed(0, _fixed, DIM * 4, _fixed_normals, DIM * 4, _nfixed);
-    if (!all_normals) normals.clear();
-    const std::vector<srrg2_batch_result> results = al.computeBatch(clouds, sizes, normals, guesses);
+    if (!all_normals) {
+      for (const float* nm : normals)
+        if (nm) throw std::runtime_error("MultiLoopDetectorBruteForce_::compute| some hints carry normals and some do not");
+      normals.clear();
+    }
+    std::vector<AlignerType*> handles{param_relocalize_aligner};
+    handles.insert(handles.end(), param_relocalize_aligners.begin(), param_relocalize_aligners.end());
+    ShardedAligners<AlignerType> sharded(handles);
+    sharded.setFixed(0, _fixed, DIM * 4, _fixed_normals, DIM * 4, _nfixed);  // aligner->setFixed, once per handle (:63)
+    const std::vector<srrg2_batch_result> results = sharded.computeBatch(clouds, sizes, normals, guesses);
     for (size_t k = 0; k < results.size(); ++k) {
       const srrg2_batch_result& r = results[k];
       if (r.status != AlignerBase::Success) {  // :80-84
@@ -240,6 +253,7 @@ public:
   using LoopClosureType    = LoopClosure<DIM>;
   // PARAMs, multi_relocalizer.h:29-43, relocalizer.h:22
   AlignerType* param_aligner               = nullptr;
+  std::vector<AlignerType*> param_aligners;  // more handles, one per device (see MultiLoopDetectorBruteForce)
   float param_max_translation              = 3.0f;
   int param_relocalize_min_inliers         = 500;
   float param_relocalize_max_chi_inliers   = 0.005f;
@@ -292,22 +306,38 @@ public:
       }
       return _relocalization_map;
     }
+    {  // a candidate whose local map does not carry the slice cannot be aligned: dropped like a hint without one
+      std::vector<const Candidate*> with_cloud;
+      for (const Candidate* c : near) {
+        if (c->moving && c->size > 0)
+          with_cloud.push_back(c);
+        else
+          _drops.emplace_back(c->closure.target_graph_id, "NO_SLICE DROP");
+      }
+      near.swap(with_cloud);
+    }
     if (near.empty()) return -1;
-    AlignerType& al = *param_aligner;
-    al.setFixed(0, _fixed, DIM * 4, _fixed_normals, DIM * 4, _nfixed);
     std::vector<const float*> clouds, normals;
     std::vector<int> sizes;
     std::vector<EstimateType> guesses;
-    bool all_normals = true;
+    bool all_normals = true, any_normals = false;
     for (const Candidate* c : near) {
       clouds.push_back(c->moving);
       normals.push_back(c->moving_normals);
       all_normals = all_normals && c->moving_normals != nullptr;
+      any_normals = any_normals || c->moving_normals != nullptr;
       sizes.push_back(c->size);
       guesses.push_back(c->closure.pose_in_target.inverse());  // :91
     }
-    if (!all_normals) normals.clear();
-    const std::vector<srrg2_batch_result> results = al.computeBatch(clouds, sizes, normals, guesses);
+    if (!all_normals) {
+      if (any_normals) throw std::runtime_error("MultiRelocalizer_::compute| some candidates carry normals and some do not");
+      normals.clear();
+    }
+    std::vector<AlignerType*> handles{param_aligner};
+    handles.insert(handles.end(), param_aligners.begin(), param_aligners.end());
+    ShardedAligners<AlignerType> sharded(handles);
+    sharded.setFixed(0, _fixed, DIM * 4, _fixed_normals, DIM * 4, _nfixed);
+    const std::vector<srrg2_batch_result> results = sharded.computeBatch(clouds, sizes, normals, guesses);
     float best_chi_average = std::numeric_limits<float>::max();
     for (size_t k = 0; k < results.size(); ++k) {
       const srrg2_batch_result& r = results[k];

@@ -1281,6 +1281,11 @@ int srrg2_amd_memcpy(void* dst, const void* src, size_t bytes, int kind, void* s
   return 0;
 }
 
+int srrg2_amd_stream_synchronize(void* stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t) stream));
+  return 0;
+}
+
 int srrg2_aligner_set_sensor_in_robot(srrg2_aligner_h a, int si, const float* T) {
   int rc = check_slice(a, si, "set_sensor_in_robot");
   if (rc) return rc;

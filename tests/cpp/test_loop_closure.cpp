@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include "srrg2_slam_amd_loop_closure.hpp"
@@ -152,6 +154,107 @@ int main() {
     ASSERT_TRUE(cl.information[0] == 1.f && cl.information[7] == 1.f && cl.information[1] == 0.f);  // Omega = I (:120-131)
     ASSERT_TRUE(cl.aligner_information[0] > 0.f);  // H of the alignment travels with the record
     ASSERT_TRUE(!cl.enabled);
+  }
+
+  // ---- the same detection spread over TWO aligner handles (k -> handle k mod 2, one host thread each; here both on
+  // device 0, on a node one per GPU): closures, drops and their order are those of the one-handle run, byte for byte,
+  // and the record table (every handle fills its rows of a zero table, the tables are summed: the all-reduce of
+  // SURVEY.md 8e done in host memory) holds every record of the one-handle batch
+  {
+    MultiAligner3DQR aligner_b;
+    aligner_b.addSlice(c);
+    aligner_b.param_max_iterations = aligner.param_max_iterations;
+    const std::vector<LoopClosure<3>> single = closures;  // (copy: the detector's vector is rewritten below)
+    const std::vector<std::pair<int, std::string>> single_drops = detector.drops();
+    detector.param_relocalize_aligners = {&aligner_b};
+    const std::vector<LoopClosure<3>>& both = detector.compute(source, hints);
+    ASSERT_TRUE(both.size() == single.size() && detector.drops() == single_drops);
+    for (size_t k = 0; k < both.size() && k < single.size(); ++k) {
+      ASSERT_TRUE(both[k].target_graph_id == single[k].target_graph_id);
+      ASSERT_TRUE(std::memcmp(both[k].measurement.data(), single[k].measurement.data(), sizeof(float) * 12) == 0);
+      ASSERT_TRUE(std::memcmp(both[k].aligner_information, single[k].aligner_information, sizeof(both[k].aligner_information)) == 0);
+      ASSERT_TRUE(both[k].num_inliers == single[k].num_inliers && both[k].chi_inliers == single[k].chi_inliers);
+    }
+    // the batch itself and its record table
+    std::vector<const float*> cl, nr;
+    std::vector<int> sz;
+    std::vector<Isometry3f> gs;
+    for (const ClosureHint<3>& h : hints)
+      if (h.moving) {
+        cl.push_back(h.moving); nr.push_back(h.moving_normals); sz.push_back(h.size); gs.push_back(h.initial_guess);
+      }
+    aligner.setFixed(0, pts[(size_t) source].data(), 12, nrm[(size_t) source].data(), 12, N);
+    const std::vector<srrg2_batch_result> one = aligner.computeBatch(cl, sz, nr, gs);
+    ShardedAligners<MultiAligner3DQR> two({&aligner, &aligner_b});
+    two.setFixed(0, pts[(size_t) source].data(), 12, nrm[(size_t) source].data(), 12, N);
+    const std::vector<srrg2_batch_result> res2 = two.computeBatch(cl, sz, nr, gs);
+    ASSERT_TRUE(one.size() == res2.size());
+    for (size_t k = 0; k < one.size() && k < res2.size(); ++k) ASSERT_TRUE(std::memcmp(&one[k], &res2[k], sizeof(srrg2_batch_result)) == 0);
+    const std::vector<double> table = two.recordTable(res2, SRRG2_SE3_QUAT_RIGHT);
+    for (size_t k = 0; k < one.size(); ++k) {
+      double rec[SRRG2_RECORD_FLOATS];
+      ASSERT_TRUE(srrg2_multi_gpu_pack_record((int) k, SRRG2_SE3_QUAT_RIGHT, &one[k], rec) == 0);
+      ASSERT_TRUE(std::memcmp(rec, table.data() + k * SRRG2_RECORD_FLOATS, sizeof(rec)) == 0);
+    }
+    detector.param_relocalize_aligners.clear();
+    detector.compute(source, hints);  // (back to the one-handle state the checks below read)
+
+    // ---- ONE alignment sharded by moving points over two handles of this process (srrg2_aligner_set_point_shard): the
+    // reduction hook adds the handles' integer sums through host memory before every control step; estimate and
+    // statistics are bit for bit those of the unsharded alignment, whatever the deal (here: even / odd points)
+    const int target = hints[0].local_map_id;
+    aligner.setFixed(0, pts[(size_t) source].data(), 12, nrm[(size_t) source].data(), 12, N);
+    aligner.setMoving(0, pts[(size_t) target].data(), 12, nrm[(size_t) target].data(), 12, N);
+    aligner.setMovingInFixed(hints[0].initial_guess);
+    aligner.compute();
+    const Isometry3f X_whole = aligner.movingInFixed();
+    const IterationStatsVector st_whole = aligner.iterationStats();
+    std::vector<float> half_p[2], half_n[2];
+    for (int i = 0; i < N; ++i)
+      for (int a = 0; a < 3; ++a) {
+        half_p[i & 1].push_back(pts[(size_t) target][(size_t) i * 3 + a]);
+        half_n[i & 1].push_back(nrm[(size_t) target][(size_t) i * 3 + a]);
+      }
+    MultiAligner3DQR* hs[2] = {&aligner, &aligner_b};
+    auto run_sharded = [&](srrg2_reduce_fn hook, void* user0, void* user1) {
+      void* users[2] = {user0, user1};
+      std::vector<std::thread> th;
+      for (int g = 0; g < 2; ++g)
+        th.emplace_back([&, g]() {
+          hs[g]->setFixed(0, pts[(size_t) source].data(), 12, nrm[(size_t) source].data(), 12, N);
+          hs[g]->setMoving(0, half_p[g].data(), 12, half_n[g].data(), 12, (int) half_p[g].size() / 3);
+          hs[g]->setPointShard(hook, users[g], N);
+          hs[g]->setMovingInFixed(hints[0].initial_guess);
+          hs[g]->compute();
+        });
+      for (std::thread& t : th) t.join();
+    };
+    {
+      HostPointShardReducer red(2);
+      run_sharded(&HostPointShardReducer::hook, red.participant(0), red.participant(1));
+      for (int g = 0; g < 2; ++g) {
+        ASSERT_TRUE(std::memcmp(hs[g]->movingInFixed().data(), X_whole.data(), sizeof(float) * 12) == 0);
+        const IterationStatsVector& sg = hs[g]->iterationStats();
+        ASSERT_TRUE(sg.size() == st_whole.size());
+        for (size_t i = 0; i < sg.size() && i < st_whole.size(); ++i) ASSERT_TRUE(std::memcmp(&sg[i], &st_whole[i], sizeof(IterationStats)) == 0);
+        hs[g]->setPointShard(nullptr, nullptr, 0);
+      }
+    }
+    // ... and the RCCL hook (librccl.so opened at run time): a one-rank communicator on this box -- the hook, its
+    // collective and the stream ordering with nothing to add -- must leave the plain alignment's bits
+    try {
+      RcclPointShardReducer rccl({0});
+      aligner.setMoving(0, pts[(size_t) target].data(), 12, nrm[(size_t) target].data(), 12, N);
+      aligner.setPointShard(&RcclPointShardReducer::hook, rccl.participant(0), N);
+      aligner.setMovingInFixed(hints[0].initial_guess);
+      aligner.compute();
+      ASSERT_TRUE(std::memcmp(aligner.movingInFixed().data(), X_whole.data(), sizeof(float) * 12) == 0);
+      aligner.setPointShard(nullptr, nullptr, 0);
+      std::printf("RCCL point-shard hook: one-rank communicator ok\n");
+    } catch (const std::runtime_error& e) {
+      std::fprintf(stderr, "RCCL hook: %s\n", e.what());
+      ++g_failures;
+    }
   }
 
   // MultiRelocalizer_ without an aligner: the best closure on the detector's statistics (multi_relocalizer_impl.cpp:27-66)
