@@ -1,21 +1,40 @@
-// srrg2_slam_amd_adapter.hpp -- the reference-side adapter: classes with the reference's
-// registry names and PARAMs that forward to the C ABI of srrg2_slam_amd.h, so that BOSS configurations written for
-// srrg2_laser_slam_2d / srrg2_proslam deserialise into them unchanged.
+// srrg2_slam_amd_adapter.hpp -- the reference-side adapter.
 //
-// This header needs the reference's own dependencies -- srrg2_core (srrg_config, srrg_property, srrg_pcl,
-// srrg_geometry) and srrg2_solver (IterationStats, VariableSE{2,3}...AD) -- which are NOT part of this repository and
-// not present in the build image.  It is therefore guarded: without <srrg_config/configurable.h> on the include path it
-// compiles to nothing (tests/test_abi_exports.py compiles it that way); inside a catkin workspace that has srrg2_core it
-// is a drop-in next to S/registration/aligners/multi_aligner.h.  Nothing in this repository's tests depends on it; the
-// same forwarding logic, on types this repository can compile, is include/srrg2_slam_amd.hpp (tested on the GPU).
+// WHAT IT IS.  A replacement of ONE class of the reference, under the reference's own name:
+//     srrg2_slam_interfaces::MultiAlignerBase_<VariableType_>      (S/registration/aligners/multi_aligner.h:19-150)
+// with the same base class (Aligner_<EstimateType, PropertyContainerBase, PropertyContainerBase>), the same PARAMs under
+// the same names (slice_processors, solver, min_num_inliers, enable_inlier_only_runs, keep_only_inlier_correspondences,
+// multi_aligner.h:34-57; max_iterations and termination_criteria come from AlignerBase, aligner.h:30-35) and the same
+// type aliases MultiAligner2D / MultiAligner3D / MultiAligner3DQR (multi_aligner.h:152-159).  In a workspace it takes the
+// place of multi_aligner.h + multi_aligner_impl.cpp and nothing else: S/instances.cpp:35-40 keeps registering
+// "MultiAligner2D", the prior slices "AlignerSliceOdom2DPrior" / "AlignerSliceOdom3DPrior" / "AlignerSliceMotionModel2D" /
+// "AlignerSliceMotionModel3D" and the termination criteria "AlignerTerminationCriteriaStandard2D" / "...3DQR" exactly as
+// before -- they are the reference's OWN classes and stay untouched -- so a BOSS configuration written for the reference
+// (or for srrg2_laser_slam_2d / srrg2_proslam on top of it) deserialises unchanged:
+//   * `slice_processors` holds the reference's slice BASE type, AlignerSliceProcessorBase_<BaseVariableType>
+//     (aligner_slice_processor_base.h:19): any registered slice -- prior slice, motion-model slice, a downstream cue
+//     slice (a subclass of AlignerSliceProcessor_, aligner_slice_processor.h:26-66, with its `finder` sub-configurable,
+//     `min_num_correspondences`, `robustifier`, `fixed_slice_name`, ...) -- goes into it;
+//   * prior slices keep THEIR logic: this class is MultiAlignerBase_, which the slice classes befriend
+//     (aligner_slice_processor_base.h:30-31, aligner_slice_processor_prior.h:31-32), so it calls slice->init(this) as the
+//     reference does in _preCompute (multi_aligner_impl.cpp:131-141) -- the slice computes its measurement
+//     (aligner_slice_odometry_prior.cpp:6-37: delta = fixed^-1 * moving from the second call on;
+//     aligner_slice_motion_model.hpp:44-79: the motion model's inverse estimate) and overrides the initial guess through
+//     aligner->setMovingInFixed() -- and then reads measurement and information matrix off the slice's own factor
+//     (SE2PriorErrorFactor / SE3PriorErrorFactorAD) into a SRRG2_SLICE_PRIOR slice of the C ABI;
+//   * cue slices are translated by a small registry (CueSliceRegistry below): the factor type says which rows the device
+//     evaluates (srrg2_slice_kind), the slice's `finder` sub-configurable gives the gate.  The reference ships NO concrete
+//     cue slice or finder (they live in srrg2_laser_slam_2d / srrg2_proslam, not a build dependency: SURVEY.md 8c), so the
+//     translators for those are one registration line each in the downstream package's registerTypes(), next to its
+//     BOSS_REGISTER_CLASS line; the PARAM names of the configuration files do not change;
+//   * termination criteria: param_termination_criteria holds the reference's AlignerTerminationCriteriaStandard_
+//     (aligner_termination_criteria.h:40-56); its five PARAMs travel through srrg2_termination_params, the windows run on
+//     the device with the reference's quirks (aligner_termination_criteria_impl.cpp:46,53).
 //
-// What is mirrored, PARAM by PARAM:
-//   MultiAlignerAMD_<Variable>             MultiAlignerBase_<Variable>             multi_aligner.h:19-150 (PARAMs :34-57)
-//     + AlignerBase PARAMs max_iterations, termination_criteria                  aligner.h:30-35
-//   AlignerSliceProcessorAMD_<Variable>    AlignerSliceProcessor_<Factor,Fixed,Moving>  aligner_slice_processor.h:56-66,133-150
-//     + base PARAMs robustifier, fixed_slice_name, moving_slice_name, frame_id, base_frame_id   aligner_slice_processor_base.h:34-53
-//   AlignerTerminationCriteriaStandard_    kept as is (its PARAMs travel through srrg2_termination_params) aligner_termination_criteria.h:40-56
-//   registration                           BOSS_REGISTER_CLASS names of instances.cpp:21-23,28-84 / instances.h:36-38,77
+// WHAT IT NEEDS.  srrg2_core and srrg2_solver, which are NOT part of this repository and not present in the build image:
+// the header is guarded and compiles to nothing without them (tests/test_abi_exports.py compiles it that way).  No
+// stand-in headers are provided.  Nothing in this repository's tests depends on it; the same forwarding logic on types this
+// repository can compile is include/srrg2_slam_amd.hpp (tested on the GPU).
 #pragma once
 
 #if defined(__has_include)
@@ -35,12 +54,20 @@
 #include <srrg_property/property_container.h>
 #include <srrg_solver/solver_core/iteration_stats.h>
 #include <srrg_solver/solver_core/robustifier.h>
+#include <srrg_solver/solver_core/solver.h>
+#include <srrg_solver/variables_and_factors/types_2d/se2_prior_error_factor.h>
 #include <srrg_solver/variables_and_factors/types_2d/variable_se2_ad.h>
+#include <srrg_solver/variables_and_factors/types_3d/se3_prior_error_factor_ad.h>
 #include <srrg_solver/variables_and_factors/types_3d/variable_se3_ad.h>
 
+// the reference's own headers that stay in place (this header replaces multi_aligner.h only)
 #include <srrg2_slam_interfaces/registration/aligners/aligner.h>
+#include <srrg2_slam_interfaces/registration/aligners/aligner_slice_processor.h>
+#include <srrg2_slam_interfaces/registration/aligners/aligner_slice_processor_base.h>
 #include <srrg2_slam_interfaces/registration/aligners/aligner_termination_criteria.h>
 
+#include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -79,126 +106,143 @@ namespace srrg2_slam_interfaces {
       for (int r = 0; r < Dim; ++r)
         for (int c = 0; c <= Dim; ++c) T.matrix()(r, c) = in[r * (Dim + 1) + c];
     }
+    inline void robustifierOf(RobustifierBase* rob, srrg2_slice_config& c) {  // RobustifierCauchy / Saturated / Clamp -> kind + threshold
+      c.robustifier = SRRG2_ROBUST_NONE;
+      if (!rob) return;
+      c.robustifier_chi_threshold = rob->param_chi_threshold.value();
+      c.robustifier               = dynamic_cast<RobustifierCauchy*>(rob)      ? SRRG2_ROBUST_CAUCHY
+                                    : dynamic_cast<RobustifierSaturated*>(rob) ? SRRG2_ROBUST_SATURATED
+                                    : dynamic_cast<RobustifierClamp*>(rob)     ? SRRG2_ROBUST_CLAMP
+                                                                               : SRRG2_ROBUST_NONE;
+    }
   }  // namespace amd_detail
 
-  // One cue slice: the PARAMs of AlignerSliceProcessor_ and of its base, plus what the C ABI needs to know about the
-  // factor and the finder that the reference expresses through template arguments and sub-configurables.
-  template <typename VariableType_>
-  class AlignerSliceProcessorAMD_ : public Configurable {
-  public:
-    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
-    using VariableType = VariableType_;
-    using EstimateType = typename VariableType::EstimateType;
-    // aligner_slice_processor_base.h:34-53
-    PARAM(PropertyConfigurable_<RobustifierBase>, robustifier, "robustifier used on this slice", 0, 0);
-    PARAM(PropertyString, fixed_slice_name, "name of the slice in the fixed scene", "", 0);
-    PARAM(PropertyString, moving_slice_name, "name of the slice in the moving scene", "", 0);
-    PARAM(PropertyString, frame_id, "name of the sensor's frame in the tf tree", "", nullptr);
-    PARAM(PropertyString, base_frame_id, "name of the base frame in the tf tree", "", nullptr);
-    // aligner_slice_processor.h:56-66 (the finder is a sub-configurable there; its PARAMs are flattened here)
-    PARAM(PropertyInt, min_num_correspondences, "minimum number of correspondences in this slice", 0, 0);
-    PARAM(PropertyInt, slice_kind, "srrg2_slice_kind: 0 point-to-point, 1 point-to-plane, 2 reprojection", SRRG2_SLICE_P2P, 0);
-    PARAM(PropertyInt, finder_kind, "srrg2_finder_kind: 1 gated nearest neighbour, 2 projective", SRRG2_FINDER_NN_GATED, 0);
-    PARAM(PropertyFloat, finder_max_distance, "finder gate [m]", 1.0f, 0);
-    PARAM(PropertyFloat, finder_normal_cos, "accept only if n_f . (R n_m) > this; <= -1 disables", -2.0f, 0);
-
-    // setSensorInRobot (aligner_slice_processor.h:149); looked up on every setMovingInFixed (_impl.cpp:20-36)
-    void setSensorInRobot(const EstimateType& sensor_in_robot_) { _sensor_in_robot = sensor_in_robot_; }
-    const EstimateType& sensorInRobot() const { return _sensor_in_robot; }
-    void setPlatform(PlatformPtr platform_) { _platform = platform_; }
-    // the per-compute lookup of aligner_slice_processor_impl.cpp:24-33
-    void updateSensorInRobot() {
-      if (!_platform || param_frame_id.value().empty() || param_base_frame_id.value().empty()) return;
-      EstimateType T;
-      if (_platform->getTransform(T, param_frame_id.value(), param_base_frame_id.value())) _sensor_in_robot = T;
-    }
-    srrg2_slice_config config() const {
-      srrg2_slice_config c;
-      srrg2_slice_default_config(&c, amd_detail::variableKind<VariableType>());
-      c.kind                    = param_slice_kind.value();
-      c.finder                  = param_finder_kind.value();
-      c.finder_max_distance     = param_finder_max_distance.value();
-      c.finder_normal_cos       = param_finder_normal_cos.value();
-      c.min_num_correspondences = param_min_num_correspondences.value();
-      amd_detail::toRowMajor(_sensor_in_robot, c.sensor_in_robot);
-      if (auto rob = param_robustifier.value()) {  // RobustifierCauchy / Saturated / Clamp -> kind + chi_threshold
-        c.robustifier_chi_threshold = rob->param_chi_threshold.value();
-        c.robustifier               = dynamic_cast<RobustifierCauchy*>(rob.get())      ? SRRG2_ROBUST_CAUCHY
-                                      : dynamic_cast<RobustifierSaturated*>(rob.get()) ? SRRG2_ROBUST_SATURATED
-                                      : dynamic_cast<RobustifierClamp*>(rob.get())     ? SRRG2_ROBUST_CLAMP
-                                                                                       : SRRG2_ROBUST_NONE;
-      }
-      return c;
-    }
-
-  protected:
-    EstimateType _sensor_in_robot = EstimateType::Identity();
-    PlatformPtr _platform         = nullptr;
+  // ---- cue slices: what the device needs to know about a downstream slice type ------------------------------------------
+  // A cue slice is an AlignerSliceProcessor_<FactorType, FixedCloud, MovingCloud> of a downstream package.  Its
+  // translator fills, from the LIVE slice object (so every PARAM of the configuration is honoured):
+  //   * the factor rows the device evaluates (srrg2_slice_kind) and the finder (srrg2_finder_kind + gate, normal gate,
+  //     camera matrix for projective finders) into `config`;
+  //   * the bound clouds as strided float arrays (coordinates / normals of the slice's _fixed_slice / _moving_slice).
+  // registerCueSlice<SliceType>(slice_kind, finder_translator) covers the common case: clouds of points with
+  // coordinates() and normal() (PointNormal2f / PointNormal3f ...), the finder read through `finder_translator`.
+  struct CueBinding {
+    srrg2_slice_config config;
+    const float* fixed_coords = nullptr;   const float* fixed_normals = nullptr;   int fixed_stride = 0;   int fixed_size = 0;
+    const float* moving_coords = nullptr;  const float* moving_normals = nullptr;  int moving_stride = 0;  int moving_size = 0;
   };
+  template <typename BaseVariableType_>
+  class CueSliceRegistry {
+  public:
+    using SliceBase  = AlignerSliceProcessorBase_<BaseVariableType_>;
+    using Translator = std::function<bool(SliceBase*, CueBinding&)>;  // false: not my slice type
+    static std::vector<Translator>& translators() {
+      static std::vector<Translator> t;
+      return t;
+    }
+    static bool translate(SliceBase* slice, CueBinding& out) {
+      for (const Translator& t : translators())
+        if (t(slice, out)) return true;
+      return false;
+    }
+  };
+  // SliceType: the downstream AlignerSliceProcessor_ subclass; FinderFn: void(FinderType&, srrg2_slice_config&) reads the
+  // finder's PARAMs (e.g. c.finder = SRRG2_FINDER_NN_GATED; c.finder_max_distance = finder.param_max_distance_m.value();)
+  template <typename SliceType, typename FinderFn>
+  inline void registerCueSlice(int slice_kind, FinderFn finder_fn) {
+    using BaseVariableType = typename SliceType::BaseVariableType;
+    using Registry         = CueSliceRegistry<BaseVariableType>;
+    Registry::translators().push_back([slice_kind, finder_fn](typename Registry::SliceBase* base, CueBinding& b) -> bool {
+      SliceType* s = dynamic_cast<SliceType*>(base);
+      if (!s) return false;
+      srrg2_slice_default_config(&b.config, amd_detail::variableKind<typename SliceType::VariableType>());
+      b.config.kind                    = slice_kind;
+      b.config.min_num_correspondences = s->param_min_num_correspondences.value();  // aligner_slice_processor.h:62-66
+      amd_detail::robustifierOf(s->param_robustifier.value().get(), b.config);     // aligner_slice_processor_base.h:34-38
+      if (!s->param_finder.value())
+        throw std::runtime_error("MultiAlignerBase_|cue slice without a finder (aligner_slice_processor_impl.cpp:8-17)");
+      finder_fn(*s->param_finder.value(), b.config);                                // aligner_slice_processor.h:56-60
+      using FixedPoint  = typename SliceType::FixedPointType;
+      using MovingPoint = typename SliceType::MovingPointType;
+      if (auto* f = s->fixed()) {
+        b.fixed_size = (int) f->size();  b.fixed_stride = (int) sizeof(FixedPoint);
+        if (!f->empty()) { b.fixed_coords = f->front().coordinates().data();  b.fixed_normals = f->front().normal().data(); }
+      }
+      if (auto* m = s->moving()) {
+        b.moving_size = (int) m->size();  b.moving_stride = (int) sizeof(MovingPoint);
+        if (!m->empty()) { b.moving_coords = m->front().coordinates().data();  b.moving_normals = m->front().normal().data(); }
+      }
+      return true;
+    });
+  }
 
+  // ---- MultiAlignerBase_ : the reference's class name, PARAMs and base class; the registration runs on the device -------
   template <typename VariableType_>
-  class MultiAlignerAMD_
+  class MultiAlignerBase_
     : public Aligner_<typename VariableType_::EstimateType, PropertyContainerBase, PropertyContainerBase> {
   public:
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
-    using VariableType = VariableType_;
-    using EstimateType = typename VariableType::EstimateType;
-    using BaseType     = Aligner_<EstimateType, PropertyContainerBase, PropertyContainerBase>;
-    using SliceType    = AlignerSliceProcessorAMD_<VariableType>;
+    using VariableType     = VariableType_;
+    using BaseVariableType = typename VariableType::BaseVariableType;
+    using EstimateType     = typename VariableType::EstimateType;
+    using BaseType         = Aligner_<EstimateType, PropertyContainerBase, PropertyContainerBase>;
+    using AlignerSliceProcessorType    = AlignerSliceProcessorBase_<BaseVariableType>;
+    using AlignerSliceProcessorTypePtr = std::shared_ptr<AlignerSliceProcessorType>;
     static constexpr int Dim = EstimateType::Dim;
-    using PointCloudType =
-      typename std::conditional<Dim == 2, PointNormal2fVectorCloud, PointNormal3fVectorCloud>::type;
+    static constexpr int D   = Dim == 2 ? 3 : 6;
 
-    // multi_aligner.h:34-57 (the solver PARAM has no counterpart: the one-variable Gauss-Newton step runs on the device)
-    PARAM_VECTOR(PropertyConfigurableVector_<SliceType>, slice_processors, "slices", &(this->_slices_changed_flag));
+    // multi_aligner.h:34-57, names and defaults unchanged (`solver` is accepted and ignored: the one-variable Gauss-Newton
+    // step of multi_aligner_impl.cpp:112 runs on the device; a configuration that sets it still loads)
+    PARAM_VECTOR(PropertyConfigurableVector_<AlignerSliceProcessorType>, slice_processors, "slices", &(this->_slices_changed_flag));
+    PARAM(PropertyConfigurable_<Solver>, solver, "this solver", std::shared_ptr<Solver>(new Solver), nullptr);
     PARAM(PropertyInt, min_num_inliers, "minimum number ofinliers", 10, nullptr);
-    PARAM(PropertyBool,
-          enable_inlier_only_runs,
-          "toggles additional inlier only runs if sufficient inliers are available",
-          false,
-          nullptr);
+    PARAM(PropertyBool, enable_inlier_only_runs, "toggles additional inlier only runs if sufficient inliers are available", false, nullptr);
     PARAM(PropertyBool,
           keep_only_inlier_correspondences,
           "toggles removal of correspondences which factors are not inliers in the last iteration",
           false,
           nullptr);
-    PARAM(PropertyInt, device, "HIP device ordinal", 0, nullptr);
 
-    MultiAlignerAMD_() = default;
-    virtual ~MultiAlignerAMD_() {
+    MultiAlignerBase_() = default;
+    virtual ~MultiAlignerBase_() {
       if (_h) srrg2_aligner_destroy(_h);
     }
+    // HIP device ordinal of this aligner (not a PARAM: configurations do not know about devices)
+    void setDevice(int device_) {
+      _device              = device_;
+      _slices_changed_flag = true;
+    }
 
-    // multi_aligner_impl.cpp:8-24: every slice finds its cloud by name in the scene and binds it
-    void setFixed(PropertyContainerBase* fixed_) override {
-      BaseType::setFixed(fixed_);
-      bindSlices();
-      for (size_t i = 0; i < param_slice_processors.size(); ++i)
-        bindCloud(fixed_, param_slice_processors.value(i)->param_fixed_slice_name.value(), (int) i, true);
+    // multi_aligner_impl.cpp:8-24: every slice demuxes the scene itself (bindFixed / bindMoving find the cloud by name in
+    // its three storage forms, aligner_slice_processor_base_impl.cpp:27-50)
+    void setFixed(PropertyContainerBase* fixed_scene_) override {
+      BaseType::setFixed(fixed_scene_);
+      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->setFixed(fixed_scene_);
+      _clouds_changed = true;
     }
-    void setMoving(PropertyContainerBase* moving_) override {
-      BaseType::setMoving(moving_);
-      bindSlices();
-      for (size_t i = 0; i < param_slice_processors.size(); ++i)
-        bindCloud(moving_, param_slice_processors.value(i)->param_moving_slice_name.value(), (int) i, false);
+    void setMoving(PropertyContainerBase* moving_scene_) override {
+      BaseType::setMoving(moving_scene_);
+      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->setMoving(moving_scene_);
+      _clouds_changed = true;
     }
-    // multi_aligner_impl.cpp:27-44
+    // multi_aligner_impl.cpp:27-44 (also what a prior slice's init() calls to override the guess)
     void setMovingInFixed(const EstimateType& moving_in_fixed_) override {
-      bindSlices();
-      float T[12];
-      amd_detail::toRowMajor(moving_in_fixed_, T);
-      amd_detail::check(srrg2_aligner_set_moving_in_fixed(_h, T));
+      if (!param_slice_processors.size()) throw std::runtime_error("MultiAlignerBase_::setMovingInFixed|no slices");  // :30
       this->_moving_in_fixed = moving_in_fixed_;
     }
+    const EstimateType& movingInFixed() const override { return this->_moving_in_fixed; }
+
     // multi_aligner_impl.cpp:47-95: blocking; status, estimate and iteration statistics are host visible on return
     void compute() override {
+      if (!param_slice_processors.size()) throw std::runtime_error("MultiAlignerBase_::compute|no slices");  // :49
+      this->_status = AlignerBase::Fail;
+      this->_iteration_stats.clear();
+      // _preCompute (:131-141): robustifiers are bound by value below; init() per slice -- prior slices compute their
+      // measurement there and override the initial guess through setMovingInFixed()
+      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->init(this);
       bindSlices();
-      for (size_t i = 0; i < param_slice_processors.size(); ++i) {  // the TF lookup of aligner_slice_processor_impl.cpp:24-33
-        float S[12];
-        param_slice_processors.value(i)->updateSensorInRobot();
-        amd_detail::toRowMajor(param_slice_processors.value(i)->sensorInRobot(), S);
-        amd_detail::check(srrg2_aligner_set_sensor_in_robot(_h, (int) i, S));
-      }
+      float T[12];
+      amd_detail::toRowMajor(this->_moving_in_fixed, T);
+      amd_detail::check(srrg2_aligner_set_moving_in_fixed(_h, T));
       srrg2_aligner_params p{this->param_max_iterations.value(), param_min_num_inliers.value(),
                              param_enable_inlier_only_runs.value() ? 1 : 0,
                              param_keep_only_inlier_correspondences.value() ? 1 : 0};
@@ -209,19 +253,17 @@ namespace srrg2_slam_interfaces {
                                    tc->param_chi_epsilon.value()};
         amd_detail::check(srrg2_aligner_set_termination(_h, &t));
       } else {
-        amd_detail::check(srrg2_aligner_set_termination(_h, nullptr));
+        amd_detail::check(srrg2_aligner_set_termination(_h, nullptr));  // null criterion: run max_iterations (aligner.h:31-35)
       }
       int st = AlignerBase::Fail;
       amd_detail::check(srrg2_aligner_compute(_h, &st));
       this->_status = static_cast<AlignerBase::Status>(st);  // identical values, aligner.h:23-28
-      float T[12];
       amd_detail::check(srrg2_aligner_get_moving_in_fixed(_h, T));
       amd_detail::fromRowMajor(T, this->_moving_in_fixed);
       int n = 0;
       amd_detail::check(srrg2_aligner_get_iteration_stats(_h, nullptr, &n));
       std::vector<srrg2_iteration_stats> s((size_t) n);
       if (n) amd_detail::check(srrg2_aligner_get_iteration_stats(_h, s.data(), &n));
-      this->_iteration_stats.clear();
       for (const srrg2_iteration_stats& e : s) {  // the fields the reference reads (multi_aligner_impl.cpp:81-82)
         IterationStats is;
         is.iteration    = e.iteration;
@@ -231,86 +273,129 @@ namespace srrg2_slam_interfaces {
         is.chi_outliers = e.chi_outliers;
         this->_iteration_stats.push_back(is);
       }
-    }
-    // multi_aligner_impl.cpp:275-285
-    int numCorrespondences() const override {
-      int n = 0;
-      amd_detail::check(srrg2_aligner_num_correspondences(_h, &n));
-      return n;
-    }
-    // aligner_slice_processor_impl.cpp:51-74: the correspondences go back into the MOVING scene as the property
-    // "<fixed_slice_name>_correspondences" (suffix: correspondence_finder.h:25)
-    void storeCorrespondences() override {
-      if (!this->_moving) return;
+      // slice->correspondences() of every cue slice, as the reference leaves them (after pruning if enabled, :214-263)
       for (size_t i = 0; i < param_slice_processors.size(); ++i) {
-        int n = 0;
-        amd_detail::check(srrg2_aligner_get_correspondences(_h, (int) i, nullptr, &n));
-        std::vector<srrg2_correspondence> buf((size_t) n);
-        if (n) amd_detail::check(srrg2_aligner_get_correspondences(_h, (int) i, buf.data(), &n));
-        const std::string name = param_slice_processors.value(i)->param_fixed_slice_name.value() + "_correspondences";
-        auto* prop = this->_moving->template property<Property_<CorrespondenceVector>>(name);
-        if (!prop) {
-          prop = new Property_<CorrespondenceVector>(name, "", this->_moving, CorrespondenceVector(), nullptr);
-        }
-        CorrespondenceVector& out = prop->value();
+        AlignerSliceProcessorTypePtr slice = param_slice_processors.value(i);
+        if (slice->isPrior()) continue;
+        int nc = 0;
+        amd_detail::check(srrg2_aligner_get_correspondences(_h, (int) i, nullptr, &nc));
+        std::vector<srrg2_correspondence> buf((size_t) nc);
+        if (nc) amd_detail::check(srrg2_aligner_get_correspondences(_h, (int) i, buf.data(), &nc));
+        CorrespondenceVector& out = slice->correspondences();
         out.clear();
         out.reserve(buf.size());
         for (const srrg2_correspondence& c : buf) out.emplace_back(Correspondence(c.fixed_idx, c.moving_idx, c.response));
       }
     }
+    // multi_aligner_impl.cpp:275-285
+    int numCorrespondences() override {
+      int n = 0;
+      if (_h) amd_detail::check(srrg2_aligner_num_correspondences(_h, &n));
+      return n;
+    }
+    // multi_aligner_impl.cpp:266-272: every slice exports ITS correspondences into the moving scene as the property
+    // "<fixed_slice_name>_correspondences" (aligner_slice_processor_impl.cpp:51-74; suffix correspondence_finder.h:25) --
+    // the slices' own code, fed by the vectors compute() filled
+    void storeCorrespondences() override {
+      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->storeCorrespondences();
+    }
+    void setPlatform(PlatformPtr platform_) override {  // multi_aligner_impl.cpp:288-295
+      BaseType::setPlatform(platform_);
+      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->setPlatform(platform_);
+    }
+    void draw(srrg2_core::ViewerCanvasPtr canvas_) const override {
+      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->draw(canvas_);
+    }
 
   protected:
-    // (re)creates the device-side aligner when the slice list changed (_slices_changed_flag, multi_aligner.h:37)
+    // (re)creates the device-side aligner from the CURRENT slice objects: slice list, PARAMs, bound clouds, prior
+    // measurements.  Cheap when nothing changed (the clouds are re-bound only after setFixed / setMoving).
     void bindSlices() {
-      if (_h && !this->_slices_changed_flag) return;
-      if (_h) srrg2_aligner_destroy(_h);
-      _h = nullptr;
-      amd_detail::check(srrg2_aligner_create(amd_detail::variableKind<VariableType>(), param_device.value(), &_h));
-      for (size_t i = 0; i < param_slice_processors.size(); ++i) {
-        srrg2_slice_config c = param_slice_processors.value(i)->config();
-        int idx              = -1;
-        amd_detail::check(srrg2_aligner_add_slice(_h, &c, &idx));
+      const size_t ns = param_slice_processors.size();
+      std::vector<srrg2_slice_config> configs(ns);
+      std::vector<CueBinding> cues(ns);
+      std::vector<EstimateType, Eigen::aligned_allocator<EstimateType>> prior_Z(ns, EstimateType::Identity());
+      for (size_t i = 0; i < ns; ++i) {
+        AlignerSliceProcessorTypePtr slice = param_slice_processors.value(i);
+        if (slice->isPrior()) {
+          // the slice's own factor after its own setupFactor() (computeCorrespondences() of a prior slice is exactly that,
+          // aligner_slice_processor_prior.h:52-55): measurement, information, robustifier
+          slice->computeCorrespondences();
+          srrg2_slice_default_config(&configs[i], amd_detail::variableKind<VariableType>());
+          configs[i].kind                     = SRRG2_SLICE_PRIOR;
+          configs[i].finder                   = SRRG2_FINDER_NONE;
+          configs[i].prior_sets_initial_guess = 0;  // the slice's init() has already set the guess through setMovingInFixed
+          amd_detail::robustifierOf(slice->param_robustifier.value().get(), configs[i]);
+          FactorBasePtr f = slice->factor();  // (throws "no fixed" / "no moving" like the reference, prior_impl.cpp:11-22)
+          if (auto* f2 = dynamic_cast<SE2PriorErrorFactor*>(f.get())) {
+            readPrior(*f2, configs[i], prior_Z[i]);
+          } else if (auto* f3 = dynamic_cast<SE3PriorErrorFactorAD*>(f.get())) {
+            readPrior(*f3, configs[i], prior_Z[i]);
+          } else {
+            throw std::runtime_error("MultiAlignerBase_|prior slice with a factor type the device does not evaluate");
+          }
+        } else {
+          if (!CueSliceRegistry<BaseVariableType>::translate(slice.get(), cues[i]))
+            throw std::runtime_error("MultiAlignerBase_|cue slice type [" + slice->className() +
+                                     "] has no translator: registerCueSlice<...>() it next to its BOSS_REGISTER_CLASS");
+          configs[i] = cues[i].config;
+          // the sensor pose the reference looks up on every setMovingInFixed (aligner_slice_processor_impl.cpp:20-36)
+          EstimateType sensor_in_robot = EstimateType::Identity();
+          if (this->_platform && !slice->param_frame_id.value().empty() && !slice->param_base_frame_id.value().empty())
+            this->_platform->getTransform(sensor_in_robot, slice->param_frame_id.value(), slice->param_base_frame_id.value());
+          amd_detail::toRowMajor(sensor_in_robot, configs[i].sensor_in_robot);
+        }
       }
-      this->_slices_changed_flag = false;
+      const bool rebuild = !_h || _slices_changed_flag || configs.size() != _bound_configs.size() ||
+                           (ns && std::memcmp(configs.data(), _bound_configs.data(), sizeof(srrg2_slice_config) * ns) != 0);
+      if (rebuild) {
+        if (_h) srrg2_aligner_destroy(_h);
+        _h = nullptr;
+        amd_detail::check(srrg2_aligner_create(amd_detail::variableKind<VariableType>(), _device, &_h));
+        for (size_t i = 0; i < ns; ++i) {
+          int idx = -1;
+          amd_detail::check(srrg2_aligner_add_slice(_h, &configs[i], &idx));
+        }
+        _bound_configs       = configs;
+        _slices_changed_flag = false;
+        _clouds_changed      = true;
+      }
+      for (size_t i = 0; i < ns; ++i) {
+        if (configs[i].kind == SRRG2_SLICE_PRIOR) {
+          float Z[12];
+          amd_detail::toRowMajor(prior_Z[i], Z);
+          amd_detail::check(srrg2_aligner_set_prior_measurement(_h, (int) i, Z));
+        } else if (_clouds_changed) {
+          const CueBinding& b = cues[i];
+          amd_detail::check(srrg2_aligner_set_fixed(_h, (int) i, b.fixed_coords, b.fixed_stride, b.fixed_normals, b.fixed_stride,
+                                                    b.fixed_size, SRRG2_MEM_HOST));
+          amd_detail::check(srrg2_aligner_set_moving(_h, (int) i, b.moving_coords, b.moving_stride, b.moving_normals,
+                                                     b.moving_stride, b.moving_size, SRRG2_MEM_HOST));
+        }
+      }
+      _clouds_changed = false;
     }
-    // the three storage forms of aligner_slice_processor_base_impl.cpp:27-50
-    void bindCloud(PropertyContainerBase* scene, const std::string& name, int slice, bool fixed) {
-      if (!scene) throw std::runtime_error("MultiAlignerAMD_::bindCloud|no scene");
-      const PointCloudType* cloud = nullptr;
-      if (auto* p = scene->template property<Property_<PointCloudType*>>(name)) cloud = p->value();
-      else if (auto* v = scene->template property<Property_<PointCloudType>>(name)) cloud = &v->value();
-      else if (auto* s = scene->template property<Property_<std::shared_ptr<PointCloudType>>>(name)) cloud = s->value().get();
-      if (!cloud) throw std::runtime_error("MultiAlignerAMD_::bindCloud|slice [" + name + "] not found in the scene");
-      using PointType = typename PointCloudType::value_type;
-      const float* coords  = cloud->empty() ? nullptr : cloud->front().coordinates().data();
-      const float* normals = cloud->empty() ? nullptr : cloud->front().normal().data();
-      amd_detail::check((fixed ? srrg2_aligner_set_fixed : srrg2_aligner_set_moving)(
-        _h, slice, coords, (int) sizeof(PointType), normals, (int) sizeof(PointType), (int) cloud->size(), SRRG2_MEM_HOST));
+    template <typename PriorFactorType>
+    static void readPrior(const PriorFactorType& f, srrg2_slice_config& c, EstimateType& Z) {
+      Z = f.measurement();
+      const auto& Om = f.informationMatrix();  // diagonal by construction (param_diagonal_info_matrix.asDiagonal())
+      for (int k = 0; k < D; ++k) c.prior_information_diag[k] = Om(k, k);
     }
-    srrg2_aligner_h _h = nullptr;
-    bool _slices_changed_flag = true;
+
+    srrg2_aligner_h _h        = nullptr;
+    int _device               = 0;
+    bool _slices_changed_flag = true;  // multi_aligner.h:37
+    bool _clouds_changed      = true;
+    std::vector<srrg2_slice_config> _bound_configs;
   };
 
-  // the registry names of the reference (multi_aligner.h:152-159, instances.cpp:21-23): a configuration that names
-  // "MultiAligner2D" loads this class when the adapter library is linked instead of the reference's aligner
-  using MultiAligner2D   = MultiAlignerAMD_<VariableSE2RightAD>;
-  using MultiAligner3D   = MultiAlignerAMD_<VariableSE3EulerRightAD>;
-  using MultiAligner3DQR = MultiAlignerAMD_<VariableSE3QuaternionRightAD>;
-  using AlignerSliceProcessorAMD2D   = AlignerSliceProcessorAMD_<VariableSE2RightAD>;
-  using AlignerSliceProcessorAMD3D   = AlignerSliceProcessorAMD_<VariableSE3EulerRightAD>;
-  using AlignerSliceProcessorAMD3DQR = AlignerSliceProcessorAMD_<VariableSE3QuaternionRightAD>;
-
-  // call from the adapter library's registerTypes() (the counterpart of srrg2_slam_interfaces_registerTypes,
-  // instances.cpp:28-84; BOSS_REGISTER_CLASS_LINKER_FRIENDLY as defined at instances.cpp:21-23)
-#define SRRG2_SLAM_AMD_REGISTER_TYPES()                                    \
-  do {                                                                     \
-    BOSS_REGISTER_CLASS(MultiAligner2D);                                   \
-    BOSS_REGISTER_CLASS(MultiAligner3D);                                   \
-    BOSS_REGISTER_CLASS(MultiAligner3DQR);                                 \
-    BOSS_REGISTER_CLASS(AlignerSliceProcessorAMD2D);                       \
-    BOSS_REGISTER_CLASS(AlignerSliceProcessorAMD3D);                       \
-    BOSS_REGISTER_CLASS(AlignerSliceProcessorAMD3DQR);                     \
-  } while (0)
+  // multi_aligner.h:152-159 -- the names instances.cpp:35 and downstream code use
+  using MultiAligner2D      = MultiAlignerBase_<VariableSE2RightAD>;
+  using MultiAligner3D      = MultiAlignerBase_<VariableSE3EulerRightAD>;
+  using MultiAligner2DPtr   = std::shared_ptr<MultiAligner2D>;
+  using MultiAligner3DPtr   = std::shared_ptr<MultiAligner3D>;
+  using MultiAligner3DQR    = MultiAlignerBase_<VariableSE3QuaternionRightAD>;
+  using MultiAligner3DQRPtr = std::shared_ptr<MultiAligner3DQR>;
 
 }  // namespace srrg2_slam_interfaces
 
