@@ -1,12 +1,13 @@
-cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r3n; mkdir -p $O; R=$GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-cd /tmp
-export SRRG2_AMD_LIB=$R/srrg2_slam_interfaces_amd/lib/libsrrg2_slam_amd_knobs.so
-rm -f $O/knob_attribution_tile.txt
-for tune in 0 3 67108867 33554435 16; do
-  rm -rf /tmp/p1
-  SRRG2_AMD_TUNE=$tune timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD -d /tmp/p1 -o p -- python $R/bench.py --workload c4 --batch 32 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  echo "tune=$tune" >> $O/knob_attribution_tile.txt
-  python $R/tools/iter_durations.py $(find /tmp/p1 -name '*.db' | head -1) 10 | cut -c1-75 >> $O/knob_attribution_tile.txt
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out/r3o
+O=gpurun_out/r3o
+SRRG2_AMD_ASYNC_CONTROL=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_given_correspondences.py tests/test_sensor_in_robot.py tests/test_reference_scenarios.py -m gpu -x -q > $O/pytest_async2.log 2>&1
+tail -3 $O/pytest_async2.log
+grep -c "timed out" $O/pytest_async2.log
+rm -f $O/ab2.txt
+for w in "--workload c2" "--workload c3" "--workload c4 --batch 8 --steps 10" "--workload c4 --batch 32 --steps 10"; do
+  timeout 600 bash tools/ab_env.sh $O/ab2.txt "$w" "SRRG2_AMD_ASYNC_CONTROL=0" "SRRG2_AMD_ASYNC_CONTROL=1" "SRRG2_AMD_ASYNC_CONTROL=0" "SRRG2_AMD_ASYNC_CONTROL=1"
 done
-cat $O/knob_attribution_tile.txt
+cat $O/ab2.txt
+SRRG2_AMD_ASYNC_CONTROL=1 python bench.py --workload c2 --no-cpu-baseline 2>&1 | grep -c "timed out"
