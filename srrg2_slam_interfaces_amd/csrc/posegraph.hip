@@ -261,6 +261,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
 #define MG_FUSE_NODES 170   // levels of at most this many nodes run inside the single-workgroup launch (one row per thread)
 #define MG_COARSEST_NODES 32
 #define MG_FUSE_BLOCKS 1200   // ... and at most this many off-diagonal blocks
+#define MG_DOWN2_THREADS 256
+#define MG_FUSE_LAST_NODES 16  // coarsest levels of at most this many nodes are solved inside the last down launch (k_mg_down2_coarsest)
 
 struct MgLevel {  // device view of one level (level 0 = the pose graph without its Fixed variables' couplings)
   int n, ne, nc, nce, np, nq;
@@ -300,6 +302,8 @@ struct MgLevel {  // device view of one level (level 0 = the pose graph without 
   float* Qf;
   const int* qcsc_start;        // [nc + 1]  Q by column (entries of a column, rows ascending)
   const int* qcsc_ent;          // [nq]
+  const int2* pcsc2;            // [np] / [nq]: the columns again as {entry, its row} (one load instead of a dependent pair)
+  const int2* qcsc2;
   double *x, *r, *res;          // [n][D] work vectors of the cycle
 };
 
@@ -516,83 +520,234 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_op(int op, const MgLevel* __r
 // lanes (rows 0 .. D-1 of 8 slots, `parts` lanes per row): the D row results of a node meet by shuffles inside the wave.
 // (one 256-thread workgroup per COARSE node: a column of Q holds hundreds of blocks on the coarse levels -- C5 level 1:
 // 342 -- and there are few columns; 32 lanes share a row of the result, the D rows meet through LDS)
+// (every lane takes WHOLE blocks of the column -- all D rows of the result from one 144-byte block load and one load of
+// the vector's node, two blocks in flight -- instead of 32 lanes per row that each pick six strided words out of every
+// block: a dense 788-row column was 25 chains of three dependent loads in a row, 34 us for 11 MB on C5's level 2;
+// profiles/r3p_*.  The columns are stored a second time as {entry, row} pairs: one load less on the chain.)
 template <int D>
-__global__ __launch_bounds__(256) void k_mg_down2(const MgLevel* __restrict__ levels, int l, const PgScalars* __restrict__ sc) {
+__device__ __forceinline__ void mg_block_tmulsub(const float* __restrict__ B, const double* __restrict__ xv, double sign,
+                                                 double (&s)[D]) {
+  // s += sign * B^T xv
+  float b[D * D];
+  if (D == 6) {
+    const float4* B4 = reinterpret_cast<const float4*>(B);  // (blocks of 36 floats: 16-byte aligned)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 v = B4[k];
+      b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) b[k] = B[k];
+  }
+  double x[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) x[c] = xv[c];
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    const double xs = sign * x[r];
+#pragma unroll
+    for (int a = 0; a < D; ++a) s[a] = s[a] + (double) b[r * D + a] * xs;
+  }
+}
+
+// the share of thread `tid` of `nth` in r_c(I) = Ps^T r - Q^T x1
+template <int D>
+__device__ __forceinline__ void mg_down2_column(const MgLevel& L, int I, int tid, int nth, double (&s)[D]) {
+#pragma unroll
+  for (int a = 0; a < D; ++a) s[a] = 0.0;
+  for (int m = L.pcsc_start[I] + tid; m < L.pcsc_start[I + 1]; m += nth) {
+    const int2 er = L.pcsc2[m];
+    mg_block_tmulsub<D>(L.Psf + (size_t) er.x * D * D, L.r + (size_t) er.y * D, 1.0, s);
+  }
+  const int qe = L.qcsc_start[I + 1];
+  for (int m0 = L.qcsc_start[I] + tid; m0 < qe; m0 += 2 * nth) {
+    const int2 e0 = L.qcsc2[m0];
+    const bool two = m0 + nth < qe;
+    const int2 e1 = two ? L.qcsc2[m0 + nth] : e0;
+    double t[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) t[a] = 0.0;
+    mg_block_tmulsub<D>(L.Qf + (size_t) e0.x * D * D, L.x + (size_t) e0.y * D, -1.0, s);
+    mg_block_tmulsub<D>(L.Qf + (size_t) e1.x * D * D, L.x + (size_t) e1.y * D, two ? -1.0 : 0.0, t);
+#pragma unroll
+    for (int a = 0; a < D; ++a) s[a] = s[a] + t[a];
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(MG_DOWN2_THREADS) void k_mg_down2(const MgLevel* __restrict__ levels, int l,
+                                                               const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
   const MgLevel L = levels[l];
   const MgLevel C = levels[l + 1];
   const int I     = blockIdx.x;
-  const int part = threadIdx.x & 31, a = threadIdx.x >> 5;  // a in 0 .. 7
-  __shared__ double rc[8];
-  double s = 0.0;
-  if (a < D) {
-    for (int m = L.pcsc_start[I] + part; m < L.pcsc_start[I + 1]; m += 32) {
-      const int e = L.pcsc_ent[m], i = L.prow_of[e];
-      const float* B = L.Psf + (size_t) e * D * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = MG_DOWN2_THREADS / 64;
+  __shared__ double part[NW][D];
+  __shared__ double rc[D];
+  double s[D];
+  mg_down2_column<D>(L, I, threadIdx.x, MG_DOWN2_THREADS, s);
 #pragma unroll
-      for (int b = 0; b < D; ++b) s = s + (double) B[b * D + a] * L.r[(size_t) i * D + b];
-    }
-    for (int m = L.qcsc_start[I] + part; m < L.qcsc_start[I + 1]; m += 32) {
-      const int q = L.qcsc_ent[m], i = L.qrow_of[q];
-      const float* B = L.Qf + (size_t) q * D * D;
+  for (int a = 0; a < D; ++a) {
 #pragma unroll
-      for (int b = 0; b < D; ++b) s = s - (double) B[b * D + a] * L.x[(size_t) i * D + b];
-    }
+    for (int off = 32; off >= 1; off >>= 1) s[a] = s[a] + __shfl_xor(s[a], off);
   }
+  if (lane == 0) {
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
-  if (part == 0) rc[a] = s;
+    for (int a = 0; a < D; ++a) part[wave][a] = s[a];
+  }
   __syncthreads();
-  if (a < D && part == 0) {
+  if (threadIdx.x < D) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t = t + part[w][threadIdx.x];
+    rc[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int a = threadIdx.x;
     double x1 = 0.0;
 #pragma unroll
     for (int c = 0; c < D; ++c) x1 = x1 + (double) C.Dinvf[((size_t) I * D + a) * D + c] * rc[c];
-    C.r[(size_t) I * D + a] = s;
+    C.r[(size_t) I * D + a] = rc[a];
     C.x[(size_t) I * D + a] = C.omega * x1;
   }
 }
 
+// The down phase of the LAST two-phase level and the dense solve of the coarsest level behind it in one launch of one
+// workgroup: with a dozen coarsest nodes the two launches (13 workgroups, then one) were 11 + 18 us of mostly launch floor
+// and load latency per cycle (profiles/r3p_*).  A wave per coarsest node, the waves meet in LDS, 8 lanes share a row of
+// the dense inverse.
+template <int D>
+__global__ __launch_bounds__(1024) void k_mg_down2_coarsest(const MgLevel* __restrict__ levels, int l, const double* __restrict__ Cinv,
+                                                            const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = levels[l];
+  const MgLevel C = levels[l + 1];
+  __shared__ double rc[MG_FUSE_LAST_NODES * D];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N = C.n * D;
+  // (the rows of the inverse this thread will need: in flight while the columns are summed)
+  const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+  double ci[(MG_FUSE_LAST_NODES * D + 7) / 8];
+#pragma unroll
+  for (int k = 0; k < (MG_FUSE_LAST_NODES * D + 7) / 8; ++k) {
+    const int c = part + 8 * k;
+    ci[k] = (row < N && c < N) ? Cinv[(size_t) row * N + c] : 0.0;
+  }
+  for (int I = wave; I < C.n; I += 16) {
+    double s[D];
+    mg_down2_column<D>(L, I, lane, 64, s);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) s[a] = s[a] + __shfl_xor(s[a], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) rc[I * D + a] = s[a];
+    }
+  }
+  __syncthreads();
+  double y = 0.0;
+#pragma unroll
+  for (int k = 0; k < (MG_FUSE_LAST_NODES * D + 7) / 8; ++k) {
+    const int c = part + 8 * k;
+    if (c < N) y = y + ci[k] * rc[c];
+  }
+  y = y + __shfl_xor(y, 4);
+  y = y + __shfl_xor(y, 2);
+  y = y + __shfl_xor(y, 1);
+  if (row < N && part == 0) {
+    C.r[row] = rc[row];
+    C.x[row] = y;
+  }
+}
+
+// y += B xv (trans == false) or B^T xv (trans == true), whole block per lane
+template <int D>
+__device__ __forceinline__ void mg_block_mul(const float* __restrict__ B, const double* __restrict__ xv, bool trans, bool on,
+                                             double (&y)[D]) {
+  float b[D * D];
+  if (D == 6) {
+    const float4* B4 = reinterpret_cast<const float4*>(B);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 v = B4[k];
+      b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) b[k] = B[k];
+  }
+  double x[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) x[c] = on ? xv[c] : 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) t = t + (double) (trans ? b[c * D + a] : b[a * D + c]) * x[c];
+    y[a] = y[a] + t;
+  }
+}
+
 // xc: the coarse correction (levels[l + 1].res when that level is a two-phase level too, else its x)
+// A node owns NL = 8 * parts adjacent lanes; every lane takes WHOLE blocks of the node's rows of H, Q and Ps (all D rows
+// of the result from one 144-byte load, two blocks in flight), the lanes of a node meet by shuffles.
 template <int D>
 __global__ __launch_bounds__(PG_THREADS) void k_mg_up2(const MgLevel* __restrict__ levels, int l, int parts, int xc_in_res,
                                                        const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
   const MgLevel L = levels[l];
   const double* __restrict__ xc = xc_in_res ? levels[l + 1].res : levels[l + 1].x;
-  const int t    = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int part = t & (parts - 1), a = (t / parts) & 7, v = t / (8 * parts);
-  const bool on  = v < L.n && a < D;
-  double y = 0.0, p = 0.0;
+  const int t  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NL = 8 * parts;
+  const int k = t & (NL - 1), v = t / NL;
+  const bool on = v < L.n;
+  double y[D], p[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) y[a] = p[a] = 0.0;
   if (on) {
-    y = mg_row_part<D, float>(L, L.Hdf, L.Hof, L.x, v, a, part, parts);
-    for (int e = L.qrow_start[v] + part; e < L.qrow_start[v + 1]; e += parts) {
-      const float* B   = L.Qf + (size_t) e * D * D;
-      const double* xo = xc + (size_t) L.qcol[e] * D;
-#pragma unroll
-      for (int c = 0; c < D; ++c) y = y + (double) B[a * D + c] * xo[c];
+    if (k == 0) mg_block_mul<D>(L.Hdf + (size_t) v * D * D, L.x + (size_t) v * D, false, true, y);
+    const int q1 = L.inc_start[v + 1];
+    for (int q0 = L.inc_start[v] + k; q0 < q1; q0 += 2 * NL) {
+      const int2 a0 = L.inc_adj[q0];
+      const bool two = q0 + NL < q1;
+      const int2 a1 = two ? L.inc_adj[q0 + NL] : a0;
+      mg_block_mul<D>(L.Hof + (size_t) (a0.y >> 1) * D * D, L.x + (size_t) a0.x * D, (a0.y & 1) != 0, true, y);
+      mg_block_mul<D>(L.Hof + (size_t) (a1.y >> 1) * D * D, L.x + (size_t) a1.x * D, (a1.y & 1) != 0, two, y);
     }
-    for (int e = L.prow_start[v] + part; e < L.prow_start[v + 1]; e += parts) {
-      const float* B   = L.Psf + (size_t) e * D * D;
-      const double* xo = xc + (size_t) L.pcol[e] * D;
+    const int qe = L.qrow_start[v + 1];
+    for (int e0 = L.qrow_start[v] + k; e0 < qe; e0 += 2 * NL) {
+      const bool two = e0 + NL < qe;
+      const int e1 = two ? e0 + NL : e0;
+      const int c0 = L.qcol[e0], c1 = L.qcol[e1];
+      mg_block_mul<D>(L.Qf + (size_t) e0 * D * D, xc + (size_t) c0 * D, false, true, y);
+      mg_block_mul<D>(L.Qf + (size_t) e1 * D * D, xc + (size_t) c1 * D, false, two, y);
+    }
+    for (int e = L.prow_start[v] + k; e < L.prow_start[v + 1]; e += NL)
+      mg_block_mul<D>(L.Psf + (size_t) e * D * D, xc + (size_t) L.pcol[e] * D, false, true, p);
+  }
+  for (int off = NL >> 1; off >= 1; off >>= 1) {
 #pragma unroll
-      for (int c = 0; c < D; ++c) p = p + (double) B[a * D + c] * xo[c];
+    for (int a = 0; a < D; ++a) {
+      y[a] = y[a] + __shfl_xor(y[a], off);
+      p[a] = p[a] + __shfl_xor(p[a], off);
     }
   }
-  for (int off = parts >> 1; off >= 1; off >>= 1) {
-    y = y + __shfl_xor(y, off);
-    p = p + __shfl_xor(p, off);
-  }
-  const double res2 = on ? L.r[(size_t) v * D + a] - y : 0.0;
-  const int base = lane & ~(8 * parts - 1);
-  double rr[D];
+  if (on && k < D) {
+    double rr[D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) rr[c] = __shfl(res2, base + c * parts);
-  if (on && part == 0) {
-    double u = 0.0;
+    for (int c = 0; c < D; ++c) rr[c] = L.r[(size_t) v * D + c] - y[c];
+    double u = 0.0, pk = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) u = u + (double) L.Dinvf[((size_t) v * D + a) * D + c] * rr[c];
-    L.res[(size_t) v * D + a] = L.x[(size_t) v * D + a] + p + L.omega * u;
+    for (int c = 0; c < D; ++c) {
+      u  = u + (double) L.Dinvf[((size_t) v * D + k) * D + c] * rr[c];
+      pk = k == c ? p[c] : pk;
+    }
+    L.res[(size_t) v * D + k] = L.x[(size_t) v * D + k] + pk + L.omega * u;
   }
 }
 
@@ -1159,13 +1314,14 @@ struct MgLevelBufs {
   DevBuf<int2> inc_adj;
   DevBuf<float> P, Hdf, Hof, Dinvf, Psf, Qf;
   DevBuf<int> qcsc_start, qcsc_ent;
+  DevBuf<int2> pcsc2, qcsc2;
   DevBuf<double> Hd, Ho, Ps, Q, Dinv, x, r, res;
   void release() {
     eij.release(); inc_start.release(); inc_adj.release(); agg.release(); rep0.release(); prow_start.release();
     pcol.release(); prow_of.release(); pcsc_start.release(); pcsc_ent.release(); qrow_start.release(); qcol.release();
     qrow_of.release(); Hd.release(); Ho.release(); P.release(); Ps.release(); Q.release(); Dinv.release(); x.release();
     r.release(); res.release(); Hdf.release(); Hof.release(); Dinvf.release(); Psf.release(); Qf.release();
-    qcsc_start.release(); qcsc_ent.release();
+    qcsc_start.release(); qcsc_ent.release(); pcsc2.release(); qcsc2.release();
   }
 };
 
@@ -1487,6 +1643,9 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       std::vector<int> cur(qcsc_start.begin(), qcsc_start.end() - 1);
       for (int e = 0; e < nq; ++e) qcsc_ent[(size_t) cur[(size_t) qcol[(size_t) e]]++] = e;  // (rows ascending)
     }
+    std::vector<int2> pcsc2((size_t) std::max(np, 1), make_int2(0, 0)), qcsc2((size_t) std::max(nq, 1), make_int2(0, 0));
+    for (int m = 0; m < np; ++m) pcsc2[(size_t) m] = make_int2(pcsc_ent[(size_t) m], prow_of[(size_t) pcsc_ent[(size_t) m]]);
+    for (int m = 0; m < nq; ++m) qcsc2[(size_t) m] = make_int2(qcsc_ent[(size_t) m], qrow_of[(size_t) qcsc_ent[(size_t) m]]);
     // coarse edges (A < B): B in the row of Q of some row of column A of Ps
     std::vector<int> ce_start, ce_col, ceij;
     pattern_rows(nc, nc, ce_start, ce_col, nullptr, [&](int A, std::vector<int>& stamp, std::vector<int>& out) {
@@ -1530,6 +1689,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         (rc = upload(L->qrow_start, qrow_start)) || (rc = upload(L->qcol, qcol)) || (rc = upload(L->qrow_of, qrow_of)) ||
         (rc = L->Ps.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Q.reserve((size_t) std::max(nq, 1) * D * D)) ||
         (rc = upload(L->qcsc_start, qcsc_start)) || (rc = upload(L->qcsc_ent, qcsc_ent)) ||
+        (rc = upload(L->pcsc2, pcsc2)) || (rc = upload(L->qcsc2, qcsc2)) ||
         (rc = L->Psf.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Qf.reserve((size_t) std::max(nq, 1) * D * D)))
       return rc;
     // next level
@@ -1558,7 +1718,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     v.pcsc_ent = L->pcsc_ent.p; v.qrow_start = L->qrow_start.p; v.qcol = L->qcol.p; v.qrow_of = L->qrow_of.p;
     v.Hdf = L->Hdf.p; v.Hof = L->Hof.p; v.Dinvf = L->Dinvf.p;
     v.Psf = l + 1 < nl ? L->Psf.p : nullptr; v.Qf = l + 1 < nl ? L->Qf.p : nullptr;
-    v.qcsc_start = L->qcsc_start.p; v.qcsc_ent = L->qcsc_ent.p;
+    v.qcsc_start = L->qcsc_start.p; v.qcsc_ent = L->qcsc_ent.p; v.pcsc2 = L->pcsc2.p; v.qcsc2 = L->qcsc2.p;
     v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Ps = L->Ps.p; v.Q = L->Q.p; v.Dinv = L->Dinv.p; v.x = L->x.p;
     v.r = L->r.p; v.res = L->res.p;
   }
@@ -1622,13 +1782,19 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     if (lf > 1)  // x1 of level 1 (the levels below get theirs from k_mg_down2)
       hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(g->levels[1]->n * D)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0,
                          g->levels_dev.p, 1, g->sc.p);
+    // (the last two-phase level's down phase and the dense coarsest solve share a launch when the coarsest level is tiny)
+    const bool fuse_last = g->coarsest_dense && lf == nl && lf >= 2 && g->levels[(size_t) nl]->n <= MG_FUSE_LAST_NODES &&
+                           g->levels[(size_t) nl]->n == g->levels[(size_t) nl - 1]->nc;
     for (int l = 1; l < lf; ++l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
-      if (Lb->nc > 0)
-        hipLaunchKernelGGL(k_mg_down2<D>, dim3((unsigned) Lb->nc), dim3(256), 0, g->stream, g->levels_dev.p, l, g->sc.p);
+      if (l == lf - 1 && fuse_last)
+        hipLaunchKernelGGL(k_mg_down2_coarsest<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, l, g->coarse_inv.p, g->sc.p);
+      else if (Lb->nc > 0)
+        hipLaunchKernelGGL(k_mg_down2<D>, dim3((unsigned) Lb->nc), dim3(MG_DOWN2_THREADS), 0, g->stream, g->levels_dev.p, l, g->sc.p);
     }
-    hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
-                       g->coarsest_dense, g->sc.p);
+    if (!fuse_last)
+      hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
+                         g->coarsest_dense, g->sc.p);
     for (int l = lf - 1; l >= 1; --l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
       const int pp = parts2(Lb, false);

@@ -1,13 +1,17 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p gpurun_out/r3o
-O=gpurun_out/r3o
-SRRG2_AMD_ASYNC_CONTROL=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_given_correspondences.py tests/test_sensor_in_robot.py tests/test_reference_scenarios.py -m gpu -x -q > $O/pytest_async2.log 2>&1
-tail -3 $O/pytest_async2.log
-grep -c "timed out" $O/pytest_async2.log
-rm -f $O/ab2.txt
-for w in "--workload c2" "--workload c3" "--workload c4 --batch 8 --steps 10" "--workload c4 --batch 32 --steps 10"; do
-  timeout 600 bash tools/ab_env.sh $O/ab2.txt "$w" "SRRG2_AMD_ASYNC_CONTROL=0" "SRRG2_AMD_ASYNC_CONTROL=1" "SRRG2_AMD_ASYNC_CONTROL=0" "SRRG2_AMD_ASYNC_CONTROL=1"
-done
-cat $O/ab2.txt
-SRRG2_AMD_ASYNC_CONTROL=1 python bench.py --workload c2 --no-cpu-baseline 2>&1 | grep -c "timed out"
+mkdir -p gpurun_out/r3q
+O=$PWD/gpurun_out/r3q
+rm -f $O/*
+timeout 900 python -m pytest tests/test_gpu_posegraph.py tests/test_gpu_graph_lifecycle.py -m gpu -x -q > $O/pytest_pg.log 2>&1
+tail -3 $O/pytest_pg.log
+for i in 1 2; do timeout 300 python tools/bench_posegraph.py >> $O/bench_pg.log 2>&1; done
+cat $O/bench_pg.log | cut -c1-330
+export TMPDIR=/tmp
+R=$PWD
+cd /tmp
+SRRG2_AMD_PG_GRAPH=0 timeout 600 rocprofv3 --kernel-trace -d $O/pgtrace -o pg -- python $R/tools/bench_posegraph.py > /dev/null 2>&1
+DB=$(find $O/pgtrace -name "*.db" | head -1)
+python $R/tools/pg_trace.py $DB > $O/pg_trace.txt
+head -24 $O/pg_trace.txt | cut -c1-120
+rm -rf $O/pgtrace

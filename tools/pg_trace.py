@@ -11,7 +11,8 @@ gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols e
 q = "select name, %s, (end-start)/1000.0 from kernels" % (gx or "0")
 agg = collections.defaultdict(list)
 for name, g, d in cur.execute(q):
-    agg[(name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""), g)].append(d)
+    short = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    agg[(short.split("(")[0], g)].append(d)
 tot = sum(sum(v) for v in agg.values())
 print("columns:", cols)
 for (name, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
