@@ -18,10 +18,12 @@
 // float64 throughout (the float32 poses are the only float32 state).  Results agree with the CPU oracle to PCG
 // tolerance, not bit for bit (dot-product order differs); tests bound the pose difference.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <set>
 #include <string>
 #include <thread>
@@ -1360,21 +1362,76 @@ int upload(DevBuf<T>& b, const std::vector<T>& v) {
   return 0;
 }
 
+// A handful of host threads for the parallel regions of build_hierarchy (a dozen per build).  Started once per build;
+// between regions they SPIN on the generation counter -- the regions follow each other within microseconds and the pool
+// lives ~15 ms: creating 16 threads per region cost more than most regions' work on the 256-thread host, and waking them
+// through a condition variable made a region's duration a lottery (2-8 ms for the same work).  Every worker acknowledges
+// every generation, so two regions never overlap.
+class HostPool {
+ public:
+  explicit HostPool(int n) : n_(std::max(n, 1)) {
+    for (int t = 1; t < n_; ++t) threads_.emplace_back([this, t] { loop(t); });
+  }
+  ~HostPool() {
+    stop_ = true;
+    generation_.fetch_add(1, std::memory_order_release);
+    for (std::thread& th : threads_) th.join();
+  }
+  int size() const { return n_; }
+  // fn(t) for t in [0, nt), nt <= size(); the caller runs t = 0 itself and returns when every t is done
+  template <typename Fn>
+  void run(int nt, Fn&& fn) {
+    nt = std::min(nt, n_);
+    if (nt <= 1) {
+      fn(0);
+      return;
+    }
+    job_ = [&fn](int t) { fn(t); };
+    nt_  = nt;
+    pending_.store(n_ - 1, std::memory_order_relaxed);
+    generation_.fetch_add(1, std::memory_order_release);
+    fn(0);
+    while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+  }
+
+ private:
+  void loop(int t) {
+    unsigned seen = 0;
+    for (;;) {
+      unsigned g;
+      while ((g = generation_.load(std::memory_order_acquire)) == seen) __builtin_ia32_pause();
+      seen = g;
+      if (stop_) return;
+      if (t < nt_) job_(t);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  int n_;
+  std::vector<std::thread> threads_;
+  std::function<void(int)> job_;
+  int nt_ = 0;
+  std::atomic<int> pending_{0};
+  std::atomic<unsigned> generation_{0};
+  std::atomic<bool> stop_{false};
+};
+
 // Rows of a sparse pattern, each the sorted set of distinct columns that `row_fn(row, stamp, out)` pushes (it marks a column
-// in `stamp` -- one int per column, initialised to -1 -- with the row's id to see it once).  The rows are independent: a
-// few host threads take contiguous chunks of them, the chunks are concatenated in order (the result does not depend on
-// the number of threads).
+// in `stamp` -- one int per column, initialised to -1 -- with the row's id to see it once).  The rows are independent: the
+// pool's threads take contiguous chunks of them (as many threads as `work`, an estimate of the inner-loop steps, pays
+// for), the chunks are copied to their places in parallel (the result does not depend on the number of threads).
 template <typename RowFn>
-void pattern_rows(int nrows, int ncols, std::vector<int>& start, std::vector<int>& cols, std::vector<int>* row_of, RowFn row_fn) {
-  const unsigned hw = std::thread::hardware_concurrency();
-  const int nthreads = (int) std::max(1u, std::min({hw ? hw : 1u, 16u, (unsigned) (nrows / 512 + 1)}));
+void pattern_rows(HostPool& pool, int nrows, int ncols, long long work, std::vector<int>& start, std::vector<int>& cols,
+                  std::vector<int>* row_of, RowFn row_fn) {
+  const int nthreads = (int) std::max(1LL, std::min({(long long) pool.size(), work / 16384 + 1, (long long) nrows}));
   std::vector<std::vector<int>> chunk_cols((size_t) nthreads), chunk_len((size_t) nthreads);
-  auto work = [&](int t) {
-    const int r0 = (int) ((long long) nrows * t / nthreads), r1 = (int) ((long long) nrows * (t + 1) / nthreads);
+  auto row_lo = [&](int t) { return (int) ((long long) nrows * t / nthreads); };
+  pool.run(nthreads, [&](int t) {
+    const int r0 = row_lo(t), r1 = row_lo(t + 1);
     std::vector<int> stamp((size_t) std::max(ncols, 1), -1), out;
     std::vector<int>& cc = chunk_cols[(size_t) t];
     std::vector<int>& ll = chunk_len[(size_t) t];
     ll.reserve((size_t) (r1 - r0));
+    cc.reserve((size_t) (work / nthreads / 2 + 16));
     for (int r = r0; r < r1; ++r) {
       out.clear();
       row_fn(r, stamp, out);
@@ -1382,42 +1439,70 @@ void pattern_rows(int nrows, int ncols, std::vector<int>& start, std::vector<int
       cc.insert(cc.end(), out.begin(), out.end());
       ll.push_back((int) out.size());
     }
-  };
-  if (nthreads == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
-    for (std::thread& th : pool) th.join();
-  }
+  });
+  std::vector<size_t> offset((size_t) nthreads + 1, 0);
+  for (int t = 0; t < nthreads; ++t) offset[(size_t) t + 1] = offset[(size_t) t] + chunk_cols[(size_t) t].size();
+  const size_t total = offset[(size_t) nthreads];
   start.assign((size_t) nrows + 1, 0);
-  size_t total = 0;
-  for (int t = 0; t < nthreads; ++t) total += chunk_cols[(size_t) t].size();
-  cols.clear();
-  cols.reserve(total);
-  if (row_of) {
-    row_of->clear();
-    row_of->reserve(total);
-  }
-  int r = 0;
-  for (int t = 0; t < nthreads; ++t) {
-    cols.insert(cols.end(), chunk_cols[(size_t) t].begin(), chunk_cols[(size_t) t].end());
+  cols.resize(total);
+  if (row_of) row_of->resize(total);
+  pool.run(nthreads, [&](int t) {
+    const std::vector<int>& cc = chunk_cols[(size_t) t];
+    if (!cc.empty()) std::memcpy(cols.data() + offset[(size_t) t], cc.data(), cc.size() * sizeof(int));
+    size_t at = offset[(size_t) t];
+    int r     = row_lo(t);
     for (int len : chunk_len[(size_t) t]) {
-      if (row_of) row_of->insert(row_of->end(), (size_t) len, r);
-      start[(size_t) r + 1] = start[(size_t) r] + len;
+      if (row_of) std::fill(row_of->begin() + (long) at, row_of->begin() + (long) (at + (size_t) len), r);
+      at += (size_t) len;
+      start[(size_t) r + 1] = (int) at;  // (= the end of row r: the global offsets are exclusive prefix sums)
       ++r;
     }
+  });
+}
+
+// The entries of a row-major pattern listed by column (rows ascending within a column) + the {entry, row} pairs the
+// two-phase kernels read.  Thread t owns a contiguous range of columns and picks its entries out of one scan of all of
+// them (the scan is cheap; a serial counting sort of C5's 546 000-entry Q was 1.5 ms).
+void columns_of(HostPool& pool, int ncols, const std::vector<int>& col_of_entry, const std::vector<int>& row_of_entry,
+                std::vector<int>& csc_start, std::vector<int>& csc_ent, std::vector<int2>& csc2) {
+  const int ne = (int) col_of_entry.size();
+  csc_start.assign((size_t) ncols + 1, 0);
+  csc_ent.assign((size_t) std::max(ne, 1), 0);
+  csc2.assign((size_t) std::max(ne, 1), make_int2(0, 0));
+  for (int e = 0; e < ne; ++e) csc_start[(size_t) col_of_entry[(size_t) e] + 1]++;
+  for (int c = 0; c < ncols; ++c) csc_start[(size_t) c + 1] += csc_start[(size_t) c];
+  const int nthreads = (int) std::max(1LL, std::min({(long long) pool.size(), (long long) ne / 32768 + 1, (long long) std::max(ncols, 1)}));
+  // column ranges of about equal numbers of entries
+  std::vector<int> c_lo((size_t) nthreads + 1, ncols);
+  c_lo[0] = 0;
+  for (int t = 1; t < nthreads; ++t) {
+    const int want = (int) ((long long) ne * t / nthreads);
+    c_lo[(size_t) t] = (int) (std::lower_bound(csc_start.begin(), csc_start.end(), want) - csc_start.begin());
+    c_lo[(size_t) t] = std::min(std::max(c_lo[(size_t) t], c_lo[(size_t) t - 1]), ncols);
   }
+  pool.run(nthreads, [&](int t) {
+    const int c0 = c_lo[(size_t) t], c1 = c_lo[(size_t) t + 1];
+    if (c0 >= c1) return;
+    std::vector<int> cur(csc_start.begin() + c0, csc_start.begin() + c1);
+    for (int e = 0; e < ne; ++e) {
+      const int c = col_of_entry[(size_t) e];
+      if (c < c0 || c >= c1) continue;
+      const int at = cur[(size_t) (c - c0)]++;
+      csc_ent[(size_t) at] = e;  // (rows ascending: the entries are scanned in row order)
+      csc2[(size_t) at]    = make_int2(e, row_of_entry[(size_t) e]);
+    }
+  });
 }
 
 // Aggregation hierarchy from the graph's structure and the current poses (host; only when the structure changed).
 int build_hierarchy(srrg2_posegraph_s* g) {
   const int V = g->V, E = g->E, D = g->D, T = g->T;
   const auto t_begin = std::chrono::steady_clock::now();
-  double ms_match = 0.0, ms_pattern = 0.0;
+  double ms_match = 0.0, ms_pattern = 0.0, ms_inc = 0.0, ms_p = 0.0, ms_q = 0.0, ms_csc = 0.0, ms_ce = 0.0, ms_up = 0.0;
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
+  HostPool pool((int) std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
   g->pg_force_tentative.clear();
   g->levels.clear();  // (the levels' device buffers stay in g->level_pool: a rebuild reuses them, they only ever grow)
   std::vector<float> poses((size_t) std::max(V, 1) * T);
@@ -1464,6 +1549,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       L->row_parts = parts;
     }
     // incidence lists in (node, edge) order
+    const auto t_inc = std::chrono::steady_clock::now();
     std::vector<int> inc_start((size_t) n + 1, 0);
     std::vector<int2> inc_adj((size_t) std::max(2 * ne, 1), make_int2(-1, 0));
     for (int e = 0; e < ne; ++e) {
@@ -1491,6 +1577,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         (rc = L->res.reserve((size_t) std::max(n, 1) * D)) || (rc = L->Hdf.reserve((size_t) std::max(n, 1) * D * D)) ||
         (rc = L->Hof.reserve((size_t) std::max(ne, 1) * D * D)) || (rc = L->Dinvf.reserve((size_t) std::max(n, 1) * D * D)))
       return rc;
+    ms_inc += ms_since(t_inc);
     int free_nodes = 0;
     for (int v = 0; v < n; ++v) free_nodes += excluded[(size_t) v] ? 0 : 1;
     if (free_nodes <= MG_COARSEST_NODES && level > 0) break;  // this is the coarsest level
@@ -1509,7 +1596,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         for (int v = 0; v < n; ++v)
           if (cur[(size_t) v] >= 0 && first[(size_t) cur[(size_t) v]] < 0) first[(size_t) cur[(size_t) v]] = v;
         // neighbours of every current aggregate
-        std::vector<int> nb_start((size_t) n + 1, 0), nb_list;  // (CSR, in edge order)
+        std::vector<int> nb_start((size_t) n + 1, 0), nb_list;  // (CSR, in edge order; serial: shared atomic counters
+        // across the host's two sockets were 2.6 x slower than one thread)
         for (int e = 0; e < ne; ++e) {
           const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
           if (a < 0 || b < 0 || a == b) continue;
@@ -1576,7 +1664,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
                     !g->pg_force_tentative.count(level);
     const long long q_limit = 64LL * std::max(n, 4096);
     for (int attempt = 0; attempt < 2; ++attempt) {
-      pattern_rows(n, nc, prow_start, pcol, &prow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
+      pattern_rows(pool, n, nc, (long long) n + 2LL * ne, prow_start, pcol, &prow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
         if (agg[(size_t) v] < 0) return;
         stamp[(size_t) agg[(size_t) v]] = v;
         out.push_back(agg[(size_t) v]);
@@ -1593,27 +1681,35 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       // upper bound of the size of Q's pattern (before duplicates are merged): cheap, and enough to stop a blow-up
       // before it is computed; the exact size is checked again below
       long long bound = 0;
-      for (int v = 0; v < n; ++v) {
-        bound += prow_start[(size_t) v + 1] - prow_start[(size_t) v];
-        for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) {
-          const int j = inc_adj[(size_t) q].x;
-          bound += prow_start[(size_t) j + 1] - prow_start[(size_t) j];
-        }
+      {
+        const int nt = (int) std::max(1LL, std::min((long long) pool.size(), ((long long) n + 2LL * ne) / 32768 + 1));
+        std::vector<long long> part((size_t) nt, 0);
+        pool.run(nt, [&](int t) {
+          long long b = 0;
+          for (int v = (int) ((long long) n * t / nt); v < (int) ((long long) n * (t + 1) / nt); ++v) {
+            b += prow_start[(size_t) v + 1] - prow_start[(size_t) v];
+            for (int q = inc_start[(size_t) v]; q < inc_start[(size_t) v + 1]; ++q) {
+              const int j = inc_adj[(size_t) q].x;
+              b += prow_start[(size_t) j + 1] - prow_start[(size_t) j];
+            }
+          }
+          part[(size_t) t] = b;
+        });
+        for (long long b : part) bound += b;
       }
       if (bound <= 16 * q_limit) break;
       smoothed = false;
     }
+    ms_p += ms_since(t_pattern);
+    const auto t_q = std::chrono::steady_clock::now();
     const int np = (int) pcol.size();
-    std::vector<int> pcsc_start((size_t) nc + 1, 0), pcsc_ent((size_t) std::max(np, 1), 0);
-    for (int e = 0; e < np; ++e) pcsc_start[(size_t) pcol[(size_t) e] + 1]++;
-    for (int I = 0; I < nc; ++I) pcsc_start[(size_t) I + 1] += pcsc_start[(size_t) I];
-    {
-      std::vector<int> cur(pcsc_start.begin(), pcsc_start.end() - 1);
-      for (int e = 0; e < np; ++e) pcsc_ent[(size_t) cur[(size_t) pcol[(size_t) e]]++] = e;  // (rows ascending)
-    }
+    std::vector<int> pcsc_start, pcsc_ent;
+    std::vector<int2> pcsc2;
+    columns_of(pool, nc, pcol, prow_of, pcsc_start, pcsc_ent, pcsc2);
     // pattern of Q = H Ps: row i = union of the rows of Ps over i and its neighbours
     std::vector<int> qrow_start, qcol, qrow_of;
-    pattern_rows(n, nc, qrow_start, qcol, &qrow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
+    const long long q_work = (long long) np * (1 + (n > 0 ? 2LL * ne / n : 0));
+    pattern_rows(pool, n, nc, q_work, qrow_start, qcol, &qrow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
       if (agg[(size_t) v] < 0) return;
       auto add_row = [&](int j) {
         for (int e = prow_start[(size_t) j]; e < prow_start[(size_t) j + 1]; ++e) {
@@ -1635,20 +1731,17 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       continue;
     }
     const int nq = (int) qcol.size();
+    ms_q += ms_since(t_q);
+    const auto t_csc = std::chrono::steady_clock::now();
     // Q by column (two-phase levels: r_c = Ps^T r - Q^T x1)
-    std::vector<int> qcsc_start((size_t) nc + 1, 0), qcsc_ent((size_t) std::max(nq, 1), 0);
-    for (int e = 0; e < nq; ++e) qcsc_start[(size_t) qcol[(size_t) e] + 1]++;
-    for (int I = 0; I < nc; ++I) qcsc_start[(size_t) I + 1] += qcsc_start[(size_t) I];
-    {
-      std::vector<int> cur(qcsc_start.begin(), qcsc_start.end() - 1);
-      for (int e = 0; e < nq; ++e) qcsc_ent[(size_t) cur[(size_t) qcol[(size_t) e]]++] = e;  // (rows ascending)
-    }
-    std::vector<int2> pcsc2((size_t) std::max(np, 1), make_int2(0, 0)), qcsc2((size_t) std::max(nq, 1), make_int2(0, 0));
-    for (int m = 0; m < np; ++m) pcsc2[(size_t) m] = make_int2(pcsc_ent[(size_t) m], prow_of[(size_t) pcsc_ent[(size_t) m]]);
-    for (int m = 0; m < nq; ++m) qcsc2[(size_t) m] = make_int2(qcsc_ent[(size_t) m], qrow_of[(size_t) qcsc_ent[(size_t) m]]);
+    std::vector<int> qcsc_start, qcsc_ent;
+    std::vector<int2> qcsc2;
+    columns_of(pool, nc, qcol, qrow_of, qcsc_start, qcsc_ent, qcsc2);
+    ms_csc += ms_since(t_csc);
+    const auto t_ce = std::chrono::steady_clock::now();
     // coarse edges (A < B): B in the row of Q of some row of column A of Ps
     std::vector<int> ce_start, ce_col, ceij;
-    pattern_rows(nc, nc, ce_start, ce_col, nullptr, [&](int A, std::vector<int>& stamp, std::vector<int>& out) {
+    pattern_rows(pool, nc, nc, (long long) nq * 4, ce_start, ce_col, nullptr, [&](int A, std::vector<int>& stamp, std::vector<int>& out) {
       for (int m = pcsc_start[(size_t) A]; m < pcsc_start[(size_t) A + 1]; ++m) {
         const int i = prow_of[(size_t) pcsc_ent[(size_t) m]];
         // (the row is ascending: skip to the first column behind A)
@@ -1668,7 +1761,9 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         ceij[2 * (size_t) k + 1] = ce_col[(size_t) k];
       }
     const int nce = (int) (ceij.size() / 2);
+    ms_ce += ms_since(t_ce);
     ms_pattern += ms_since(t_pattern);
+    const auto t_up = std::chrono::steady_clock::now();
     L->nc  = nc;
     L->nce = nce;
     L->np  = np;
@@ -1692,6 +1787,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         (rc = upload(L->pcsc2, pcsc2)) || (rc = upload(L->qcsc2, qcsc2)) ||
         (rc = L->Psf.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Qf.reserve((size_t) std::max(nq, 1) * D * D)))
       return rc;
+    ms_up += ms_since(t_up);
     // next level
     n = nc;
     eij.swap(ceij);
@@ -1703,6 +1799,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative");
     std::fprintf(stderr, " coarsest %s; built in %.1f ms on the host (matching %.1f, patterns %.1f)\n",
                  g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, ms_pattern);
+    std::fprintf(stderr, "  incidences + uploads %.1f, P pattern %.1f, Q pattern %.1f, column lists %.1f, coarse edges %.1f, uploads %.1f ms\n",
+                 ms_inc, ms_p, ms_q, ms_csc, ms_ce, ms_up);
   }
   // device views
   const int nl = (int) g->levels.size();
