@@ -434,7 +434,8 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
                                "tolerance 1e-6 (CG preconditioned by a smoothed-aggregation multigrid V-cycle), pose 0 fixed" % (V, E, len(st)),
                    "pcg_iterations": [s_["pcg_iterations"] for s_ in st], "chi_first_last": [st[0]["chi"], st[-1]["chi"]],
                    "every_linear_solve_converged": bool(converged)},
-        "roofline": {"bound": "hbm", "kernel": "one PCG iteration = k_pg_spmv + V-cycle (k_mg_op x levels, k_mg_coarse_cycle) + vector kernels; "
+        "roofline": {"bound": "hbm", "kernel": "one PCG iteration = k_pg_spmv + V-cycle (k_mg_op on level 0, k_mg_down2 / k_mg_up2 below it, k_mg_down2_coarsest) + "
+                                               "vector kernels; "
                                                "achieved = algorithmic bytes of the whole solve / its wall time",
                      "achieved": alg / best / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / best / 1e9 / 8000.0,
                      "traffic": None, "algorithmic_bytes": alg},

@@ -2028,6 +2028,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       // solve() into a HIP graph and replayed; every pointer and scalar it carries is fixed for the whole call.
       if (chunk == PCG_CHUNK && use_graph && !chunk_exec && !graph_failed) {
         hipGraph_t graph = nullptr;
+        const auto t_cap = std::chrono::steady_clock::now();
         if (hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
           launch_iterations(0, PCG_CHUNK);
           if (hipStreamEndCapture(g->stream, &graph) != hipSuccess || !graph ||
@@ -2039,6 +2040,9 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
           graph_failed = true;
           (void) hipGetLastError();
         }
+        if (std::getenv("SRRG2_AMD_PG_DEBUG"))
+          std::fprintf(stderr, "posegraph: CG chunk captured and instantiated in %.2f ms\n",
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cap).count());
       }
       if (chunk == PCG_CHUNK && chunk_exec) {
         HIP_TRY(hipGraphLaunch(chunk_exec, g->stream));
