@@ -64,6 +64,8 @@ struct SliceDev {
   float robust_thr;
   float normal_cos;
   int use_normal_gate;
+  int gather_prev;  // the previous neighbour and its normal are re-read from the fixed cloud through prev_pos (batches: the cloud
+                    // is shared by all alignments and stays in L2) instead of kept per moving point in prev_f / prev_n
   int variable_kind;
   // projective finder (organised fixed cloud in ingest order + per-problem z-buffer)
   int finder;           // srrg2_finder_kind

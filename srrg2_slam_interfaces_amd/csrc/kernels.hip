@@ -730,9 +730,11 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
       }
     }
     if (!kept) {  // (a skipped search keeps its neighbour: only the exclusion radius changes)
-      S.prev_f[gi]   = fm;  // (.w = NO_MATCH: none)
       S.prev_pos[gi] = (active && bidx != NO_MATCH) ? bpos : -1;
-      if (PLANE || S.use_normal_gate) S.prev_n[gi] = nf;
+      if (!S.gather_prev) {  // (with gather_prev the position is all the next pass reads)
+        S.prev_f[gi] = fm;  // (.w = NO_MATCH: none)
+        if (PLANE || S.use_normal_gate) S.prev_n[gi] = nf;
+      }
     }
     S.prev_m[gi] = excl;
     // (the correspondence record {match, resp, fstat} is not stored: k_icp_outputs derives it on demand)
@@ -797,10 +799,18 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
   if (inrange) {
     p = S.mpts[gi];
     if (use_prior) {  // previous nearest neighbour {x, y, z, index}, its normal, exclusion radius: independent loads
-      pf   = S.prev_f[gi];
       pm   = S.prev_m[gi];
-      if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
       if (S.use_normal_gate) pnm = S.mnrm[gi];
+      if (S.gather_prev) {  // (batches: through its position in the L2-resident fixed cloud, 8 instead of 40 streamed bytes)
+        const int ppos = S.prev_pos[gi];
+        if (ppos >= 0 && ppos < S.grid.n) {
+          pf = S.grid.pts[ppos];
+          if (PLANE || S.use_normal_gate) pn = S.grid.nrm[ppos];
+        }
+      } else {
+        pf = S.prev_f[gi];
+        if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
+      }
     }
   }
   const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
@@ -1569,10 +1579,18 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
   if (inrange) {
     p = S.mpts[gi];
     if (use_prior) {
-      pf = S.prev_f[gi];
       pm = S.prev_m[gi];
-      if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
       if (S.use_normal_gate) pnm = S.mnrm[gi];
+      if (S.gather_prev) {  // (as in icp_step_body)
+        const int ppos = S.prev_pos[gi];
+        if (ppos >= 0 && ppos < S.grid.n) {
+          pf = S.grid.pts[ppos];
+          if (PLANE || S.use_normal_gate) pn = S.grid.nrm[ppos];
+        }
+      } else {
+        pf = S.prev_f[gi];
+        if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
+      }
     }
   }
   const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
@@ -2172,9 +2190,11 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       linearize(std::false_type{}, acc2, open, p[k], fk, nk, pnm[k], qx, qy, qz, sbest[k]);
     if (open) {
       S.prev_m[gi_[k]]   = sexcl[k];
-      S.prev_f[gi_[k]]   = fk;
       S.prev_pos[gi_[k]] = sidx[k] != NO_MATCH ? spos[k] : -1;
-      if (PLANE || ngate) S.prev_n[gi_[k]] = nk;
+      if (!GATHER) {
+        S.prev_f[gi_[k]] = fk;
+        if (PLANE || ngate) S.prev_n[gi_[k]] = nk;
+      }
     }
   }
   block_reduce_store_biased<1>(acc2, S.partials, prob, blockIdx.x, PPT);
@@ -2200,7 +2220,14 @@ __global__ __launch_bounds__(256) void k_icp_outputs(SliceDev S, const ProblemDe
   uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
   const float4 p = S.mpts[gi];
   if (st->npasses > 0 && finite3(p.x, p.y, p.z)) {
-    const float4 f = S.prev_f[gi];
+    float4 f = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
+    int fpos = -1;
+    if (S.gather_prev) {
+      fpos = S.prev_pos[gi];
+      if (fpos >= 0 && fpos < S.grid.n) f = S.grid.pts[fpos];
+    } else {
+      f = S.prev_f[gi];
+    }
     if (__float_as_int(f.w) != NO_MATCH) {
       float T[12];
       load_T(st->Tlast[S.slice_idx], T);
@@ -2211,7 +2238,7 @@ __global__ __launch_bounds__(256) void k_icp_outputs(SliceDev S, const ProblemDe
       const float best = key_best(k1);
       bool found       = best <= S.grid.gate2;
       float4 nf        = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (found && (PLANE || S.use_normal_gate)) nf = S.prev_n[gi];
+      if (found && (PLANE || S.use_normal_gate)) nf = S.gather_prev ? S.grid.nrm[fpos] : S.prev_n[gi];
       if (found && S.use_normal_gate) {
         const float4 nm = S.mnrm[gi];
         float dot;
