@@ -2936,14 +2936,22 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
   cur.num_correspondences = num_correspondences(C, st);
   cur.chi_inliers         = (float) chi_in;
   cur.chi_outliers        = (float) chi_out;
-  if (KNOB(C.tune, 134217728)) {  // (timing: without the solve and everything behind it)
+  // (timing, profiling builds: bits 27..29 of the mask select how far the step runs -- 1: without the solve and
+  // everything behind it, 2: up to and including the solve, 3: + the stores of H, b, dx, 5: + box-plus, 6: + the finder
+  // transforms, 4: everything but the termination criterion and the queue bookkeeping)
+#ifdef SRRG2_TIMING_KNOBS
+  const int stage = (C.tune >> 27) & 7;
+#else
+  constexpr int stage = 0;
+#endif
+  if (stage == 1) {
     st->nstats++;
     st->last_H[0] = H[0] + b[0];
     return;
   }
   int bad                 = dm::solve<D>(H, b, dx);
   cur.solver_status       = bad ? 1 : 0;
-  if (KNOB(C.tune, 268435456)) {  // (timing: up to and including the solve)
+  if (stage == 2) {
     st->nstats++;
     st->last_dx[0] = dx[0] + dx[D - 1];
     return;
@@ -2955,19 +2963,31 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
     st->last_b[i]  = b[i];
     st->last_dx[i] = bad ? 0.0 : dx[i];
   }
+  if (stage == 3) {
+    st->nstats++;
+    return;
+  }
   for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];  // the estimate this iteration's finder passes ran with
   if (!bad) dm::box_plus(C.variable_kind, st->X, dx);  // solver Success: multi_aligner_impl.cpp:118-121
+  if (stage == 5) {
+    st->nstats++;
+    return;
+  }
   for (int s = 0; s < C.nslices; ++s) {
     if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
     for (int i = 0; i < 12; ++i) st->Tfprev[s][i] = st->Tf[s][i];
     if (!bad) finder_transform_of(C.slices[s].Sinv, C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3, st->X, st->Tf[s]);
+  }
+  if (stage == 6) {
+    st->nstats++;
+    return;
   }
   for (int s = 0; s < C.nslices; ++s)  // the fixed-point scale of given-correspondences slices follows the estimate
     if (C.slices[s].finder == SRRG2_FINDER_CORRESPONDENCES && C.slices[s].kind != SRRG2_SLICE_PRIOR)
       st->kexp[s] = slice_exponent(C, C.slices[s], prob, 0, st->X);
   if (st->nstats < C.max_stats) stats[(size_t) prob * C.max_stats + st->nstats] = cur;
   st->nstats++;
-  if (KNOB(C.tune, 536870912)) return;  // (timing: without the termination criterion and the queue bookkeeping)
+  if (stage == 4) return;  // (timing: without the termination criterion and the queue bookkeeping)
   if (C.has_term && has_to_stop(C, st, cur)) st->done = 1;  // :124-126
   for (int s = 0; s < C.nslices; ++s)
     if (C.slices[s].qcount) {

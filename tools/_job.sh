@@ -1,18 +1,20 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-O=gpurun_out/r3final; mkdir -p $O
-python bench.py > $O/bench_default.json 2>$O/bench_default.err
-python bench.py --workload c2 > $O/bench_c2.json 2>$O/bench_c2.err
-python bench.py --workload c3 --no-cpu-baseline > $O/bench_c3.json 2>$O/bench_c3.err
-python bench.py --workload c4 --no-cpu-baseline > $O/bench_c4.json 2>$O/bench_c4.err
-python bench.py --workload c4 --batch 256 --no-cpu-baseline > $O/bench_c4_256.json 2>>$O/bench_c4.err
-timeout 900 python bench.py --workload c5 > $O/bench_c5.json 2>$O/bench_c5.err
-for f in bench_default bench_c2 bench_c3 bench_c4 bench_c4_256; do python - $O/$f.json <<'PY'
-import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d.get('roofline') or {}
-print(sys.argv[1].split('/')[-1], round(d['value']), round(d['ms_per_step'],4), 'frac', round(r.get('frac',0),4), 'traffic', r.get('traffic'), (d.get('cpu_baseline') or {}).get('value'))
-for k in ('c3','c4_256','c4_32','c4_8','c5'):
-    if k in d: print('   ', k, round(d[k]['value'],1), round(d[k]['ms_per_step'],4), round(d[k]['roofline']['frac'],4), d[k]['roofline'].get('traffic'))
-PY
+R=$PWD
+O=$R/gpurun_out/r3t; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.txt 2>&1
+tail -2 $O/pytest_gpu.txt
+cd /tmp
+for w in c2 c3; do
+  rm -rf /tmp/trk
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/trk -o t -- python $R/bench.py --workload $w --steps 30 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python $R/tools/rocpd_summary.py /tmp/s.txt kernel_trace_stats=$(find /tmp/trk -name '*.db' | head -1) > /dev/null 2>&1
+  echo "$w: $(grep '^k_icp_control' /tmp/s.txt | cut -d'|' -f1-4 | cut -c1-20,100-)"
 done
-cut -c1-300 $O/bench_c5.json
+cd $R
+rm -f $O/ab.txt
+for w in "--workload c2" "--workload c3" "--workload c4 --batch 32 --steps 10" "--workload c4 --batch 8 --steps 10"; do
+  bash tools/ab_env.sh $O/ab.txt "$w" "-" "-"
+done
+cat $O/ab.txt
