@@ -37,6 +37,20 @@ def test_matches_oracle(oracle, product, kind):
     assert sg[-1]["chi"] < 0.2 * sg[0]["chi"]
 
 
+def test_se2_matches_oracle_on_a_four_level_hierarchy(oracle, product):
+    """3 000 SE(2) poses: 3 000 -> ~375 -> ~47 -> ~6 nodes, so the 3 x 3-block instances of the two-phase cycle kernels
+    (k_mg_down2 / k_mg_up2 / k_mg_down2_coarsest: whole blocks per lane) all run; poses within 1e-5 of the oracle's
+    block-Jacobi PCG"""
+    g = syn.pose_graph_2d(V=3000, E=9000)
+    ref, gpu = oracle.OraclePoseGraph(abi.SE2_RIGHT), product.PoseGraph(abi.SE2_RIGHT)
+    for pg in (ref, gpu):
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+    sr, sg = ref.solve(_tight()), gpu.solve(_tight())
+    assert len(sr) == len(sg)
+    assert all(s["solver_status"] == 0 for s in sg)
+    assert np.max(np.abs(ref.poses() - gpu.poses())) <= 1e-5
+
+
 def test_information_matrices_disabled_factors_fixed_mask(oracle, product):
     kind = abi.SE3_QUAT_RIGHT
     g = syn.pose_graph_3d(V=150, E=500, seed=22)
