@@ -1,5 +1,10 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-SRRG2_AMD_HOSTTIME=1 python bench.py --workload c2 --steps 12 --warmup 3 --no-cpu-baseline 2>&1 | grep "compute:" | tail -8
-SRRG2_AMD_HOSTTIME=1 python bench.py --workload c3 --steps 6 --warmup 3 --no-cpu-baseline 2>&1 | grep "compute:" | tail -3
-SRRG2_AMD_HOSTTIME=1 python bench.py --workload c4 --batch 32 --steps 6 --warmup 3 --no-cpu-baseline 2>&1 | grep "compute:\|upload" | tail -4
+O=gpurun_out/r3w; mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+python bench.py > $O/bench_default.json 2>$O/bench_default.err; python - $O/bench_default.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(round(d['value']), d['ms_per_step'], [ (k, round(d[k]['value'],1)) for k in ('c3','c4_256','c4_32','c4_8','c5')])
+PY
