@@ -1324,7 +1324,8 @@ struct TileBox {
 __device__ unsigned long long g_tile_stats[4 * 16];
 #define TILE_STAT(it, k, v)                                                                             \
   do {                                                                                                  \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_tile_stats[((it) < 3 ? (it) : 3) * 16 + (k)], (unsigned long long) (v)); \
+    const unsigned long long v_ = (unsigned long long) (v); /* (by every lane: v may hold a ballot) */  \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_tile_stats[((it) < 3 ? (it) : 3) * 16 + (k)], v_);        \
   } while (0)
 #else
 #define TILE_STAT(it, k, v) do { } while (0)
