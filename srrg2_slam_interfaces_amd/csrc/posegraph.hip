@@ -668,23 +668,16 @@ __global__ __launch_bounds__(1024) void k_mg_down2_coarsest(const MgLevel* __res
 }
 
 // y += B xv (trans == false) or B^T xv (trans == true), whole block per lane
-template <int D, typename BT = float>
-__device__ __forceinline__ void mg_block_mul(const BT* __restrict__ B, const double* __restrict__ xv, bool trans, bool on,
+template <int D>
+__device__ __forceinline__ void mg_block_mul(const float* __restrict__ B, const double* __restrict__ xv, bool trans, bool on,
                                              double (&y)[D]) {
-  BT b[D * D];
-  if (D == 6 && sizeof(BT) == 4) {
-    const float4* B4 = reinterpret_cast<const float4*>(B);  // (blocks of 36 floats: 16-byte aligned)
+  float b[D * D];
+  if (D == 6) {
+    const float4* B4 = reinterpret_cast<const float4*>(B);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const float4 v = B4[k];
-      b[4 * k] = (BT) v.x; b[4 * k + 1] = (BT) v.y; b[4 * k + 2] = (BT) v.z; b[4 * k + 3] = (BT) v.w;
-    }
-  } else if (D == 6 && sizeof(BT) == 8) {
-    const double2* B2 = reinterpret_cast<const double2*>(B);  // (blocks of 36 doubles: 32-byte aligned)
-#pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      const double2 v = B2[k];
-      b[2 * k] = (BT) v.x; b[2 * k + 1] = (BT) v.y;
+      b[4 * k] = v.x; b[4 * k + 1] = v.y; b[4 * k + 2] = v.z; b[4 * k + 3] = v.w;
     }
   } else {
 #pragma unroll
@@ -699,55 +692,6 @@ __device__ __forceinline__ void mg_block_mul(const BT* __restrict__ B, const dou
 #pragma unroll
     for (int c = 0; c < D; ++c) t = t + (double) (trans ? b[c * D + a] : b[a * D + c]) * x[c];
     y[a] = y[a] + t;
-  }
-}
-
-// y = H x for node v of a level with short rows (level 0: ~8 incidences), the share of lane k of the node's 8 lanes: whole
-// blocks per lane (one 144- / 288-byte block and one load of the neighbour's D doubles give all D rows), two in flight;
-// the 8 lanes meet by shuffles (every lane ends up with the node's D sums).  One thread per ROW (mg_row) asks the texture
-// path for six 24-byte pieces of every block and six copies of the neighbour's vector.
-template <int D, typename BT>
-__device__ __forceinline__ void mg_node_rows(const MgLevel& L, const BT* __restrict__ Hd, const BT* __restrict__ Ho,
-                                             const double* __restrict__ x, int v, int k, bool on, double (&y)[D]) {
-#pragma unroll
-  for (int a = 0; a < D; ++a) y[a] = 0.0;
-  if (on) {
-    if (k == 0) mg_block_mul<D, BT>(Hd + (size_t) v * D * D, x + (size_t) v * D, false, true, y);
-    const int q1 = L.inc_start[v + 1];
-    for (int q0 = L.inc_start[v] + k; q0 < q1; q0 += 16) {
-      const int2 a0 = L.inc_adj[q0];
-      const bool two = q0 + 8 < q1;
-      const int2 a1 = two ? L.inc_adj[q0 + 8] : a0;
-      mg_block_mul<D, BT>(Ho + (size_t) (a0.y >> 1) * D * D, x + (size_t) a0.x * D, (a0.y & 1) != 0, true, y);
-      mg_block_mul<D, BT>(Ho + (size_t) (a1.y >> 1) * D * D, x + (size_t) a1.x * D, (a1.y & 1) != 0, two, y);
-    }
-  }
-#pragma unroll
-  for (int off = 4; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int a = 0; a < D; ++a) y[a] = y[a] + __shfl_xor(y[a], off);
-  }
-}
-template <int D>
-__device__ __forceinline__ double mg_pick(const double (&y)[D], int k) {
-  double r = 0.0;
-#pragma unroll
-  for (int c = 0; c < D; ++c) r = k == c ? y[c] : r;
-  return r;
-}
-
-// res = r - H x, eight lanes per node (level 0 of the cycle)
-template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_residual_nodes(const MgLevel* __restrict__ levels, int l,
-                                                                  const PgScalars* __restrict__ sc) {
-  if (sc->done || sc->bad) return;
-  const MgLevel L = levels[l];
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ((L.n * 8 + 63) & ~63); t += gridDim.x * blockDim.x) {
-    const int k = t & 7, v = t >> 3;
-    const bool on = v < L.n;
-    double y[D];
-    mg_node_rows<D, float>(L, L.Hdf, L.Hof, L.x, v, k, on, y);
-    if (on && k < D) L.res[(size_t) v * D + k] = L.r[(size_t) v * D + k] - mg_pick<D>(y, k);
   }
 }
 
@@ -1297,29 +1241,6 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(const MgLevel* __restric
     const double y = mg_row<D, double>(L, L.Hd, L.Ho, p, v, row);
     Ap[t] = y;
     pap   = pap + y * p[t];
-  }
-  pap = block_sum(pap);
-  if (threadIdx.x == 0) part_pAp[blockIdx.x] = pap;
-}
-
-// the same with eight lanes per node and whole float64 blocks per lane (mg_node_rows)
-template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_spmv_nodes(const MgLevel* __restrict__ levels, const double* __restrict__ p,
-                                                              double* __restrict__ Ap, double* __restrict__ part_pAp,
-                                                              const PgScalars* __restrict__ sc) {
-  if (sc->done || sc->bad) return;
-  const MgLevel L = levels[0];
-  double pap = 0.0;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ((L.n * 8 + 63) & ~63); t += gridDim.x * blockDim.x) {
-    const int k = t & 7, v = t >> 3;
-    const bool on = v < L.n;
-    double y[D];
-    mg_node_rows<D, double>(L, L.Hd, L.Ho, p, v, k, on, y);
-    if (on && k < D) {
-      const double yk = mg_pick<D>(y, k);
-      Ap[(size_t) v * D + k] = yk;
-      pap = pap + yk * p[(size_t) v * D + k];
-    }
   }
   pap = block_sum(pap);
   if (threadIdx.x == 0) part_pAp[blockIdx.x] = pap;
@@ -1946,8 +1867,6 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   // levels 1 .. lf-1 take ONE launch down and ONE up (k_mg_down2 / k_mg_up2) instead of three each; level 0, where the
   // passes are long enough to be bound by their bytes (Q is 2.2 x the size of H there), keeps its six phases
   static const bool two_phase = !(std::getenv("SRRG2_AMD_PG_TWO_PHASE") && std::atoi(std::getenv("SRRG2_AMD_PG_TWO_PHASE")) == 0);
-  // level 0's operator passes (the cycle's two residuals, CG's SpMV) with eight lanes per node and whole blocks per lane
-  static const bool node_rows = !(std::getenv("SRRG2_AMD_PG_NODE_ROWS") && std::atoi(std::getenv("SRRG2_AMD_PG_NODE_ROWS")) == 0);
   auto parts2 = [&](const MgLevelBufs* Lb, bool down) {
     int p2 = down ? Lb->col_parts : std::max(Lb->row_parts, Lb->prow_parts);
     return std::min(std::max(p2, 1), 8);
@@ -1956,10 +1875,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     const MgLevelBufs* L0b = g->levels[0];
     const int bl0 = blocks_for(L0b->n * D), bc0 = blocks_for(L0b->nc * D * L0b->col_parts), br0 = blocks_for(L0b->n * D * L0b->row_parts);
     hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, g->levels_dev.p, 0, g->sc.p);
-    if (node_rows)
-      hipLaunchKernelGGL(k_mg_residual_nodes<D>, dim3(blocks_for(L0b->n * 8)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, 0, g->sc.p);
-    else
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, 0, g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, 0, g->sc.p);
     hipLaunchKernelGGL(k_mg_op<D>, dim3(bc0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, g->levels_dev.p, 0, g->sc.p);
     if (lf > 1)  // x1 of level 1 (the levels below get theirs from k_mg_down2)
       hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(g->levels[1]->n * D)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0,
@@ -1988,10 +1904,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       hipLaunchKernelGGL(k_mg_prolong_res<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, 0, g->sc.p);
     else
       hipLaunchKernelGGL(k_mg_op<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, g->levels_dev.p, 0, g->sc.p);
-    if (node_rows)
-      hipLaunchKernelGGL(k_mg_residual_nodes<D>, dim3(blocks_for(L0b->n * 8)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, 0, g->sc.p);
-    else
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, 0, g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, 0, g->sc.p);
     hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, g->levels_dev.p, 0, g->sc.p);
   };
   auto vcycle = [&]() {
@@ -2098,10 +2011,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       for (int k = 0; k < count; ++k) {
         double* rz_cur = ((first + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
         double* rz_nxt = ((first + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
-        if (node_rows)
-          hipLaunchKernelGGL(k_pg_spmv_nodes<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
-        else
-          hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
+        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_update_xr, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance, g->p.p,
                            g->Ap.p, g->x.p, r, rz_cur, g->part_pAp.p, g->part_rr.p, g->part_bb.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_converged, dim3(1), dim3(PG_THREADS), 0, g->stream, nb, (double) p->pcg_tolerance, g->part_rr.p,
