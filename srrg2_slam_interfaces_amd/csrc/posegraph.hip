@@ -1345,6 +1345,16 @@ struct srrg2_posegraph_s {
   DevBuf<MgLevel> levels_dev;
   DevBuf<double> coarse_A, coarse_inv;
   int coarsest_dense = 1;
+  // experiment switches, read from the SRRG2_AMD_PG_* environment ONCE, in srrg2_posegraph_create (DESIGN.md "Strategy knobs")
+  struct Switches {
+    int match_passes = 3;       // SRRG2_AMD_PG_PASSES
+    double omega_p = 0.0;       // SRRG2_AMD_PG_OMEGA_P (set to MG_OMEGA_P at create)
+    double omega = 0.0;         // SRRG2_AMD_PG_OMEGA   (set to MG_OMEGA at create)
+    double lag_below = 0.0;     // SRRG2_AMD_PG_LAG
+    bool two_phase = true;      // SRRG2_AMD_PG_TWO_PHASE
+    bool use_graph = true;      // SRRG2_AMD_PG_GRAPH
+    bool debug = false;         // SRRG2_AMD_PG_DEBUG
+  } sw;
   bool mg_dirty      = true;
   // host mirrors for the incremental interface (incidence lists are rebuilt lazily from these)
   std::vector<int> h_ij;
@@ -1531,7 +1541,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   g->coarsest_dense = 1;
   // matching passes per level: 2 -> aggregates of <= 4 poses, 3 -> <= 8 (fewer levels, slower convergence; measured in
   // DESIGN.md section 6)
-  const int match_passes = std::getenv("SRRG2_AMD_PG_PASSES") ? std::max(1, std::atoi(std::getenv("SRRG2_AMD_PG_PASSES"))) : 3;
+  const int match_passes = g->sw.match_passes;
   for (int level = 0; level < MG_MAX_LEVELS; ++level) {
     const int ne = (int) (eij.size() / 2);
     if ((size_t) level >= g->level_pool.size()) g->level_pool.push_back(new MgLevelBufs());
@@ -1660,7 +1670,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     // its degree.  When the pattern of Q would exceed 64 blocks per node (C5: 11 / 43 / 77 on its three levels) this
     // level falls back to the tentative interpolation (row = the node's own aggregate, no smoothing).
     std::vector<int> prow_start, pcol, prow_of;
-    bool smoothed = !(std::getenv("SRRG2_AMD_PG_OMEGA_P") && std::atof(std::getenv("SRRG2_AMD_PG_OMEGA_P")) == 0.0) &&
+    bool smoothed = g->sw.omega_p != 0.0 &&
                     !g->pg_force_tentative.count(level);
     const long long q_limit = 64LL * std::max(n, 4096);
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1794,7 +1804,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     rep0.swap(crep0);
     excluded.assign((size_t) n, 0);
   }
-  if (std::getenv("SRRG2_AMD_PG_DEBUG")) {
+  if (g->sw.debug) {
     std::fprintf(stderr, "posegraph hierarchy:");
     for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative");
     std::fprintf(stderr, " coarsest %s; built in %.1f ms on the host (matching %.1f, patterns %.1f)\n",
@@ -1809,7 +1819,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     MgLevelBufs* L = g->levels[(size_t) l];
     MgLevel& v     = views[(size_t) l];
     v.n = L->n; v.ne = L->ne; v.nc = L->nc; v.nce = L->nce; v.np = L->np; v.nq = L->nq;
-    v.omega = std::getenv("SRRG2_AMD_PG_OMEGA") ? std::atof(std::getenv("SRRG2_AMD_PG_OMEGA")) : MG_OMEGA;
+    v.omega = g->sw.omega;
     v.row_parts = L->row_parts; v.col_parts = L->col_parts; v.prow_parts = L->prow_parts;
     v.eij = L->eij.p; v.inc_start = L->inc_start.p; v.inc_adj = L->inc_adj.p; v.agg = L->agg.p; v.rep0 = L->rep0.p;
     v.prow_start = L->prow_start.p; v.pcol = L->pcol.p; v.prow_of = L->prow_of.p; v.pcsc_start = L->pcsc_start.p;
@@ -1862,11 +1872,11 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     if (g->levels[(size_t) l]->n <= MG_FUSE_NODES && g->levels[(size_t) l]->ne <= MG_FUSE_BLOCKS) { lf = l; break; }
   auto blocks_for = [](int items) { return std::max(std::min((items + PG_THREADS - 1) / PG_THREADS, 2048), 1); };
   // damping of the Jacobi sweep that smooths the interpolation (0: plain aggregation)
-  const double omega_p = std::getenv("SRRG2_AMD_PG_OMEGA_P") ? std::atof(std::getenv("SRRG2_AMD_PG_OMEGA_P")) : MG_OMEGA_P;
+  const double omega_p = g->sw.omega_p;
   // z = V-cycle(r): input levels[0].r (= g->r aliased below), output levels[0].x
   // levels 1 .. lf-1 take ONE launch down and ONE up (k_mg_down2 / k_mg_up2) instead of three each; level 0, where the
   // passes are long enough to be bound by their bytes (Q is 2.2 x the size of H there), keeps its six phases
-  static const bool two_phase = !(std::getenv("SRRG2_AMD_PG_TWO_PHASE") && std::atoi(std::getenv("SRRG2_AMD_PG_TWO_PHASE")) == 0);
+  const bool two_phase = g->sw.two_phase;
   auto parts2 = [&](const MgLevelBufs* Lb, bool down) {
     int p2 = down ? Lb->col_parts : std::max(Lb->row_parts, Lb->prow_parts);
     return std::min(std::max(p2, 1), 8);
@@ -1930,12 +1940,12 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     }
   };
   // SRRG2_AMD_PG_LAG: largest step (max |dx| over all variables) below which the next iteration keeps the hierarchy; 0 = never
-  const double lag_below = std::getenv("SRRG2_AMD_PG_LAG") ? std::atof(std::getenv("SRRG2_AMD_PG_LAG")) : 0.0;
+  const double lag_below = g->sw.lag_below;
   bool hierarchy_fresh   = false;
   double prev_max_dx     = 1e300;
   int nstats = 0;
   constexpr int PCG_CHUNK = 10;  // CG iterations between two looks at the convergence flag
-  static const bool use_graph = !(std::getenv("SRRG2_AMD_PG_GRAPH") && std::atoi(std::getenv("SRRG2_AMD_PG_GRAPH")) == 0);
+  const bool use_graph = g->sw.use_graph;
   hipGraphExec_t chunk_exec = nullptr;
   bool graph_failed = false;
   struct ExecGuard {  // (every return path below releases the instantiated graph)
@@ -2040,7 +2050,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
           graph_failed = true;
           (void) hipGetLastError();
         }
-        if (std::getenv("SRRG2_AMD_PG_DEBUG"))
+        if (g->sw.debug)
           std::fprintf(stderr, "posegraph: CG chunk captured and instantiated in %.2f ms\n",
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cap).count());
       }
@@ -2066,7 +2076,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       HIP_TRY(hipMemcpyAsync(&h2, g->sc.p, sizeof(h2), hipMemcpyDeviceToHost, g->stream));
       HIP_TRY(hipStreamSynchronize(g->stream));
       std::memcpy(&prev_max_dx, &h2.max_dx_bits, sizeof(double));
-      if (std::getenv("SRRG2_AMD_PG_DEBUG")) std::fprintf(stderr, "posegraph: iteration %d, max |dx| %.3e\n", it, prev_max_dx);
+      if (g->sw.debug) std::fprintf(stderr, "posegraph: iteration %d, max |dx| %.3e\n", it, prev_max_dx);
     }
     srrg2_posegraph_stats st{};
     st.iteration      = it;
@@ -2151,6 +2161,16 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
   g->D      = variable_kind == SRRG2_SE2_RIGHT ? 3 : 6;
   g->T      = variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
   g->device = device;
+  {  // the experiment switches: environment read once, here
+    auto num = [](const char* name, double dflt) { const char* e = std::getenv(name); return e ? std::atof(e) : dflt; };
+    g->sw.match_passes = std::max(1, (int) num("SRRG2_AMD_PG_PASSES", 3.0));
+    g->sw.omega_p      = num("SRRG2_AMD_PG_OMEGA_P", MG_OMEGA_P);
+    g->sw.omega        = num("SRRG2_AMD_PG_OMEGA", MG_OMEGA);
+    g->sw.lag_below    = num("SRRG2_AMD_PG_LAG", 0.0);
+    g->sw.two_phase    = num("SRRG2_AMD_PG_TWO_PHASE", 1.0) != 0.0;
+    g->sw.use_graph    = num("SRRG2_AMD_PG_GRAPH", 1.0) != 0.0;
+    g->sw.debug        = std::getenv("SRRG2_AMD_PG_DEBUG") != nullptr;
+  }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
     delete g;
     return fail(SRRG2_E_HIP, "posegraph_create: cannot create stream");
