@@ -1606,17 +1606,19 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         for (int v = 0; v < n; ++v)
           if (cur[(size_t) v] >= 0 && first[(size_t) cur[(size_t) v]] < 0) first[(size_t) cur[(size_t) v]] = v;
         // neighbours of every current aggregate
+        // (the first pass needs no lists: every aggregate is one node, its incidence list IS its neighbour list)
+        const bool direct = pass == 0;
         std::vector<int> nb_start((size_t) n + 1, 0), nb_list;  // (CSR, in edge order; serial: shared atomic counters
         // across the host's two sockets were 2.6 x slower than one thread)
-        for (int e = 0; e < ne; ++e) {
+        for (int e = 0; e < ne && !direct; ++e) {
           const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
           if (a < 0 || b < 0 || a == b) continue;
           nb_start[(size_t) a + 1]++;
           nb_start[(size_t) b + 1]++;
         }
-        for (int a = 0; a < n; ++a) nb_start[(size_t) a + 1] += nb_start[(size_t) a];
+        for (int a = 0; a < n && !direct; ++a) nb_start[(size_t) a + 1] += nb_start[(size_t) a];
         nb_list.resize((size_t) std::max(nb_start[(size_t) n], 1));
-        {
+        if (!direct) {
           std::vector<int> fill(nb_start.begin(), nb_start.end() - 1);
           for (int e = 0; e < ne; ++e) {
             const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
@@ -1632,9 +1634,11 @@ int build_hierarchy(srrg2_posegraph_s* g) {
           position(rep0[(size_t) first[(size_t) a]], pa);
           int best = -1;
           float bd = 3.0e38f;
-          for (int k = nb_start[(size_t) a]; k < nb_start[(size_t) a + 1]; ++k) {
-            const int b = nb_list[(size_t) k];
-            if (match[(size_t) b] >= 0 || b == a) continue;
+          const int k0 = direct ? inc_start[(size_t) a] : nb_start[(size_t) a];
+          const int k1 = direct ? inc_start[(size_t) a + 1] : nb_start[(size_t) a + 1];
+          for (int k = k0; k < k1; ++k) {
+            const int b = direct ? inc_adj[(size_t) k].x : nb_list[(size_t) k];
+            if (b < 0 || cur[(size_t) b] < 0 || match[(size_t) b] >= 0 || b == a) continue;
             float pb[3];
             position(rep0[(size_t) first[(size_t) b]], pb);
             const float d = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]);
