@@ -139,17 +139,26 @@ public:
   }
 
 private:
+  // Every call takes BOTH barriers whatever happens on this rank: a rank that left early (a failed wait or copy) would
+  // leave its peers blocked in the first barrier, and -- run_compute keeps calling the hook after a failure so that the
+  // collectives stay matched -- its next call would pair with the wrong barrier generation.  A local failure is recorded
+  // in the shared flag before the first barrier; every rank returns 1 for that call, after the second barrier, and the
+  // last one to leave clears the flag so that the reducer can be used again.
   int reduce(int rank, int op, void* dev, size_t count, void* stream) {
     const size_t bytes = count * (op == SRRG2_REDUCE_SUM_I64 ? 8 : 4);
     std::vector<char>& mine = _bufs[(size_t) rank];
-    mine.resize(bytes);
+    mine.assign(bytes, 0);
     // the producers of the buffer are ordered on `stream`: wait for them, then read
-    if (srrg2_amd_stream_synchronize(stream) || srrg2_amd_memcpy(mine.data(), dev, bytes, 0, nullptr)) return 1;
+    if (srrg2_amd_stream_synchronize(stream) || srrg2_amd_memcpy(mine.data(), dev, bytes, 0, nullptr)) {
+      std::lock_guard<std::mutex> lock(_m);
+      _failed = true;
+    }
     barrier();
     if (rank == 0) {
       _result.assign(bytes, 0);
       for (int g = 0; g < _G; ++g) {
         if (_bufs[(size_t) g].size() != bytes) {
+          std::lock_guard<std::mutex> lock(_m);
           _failed = true;
           break;
         }
@@ -165,8 +174,25 @@ private:
       }
     }
     barrier();
-    if (_failed) return 1;
-    return srrg2_amd_memcpy(dev, _result.data(), bytes, 1, nullptr) ? 1 : 0;  // (synchronous: visible to the stream's next launch)
+    bool failed;
+    {
+      std::lock_guard<std::mutex> lock(_m);
+      failed = _failed;
+    }
+    // (synchronous copy: visible to the stream's next launch; a failed call leaves the buffer as it was)
+    const int rc = failed ? 1 : (srrg2_amd_memcpy(dev, _result.data(), bytes, 1, nullptr) ? 1 : 0);
+    {  // the last rank to have read the flag clears it: the next collective starts clean
+      std::lock_guard<std::mutex> lock(_m);
+      if (++_observed == _G) {
+        _observed = 0;
+        _failed   = false;
+      }
+    }
+    // (no rank can set _failed for the NEXT call before every rank has left this one's second barrier -- all of them have,
+    // or this code would not run -- but one may set it before the slowest rank has read it here; the third barrier closes
+    // that window)
+    barrier();
+    return rc;
   }
   void barrier() {
     std::unique_lock<std::mutex> lock(_m);
@@ -185,7 +211,7 @@ private:
   std::vector<char> _result;
   std::mutex _m;
   std::condition_variable _cv;
-  int _arrived = 0, _generation = 0;
+  int _arrived = 0, _generation = 0, _observed = 0;
   bool _failed = false;
 };
 

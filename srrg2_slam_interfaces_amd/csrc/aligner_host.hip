@@ -374,7 +374,12 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   geti("SRRG2_AMD_LDS_TILE", t->lds_tile);
   getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
   getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
+  // (the environment bypasses srrg2_aligner_set_tuning's range check: clamp to what that check accepts)
   if (t->fast_points_per_thread < 1) t->fast_points_per_thread = 1;
+  if (t->fast_from_iteration < 1) t->fast_from_iteration = 1;  // (iteration 0 has no previous neighbours to certify)
+  if (t->msort_key_bits > 18) t->msort_key_bits = 18;
+  if (t->msort_key_bits < -1) t->msort_key_bits = -1;
+  if (t->msort_segments < 0) t->msort_segments = 0;
   if (!(t->cell_target > 0.f)) t->cell_target = 8.0f;
 }
 
@@ -430,7 +435,10 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   const int mk    = a->tuning.msort_key_bits;
   const int aniso = mk >= 0 ? 1 : 0;
   const int bits  = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
-  const int kbits = aniso ? (mk > 0 ? mk : (K <= 4 ? 18 : 15)) : 3 * bits;
+  int kbits       = aniso ? (mk > 0 ? mk : (K <= 4 ? 18 : 15)) : 3 * bits;
+  kbits           = std::min(kbits, 18);  // (more than 6 bits per axis would collide in the key's bit spreading)
+  // (the global-histogram sort indexes K << kbits cells with an int: coarser keys when a huge batch asks for fine ones)
+  while (kbits > 3 && ((long long) K << kbits) > 0x3fffffffLL) --kbits;
   // small key spaces: one workgroup per problem sorts straight from the caller's (staged) layout, with the problem
   // table read from pinned host memory (no copies, memsets or waits on the stream); the ingest-order copy of the
   // clouds, which this path does not produce, is only read by given-correspondences slices
@@ -897,7 +905,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           // The deferred-search kernel pays off while many points are open; once the searches are mostly skipped
           // its launch costs more than finishing a few near points inside the step kernel (queue_on, decided below).
           SliceDev sd = sdev[si];
-          const bool fast = (slot0 > 0 || it >= fast_from) && !(C.tune & 4) && nm_max >= fast_min;
+          // (it >= 1 in the first run whatever the knob says: iteration 0 has no previous neighbours)
+          const bool fast = (slot0 > 0 || (it >= fast_from && it >= 1)) && !(C.tune & 4) && nm_max >= fast_min;
           if (!queue_on[si] || (s->fast_queue_only && !fast)) {
             sd.queue  = nullptr;
             sd.qcount = nullptr;
@@ -1075,7 +1084,10 @@ int srrg2_aligner_get_tuning(srrg2_aligner_h a, srrg2_aligner_tuning* t) {
 
 int srrg2_aligner_set_tuning(srrg2_aligner_h a, const srrg2_aligner_tuning* t) {
   if (!a || !t) return fail(SRRG2_E_INVALID, "set_tuning: null argument");
-  if (t->fast_points_per_thread < 1 || t->fast_from_iteration < 0 || !(t->cell_target > 0.f) || t->msort_key_bits > 18)
+  // (fast_from_iteration >= 1: the converged-pass kernel certifies against the neighbours the PREVIOUS pass of this
+  // compute() left behind; at iteration 0 there are none -- ADVICE r3)
+  if (t->fast_points_per_thread < 1 || t->fast_from_iteration < 1 || !(t->cell_target > 0.f) || t->msort_key_bits > 18 ||
+      t->msort_key_bits < -1 || t->msort_segments < 0)
     return fail(SRRG2_E_INVALID, "set_tuning: value out of range");
   a->tuning = *t;
   return 0;

@@ -650,6 +650,7 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
   int bx = (max_nm + 255) / 256;
   if (bx > 1024) bx = 1024;
   dim3 grid(bx, K);
+  if (((long long) K << kbits) > 0x3fffffffLL) return;  // (the caller lowers kbits first: upload_moving)
   const int ncell = K << kbits;
   // (few, grid-striding blocks per problem for the bounding box: its cost is the atomics, not the reads)
   hipLaunchKernelGGL(k_msort_bbox, dim3(bx < 32 ? bx : 32, K), dim3(256), 0, s, pts, probs, bb);

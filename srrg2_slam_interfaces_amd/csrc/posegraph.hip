@@ -27,6 +27,9 @@
 #include <set>
 #include <string>
 #include <thread>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #include <vector>
 
 #include "det_math.h"
@@ -1383,12 +1386,27 @@ class HostPool {
     for (int t = 1; t < n_; ++t) threads_.emplace_back([this, t] { loop(t); });
   }
   ~HostPool() {
-    stop_ = true;
-    generation_.fetch_add(1, std::memory_order_release);
+    stop_.store(true, std::memory_order_release);
+    word_.store(((unsigned long long) ++gen_ << 32), std::memory_order_release);
     for (std::thread& th : threads_) th.join();
   }
   int size() const { return n_; }
-  // fn(t) for t in [0, nt), nt <= size(); the caller runs t = 0 itself and returns when every t is done
+  // CPUs this process may actually run on (affinity mask / cgroup cpuset), not the machine's: under a CPU quota or on an
+  // oversubscribed host more spinning workers than usable cores make every region wait for the scheduler
+  static int usable_cpus() {
+    int n = (int) std::thread::hardware_concurrency();
+#if defined(__linux__)
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      const int c = CPU_COUNT(&set);
+      if (c > 0) n = n > 0 ? std::min(n, c) : c;
+    }
+#endif
+    return std::max(n, 1);
+  }
+  // fn(t) for t in [0, nt), nt <= size(); the caller runs t = 0 itself and returns when every PARTICIPATING t is done
+  // (workers t >= nt only note the generation: a region never waits for a thread that has nothing to do in it)
   template <typename Fn>
   void run(int nt, Fn&& fn) {
     nt = std::min(nt, n_);
@@ -1397,31 +1415,50 @@ class HostPool {
       return;
     }
     job_ = [&fn](int t) { fn(t); };
-    nt_  = nt;
-    pending_.store(n_ - 1, std::memory_order_relaxed);
-    generation_.fetch_add(1, std::memory_order_release);
+    pending_.store(nt - 1, std::memory_order_relaxed);
+    // generation and participant count travel in ONE word: a worker decides from the snapshot it woke up on, never from a
+    // count that a later region has already overwritten
+    word_.store(((unsigned long long) ++gen_ << 32) | (unsigned) nt, std::memory_order_release);
     fn(0);
-    while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    unsigned spins = 0;
+    while (pending_.load(std::memory_order_acquire) != 0) relax(spins);
   }
 
  private:
+  // spin briefly (the regions follow each other within microseconds), then give the core away
+  static void relax(unsigned& spins) {
+    if (++spins < 4096u) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#elif defined(__aarch64__)
+      asm volatile("yield" ::: "memory");
+#endif
+    } else {
+      std::this_thread::yield();
+    }
+  }
   void loop(int t) {
     unsigned seen = 0;
     for (;;) {
-      unsigned g;
-      while ((g = generation_.load(std::memory_order_acquire)) == seen) __builtin_ia32_pause();
-      seen = g;
-      if (stop_) return;
-      if (t < nt_) job_(t);
-      pending_.fetch_sub(1, std::memory_order_release);
+      unsigned long long w;
+      unsigned spins = 0;
+      while ((unsigned) ((w = word_.load(std::memory_order_acquire)) >> 32) == seen) relax(spins);
+      if (stop_.load(std::memory_order_acquire)) return;
+      // (a worker that was descheduled across several regions it had no part in catches up here: it can only have missed
+      // generations whose count was <= t, or run() would still be waiting for it)
+      seen = (unsigned) (w >> 32);
+      if (t < (int) (unsigned) w) {
+        job_(t);
+        pending_.fetch_sub(1, std::memory_order_release);
+      }
     }
   }
   int n_;
   std::vector<std::thread> threads_;
   std::function<void(int)> job_;
-  int nt_ = 0;
   std::atomic<int> pending_{0};
-  std::atomic<unsigned> generation_{0};
+  std::atomic<unsigned long long> word_{0};  // generation << 32 | participants of that generation
+  unsigned gen_ = 0;                          // (written by the owning thread only)
   std::atomic<bool> stop_{false};
 };
 
@@ -1512,7 +1549,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
-  HostPool pool((int) std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+  HostPool pool(std::min(16, HostPool::usable_cpus()));
   g->pg_force_tentative.clear();
   g->levels.clear();  // (the levels' device buffers stay in g->level_pool: a rebuild reuses them, they only ever grow)
   std::vector<float> poses((size_t) std::max(V, 1) * T);
