@@ -489,7 +489,10 @@ typedef struct srrg2_aligner_tuning {
   float   cell_target;          /* SRRG2_AMD_CELL_TARGET: points per occupied grid cell the automatic cell size aims at (8) */
   float   rmax_cap;             /* SRRG2_AMD_RMAX_CAP: largest cube radius (cells) needed to cover the gate; 0 = default
                                    (3 for 2-D clouds, none for 3-D)                                                    */
-  int32_t reserved_[10];
+  int32_t search_lists;         /* SRRG2_AMD_SEARCH_LISTS: search passes walk per-cell lists of occupied neighbour cells built
+                                   once per fixed cloud (k_icp_step_cnl): 0 = never, 1 = batches of more than 4 alignments,
+                                   2 = every alignment; -1 = automatic (carved out of reserved_: same struct size)        */
+  int32_t reserved_[9];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */
 void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t);

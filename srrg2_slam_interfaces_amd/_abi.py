@@ -113,7 +113,8 @@ class AlignerTuning(C.Structure):
         ("lds_tile", C.c_int32),
         ("cell_target", C.c_float),
         ("rmax_cap", C.c_float),
-        ("reserved_", C.c_int32 * 10),
+        ("search_lists", C.c_int32),
+        ("reserved_", C.c_int32 * 9),
     ]
 
 

@@ -40,6 +40,11 @@ struct Slice {
   DevBuf<int> cell_start, cursor, scan_sums, pos_of;
   DevBuf<unsigned> scalars;  // [0..2] bbox min keys, [3..5] bbox max keys, [6] nvalid, [7] ninf bits, [8] scan total
   GridDev grid{};
+  // cell neighbour lists of the grid (GridDev::list_*), built by the first compute() that wants them after a set_fixed
+  DevBuf<int> list_start, list_sums;
+  DevBuf<uint2> list_ent;
+  DevBuf<int4> list_offs;
+  bool lists_tried = false;  // built, or found not to pay / fit (grid.list_R says which)
   int nf          = 0;
   float probe_h = 0.f, probe_ext = 0.f, probe_gate = 0.f, probe_target = 0.f;  // last automatic cell size and the cloud it was probed on
   int probe_n   = 0;
@@ -91,6 +96,7 @@ struct Slice {
     ms_probs_host_cap = 0;
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
     cell_start.release(); cursor.release(); scan_sums.release(); scalars.release(); pos_of.release();
+    list_start.release(); list_sums.release(); list_ent.release(); list_offs.release();
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
@@ -320,6 +326,8 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     }
   }
   GridDev& g = s->grid;
+  g.list_R       = 0;      // (the neighbour lists belong to the previous grid)
+  s->lists_tried = false;
   grid_dims(h, g);
   g.gate2     = gate * gate;
   g.gate2_ext = (gate * 1.25f) * (gate * 1.25f);
@@ -351,6 +359,74 @@ int build_grid(srrg2_aligner* a, Slice* s) {
   return 0;
 }
 
+// Cell neighbour lists of a slice's grid (k_icp_step_cnl; GridDev::list_*): once per grid, on the first compute() that wants
+// them.  Leaves grid.list_R = 0 when the lists are not available: a cube radius above CNL_MAX_R (dense clouds: the lists
+// would hold thousands of cells each) or more entries than `max_entries`.
+int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
+  if (s->lists_tried) return 0;
+  s->lists_tried = true;
+  GridDev& g     = s->grid;
+  g.list_R       = 0;
+  const int R    = g.rmax;
+  if (R < 1 || R > CNL_MAX_R || s->nf <= 0) return 0;
+  const int dim = a->dim;
+  // the offsets whose cells can hold a point within the extended gate of a query of the centre cell, by (class, centre
+  // distance); class m = sum_i max(|d_i| - 1, 0)^2 = squared separation of the two cells in cells
+  auto class_bound2 = [&](int m) {
+    if (m <= 0) return -1.0f;
+    const float b = (std::sqrt((float) m) - 0.01f) * g.h;
+    return (b * b) * 0.9999f;
+  };
+  struct Off { int x, y, z, cls, c2; };
+  std::vector<Off> offs;
+  const int Rz = dim == 3 ? R : 0;
+  for (int z = -Rz; z <= Rz; ++z)
+    for (int y = -R; y <= R; ++y)
+      for (int x = -R; x <= R; ++x) {
+        auto sep = [](int d) { const int v = std::abs(d) - 1; return v > 0 ? v * v : 0; };
+        const int m = sep(x) + sep(y) + sep(z);
+        if (m > CNL_MAX_CLASS || class_bound2(m) > g.gate2_ext) continue;
+        offs.push_back(Off{x, y, z, m, x * x + y * y + z * z});
+      }
+  std::stable_sort(offs.begin(), offs.end(), [](const Off& p, const Off& q) { return p.cls != q.cls ? p.cls < q.cls : p.c2 < q.c2; });
+  std::vector<int4> offs4(offs.size());
+  for (size_t k = 0; k < offs.size(); ++k) offs4[k] = make_int4(offs[k].x, offs[k].y, offs[k].z, offs[k].cls);
+  g.lnx = g.nx + 2 * R;
+  g.lny = g.ny + 2 * R;
+  g.lnz = dim == 3 ? g.nz + 2 * R : 1;
+  const long long ncell_ll = (long long) g.lnx * g.lny * g.lnz;
+  if (ncell_ll > (1LL << 28)) return 0;
+  const int ncell = (int) ncell_ll;
+  for (int m = 0; m <= CNL_MAX_CLASS; ++m) g.cls_b2[m] = class_bound2(m);
+  g.cls_b2[CNL_MAX_CLASS + 1] = 3.0e38f;
+  int rc;
+  if ((rc = s->list_offs.reserve(offs4.size()))) return rc;
+  if ((rc = s->list_start.reserve((size_t) ncell + 1))) return rc;
+  if ((rc = s->list_sums.reserve((size_t) srrg2amd::scan_num_blocks(ncell) + 2))) return rc;
+  HIP_TRY(hipMemcpyAsync(s->list_offs.p, offs4.data(), offs4.size() * sizeof(int4), hipMemcpyHostToDevice, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));  // (offs4 is a stack-lifetime host buffer)
+  g.list_R = R;  // (the build kernels read the extended dimensions and R from the grid)
+  srrg2amd::launch_cnl_build(g, s->list_offs.p, (int) offs4.size(), s->list_start.p, nullptr, a->stream);
+  int* total_dev = s->list_sums.p + s->list_sums.cap - 1;
+  srrg2amd::launch_exclusive_scan(s->list_start.p, ncell, s->list_sums.p, total_dev, a->stream);
+  int total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(int), hipMemcpyDeviceToHost, a->stream));
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  if (total < 0 || (long long) total > max_entries) {
+    g.list_R = 0;
+    return 0;
+  }
+  if ((rc = s->list_ent.reserve((size_t) std::max(total, 1) + 8))) {
+    g.list_R = 0;
+    return rc;
+  }
+  g.list_start = s->list_start.p;
+  g.list_ent   = s->list_ent.p;
+  srrg2amd::launch_cnl_build(g, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_ent.p, a->stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // defaults overridden by the SRRG2_AMD_* variables; called once per handle, from srrg2_aligner_create
 void tuning_from_environment(srrg2_aligner_tuning* t) {
   srrg2_aligner_default_tuning(t);
@@ -372,6 +448,7 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   geti("SRRG2_AMD_MSORT_SEGMENTS", t->msort_segments);
   geti("SRRG2_AMD_MSORT_BITS", t->msort_key_bits);
   geti("SRRG2_AMD_LDS_TILE", t->lds_tile);
+  geti("SRRG2_AMD_SEARCH_LISTS", t->search_lists);
   getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
   getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
   // (the environment bypasses srrg2_aligner_set_tuning's range check: clamp to what that check accepts)
@@ -610,6 +687,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // single alignments are launch / latency bound and neutral to 1.5 % slower with it: 30 k points 41.7 -> 41.1 k it/s,
   // profiles/r3i_ab_tile_default.txt)
   const int lds_tile = tn.lds_tile >= 0 ? tn.lds_tile : (K > 4 ? 1 : 0);
+  // search passes over the cell neighbour lists of the grid (k_icp_step_cnl, round 4): 0 = never, 1 = batches of more than
+  // four alignments, 2 = every alignment (no deferred-search queue then); -1 = automatic
+  const int search_lists = tn.search_lists >= 0 ? tn.search_lists : 1;
+  std::vector<char> cnl((size_t) std::max(nslices, 1), 0);
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
   for (int si = 0; si < nslices; ++si) {
@@ -643,7 +724,13 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // without the queue 3 k / 10 k / 30 k / 60 k points take 0.286 / 0.249 / 0.254 / 0.272 ms per compute() instead of
     // 0.307 / 0.271 / 0.264 / 0.277 ms; equal at 80-100 k; 150 k: 0.356 ms with the queue, 0.462 ms without)
     const int queue_min = tn.queue_min_points;
-    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small;
+    if (s->cfg.finder == SRRG2_FINDER_NN_GATED && !small && (search_lists >= 2 || (search_lists == 1 && K > 4))) {
+      // (the lists are built once per grid; 32 Mi entries = 256 MB: far above C2 / C4, a guard for dense clouds)
+      if ((rc = ensure_lists(a, s, 32LL << 20))) return rc;
+      cnl[(size_t) si] = s->grid.list_R > 0 ? 1 : 0;
+    }
+    const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small &&
+                           !cnl[(size_t) si];
     // batches: the converged pass (k_icp_step_fast) hands the points whose certificate failed to the deferred-search
     // kernel; the first iterations (k_icp_step) finish their open points themselves
     const bool fast_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && K > 4 && !small && fast_batch_queue;
@@ -914,6 +1001,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           if (fast)
             srrg2amd::launch_icp_step_fast(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, fast_ppt,
                                            fast_gather, a->stream);
+          else if (cnl[(size_t) si] && !sd.queue)
+            srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
           else if (!sd.queue && lds_tile > 0 && !small)
             srrg2amd::launch_icp_step_tile(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
                                            lds_tile == 2 ? 504 : 416, a->stream);
@@ -1072,6 +1161,7 @@ void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t) {
   t->msort_segments         = 0;
   t->msort_key_bits         = 0;
   t->lds_tile               = -1;
+  t->search_lists           = -1;
   t->cell_target            = 8.0f;
   t->rmax_cap               = 0.f;
 }

@@ -2201,6 +2201,347 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   block_reduce_store_biased<1>(acc2, S.partials, prob, blockIdx.x, PPT);
 }
 
+// ============================================================================================
+// Search passes over CELL NEIGHBOUR LISTS (k_icp_step_cnl, round 4).
+//
+// The grid kernels above enumerate CELLS -- the rows of the 3^DIM block, then the shell of the 5^DIM cube, then cubes of
+// growing radius -- and most of what they enumerate is empty: a cloud is a surface, one cell in six of a block holds points.
+// On the tiles the bookkeeping of (mostly empty) rows, the second staging for the shell and the cooperative scans behind it
+// were 46 % of the first pass' vector instructions (profiles/r3n_tile_kernel_knob_attribution.txt), the candidates
+// themselves a fifth.  The fixed cloud is set once and searched by every iteration of every alignment of a batch, so the
+// enumeration is done ONCE, at set_fixed: every cell of the (extended) grid gets the list of OCCUPIED cells that can hold a
+// point within the extended gate of a query in it (GridDev::list_*, ~20 entries of 8 bytes per cell on C4, at most 16
+// points per entry), sorted by the class of the cell pair (squared separation in cells), then by centre distance.
+// A search is then:
+//   0. per lane: the first entry (the query's own cell when it is occupied) is scanned; its best candidate (+ the pad that
+//      lets the scan prove an exclusion margin), or the ball of the previous neighbour, is the ball everything else is
+//      pruned to;
+//   A. per lane: the entry headers, four loads in flight: stop at the first class whose separation exceeds the ball; an
+//      entry whose cell lies outside the ball (three slab distances, in cell units) is dropped; the survivors of ALL lanes
+//      are appended to ONE pool of the wave in LDS (ballot + mbcnt: compact, in order);
+//   B. the wave works the pool off together, item s by lane s mod 64 -- a wave is as slow as its busiest lane, and with one
+//      list per lane a single point without a neighbour inside the gate (all ~20 entries survive) kept the other 63 lanes
+//      waiting: 28 group iterations per wave on the first pass for ~8 per lane on average (profiles/r4c_*).  The worker
+//      merges its item's (key, runner-up) into the owner's slot with two LDS atomics: min of the 64-bit key, and the loser
+//      of that min -- the larger of the old and the new key -- is a candidate for the runner-up.
+// One mechanism covers the whole gate ball: no second phase, no staging, no tile that may not fit, no deferred-search
+// queue.  Same candidates-within-the-ball, same key minimum (d2 bits << 32 | index) => the same exact nearest neighbour
+// as every other path; runner-up and completeness radius leave an exclusion radius that is as valid.
+// ============================================================================================
+namespace {
+
+constexpr int CNL_POOL = 512;  // survivor entries of a wave between two rounds of phase B (a step of phase A adds <= 256)
+
+struct CnlWave {               // per wave, in LDS
+  uint2 pool[CNL_POOL];        // {position of the first candidate, owner lane | count << 8}
+  unsigned long long key[64];  // running minimum key of every lane's query
+  unsigned b2[64];             // ... and the squared distance of its runner-up (float bits: d2 >= 0 orders like the bits)
+  float q[3][64];              // the queries
+};
+
+// up to four candidates pts[j .. j + 3], the first `cnt` of them valid; lanes without work issue no load and run no test
+// (reads up to 3 entries past the range, masked out: the sorted array has slack behind it)
+template <int DIM>
+__device__ __forceinline__ void test_group_glb(const float4* __restrict__ pts, int j, int cnt, float qx, float qy, float qz,
+                                               unsigned long long& bkey, float& b2) {
+  if (cnt > 0) {
+    const float4 a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
+    test_candidate2<DIM>(a0, qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(a1, qx, qy, qz, cnt > 1, bkey, b2);
+    test_candidate2<DIM>(a2, qx, qy, qz, cnt > 2, bkey, b2);
+    test_candidate2<DIM>(a3, qx, qy, qz, cnt > 3, bkey, b2);
+  }
+}
+
+// Phase B: the wave works off the n pooled survivors; results are merged into the owners' slots.
+template <int DIM>
+__device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, CnlWave& w, int lane, int n) {
+  wave_lds_sync();  // (pool entries, queries and slots written by other lanes)
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int s     = s0 + lane;
+    const bool have = s < n;
+    uint2 it        = make_uint2(0u, 0u);
+    if (have) it = w.pool[s];
+    const int owner = (int) (it.y & 63u);
+    int cnt         = have ? (int) (it.y >> 8) : 0;
+    int j           = (int) it.x;
+    const float qx = w.q[0][owner], qy = w.q[1][owner], qz = DIM == 3 ? w.q[2][owner] : 0.f;
+    unsigned long long key = NO_KEY;
+    float lb2              = INFINITY;
+    while (__any(cnt > 0)) {
+      test_group_glb<DIM>(pts, j, cnt, qx, qy, qz, key, lb2);
+      j += 4;
+      cnt -= 4;
+    }
+    if (have) {
+      const unsigned long long old   = atomicMin(&w.key[owner], key);
+      const unsigned long long loser = old > key ? old : key;  // (not the minimum any more: a runner-up candidate)
+      const unsigned l2              = min((unsigned) (loser >> 32), __float_as_uint(lb2));
+      atomicMin(&w.b2[owner], l2);
+    }
+  }
+  wave_lds_sync();
+}
+
+}  // namespace
+
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                      ProblemState* __restrict__ states) {
+  constexpr int NW = 4;
+  const int prob   = blockIdx.y;
+  const ProblemState* st = &states[prob];
+  if (st->done || st->finished) return;
+  const ProblemDev pd = probs[prob];
+  const int tile      = blockIdx.x;
+  if (tile * (NW * 64) >= pd.nm) return;  // (batches of unequal clouds)
+  float T[12];
+  load_T(st->Tf[S.slice_idx], T);
+  const double scale = dm::pow2(st->kexp[S.slice_idx]);
+  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const float thr    = S.robust_thr;
+  const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  const GridDev& g   = S.grid;
+  const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
+  const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
+  float Tprev[12];
+  load_T(st->Tfprev[S.slice_idx], Tprev);
+
+  __shared__ CnlWave wlds[NW];
+
+  const int i        = tile * (NW * 64) + threadIdx.x;
+  const int lane     = threadIdx.x & 63;
+  const int wid      = threadIdx.x >> 6;
+  const bool inrange = i < pd.nm;
+  const int gi       = pd.moff + (inrange ? i : 0);
+  float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pf          = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
+  float4 pn          = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pnm         = make_float4(0.f, 0.f, 0.f, 0.f);
+  float pm           = 0.f;
+  if (inrange) {
+    p = S.mpts[gi];
+    if (use_prior) {
+      pm = S.prev_m[gi];
+      if (S.use_normal_gate) pnm = S.mnrm[gi];
+      if (S.gather_prev) {  // (as in icp_step_body)
+        const int ppos = S.prev_pos[gi];
+        if (ppos >= 0 && ppos < S.grid.n) {
+          pf = S.grid.pts[ppos];
+          if (PLANE || S.use_normal_gate) pn = S.grid.nrm[ppos];
+        }
+      } else {
+        pf = S.prev_f[gi];
+        if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
+      }
+    }
+  }
+  const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
+  const int oi        = pd.moff + __float_as_int(p.w);
+  const bool active   = inrange && finite3(p.x, p.y, p.z);
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  float best = INFINITY;
+  int bidx = NO_MATCH;
+  float excl = 0.f, r2box = INFINITY;
+  bool skipped = false;
+  if (active) {
+    transform_point<DIM>(T, p, qx, qy, qz);
+    // temporal coherence, exactly as in icp_step_body: (a) the previous neighbour is provably still the nearest,
+    // (b) the search is trimmed to its ball, (c) still nothing within the gate
+    if (use_prior && has_prev) {
+      unsigned long long k1 = NO_KEY;
+      test_candidate<DIM>(pf, qx, qy, qz, true, k1);
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p, px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      const float d1 = sqrtf(key_best(k1));
+      if (d1 * 1.00001f + dl * 1.00001f < pm * 0.99999f && !(S.tune & 4096)) {
+        skipped = true;
+        best    = key_best(k1);
+        bidx    = key_idx(k1);
+        excl    = pm * 0.9999999f - dl * 1.00001f;
+      } else {
+        const float pad = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+        const float rr  = (d1 + pad) * 1.00001f;
+        r2box           = fminf(rr * rr, gfar);
+      }
+    } else if (use_prior && !has_prev && pm > 0.f && !(S.tune & (4096 | 65536))) {
+      float px, py, pz;
+      transform_point<DIM>(Tprev, p, px, py, pz);
+      const float ex = qx - px, ey = qy - py, ez = qz - pz;
+      const float dl = sqrtf((ex * ex + ey * ey) + ez * ez);
+      if (sqrtf(g.gate2) * 1.00001f + dl * 1.00001f < pm * 0.99999f) {
+        skipped = true;
+        excl    = pm * 0.9999999f - dl * 1.00001f;
+      }
+    }
+  }
+  const bool need = active && !skipped && !KNOB(S.tune, 16);
+  if (__any(need)) {
+    CnlWave& w   = wlds[wid];
+    const int R  = g.list_R;
+    // the query in cell units: cell c + fraction u along every axis
+    const float ux0 = (qx - g.ox) * g.inv_h, uy0 = (qy - g.oy) * g.inv_h, uz0 = DIM == 3 ? (qz - g.oz) * g.inv_h : 0.f;
+    const int cx = cell_coord(qx, g.ox, g.inv_h);
+    const int cy = cell_coord(qy, g.oy, g.inv_h);
+    const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+    const int lx = cx + R, ly = cy + R, lz = DIM == 3 ? cz + R : 0;
+    // (a query outside the extended grid is farther than the extended gate from every fixed point: no list, no match)
+    const bool inl = need && lx >= 0 && lx < g.lnx && ly >= 0 && ly < g.lny && lz >= 0 && lz < g.lnz;
+    int e = 0, eend = 0;
+    if (inl) {
+      const int lc = (lz * g.lny + ly) * g.lnx + lx;
+      e            = g.list_start[lc];
+      eend         = g.list_start[lc + 1];
+    }
+    unsigned long long bkey = NO_KEY;
+    float b2 = INFINITY;
+    float L  = fminf(r2box, gfar);  // squared radius of the ball the search is pruned to
+    // ---- phase 0: the first entry of the list; its best candidate (+ pad) bounds the rest
+    {
+      const bool p0 = e < eend;
+      uint2 h0      = make_uint2(0u, 0u);
+      if (p0) h0 = g.list_ent[e];
+      int j = (int) h0.x, cnt = p0 ? (int) (h0.y & 15u) + 1 : 0;
+      while (__any(cnt > 0)) {
+        test_group_glb<DIM>(g.pts, j, cnt, qx, qy, qz, bkey, b2);
+        j += 4;
+        cnt -= 4;
+      }
+      if (p0) {
+        ++e;
+        if (key_idx(bkey) != NO_MATCH) {
+          const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+          L              = fminf(L, rb * rb);
+        }
+      }
+    }
+    w.key[lane]  = bkey;
+    w.b2[lane]   = __float_as_uint(b2);
+    w.q[0][lane] = qx;
+    w.q[1][lane] = qy;
+    if (DIM == 3) w.q[2][lane] = qz;
+    // ---- phase A: the headers.  Distances in cell units: with u = the query's fraction of its own cell, the cell at offset d
+    // along an axis spans [d - u, d - u + 1] around the query, so it is max(d - u, u - d - 1, 0) away -- shrunk by
+    // m = 1.1 % of a cell + 1e-6 of the coordinate, which covers the float32 rounding of cell assignments (a point's cell is
+    // floor(fl(fl(x - o) * inv_h))) and of these expressions.  The header carries d + R as a byte: one conversion
+    // (v_cvt_f32_ubyte), two subtractions from per-lane constants, one v_max3 per axis.
+    const float Lc  = L * 1.00002f;
+    const float Lcc = (Lc * g.inv_h) * g.inv_h * 1.0001f;
+    int mmax = -1;  // largest class whose cells can reach into the ball
+#pragma unroll
+    for (int m = 0; m <= CNL_MAX_CLASS; ++m) mmax += g.cls_b2[m] <= Lc ? 1 : 0;
+    const float fR = (float) R;
+    const float mx = 0.011f + fabsf(ux0) * 1e-6f, my = 0.011f + fabsf(uy0) * 1e-6f, mz = 0.011f + fabsf(uz0) * 1e-6f;
+    const float ux = ux0 - (float) cx, uy = uy0 - (float) cy, uz = uz0 - (float) cz;
+    // t = max(s - ca, cb - s, 0) with s = d + R:  d - u - m = s - (R + u + m),  u - d - 1 - m = (R + u - 1 - m) - s
+    const float cax = (fR + ux) + mx, cbx = ((fR + ux) - 1.f) - mx;
+    const float cay = (fR + uy) + my, cby = ((fR + uy) - 1.f) - my;
+    const float caz = (fR + uz) + mz, cbz = ((fR + uz) - 1.f) - mz;
+    int pool_n = 0;  // (wave-uniform)
+    while (__any(e < eend)) {
+      uint2 hd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hd[k] = make_uint2(0u, 0xf0u);  // (class 15: beyond every ball)
+        if (e + k < eend) hd[k] = g.list_ent[e + k];
+      }
+      bool stop = e >= eend;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned code = hd[k].y;
+        // (sorted by class: nothing behind the first entry of a class beyond the ball can reach into it)
+        stop = stop || (int) ((code >> 4) & 15u) > mmax;
+        const float sx = (float) ((code >> 8) & 255u), sy = (float) ((code >> 16) & 255u);
+        const float tx = fmaxf(fmaxf(sx - cax, cbx - sx), 0.f);
+        const float ty = fmaxf(fmaxf(sy - cay, cby - sy), 0.f);
+        float d2c      = __fmaf_rn(ty, ty, tx * tx);
+        if (DIM == 3) {
+          const float sz = (float) (code >> 24);
+          const float tz = fmaxf(fmaxf(sz - caz, cbz - sz), 0.f);
+          d2c            = __fmaf_rn(tz, tz, d2c);
+        }
+        const bool surv             = !stop && !(d2c > Lcc);
+        const unsigned long long bm = __ballot(surv);
+        if (surv) {
+          const int slot = pool_n + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bm, 0u));
+          w.pool[slot]   = make_uint2(hd[k].x, (unsigned) lane | (((code & 15u) + 1u) << 8));
+        }
+        pool_n += __popcll(bm);
+      }
+      e = stop ? eend : min(e + 4, eend);
+      if (pool_n > CNL_POOL - 256) {  // (the next step may add 4 x 64)
+        cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);
+        pool_n = 0;
+      }
+    }
+    cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);  // (also the barrier before the slots are read back)
+    if (need) {
+      bkey = w.key[lane];
+      b2   = __uint_as_float(w.b2[lane]);
+      best = key_best(bkey);
+      bidx = key_idx(bkey);
+      // every fixed point that was not examined is farther than the ball (a pruned or unreached cell) or than the extended
+      // gate (a cell outside the list): nothing but the winner is closer than this
+      excl = sqrtf(fminf(b2, fminf(L, g.gate2_ext))) * 0.99999f;
+    }
+  }
+  // ---- gates, rows, factor terms: straight-line as in the converged-pass kernel (every lane produces the 32 biased values,
+  // a lane without a correspondence with weight 0: no control flow around the accumulators -- finish_point's branches made
+  // the compiler re-materialise them on every path, ~150 register moves per point)
+  (void) oi;
+  constexpr int D    = DIM == 3 ? 6 : 3;
+  constexpr int ROWS = PLANE ? 1 : DIM;
+  const bool ngate   = S.use_normal_gate != 0;
+  const bool has     = active && bidx != NO_MATCH;
+  int bpos           = -1;
+  float4 fm          = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
+  float4 nf          = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (skipped) {  // (a kept neighbour comes with its coordinates and normal)
+    fm = pf;
+    nf = pn;
+  } else if (has) {
+    bpos = g.pos_of[bidx];  // (the searches track keys, not positions)
+    fm   = g.pts[bpos];
+    if (PLANE || ngate) nf = g.nrm[bpos];
+  }
+  bool found = has && best <= g.gate2;
+  if (ngate) {
+    float4 nmk = pnm;
+    if (!use_prior && found) nmk = S.mnrm[gi];  // (with a prior the normal was loaded together with it)
+    float dot;
+    if constexpr (DIM == 3) {
+      const float rx = (T[0] * nmk.x + T[1] * nmk.y) + T[2] * nmk.z;
+      const float ry = (T[4] * nmk.x + T[5] * nmk.y) + T[6] * nmk.z;
+      const float rz = (T[8] * nmk.x + T[9] * nmk.y) + T[10] * nmk.z;
+      dot            = (nf.x * rx + nf.y * ry) + nf.z * rz;
+    } else {
+      const float rx = T[0] * nmk.x + T[1] * nmk.y;
+      const float ry = T[4] * nmk.x + T[5] * nmk.y;
+      dot            = nf.x * rx + nf.y * ry;
+    }
+    found = found && dot > S.normal_cos;
+  }
+  long long acc[ACC_N];
+  {
+    float J[ROWS][D], er[ROWS];
+    point_rows<DIM, PLANE>(T, kk, p, qx, qy, qz, fm, nf, J, er);
+    (void) factor_accumulate_flat<D, ROWS, true>(J, er, found, rk, thr, scale, acc);
+  }
+  if (inrange) {
+    if (!skipped) {  // (a skipped search keeps its neighbour: only the exclusion radius changes)
+      S.prev_pos[gi] = has ? bpos : -1;
+      if (!S.gather_prev) {
+        S.prev_f[gi] = fm;  // (.w = NO_MATCH: none)
+        if (PLANE || ngate) S.prev_n[gi] = nf;
+      }
+    }
+    S.prev_m[gi] = excl;
+  }
+  block_reduce_store_biased<NW>(acc, S.partials, prob, tile, 1);
+}
+
 // The correspondence records of the nearest-neighbour passes, on demand (get_correspondences, factor status, the scene
 // merger): slice->correspondences() and the factor statistics of the last linearisation (multi_aligner_impl.cpp:215,244)
 // re-derived from what the last executed pass left behind -- every point's nearest neighbour (prev_f / prev_n) and the
@@ -3350,6 +3691,24 @@ void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemD
     if (plane) TILE_LAUNCH(2, true); else TILE_LAUNCH(2, false);
   }
 #undef TILE_LAUNCH
+}
+
+// the search pass over the cell neighbour lists of the grid (S.grid.list_R > 0)
+void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
+                         int max_nm, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0) return;
+  dim3 grid((max_nm + 255) / 256, K);
+  if (dim == 3) {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_cnl<3, true>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_cnl<3, false>), grid, dim3(256), 0, s, S, probs, states);
+  } else {
+    if (plane)
+      hipLaunchKernelGGL((k_icp_step_cnl<2, true>), grid, dim3(256), 0, s, S, probs, states);
+    else
+      hipLaunchKernelGGL((k_icp_step_cnl<2, false>), grid, dim3(256), 0, s, S, probs, states);
+  }
 }
 
 template <int PPT, bool GATHER>

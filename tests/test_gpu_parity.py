@@ -11,14 +11,16 @@ pytestmark = pytest.mark.gpu
 
 # (deferred-search kernel for single alignments?, first iteration run by the converged-pass kernel, points per thread of
 # that kernel, batches hand their failed certificates to the deferred-search kernel?, kept neighbours gathered from the
-# fixed cloud?)
+# fixed cloud?, search passes over the cell neighbour lists: 0 never / 1 batches / 2 every alignment)
 _PATHS = {
-    "deferred-search kernel": ("0", None, None, None, None),
-    "searches finished in the step kernel": ("1000000000", None, None, None, None),
-    "converged-pass kernel from iteration 1, deferred searches, 4 points per thread": ("0", "1", "4", "1", "0"),
-    "converged-pass kernel from iteration 1, wave-cooperative searches, gathered neighbours": ("1000000000", "1", "1", "0", "1"),
-    "converged-pass kernel from iteration 2, 2 points per thread, streamed neighbours": ("1000000000", "2", "2", "0", "0"),
-    "converged-pass kernel never": ("0", "1000000", None, None, None),
+    "deferred-search kernel": ("0", None, None, None, None, "1"),
+    "searches finished in the step kernel": ("1000000000", None, None, None, None, "0"),
+    "converged-pass kernel from iteration 1, deferred searches, 4 points per thread": ("0", "1", "4", "1", "0", "0"),
+    "converged-pass kernel from iteration 1, wave-cooperative searches, gathered neighbours": ("1000000000", "1", "1", "0", "1", "1"),
+    "converged-pass kernel from iteration 2, 2 points per thread, streamed neighbours": ("1000000000", "2", "2", "0", "0", "0"),
+    "converged-pass kernel never": ("0", "1000000", None, None, None, "0"),
+    "cell neighbour lists for every search pass": ("0", None, None, None, None, "2"),
+    "cell neighbour lists, converged-pass kernel never, gathered neighbours": ("0", "1000000", None, None, "1", "2"),
 }
 
 
@@ -28,13 +30,15 @@ def search_path(request, monkeypatch):
     inside k_icp_step below (SRRG2_AMD_QUEUE_MIN); the converged-pass kernel k_icp_step_fast takes over from iteration 3
     (SRRG2_AMD_FAST_FROM) with 1 / 2 / 4 points per thread (SRRG2_AMD_FAST_PPT), its failed certificates go to the
     deferred-search kernel or are searched by their wave (SRRG2_AMD_FAST_QUEUE for batches), kept neighbours are streamed
-    from per-point arrays or gathered from the fixed cloud (SRRG2_AMD_FAST_GATHER).  Every scenario of this module runs
-    on all of these paths: they must give the same bits."""
-    qmin, fast_from, ppt, fq, gather = _PATHS[request.param]
+    from per-point arrays or gathered from the fixed cloud (SRRG2_AMD_FAST_GATHER); the search passes walk the grid
+    (k_icp_step / k_icp_step_tile) or the cell neighbour lists (k_icp_step_cnl, SRRG2_AMD_SEARCH_LISTS).  Every scenario of
+    this module runs on all of these paths: they must give the same bits."""
+    qmin, fast_from, ppt, fq, gather, lists = _PATHS[request.param]
     monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", qmin)
     monkeypatch.setenv("SRRG2_AMD_FAST_MIN", "0")  # (the converged-pass kernel also on this module's small clouds)
+    monkeypatch.setenv("SRRG2_AMD_SMALL_MAX", "1024" if lists != "2" else "0")  # (lists: also the small clouds of this module)
     for name, val in (("SRRG2_AMD_FAST_FROM", fast_from), ("SRRG2_AMD_FAST_PPT", ppt), ("SRRG2_AMD_FAST_QUEUE", fq),
-                      ("SRRG2_AMD_FAST_GATHER", gather)):
+                      ("SRRG2_AMD_FAST_GATHER", gather), ("SRRG2_AMD_SEARCH_LISTS", lists)):
         if val is None:
             monkeypatch.delenv(name, raising=False)
         else:

@@ -12,12 +12,13 @@ pytestmark = pytest.mark.gpu
 
 
 def test_tuning_defaults_and_round_trip(product, monkeypatch):
-    for name in ("SRRG2_AMD_LDS_TILE", "SRRG2_AMD_FAST_FROM", "SRRG2_AMD_CELL_TARGET", "SRRG2_AMD_TUNE"):
+    for name in ("SRRG2_AMD_LDS_TILE", "SRRG2_AMD_FAST_FROM", "SRRG2_AMD_CELL_TARGET", "SRRG2_AMD_TUNE", "SRRG2_AMD_SEARCH_LISTS"):
         monkeypatch.delenv(name, raising=False)
     al = product.MultiAligner(abi.SE3_QUAT_RIGHT)
     t = al.tuning()
     assert (t.strategy_mask, t.queue_probe_iteration, t.small_max_points, t.fast_from_iteration) == (0, 1, 1024, 3)
     assert (t.lds_tile, t.fast_gather, t.msort_key_bits, t.queue_min_points) == (-1, -1, 0, 90000)
+    assert t.search_lists == -1
     assert t.cell_target == pytest.approx(8.0)
     al.set_tuning(lds_tile=2, fast_from_iteration=1, cell_target=6.0)
     t = al.tuning()
@@ -25,6 +26,17 @@ def test_tuning_defaults_and_round_trip(product, monkeypatch):
     assert t.small_max_points == 1024  # (untouched fields keep their values)
     with pytest.raises(KeyError):
         al.set_tuning(no_such_knob=1)
+    # iteration 0 has no previous neighbours for the converged-pass kernel to certify against: rejected, and an
+    # environment value below 1 is clamped when the handle is created
+    with pytest.raises(Exception):
+        al.set_tuning(fast_from_iteration=0)
+    assert al.tuning().fast_from_iteration == 1
+    monkeypatch.setenv("SRRG2_AMD_FAST_FROM", "0")
+    monkeypatch.setenv("SRRG2_AMD_MSORT_BITS", "40")
+    t0 = product.MultiAligner(abi.SE3_QUAT_RIGHT).tuning()
+    assert (t0.fast_from_iteration, t0.msort_key_bits) == (1, 18)
+    monkeypatch.delenv("SRRG2_AMD_FAST_FROM")
+    monkeypatch.delenv("SRRG2_AMD_MSORT_BITS")
     # the environment is read once, when a handle is created
     monkeypatch.setenv("SRRG2_AMD_LDS_TILE", "0")
     assert al.tuning().lds_tile == 2
@@ -53,8 +65,11 @@ def test_batches_give_the_same_bits_under_every_search_pass_kernel(oracle, produ
         return al.compute_batch(movs, [syn.identity(3)] * K, nrms)
 
     ref = run(oracle.OracleAligner(abi.SE3_QUAT_RIGHT))
-    for knobs in ({"lds_tile": 0}, {"lds_tile": 1}, {"lds_tile": 2}, {"lds_tile": 1, "cell_target": 3.0},
-                  {"lds_tile": 1, "msort_key_bits": -1}, {"lds_tile": 1, "fast_from_iteration": 1}):
+    for knobs in ({"lds_tile": 0, "search_lists": 0}, {"lds_tile": 1, "search_lists": 0}, {"lds_tile": 2, "search_lists": 0},
+                  {"lds_tile": 1, "cell_target": 3.0, "search_lists": 0}, {"lds_tile": 1, "msort_key_bits": -1, "search_lists": 0},
+                  {"lds_tile": 1, "fast_from_iteration": 1, "search_lists": 0},
+                  {"search_lists": 1}, {"search_lists": 2, "cell_target": 3.0}, {"search_lists": 1, "cell_target": 20.0},
+                  {"search_lists": 1, "fast_from_iteration": 1}, {"search_lists": 1, "fast_from_iteration": 100}):
         got = run(product.MultiAligner(abi.SE3_QUAT_RIGHT), **knobs)
         for r, g in zip(ref, got):
             assert r["status"] == g["status"], knobs
