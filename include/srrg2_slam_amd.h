@@ -492,7 +492,12 @@ typedef struct srrg2_aligner_tuning {
   int32_t search_lists;         /* SRRG2_AMD_SEARCH_LISTS: search passes walk per-cell lists of occupied neighbour cells built
                                    once per fixed cloud (k_icp_step_cnl): 0 = never, 1 = batches of more than 4 alignments,
                                    2 = every alignment; -1 = automatic (carved out of reserved_: same struct size)        */
-  int32_t reserved_[9];
+  int32_t search_team;          /* SRRG2_AMD_SEARCH_TEAM: lanes per moving point of that kernel, 1 or 4; 0 = automatic (4 for up
+                                   to four alignments per launch, 1 for batches)                                         */
+  int32_t batch_pipeline;       /* SRRG2_AMD_BATCH_PIPELINE: compute_batch runs its alignments as two halves on two streams (one
+                                   half's control steps and sort under the other half's passes): 0 = never, 1 = every batch,
+                                   -1 = automatic (from 8 alignments per call on)                                        */
+  int32_t reserved_[7];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */
 void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t);

@@ -114,7 +114,9 @@ class AlignerTuning(C.Structure):
         ("cell_target", C.c_float),
         ("rmax_cap", C.c_float),
         ("search_lists", C.c_int32),
-        ("reserved_", C.c_int32 * 9),
+        ("search_team", C.c_int32),
+        ("batch_pipeline", C.c_int32),
+        ("reserved_", C.c_int32 * 7),
     ]
 
 

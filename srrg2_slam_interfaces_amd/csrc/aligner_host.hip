@@ -45,6 +45,7 @@ struct Slice {
   DevBuf<uint2> list_ent;
   DevBuf<int4> list_offs;
   bool lists_tried = false;  // built, or found not to pay / fit (grid.list_R says which)
+  int grid_computes = 0;     // compute() calls on this grid so far (a grid searched a second time gets its lists)
   int nf          = 0;
   float probe_h = 0.f, probe_ext = 0.f, probe_gate = 0.f, probe_target = 0.f;  // last automatic cell size and the cloud it was probed on
   int probe_n   = 0;
@@ -109,6 +110,13 @@ struct Slice {
 struct srrg2_aligner_s {
   int kind = 0, dim = 3, dof = 6, tsize = 12, device = 0;
   hipStream_t stream = nullptr;
+  // Batches run as TWO half-batches on two streams (run_compute, "pipelined"): while one half's control step -- one
+  // workgroup per alignment, ~10 us of an otherwise idle chip per iteration -- and kernel boundary pass, the other half's
+  // pass kernel has the chip.  The halves share nothing but read-only data (fixed cloud, grid, lists).
+  hipStream_t stream2   = nullptr;
+  hipEvent_t ev_staged  = nullptr;  // the staging copies of a batch upload (stream) before the second half's sort (stream2)
+  bool stream2_dirty    = false;    // stream2 may still be running the tail of the last pipelined batch
+  int batch_split       = 0;        // upload_moving -> run_compute: the batch at hand is split at this alignment (0: not)
   srrg2_aligner_params params{10, 10, 0, 0};
   // point-sharded alignment (srrg2_aligner_set_point_shard): the host side's reduction and the global point count
   srrg2_reduce_fn reduce_fn = nullptr;
@@ -170,6 +178,16 @@ void identity(int kind, float* T) {
 
 int set_device(srrg2_aligner* a) {
   HIP_TRY(hipSetDevice(a->device));
+  return 0;
+}
+
+// Everything outside a pipelined batch runs on `stream` alone: before it touches state the second half of the last pipelined
+// batch wrote, that half's stream must have retired (its results were seen by the host long ago: the wait is a formality).
+int quiesce_stream2(srrg2_aligner* a) {
+  if (a->stream2_dirty) {
+    a->stream2_dirty = false;
+    HIP_TRY(hipStreamSynchronize(a->stream2));
+  }
   return 0;
 }
 
@@ -326,8 +344,9 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     }
   }
   GridDev& g = s->grid;
-  g.list_R       = 0;      // (the neighbour lists belong to the previous grid)
-  s->lists_tried = false;
+  g.list_R         = 0;      // (the neighbour lists belong to the previous grid)
+  s->lists_tried   = false;
+  s->grid_computes = 0;
   grid_dims(h, g);
   g.gate2     = gate * gate;
   g.gate2_ext = (gate * 1.25f) * (gate * 1.25f);
@@ -424,6 +443,8 @@ int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
   g.list_ent   = s->list_ent.p;
   srrg2amd::launch_cnl_build(g, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_ent.p, a->stream);
   HIP_TRY(hipGetLastError());
+  // (complete before anybody reads them: the second half of a pipelined batch runs on another stream)
+  HIP_TRY(hipStreamSynchronize(a->stream));
   return 0;
 }
 
@@ -449,6 +470,8 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   geti("SRRG2_AMD_MSORT_BITS", t->msort_key_bits);
   geti("SRRG2_AMD_LDS_TILE", t->lds_tile);
   geti("SRRG2_AMD_SEARCH_LISTS", t->search_lists);
+  geti("SRRG2_AMD_SEARCH_TEAM", t->search_team);
+  geti("SRRG2_AMD_BATCH_PIPELINE", t->batch_pipeline);
   getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
   getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
   // (the environment bypasses srrg2_aligner_set_tuning's range check: clamp to what that check accepts)
@@ -457,6 +480,7 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   if (t->msort_key_bits > 18) t->msort_key_bits = 18;
   if (t->msort_key_bits < -1) t->msort_key_bits = -1;
   if (t->msort_segments < 0) t->msort_segments = 0;
+  if (t->search_team < 0) t->search_team = 0;
   if (!(t->cell_target > 0.f)) t->cell_target = 8.0f;
 }
 
@@ -471,8 +495,13 @@ int check_slice(srrg2_aligner* a, int si, const char* what) {
 // return).  compute_batch passes false: it returns after the compute() that follows on the same stream has delivered
 // its results, and the launches of that compute() overlap the sort instead of waiting behind it.
 int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const float* normals, int ns,
-                  const int32_t* offsets, int K, int mem, bool wait = true) {
+                  const int32_t* offsets, int K, int mem, bool wait = true, int split = 0) {
   Slice* s    = a->slices[si];
+  a->batch_split = 0;
+  {
+    int rcq = quiesce_stream2(a);
+    if (rcq) return rcq;
+  }
   if (a->records_state == 1) a->records_state = 2;  // (the records of the last compute() can no longer be derived)
   const int n = offsets[K] - offsets[0];
   int rc;
@@ -525,11 +554,37 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     if (s->ms_pending) HIP_TRY(hipStreamSynchronize(a->stream));  // (set_moving twice without a compute() in between)
     s->ms_pending = false;
     std::memcpy(s->ms_probs_host, pd.data(), (size_t) K * sizeof(ProblemDev));
-    if (srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, kbits, aniso, a->tuning.msort_segments,
-                                     max_nm, s->moving.p, normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream)) {
+    bool sorted = false;
+    if (split > 0 && split < K && a->stream2) {
+      // pipelined batch: the second half is sorted on the second stream (behind the staging copies of this call), under the
+      // first half's first pass
+      if (mem == SRRG2_MEM_HOST) {
+        HIP_TRY(hipEventRecord(a->ev_staged, a->stream));
+        HIP_TRY(hipStreamWaitEvent(a->stream2, a->ev_staged, 0));
+      }
+      int nmA = 0, nmB = 0;
+      for (int k = 0; k < K; ++k) (k < split ? nmA : nmB) = std::max(k < split ? nmA : nmB, pd[k].nm);
+      sorted = srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, split, a->dim, kbits, aniso,
+                                            a->tuning.msort_segments, nmA, s->moving.p, normals ? s->moving_nrm.p : nullptr,
+                                            s->pinf.p, a->stream) &&
+               srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host + split, K - split, a->dim, kbits, aniso,
+                                            a->tuning.msort_segments, nmB, s->moving.p, normals ? s->moving_nrm.p : nullptr,
+                                            s->pinf.p + split, a->stream2);
+      if (sorted) {
+        a->batch_split   = split;
+        a->stream2_dirty = true;
+      }
+    } else {
+      sorted = srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, kbits, aniso, a->tuning.msort_segments,
+                                            max_nm, s->moving.p, normals ? s->moving_nrm.p : nullptr, s->pinf.p, a->stream);
+    }
+    if (sorted) {
       HIP_TRY(hipGetLastError());
       // the caller may reuse its buffer on return (host or device memory: the ingest has finished reading it)
-      if (wait) HIP_TRY(hipStreamSynchronize(a->stream));
+      if (wait) {
+        HIP_TRY(hipStreamSynchronize(a->stream));
+        if (a->batch_split) HIP_TRY(hipStreamSynchronize(a->stream2));
+      }
       s->ms_pending         = !wait;  // (the sort reads the pinned problem table: the compute() that follows drains the stream)
       s->nm_total           = n;
       s->has_moving         = true;
@@ -577,6 +632,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   auto t_begin = std::chrono::steady_clock::now();
   int rc;
   if ((rc = set_device(a))) return rc;
+  // (a pipelined batch: upload_moving has already put the second half's sort on the second stream)
+  const int split = (K > 1 && a->batch_split > 0 && a->batch_split < K) ? a->batch_split : 0;
+  a->batch_split  = 0;
+  if (!split && (rc = quiesce_stream2(a))) return rc;
   const int nslices = (int) a->slices.size();
   // sanity checks (reference: sanityCheck throws, aligner_slice_processor_impl.cpp:8-17;
   // aligner_slice_processor_prior_impl.cpp:11-22)
@@ -687,9 +746,19 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // single alignments are launch / latency bound and neutral to 1.5 % slower with it: 30 k points 41.7 -> 41.1 k it/s,
   // profiles/r3i_ab_tile_default.txt)
   const int lds_tile = tn.lds_tile >= 0 ? tn.lds_tile : (K > 4 ? 1 : 0);
-  // search passes over the cell neighbour lists of the grid (k_icp_step_cnl, round 4): 0 = never, 1 = batches of more than
-  // four alignments, 2 = every alignment (no deferred-search queue then); -1 = automatic
-  const int search_lists = tn.search_lists >= 0 ? tn.search_lists : 1;
+  // Search passes over the cell neighbour lists of the grid (k_icp_step_cnl, round 4): 0 = never, 1 = batches of more than
+  // four alignments, 2 = every alignment (no deferred-search queue then).  -1 = automatic: batches always (the build --
+  // two kernels, ~0.2 ms at 100 k points, two host waits -- is shared by all their alignments); single alignments from the
+  // SECOND compute() on a fixed cloud on: a relocalizer or a loop detector aligns many clouds against one map and gains
+  // ~15 % per compute(), a tracker sets a new fixed cloud every frame and would pay the build for one alignment
+  // (tools/bench_tracker.py: compute 0.26 -> 0.54 ms per frame with the lists built every frame).
+  const int search_lists = tn.search_lists;
+  // lanes per moving point of that kernel: 1 = throughput, 4 = latency (a single alignment leaves the chip half empty and
+  // its first pass, where every point searches without a bound, is a chain of dependent round trips: four lanes share a
+  // point's headers and candidates: C2 55.7 -> 29.7 us; the passes with priors, where a fraction of the points search, are
+  // better off with one lane: 14.3 vs 18.3 us on the third pass); 0 = automatic: 4 on the first pass of up to four
+  // alignments per launch, 1 otherwise
+  const int search_team_knob = tn.search_team;
   std::vector<char> cnl((size_t) std::max(nslices, 1), 0);
   std::vector<SliceDev> sdev((size_t) nslices);
   int first_cue = -1;
@@ -724,7 +793,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // without the queue 3 k / 10 k / 30 k / 60 k points take 0.286 / 0.249 / 0.254 / 0.272 ms per compute() instead of
     // 0.307 / 0.271 / 0.264 / 0.277 ms; equal at 80-100 k; 150 k: 0.356 ms with the queue, 0.462 ms without)
     const int queue_min = tn.queue_min_points;
-    if (s->cfg.finder == SRRG2_FINDER_NN_GATED && !small && (search_lists >= 2 || (search_lists == 1 && K > 4))) {
+    const bool want_lists = search_lists >= 2 || (search_lists == 1 && K > 4) ||
+                            (search_lists < 0 && (K > 4 || s->grid_computes >= 1 || s->lists_tried));
+    s->grid_computes++;
+    if (s->cfg.finder == SRRG2_FINDER_NN_GATED && !small && want_lists) {
       // (the lists are built once per grid; 32 Mi entries = 256 MB: far above C2 / C4, a guard for dense clouds)
       if ((rc = ensure_lists(a, s, 32LL << 20))) return rc;
       cnl[(size_t) si] = s->grid.list_R > 0 ? 1 : 0;
@@ -863,7 +935,19 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   }
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
   auto t_prep = std::chrono::steady_clock::now();
-  srrg2amd::launch_icp_init(C, a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, a->stream);
+  // the halves of a pipelined batch: problems [0, split) on `stream`, [split, K) on `stream2`; otherwise one range
+  const int nhalves = split ? 2 : 1;
+  const int h0[2] = {0, split}, hn[2] = {split ? split : K, K - split};
+  hipStream_t hstream[2] = {a->stream, a->stream2};
+  CtlParams Ch[2] = {C, C};
+  for (int h = 0; h < nhalves; ++h) {
+    Ch[h].prob0 = h0[h];
+    Ch[h].nprob = hn[h];
+  }
+  if (split && (small || a->reduce_fn || a->profile || !a->timeline_path.empty()))
+    return fail(SRRG2_E_STATE, "internal: a pipelined batch on a path that cannot be split");
+  for (int h = 0; h < nhalves; ++h)
+    srrg2amd::launch_icp_init(Ch[h], a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, hstream[h]);
   auto t_init = std::chrono::steady_clock::now();
 
   if (small) {
@@ -894,7 +978,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   std::vector<char> queue_on((size_t) std::max(nslices, 1), 1);
   bool probed = false;
   bool final_launched = false;  // the last control step of compute() carried the post / finalize steps
-  auto control = [&](int it, bool last_phase) {
+  auto control = [&](int it, bool last_phase, int h) {
     if (a->reduce_fn) {  // the ranks' partial sums, added in place, before anybody looks at them
       // (after a failure the hook is still called for the remaining control steps: the collectives of the ranks stay
       // matched -- a rank that stopped calling would leave its healthy peers hanging in theirs -- and the error is
@@ -904,11 +988,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         hook_failed = true;
     }
     if (last_phase && it == a->params.max_iterations - 1) {
-      srrg2amd::launch_icp_control_final(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
-                                         !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
+      srrg2amd::launch_icp_control_final(Ch[h], a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                         !a->params.enable_inlier_only_runs /* post step inside */, hstream[h]);
       final_launched = true;
     } else {
-      srrg2amd::launch_icp_control(C, a->states.p, a->stats.p, a->stream);
+      srrg2amd::launch_icp_control(Ch[h], a->states.p, a->stats.p, hstream[h]);
     }
   };
   auto run_phase = [&](int slot0, bool last_phase) -> int {
@@ -958,7 +1042,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         srrg2amd::launch_proj_step_pack(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
         for (int si : proj_group) sdev[si].zbuf_parity ^= 1;
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
-        control(it, last_phase);
+        control(it, last_phase, 0);
         continue;
       }
       for (int si = 0; si < nslices; ++si) {
@@ -998,20 +1082,27 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             sd.queue  = nullptr;
             sd.qcount = nullptr;
           }
-          if (fast)
-            srrg2amd::launch_icp_step_fast(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, fast_ppt,
-                                           fast_gather, a->stream);
-          else if (cnl[(size_t) si] && !sd.queue)
-            srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
-          else if (!sd.queue && lds_tile > 0 && !small)
-            srrg2amd::launch_icp_step_tile(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max,
-                                           lds_tile == 2 ? 504 : 416, a->stream);
-          else
-            srrg2amd::launch_icp_step(a->dim, plane, sd, a->probs.p + (size_t) si * K, a->states.p, K, nm_max, a->stream);
+          for (int h = 0; h < nhalves; ++h) {
+            // (a pipelined batch has one cue slice: each half's pass is followed by that half's control step on its stream)
+            sd.prob0 = h0[h];
+            const ProblemDev* pt = a->probs.p + (size_t) si * K;
+            hipStream_t hs = hstream[h];
+            const int Kh   = hn[h];
+            if (fast)
+              srrg2amd::launch_icp_step_fast(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, fast_ppt, fast_gather, hs);
+            else if (cnl[(size_t) si] && !sd.queue)
+              srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, pt, a->states.p, Kh, nm_max,
+                                            search_team_knob > 0 ? search_team_knob : ((K <= 4 && slot0 == 0 && it == 0) ? 4 : 1), hs);
+            else if (!sd.queue && lds_tile > 0 && !small)
+              srrg2amd::launch_icp_step_tile(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, lds_tile == 2 ? 504 : 416, hs);
+            else
+              srrg2amd::launch_icp_step(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, hs);
+            if (split) control(it, last_phase, h);
+          }
         }
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }
-      control(it, last_phase);
+      if (!split) control(it, last_phase, 0);
     }
     return 0;
   };
@@ -1020,15 +1111,17 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   } else {
     if ((rc = run_phase(0, !a->params.enable_inlier_only_runs))) return rc;
     if (a->params.enable_inlier_only_runs) {
-      srrg2amd::launch_icp_post(C, a->states.p, a->stats.p, a->stream);
+      for (int h = 0; h < nhalves; ++h) srrg2amd::launch_icp_post(Ch[h], a->states.p, a->stats.p, hstream[h]);
       if ((rc = run_phase(a->params.max_iterations, true))) return rc;
     }
   }
   // results land in pinned host memory (written by k_icp_finalize): the only host-device interaction of compute() after
   // the launches is this wait
   if (!final_launched)  // (max_iterations < 1)
-    srrg2amd::launch_icp_finalize(C, a->states.p, a->stats.p, a->outs_host, a->stats_host,
-                                  !a->params.enable_inlier_only_runs /* post step inside */, a->stream);
+    for (int h = 0; h < nhalves; ++h)
+      srrg2amd::launch_icp_finalize(Ch[h], a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                    !a->params.enable_inlier_only_runs /* post step inside */, hstream[h]);
+  if (split) a->stream2_dirty = true;
   HIP_TRY(hipGetLastError());
   const bool hosttime = a->hosttime;
   auto t_enq = std::chrono::steady_clock::now();
@@ -1040,13 +1133,17 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   for (int k = 0; k < K && seen; ++k) {
     volatile int* flag = &a->outs_host[k].seq;
     int spins          = 0;
+    hipStream_t qs = (split && k >= split) ? a->stream2 : a->stream;
     while (*flag != C.seq)
-      if ((++spins & 4095) == 0 && hipStreamQuery(a->stream) != hipErrorNotReady) {
+      if ((++spins & 4095) == 0 && hipStreamQuery(qs) != hipErrorNotReady) {
         seen = *flag == C.seq;  // (drained: either the flag has just arrived or a launch failed)
         break;
       }
   }
-  if (!seen || a->profile || !a->timeline_path.empty()) HIP_TRY(hipStreamSynchronize(a->stream));
+  if (!seen || a->profile || !a->timeline_path.empty()) {
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    if (split) HIP_TRY(hipStreamSynchronize(a->stream2));
+  }
   if (hook_failed) return fail(SRRG2_E_INVALID, "the reduction hook of the point-sharded alignment failed");
   if (hosttime) {
     auto t_end = std::chrono::steady_clock::now();
@@ -1104,6 +1201,7 @@ int materialize_records(srrg2_aligner* a) {
   if (a->records_state != 1) return 0;
   int rc;
   if ((rc = set_device(a))) return rc;
+  if ((rc = quiesce_stream2(a))) return rc;
   for (size_t si = 0; si < a->slices.size() && si < a->last_sdev.size(); ++si) {
     Slice* s = a->slices[si];
     if (s->cfg.kind == SRRG2_SLICE_PRIOR || s->cfg.finder != SRRG2_FINDER_NN_GATED) continue;
@@ -1162,6 +1260,8 @@ void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t) {
   t->msort_key_bits         = 0;
   t->lds_tile               = -1;
   t->search_lists           = -1;
+  t->search_team            = 0;
+  t->batch_pipeline         = -1;
   t->cell_target            = 8.0f;
   t->rmax_cap               = 0.f;
 }
@@ -1177,7 +1277,7 @@ int srrg2_aligner_set_tuning(srrg2_aligner_h a, const srrg2_aligner_tuning* t) {
   // (fast_from_iteration >= 1: the converged-pass kernel certifies against the neighbours the PREVIOUS pass of this
   // compute() left behind; at iteration 0 there are none -- ADVICE r3)
   if (t->fast_points_per_thread < 1 || t->fast_from_iteration < 1 || !(t->cell_target > 0.f) || t->msort_key_bits > 18 ||
-      t->msort_key_bits < -1 || t->msort_segments < 0)
+      t->msort_key_bits < -1 || t->msort_segments < 0 || t->search_team < 0)
     return fail(SRRG2_E_INVALID, "set_tuning: value out of range");
   a->tuning = *t;
   return 0;
@@ -1225,7 +1325,11 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
   tuning_from_environment(&a->tuning);
   if (const char* tl = std::getenv("SRRG2_AMD_TIMELINE")) a->timeline_path = tl;
   a->hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming) != hipSuccess) {
+    if (a->stream) (void) hipStreamDestroy(a->stream);
+    if (a->stream2) (void) hipStreamDestroy(a->stream2);
     delete a;
     return fail(SRRG2_E_HIP, "create: cannot create stream");
   }
@@ -1237,6 +1341,7 @@ int srrg2_aligner_destroy(srrg2_aligner_h a) {
   if (!a) return 0;
   (void) hipSetDevice(a->device);
   if (a->stream) (void) hipStreamSynchronize(a->stream);
+  if (a->stream2) (void) hipStreamSynchronize(a->stream2);
   for (Slice* s : a->slices) {
     s->release();
     delete s;
@@ -1251,6 +1356,8 @@ int srrg2_aligner_destroy(srrg2_aligner_h a) {
     (void) hipEventDestroy(ev.first);
     (void) hipEventDestroy(ev.second);
   }
+  if (a->ev_staged) (void) hipEventDestroy(a->ev_staged);
+  if (a->stream2) (void) hipStreamDestroy(a->stream2);
   if (a->stream) (void) hipStreamDestroy(a->stream);
   delete a;
   return 0;
@@ -1328,6 +1435,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   Slice* s = a->slices[si];
   if (s->cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_fixed on a prior slice: use set_prior_measurement");
   if ((rc = set_device(a))) return rc;
+  if ((rc = quiesce_stream2(a))) return rc;
   if (a->records_state == 1) a->records_state = 2;
   if ((rc = s->fixed_raw.reserve((size_t) std::max(n, 1)))) return rc;
   if (normals && (rc = s->fixed_nrm_raw.reserve((size_t) std::max(n, 1)))) return rc;
@@ -1635,7 +1743,24 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
   int rc;
   if ((rc = set_device(a))) return rc;
   const auto t_up0 = std::chrono::steady_clock::now();
-  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false))) return rc;
+  // Pipelined batches: the alignments are independent, so the batch runs as two halves on two streams -- while one half's
+  // control step (one workgroup per alignment on an otherwise idle chip, ~10 us per iteration, + the kernel boundaries) and
+  // Morton sort pass, the other half's pass kernel has the chip.  Same kernels on the same data: the same bits.
+  // tuning.batch_pipeline: 0 = never, 1 = every batch of >= 2, -1 = automatic (from 8 alignments per launch on)
+  int split = 0;
+  {
+    const srrg2_aligner_tuning& tn = a->tuning;
+    int max_nm = 0;
+    for (int k = 0; k < K; ++k) max_nm = std::max(max_nm, offsets[k + 1] - offsets[k]);
+    bool one_cue = true;
+    for (size_t si = 1; si < a->slices.size(); ++si)
+      if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR) one_cue = false;
+    const int min_k = tn.batch_pipeline == 0 ? (1 << 30) : (tn.batch_pipeline > 0 ? 2 : 8);
+    if (K >= min_k && one_cue && a->slices[0]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm > tn.small_max_points &&
+        !tn.fast_batch_queue && !a->reduce_fn && !a->profile && a->timeline_path.empty() && a->stream2)
+      split = (K + 1) / 2;
+  }
+  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false, split))) return rc;
   if (a->hosttime)
     std::fprintf(stderr, "compute_batch: upload_moving (enqueue) %.1f us\n",
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_up0).count());

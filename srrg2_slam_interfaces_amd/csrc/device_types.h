@@ -101,6 +101,8 @@ struct SliceDev {
   unsigned long long* dbg;  // -DSRRG2_TIMELINE builds only: [iteration < 32][wave][16] shader-clock stamps, or null
   int tune;             // strategy switches (env SRRG2_AMD_TUNE; all exact); the result-changing timing knobs exist only
                         // in -DSRRG2_TIMING_KNOBS builds (kernels.hip: KNOB)
+  int prob0;            // first problem of the launch (blockIdx.y = 0): a launch may cover a sub-range of the batch (the two
+                        // halves of a pipelined batch run on two streams)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
 };
 
@@ -179,5 +181,6 @@ struct CtlParams {
   int tune;       // SRRG2_AMD_TUNE (see SliceDev::tune)
   int probe_it;   // iteration after which the use of the deferred-search queue is decided (-1: never)
   int seq;        // sequence number of this compute() (completion flag in ProblemOut)
+  int prob0, nprob;  // the problems [prob0, prob0 + nprob) of the batch are this launch's (nprob = 0: all K)
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

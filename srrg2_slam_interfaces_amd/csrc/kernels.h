@@ -19,7 +19,7 @@ void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm,
 void launch_cnl_build(const GridDev& g, const int4* offs, int noffs, int* list_start, uint2* ent, hipStream_t s);
 // search pass over the cell neighbour lists (any number of alignments per launch; no deferred-search queue)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                         int max_nm, hipStream_t s);
+                         int max_nm, int team, hipStream_t s);
 // Morton sort of K moving clouds (counts/cursor: (K << kbits) + 1 ints; bb: K*6 keys initialised to
 // {0xffffffff x3, 0 x3}; counts zeroed)
 // kbits = total key bits (2^kbits cells per cloud); aniso != 0: bits dealt to the axes by extent (kernels_prep.hip: KeySpec);

@@ -629,6 +629,216 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
   wexcl2 = fminf(v, fminf(sr2, bound2_of(max(sr, 0), g.h)));
 }
 
+// ============================================================================================
+// Searches over CELL NEIGHBOUR LISTS (round 4): cnl_search, used by k_icp_step_cnl (the search passes) and by the converged-
+// pass kernel for the points whose certificate failed.
+//
+// The grid kernels enumerate CELLS -- the rows of the 3^DIM block, then the shell of the 5^DIM cube, then cubes of growing
+// radius -- and most of what they enumerate is empty: a cloud is a surface, one cell in six of a block holds points.  On the
+// tiles the bookkeeping of (mostly empty) rows, the second staging for the shell and the cooperative scans behind it were
+// 46 % of the first pass' vector instructions (profiles/r3n_tile_kernel_knob_attribution.txt), the candidates themselves a
+// fifth.  The fixed cloud is set once and searched by every iteration of every alignment, so the enumeration is done ONCE
+// per fixed cloud: every cell of the (extended) grid gets the list of OCCUPIED cells that can hold a point within the
+// extended gate of a query in it (GridDev::list_*, ~20 entries of 8 bytes per cell on C4, at most 16 points per entry),
+// sorted by the class of the cell pair (squared separation in cells), then by centre distance.  A search is then:
+//   0. the first entry (the query's own cell when it is occupied) is scanned; its best candidate (+ the pad that lets the
+//      scan prove an exclusion margin), or the ball of the previous neighbour, is the ball everything else is pruned to;
+//   A. the entry headers, four loads in flight per lane: stop at the first class whose separation exceeds the ball; an
+//      entry whose cell lies outside the ball (three slab distances, in cell units) is dropped; the survivors of ALL lanes
+//      are appended to ONE pool of the wave in LDS (ballot + mbcnt: compact, in order);
+//   B. the wave works the pool off together, item s by lane s mod 64 -- a wave is as slow as its busiest lane, and with one
+//      list per lane a single point without a neighbour inside the gate (all ~20 entries survive) kept the other 63 lanes
+//      waiting: 28 group iterations per wave on the first pass for ~8 per lane on average (profiles/r4c_*).  The worker
+//      merges its item's (key, runner-up) into the owner's slot with two LDS atomics: min of the 64-bit key, and the loser
+//      of that min -- the larger of the old and the new key -- is a candidate for the runner-up.
+// TEAM lanes share one query (TEAM = 1: throughput, one query per lane; TEAM = 4: a single alignment is a chain of
+// dependent round trips on a half-empty chip -- four lanes split the first entry's candidates and the headers, and a wave's
+// pool is a quarter as long).
+// One mechanism covers the whole gate ball: no second phase, no staging, no tile that may not fit, no deferred-search
+// queue.  Same candidates-within-the-ball, same key minimum (d2 bits << 32 | index) => the same exact nearest neighbour
+// as every other path; runner-up and completeness radius leave an exclusion radius that is as valid.
+// ============================================================================================
+namespace {
+
+constexpr int CNL_POOL = 512;  // survivor entries of a wave between two rounds of phase B (a step of phase A adds <= 256)
+
+struct CnlWave {               // per wave, in LDS
+  uint2 pool[CNL_POOL];        // {position of the first candidate, owner lane | count << 8}
+  unsigned long long key[64];  // running minimum key of every lane's query
+  unsigned b2[64];             // ... and the squared distance of its runner-up (float bits: d2 >= 0 orders like the bits)
+  float q[3][64];              // the queries
+};
+
+// up to four candidates pts[j .. j + 3], the first `cnt` of them valid; lanes without work issue no load and run no test
+// (reads up to 3 entries past the range, masked out: the sorted array has slack behind it)
+template <int DIM>
+__device__ __forceinline__ void test_group_glb(const float4* __restrict__ pts, int j, int cnt, float qx, float qy, float qz,
+                                               unsigned long long& bkey, float& b2) {
+  if (cnt > 0) {
+    const float4 a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
+    test_candidate2<DIM>(a0, qx, qy, qz, true, bkey, b2);
+    test_candidate2<DIM>(a1, qx, qy, qz, cnt > 1, bkey, b2);
+    test_candidate2<DIM>(a2, qx, qy, qz, cnt > 2, bkey, b2);
+    test_candidate2<DIM>(a3, qx, qy, qz, cnt > 3, bkey, b2);
+  }
+}
+
+// Phase B: the wave works off the n pooled survivors; results are merged into the owners' slots.
+template <int DIM>
+__device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, CnlWave& w, int lane, int n) {
+  wave_lds_sync();  // (pool entries, queries and slots written by other lanes)
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int s     = s0 + lane;
+    const bool have = s < n;
+    uint2 it        = make_uint2(0u, 0u);
+    if (have) it = w.pool[s];
+    const int owner = (int) (it.y & 63u);
+    int cnt         = have ? (int) (it.y >> 8) : 0;
+    int j           = (int) it.x;
+    const float qx = w.q[0][owner], qy = w.q[1][owner], qz = DIM == 3 ? w.q[2][owner] : 0.f;
+    unsigned long long key = NO_KEY;
+    float lb2              = INFINITY;
+    while (__any(cnt > 0)) {
+      test_group_glb<DIM>(pts, j, cnt, qx, qy, qz, key, lb2);
+      j += 4;
+      cnt -= 4;
+    }
+    if (have) {
+      const unsigned long long old   = atomicMin(&w.key[owner], key);
+      const unsigned long long loser = old > key ? old : key;  // (not the minimum any more: a runner-up candidate)
+      const unsigned l2              = min((unsigned) (loser >> 32), __float_as_uint(lb2));
+      atomicMin(&w.b2[owner], l2);
+    }
+  }
+  wave_lds_sync();
+}
+
+// The exact gated nearest neighbour of the wave's queries over the cell neighbour lists.  Called by every lane of the wave
+// (wave-uniform control flow); the TEAM lanes of a team pass the same query and the same `need` / `r2box`.
+//   r2box : squared radius of a ball known to hold the nearest neighbour (the previous neighbour's), or +inf
+//   gfar  : squared radius the search reaches to (the gate, or the extended gate once priors exist)
+// Returns, in the first lane of every team with `need`: bkey = the minimum key over the fixed points inside the ball
+// (NO_KEY: none), b2 = squared distance of the runner-up among the points examined, L = squared radius inside which every
+// fixed point was examined (every point not examined is farther than min(L, extended gate)).
+template <int DIM, int TEAM>
+__device__ __forceinline__ void cnl_search(const GridDev& g, CnlWave& w, int lane, bool need, float qx, float qy, float qz,
+                                           float r2box, float gfar, unsigned long long& bkey, float& b2, float& L) {
+  const int R  = g.list_R;
+  const int tl = lane & (TEAM - 1);   // lane within its team
+  const int owner_lane = lane - tl;   // the team's slot
+  // the query in cell units: cell c + fraction u along every axis
+  const float ux0 = (qx - g.ox) * g.inv_h, uy0 = (qy - g.oy) * g.inv_h, uz0 = DIM == 3 ? (qz - g.oz) * g.inv_h : 0.f;
+  const int cx = cell_coord(qx, g.ox, g.inv_h);
+  const int cy = cell_coord(qy, g.oy, g.inv_h);
+  const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
+  const int lx = cx + R, ly = cy + R, lz = DIM == 3 ? cz + R : 0;
+  // (a query outside the extended grid is farther than the extended gate from every fixed point: no list, no match)
+  const bool inl = need && lx >= 0 && lx < g.lnx && ly >= 0 && ly < g.lny && lz >= 0 && lz < g.lnz;
+  int e = 0, eend = 0;
+  if (inl) {
+    const int lc = (lz * g.lny + ly) * g.lnx + lx;
+    e            = g.list_start[lc];
+    eend         = g.list_start[lc + 1];
+  }
+  bkey = NO_KEY;
+  b2   = INFINITY;
+  L    = fminf(r2box, gfar);  // squared radius of the ball the search is pruned to
+  // ---- phase 0: the first entry of the list; its best candidate (+ pad) bounds the rest
+  {
+    const bool p0 = e < eend;
+    uint2 h0      = make_uint2(0u, 0u);
+    if (p0) h0 = g.list_ent[e];
+    int j = (int) h0.x + 4 * tl, cnt = p0 ? (int) (h0.y & 15u) + 1 - 4 * tl : 0;
+    while (__any(cnt > 0)) {
+      test_group_glb<DIM>(g.pts, j, cnt, qx, qy, qz, bkey, b2);
+      j += 4 * TEAM;
+      cnt -= 4 * TEAM;
+    }
+#pragma unroll
+    for (int off = 1; off < TEAM; off <<= 1) {  // the team's (key, runner-up)
+      const unsigned long long ok = __shfl_xor(bkey, off);
+      const float ob2             = __shfl_xor(b2, off);
+      const unsigned long long lo = ok < bkey ? ok : bkey, hi = ok < bkey ? bkey : ok;
+      b2   = fminf(fminf(b2, ob2), __uint_as_float((unsigned) (hi >> 32)));
+      bkey = lo;
+    }
+    if (p0) {
+      ++e;
+      if (key_idx(bkey) != NO_MATCH) {
+        const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+        L              = fminf(L, rb * rb);
+      }
+    }
+  }
+  if (tl == 0) {
+    w.key[lane]  = bkey;
+    w.b2[lane]   = __float_as_uint(b2);
+    w.q[0][lane] = qx;
+    w.q[1][lane] = qy;
+    if (DIM == 3) w.q[2][lane] = qz;
+  }
+  // ---- phase A: the headers.  Distances in cell units: with u = the query's fraction of its own cell, the cell at offset d
+  // along an axis spans [d - u, d - u + 1] around the query, so it is max(d - u, u - d - 1, 0) away -- shrunk by
+  // m = 1.1 % of a cell + 1e-6 of the coordinate, which covers the float32 rounding of cell assignments (a point's cell is
+  // floor(fl(fl(x - o) * inv_h))) and of these expressions.  The header carries d + R as a byte: one conversion
+  // (v_cvt_f32_ubyte), two subtractions from per-lane constants, one v_max3 per axis.
+  const float Lc  = L * 1.00002f;
+  const float Lcc = (Lc * g.inv_h) * g.inv_h * 1.0001f;
+  int mmax = -1;  // largest class whose cells can reach into the ball
+#pragma unroll
+  for (int m = 0; m <= CNL_MAX_CLASS; ++m) mmax += g.cls_b2[m] <= Lc ? 1 : 0;
+  const float fR = (float) R;
+  const float mx = 0.011f + fabsf(ux0) * 1e-6f, my = 0.011f + fabsf(uy0) * 1e-6f, mz = 0.011f + fabsf(uz0) * 1e-6f;
+  const float ux = ux0 - (float) cx, uy = uy0 - (float) cy, uz = uz0 - (float) cz;
+  // t = max(s - ca, cb - s, 0) with s = d + R:  d - u - m = s - (R + u + m),  u - d - 1 - m = (R + u - 1 - m) - s
+  const float cax = (fR + ux) + mx, cbx = ((fR + ux) - 1.f) - mx;
+  const float cay = (fR + uy) + my, cby = ((fR + uy) - 1.f) - my;
+  const float caz = (fR + uz) + mz, cbz = ((fR + uz) - 1.f) - mz;
+  int pool_n = 0;  // (wave-uniform)
+  e += 4 * tl;     // the lanes of a team take the headers four at a time, in turn
+  while (__any(e < eend)) {
+    uint2 hd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hd[k] = make_uint2(0u, 0xf0u);  // (class 15: beyond every ball)
+      if (e + k < eend) hd[k] = g.list_ent[e + k];
+    }
+    bool stop = e >= eend;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned code = hd[k].y;
+      // (sorted by class: nothing behind the first entry of a class beyond the ball can reach into it)
+      stop = stop || (int) ((code >> 4) & 15u) > mmax;
+      const float sx = (float) ((code >> 8) & 255u), sy = (float) ((code >> 16) & 255u);
+      const float tx = fmaxf(fmaxf(sx - cax, cbx - sx), 0.f);
+      const float ty = fmaxf(fmaxf(sy - cay, cby - sy), 0.f);
+      float d2c      = __fmaf_rn(ty, ty, tx * tx);
+      if (DIM == 3) {
+        const float sz = (float) (code >> 24);
+        const float tz = fmaxf(fmaxf(sz - caz, cbz - sz), 0.f);
+        d2c            = __fmaf_rn(tz, tz, d2c);
+      }
+      const bool surv             = !stop && !(d2c > Lcc);
+      const unsigned long long bm = __ballot(surv);
+      if (surv) {
+        const int slot = pool_n + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bm, 0u));
+        w.pool[slot]   = make_uint2(hd[k].x, (unsigned) owner_lane | (((code & 15u) + 1u) << 8));
+      }
+      pool_n += __popcll(bm);
+    }
+    e = stop ? eend : min(e + 4 * TEAM, eend);
+    if (pool_n > CNL_POOL - 256) {  // (the next step may add 4 x 64)
+      cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);
+      pool_n = 0;
+    }
+  }
+  cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);  // (also the barrier before the slots are read back)
+  bkey = w.key[owner_lane];
+  b2   = __uint_as_float(w.b2[owner_lane]);
+}
+
+}  // namespace
+
 // gates, normals, residual rows, factor arithmetic and the per-point outputs of ONE searched moving point
 template <int DIM, bool PLANE>
 __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, int rk, float thr, float kk, double scale,
@@ -1193,7 +1403,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
 template <int DIM, bool PLANE>
 __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* __restrict__ probs,
                                                   ProblemState* __restrict__ states) {
-  const int prob   = blockIdx.y;
+  const int prob   = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   icp_step_body<DIM, PLANE, 4>(S, probs[prob], st, prob, blockIdx.x, gridDim.x, gridDim.y, nullptr);
@@ -1541,7 +1751,7 @@ template <int DIM, bool PLANE, int CAP>
 __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const ProblemDev* __restrict__ probs,
                                                        ProblemState* __restrict__ states) {
   constexpr int NW = 4;
-  const int prob   = blockIdx.y;
+  const int prob   = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   const ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
@@ -1961,7 +2171,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
                                                        ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
-  const int prob     = blockIdx.y;
+  const int prob     = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   const ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
@@ -1983,7 +2193,14 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   const bool cert_a  = !(S.tune & 4096), cert_c = !(S.tune & (4096 | 65536));
   const int lane     = threadIdx.x & 63;
   const int wid      = threadIdx.x >> 6;
-  __shared__ int coop_lds[4][288];  // (64-lane scans need 264 ints, four 16-lane teams 4 x 72)
+  // (the row tables of the cooperative grid scans -- 64-lane scans need 264 ints, four 16-lane teams 4 x 72 -- or, when the
+  // grid has cell neighbour lists, the wave's pool of cnl_search: never live together)
+  union FastWaveLds {
+    CnlWave cnl;
+    int coop[288];
+  };
+  __shared__ FastWaveLds fast_lds[4];
+  int* const coop_lds_w = fast_lds[wid].coop;
 
   // gates, rows and factor terms of a point whose nearest neighbour {fk, nk} is known (valid); straight-line
   auto linearize = [&](auto first, long long (&acc)[ACC_N], bool valid, const float4 pk, const float4 fk, const float4 nk,
@@ -2123,6 +2340,21 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
     if (!__ballot(open)) continue;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (open) transform_point<DIM>(T, p[k], qx, qy, qz);
+    // The grid has cell neighbour lists and the wave has more than a few open points (a pass before convergence, a partial
+    // overlap: C2 at 60 % overlap 24.9 -> 43.0 k it/s): all of them in one pooled search.  A settled pass leaves a wave one
+    // or two: the 16-lane cooperative scans below finish those in fewer dependent round trips (C2 converged pass 8.6 us
+    // against 11 us with the pooled search for every open point).
+    if (g.list_R > 0 && __popcll(__ballot(open)) > 4) {
+      unsigned long long skey;
+      float sb2, sL;
+      cnl_search<DIM, 1>(g, fast_lds[wid].cnl, lane, open, qx, qy, qz, open_ball2[k], gfar, skey, sb2, sL);
+      if (open) {
+        sbest[k] = key_best(skey);
+        sidx[k]  = key_idx(skey);
+        sexcl[k] = sqrtf(fminf(sb2, fminf(sL, g.gate2_ext))) * 0.99999f;
+      }
+      continue;
+    }
     const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
     // small balls (the usual case: the ball of the previous neighbour): four searches per pass, 16 lanes each
     unsigned long long near = __ballot(open && r2 == 2);
@@ -2141,7 +2373,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
       float wbest, wexcl2;
       int widx, wpos;
-      coop_scan<DIM, 16>(g, lane, coop_lds[wid], sqx, sqy, sqz, scx, scy, scz, mine >= 0 ? 2 : -1, sball, wbest, widx, wpos, wexcl2);
+      coop_scan<DIM, 16>(g, lane, coop_lds_w, sqx, sqy, sqz, scx, scy, scz, mine >= 0 ? 2 : -1, sball, wbest, widx, wpos, wexcl2);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {  // the result of team t goes to the lane that owns the point
         const float rb = __shfl(wbest, 16 * t), re = __shfl(wexcl2, 16 * t);
@@ -2163,7 +2395,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
       float wbest, wexcl2;
       int widx, wpos;
-      coop_scan<DIM, 64>(g, lane, coop_lds[wid], sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(open_ball2[k], src),
+      coop_scan<DIM, 64>(g, lane, coop_lds_w, sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(open_ball2[k], src),
                          wbest, widx, wpos, wexcl2);
       if (lane == src) {
         sbest[k] = wbest;
@@ -2202,99 +2434,19 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
 }
 
 // ============================================================================================
-// Search passes over CELL NEIGHBOUR LISTS (k_icp_step_cnl, round 4).
-//
-// The grid kernels above enumerate CELLS -- the rows of the 3^DIM block, then the shell of the 5^DIM cube, then cubes of
-// growing radius -- and most of what they enumerate is empty: a cloud is a surface, one cell in six of a block holds points.
-// On the tiles the bookkeeping of (mostly empty) rows, the second staging for the shell and the cooperative scans behind it
-// were 46 % of the first pass' vector instructions (profiles/r3n_tile_kernel_knob_attribution.txt), the candidates
-// themselves a fifth.  The fixed cloud is set once and searched by every iteration of every alignment of a batch, so the
-// enumeration is done ONCE, at set_fixed: every cell of the (extended) grid gets the list of OCCUPIED cells that can hold a
-// point within the extended gate of a query in it (GridDev::list_*, ~20 entries of 8 bytes per cell on C4, at most 16
-// points per entry), sorted by the class of the cell pair (squared separation in cells), then by centre distance.
-// A search is then:
-//   0. per lane: the first entry (the query's own cell when it is occupied) is scanned; its best candidate (+ the pad that
-//      lets the scan prove an exclusion margin), or the ball of the previous neighbour, is the ball everything else is
-//      pruned to;
-//   A. per lane: the entry headers, four loads in flight: stop at the first class whose separation exceeds the ball; an
-//      entry whose cell lies outside the ball (three slab distances, in cell units) is dropped; the survivors of ALL lanes
-//      are appended to ONE pool of the wave in LDS (ballot + mbcnt: compact, in order);
-//   B. the wave works the pool off together, item s by lane s mod 64 -- a wave is as slow as its busiest lane, and with one
-//      list per lane a single point without a neighbour inside the gate (all ~20 entries survive) kept the other 63 lanes
-//      waiting: 28 group iterations per wave on the first pass for ~8 per lane on average (profiles/r4c_*).  The worker
-//      merges its item's (key, runner-up) into the owner's slot with two LDS atomics: min of the 64-bit key, and the loser
-//      of that min -- the larger of the old and the new key -- is a candidate for the runner-up.
-// One mechanism covers the whole gate ball: no second phase, no staging, no tile that may not fit, no deferred-search
-// queue.  Same candidates-within-the-ball, same key minimum (d2 bits << 32 | index) => the same exact nearest neighbour
-// as every other path; runner-up and completeness radius leave an exclusion radius that is as valid.
+// The search pass over the cell neighbour lists (cnl_search above): TEAM lanes per moving point.
 // ============================================================================================
-namespace {
-
-constexpr int CNL_POOL = 512;  // survivor entries of a wave between two rounds of phase B (a step of phase A adds <= 256)
-
-struct CnlWave {               // per wave, in LDS
-  uint2 pool[CNL_POOL];        // {position of the first candidate, owner lane | count << 8}
-  unsigned long long key[64];  // running minimum key of every lane's query
-  unsigned b2[64];             // ... and the squared distance of its runner-up (float bits: d2 >= 0 orders like the bits)
-  float q[3][64];              // the queries
-};
-
-// up to four candidates pts[j .. j + 3], the first `cnt` of them valid; lanes without work issue no load and run no test
-// (reads up to 3 entries past the range, masked out: the sorted array has slack behind it)
-template <int DIM>
-__device__ __forceinline__ void test_group_glb(const float4* __restrict__ pts, int j, int cnt, float qx, float qy, float qz,
-                                               unsigned long long& bkey, float& b2) {
-  if (cnt > 0) {
-    const float4 a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
-    test_candidate2<DIM>(a0, qx, qy, qz, true, bkey, b2);
-    test_candidate2<DIM>(a1, qx, qy, qz, cnt > 1, bkey, b2);
-    test_candidate2<DIM>(a2, qx, qy, qz, cnt > 2, bkey, b2);
-    test_candidate2<DIM>(a3, qx, qy, qz, cnt > 3, bkey, b2);
-  }
-}
-
-// Phase B: the wave works off the n pooled survivors; results are merged into the owners' slots.
-template <int DIM>
-__device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, CnlWave& w, int lane, int n) {
-  wave_lds_sync();  // (pool entries, queries and slots written by other lanes)
-  for (int s0 = 0; s0 < n; s0 += 64) {
-    const int s     = s0 + lane;
-    const bool have = s < n;
-    uint2 it        = make_uint2(0u, 0u);
-    if (have) it = w.pool[s];
-    const int owner = (int) (it.y & 63u);
-    int cnt         = have ? (int) (it.y >> 8) : 0;
-    int j           = (int) it.x;
-    const float qx = w.q[0][owner], qy = w.q[1][owner], qz = DIM == 3 ? w.q[2][owner] : 0.f;
-    unsigned long long key = NO_KEY;
-    float lb2              = INFINITY;
-    while (__any(cnt > 0)) {
-      test_group_glb<DIM>(pts, j, cnt, qx, qy, qz, key, lb2);
-      j += 4;
-      cnt -= 4;
-    }
-    if (have) {
-      const unsigned long long old   = atomicMin(&w.key[owner], key);
-      const unsigned long long loser = old > key ? old : key;  // (not the minimum any more: a runner-up candidate)
-      const unsigned l2              = min((unsigned) (loser >> 32), __float_as_uint(lb2));
-      atomicMin(&w.b2[owner], l2);
-    }
-  }
-  wave_lds_sync();
-}
-
-}  // namespace
-
-template <int DIM, bool PLANE>
+template <int DIM, bool PLANE, int TEAM>
 __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemDev* __restrict__ probs,
                                                       ProblemState* __restrict__ states) {
-  constexpr int NW = 4;
-  const int prob   = blockIdx.y;
+  constexpr int NW  = 4;
+  constexpr int PPB = NW * 64 / TEAM;  // moving points per workgroup
+  const int prob    = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   const ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
   const int tile      = blockIdx.x;
-  if (tile * (NW * 64) >= pd.nm) return;  // (batches of unequal clouds)
+  if (tile * PPB >= pd.nm) return;  // (batches of unequal clouds)
   float T[12];
   load_T(st->Tf[S.slice_idx], T);
   const double scale = dm::pow2(st->kexp[S.slice_idx]);
@@ -2309,9 +2461,10 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemD
 
   __shared__ CnlWave wlds[NW];
 
-  const int i        = tile * (NW * 64) + threadIdx.x;
+  const int i        = tile * PPB + (int) threadIdx.x / TEAM;
   const int lane     = threadIdx.x & 63;
   const int wid      = threadIdx.x >> 6;
+  const bool leader  = (threadIdx.x & (TEAM - 1)) == 0;
   const bool inrange = i < pd.nm;
   const int gi       = pd.moff + (inrange ? i : 0);
   float4 p           = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2337,7 +2490,6 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemD
     }
   }
   const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
-  const int oi        = pd.moff + __float_as_int(p.w);
   const bool active   = inrange && finite3(p.x, p.y, p.z);
   float qx = 0.f, qy = 0.f, qz = 0.f;
   float best = INFINITY;
@@ -2379,107 +2531,10 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemD
   }
   const bool need = active && !skipped && !KNOB(S.tune, 16);
   if (__any(need)) {
-    CnlWave& w   = wlds[wid];
-    const int R  = g.list_R;
-    // the query in cell units: cell c + fraction u along every axis
-    const float ux0 = (qx - g.ox) * g.inv_h, uy0 = (qy - g.oy) * g.inv_h, uz0 = DIM == 3 ? (qz - g.oz) * g.inv_h : 0.f;
-    const int cx = cell_coord(qx, g.ox, g.inv_h);
-    const int cy = cell_coord(qy, g.oy, g.inv_h);
-    const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
-    const int lx = cx + R, ly = cy + R, lz = DIM == 3 ? cz + R : 0;
-    // (a query outside the extended grid is farther than the extended gate from every fixed point: no list, no match)
-    const bool inl = need && lx >= 0 && lx < g.lnx && ly >= 0 && ly < g.lny && lz >= 0 && lz < g.lnz;
-    int e = 0, eend = 0;
-    if (inl) {
-      const int lc = (lz * g.lny + ly) * g.lnx + lx;
-      e            = g.list_start[lc];
-      eend         = g.list_start[lc + 1];
-    }
-    unsigned long long bkey = NO_KEY;
-    float b2 = INFINITY;
-    float L  = fminf(r2box, gfar);  // squared radius of the ball the search is pruned to
-    // ---- phase 0: the first entry of the list; its best candidate (+ pad) bounds the rest
-    {
-      const bool p0 = e < eend;
-      uint2 h0      = make_uint2(0u, 0u);
-      if (p0) h0 = g.list_ent[e];
-      int j = (int) h0.x, cnt = p0 ? (int) (h0.y & 15u) + 1 : 0;
-      while (__any(cnt > 0)) {
-        test_group_glb<DIM>(g.pts, j, cnt, qx, qy, qz, bkey, b2);
-        j += 4;
-        cnt -= 4;
-      }
-      if (p0) {
-        ++e;
-        if (key_idx(bkey) != NO_MATCH) {
-          const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
-          L              = fminf(L, rb * rb);
-        }
-      }
-    }
-    w.key[lane]  = bkey;
-    w.b2[lane]   = __float_as_uint(b2);
-    w.q[0][lane] = qx;
-    w.q[1][lane] = qy;
-    if (DIM == 3) w.q[2][lane] = qz;
-    // ---- phase A: the headers.  Distances in cell units: with u = the query's fraction of its own cell, the cell at offset d
-    // along an axis spans [d - u, d - u + 1] around the query, so it is max(d - u, u - d - 1, 0) away -- shrunk by
-    // m = 1.1 % of a cell + 1e-6 of the coordinate, which covers the float32 rounding of cell assignments (a point's cell is
-    // floor(fl(fl(x - o) * inv_h))) and of these expressions.  The header carries d + R as a byte: one conversion
-    // (v_cvt_f32_ubyte), two subtractions from per-lane constants, one v_max3 per axis.
-    const float Lc  = L * 1.00002f;
-    const float Lcc = (Lc * g.inv_h) * g.inv_h * 1.0001f;
-    int mmax = -1;  // largest class whose cells can reach into the ball
-#pragma unroll
-    for (int m = 0; m <= CNL_MAX_CLASS; ++m) mmax += g.cls_b2[m] <= Lc ? 1 : 0;
-    const float fR = (float) R;
-    const float mx = 0.011f + fabsf(ux0) * 1e-6f, my = 0.011f + fabsf(uy0) * 1e-6f, mz = 0.011f + fabsf(uz0) * 1e-6f;
-    const float ux = ux0 - (float) cx, uy = uy0 - (float) cy, uz = uz0 - (float) cz;
-    // t = max(s - ca, cb - s, 0) with s = d + R:  d - u - m = s - (R + u + m),  u - d - 1 - m = (R + u - 1 - m) - s
-    const float cax = (fR + ux) + mx, cbx = ((fR + ux) - 1.f) - mx;
-    const float cay = (fR + uy) + my, cby = ((fR + uy) - 1.f) - my;
-    const float caz = (fR + uz) + mz, cbz = ((fR + uz) - 1.f) - mz;
-    int pool_n = 0;  // (wave-uniform)
-    while (__any(e < eend)) {
-      uint2 hd[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        hd[k] = make_uint2(0u, 0xf0u);  // (class 15: beyond every ball)
-        if (e + k < eend) hd[k] = g.list_ent[e + k];
-      }
-      bool stop = e >= eend;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned code = hd[k].y;
-        // (sorted by class: nothing behind the first entry of a class beyond the ball can reach into it)
-        stop = stop || (int) ((code >> 4) & 15u) > mmax;
-        const float sx = (float) ((code >> 8) & 255u), sy = (float) ((code >> 16) & 255u);
-        const float tx = fmaxf(fmaxf(sx - cax, cbx - sx), 0.f);
-        const float ty = fmaxf(fmaxf(sy - cay, cby - sy), 0.f);
-        float d2c      = __fmaf_rn(ty, ty, tx * tx);
-        if (DIM == 3) {
-          const float sz = (float) (code >> 24);
-          const float tz = fmaxf(fmaxf(sz - caz, cbz - sz), 0.f);
-          d2c            = __fmaf_rn(tz, tz, d2c);
-        }
-        const bool surv             = !stop && !(d2c > Lcc);
-        const unsigned long long bm = __ballot(surv);
-        if (surv) {
-          const int slot = pool_n + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) bm, 0u));
-          w.pool[slot]   = make_uint2(hd[k].x, (unsigned) lane | (((code & 15u) + 1u) << 8));
-        }
-        pool_n += __popcll(bm);
-      }
-      e = stop ? eend : min(e + 4, eend);
-      if (pool_n > CNL_POOL - 256) {  // (the next step may add 4 x 64)
-        cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);
-        pool_n = 0;
-      }
-    }
-    cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);  // (also the barrier before the slots are read back)
+    unsigned long long bkey;
+    float b2, L;
+    cnl_search<DIM, TEAM>(g, wlds[wid], lane, need, qx, qy, qz, r2box, gfar, bkey, b2, L);
     if (need) {
-      bkey = w.key[lane];
-      b2   = __uint_as_float(w.b2[lane]);
       best = key_best(bkey);
       bidx = key_idx(bkey);
       // every fixed point that was not examined is farther than the ball (a pruned or unreached cell) or than the extended
@@ -2489,12 +2544,11 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemD
   }
   // ---- gates, rows, factor terms: straight-line as in the converged-pass kernel (every lane produces the 32 biased values,
   // a lane without a correspondence with weight 0: no control flow around the accumulators -- finish_point's branches made
-  // the compiler re-materialise them on every path, ~150 register moves per point)
-  (void) oi;
+  // the compiler re-materialise them on every path, ~150 register moves per point).  One lane of a team carries the point.
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   const bool ngate   = S.use_normal_gate != 0;
-  const bool has     = active && bidx != NO_MATCH;
+  const bool has     = active && leader && bidx != NO_MATCH;
   int bpos           = -1;
   float4 fm          = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
   float4 nf          = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2529,7 +2583,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemD
     point_rows<DIM, PLANE>(T, kk, p, qx, qy, qz, fm, nf, J, er);
     (void) factor_accumulate_flat<D, ROWS, true>(J, er, found, rk, thr, scale, acc);
   }
-  if (inrange) {
+  if (inrange && leader) {
     if (!skipped) {  // (a skipped search keeps its neighbour: only the exclusion radius changes)
       S.prev_pos[gi] = has ? bpos : -1;
       if (!S.gather_prev) {
@@ -2551,7 +2605,7 @@ __global__ __launch_bounds__(256) void k_icp_outputs(SliceDev S, const ProblemDe
                                                      const ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
-  const int prob     = blockIdx.y;
+  const int prob     = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   const ProblemState* st = &states[prob];
   const ProblemDev pd    = probs[prob];
   const int i            = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2622,7 +2676,7 @@ __global__ __launch_bounds__(256) void k_icp_outputs(SliceDev S, const ProblemDe
 template <int DIM, bool PLANE>
 __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const ProblemDev* __restrict__ probs,
                                                         ProblemState* __restrict__ states) {
-  const int prob   = blockIdx.y;
+  const int prob   = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
@@ -2776,7 +2830,7 @@ __global__ __launch_bounds__(256) void k_icp_step_corr(SliceDev S, const Problem
                                                        ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
-  const int prob     = blockIdx.y;
+  const int prob     = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   ProblemState* st   = &states[prob];
   if (st->done || st->finished) return;
   const ProblemDev pd = probs[prob];
@@ -3354,7 +3408,7 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
 __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs_host,
                                                  ProblemDev* __restrict__ probs, ProblemState* __restrict__ states,
                                                  const float* __restrict__ guesses_host, int tsize) {
-  const int prob = blockIdx.x;
+  const int prob = blockIdx.x + C.prob0;
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
@@ -3452,7 +3506,7 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
 
 __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* __restrict__ states,
                                                      srrg2_iteration_stats* __restrict__ stats) {
-  const int prob   = blockIdx.x;
+  const int prob   = blockIdx.x + C.prob0;
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
   // The sequential part reads and writes ~100 words of the state, with stores to other arrays in between that the
@@ -3487,7 +3541,8 @@ __device__ void icp_post_one(const CtlParams& C, ProblemState* st, const srrg2_i
 
 __global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const srrg2_iteration_stats* __restrict__ stats) {
   int prob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (prob >= C.K) return;
+  if (prob >= (C.nprob > 0 ? C.nprob : C.K)) return;
+  prob += C.prob0;
   icp_post_one(C, &states[prob], stats, prob);
 }
 
@@ -3537,7 +3592,7 @@ __global__ __launch_bounds__(64) void k_icp_finalize(CtlParams C, ProblemState* 
                                                      const srrg2_iteration_stats* __restrict__ stats,
                                                      ProblemOut* __restrict__ outs_host,
                                                      srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
-  icp_finalize_block(C, &states[blockIdx.x], stats, outs_host, stats_host, blockIdx.x, with_post != 0);
+  icp_finalize_block(C, &states[blockIdx.x + C.prob0], stats, outs_host, stats_host, blockIdx.x + C.prob0, with_post != 0);
 }
 
 // The control step of the LAST iteration of compute() with the (post and) finalize steps behind it: nothing lies
@@ -3546,7 +3601,7 @@ __global__ __launch_bounds__(256) void k_icp_control_final(CtlParams C, ProblemS
                                                            srrg2_iteration_stats* __restrict__ stats,
                                                            ProblemOut* __restrict__ outs_host,
                                                            srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
-  const int prob = blockIdx.x;
+  const int prob = blockIdx.x + C.prob0;
   __shared__ ProblemState sst;  // (see k_icp_control)
   state_to_lds(&sst, &states[prob]);
   __syncthreads();
@@ -3693,22 +3748,30 @@ void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemD
 #undef TILE_LAUNCH
 }
 
-// the search pass over the cell neighbour lists of the grid (S.grid.list_R > 0)
+// the search pass over the cell neighbour lists of the grid (S.grid.list_R > 0); team = lanes per moving point (1 or 4)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                         int max_nm, hipStream_t s) {
+                         int max_nm, int team, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
-  dim3 grid((max_nm + 255) / 256, K);
-  if (dim == 3) {
-    if (plane)
-      hipLaunchKernelGGL((k_icp_step_cnl<3, true>), grid, dim3(256), 0, s, S, probs, states);
-    else
-      hipLaunchKernelGGL((k_icp_step_cnl<3, false>), grid, dim3(256), 0, s, S, probs, states);
-  } else {
-    if (plane)
-      hipLaunchKernelGGL((k_icp_step_cnl<2, true>), grid, dim3(256), 0, s, S, probs, states);
-    else
-      hipLaunchKernelGGL((k_icp_step_cnl<2, false>), grid, dim3(256), 0, s, S, probs, states);
-  }
+#define CNL_LAUNCH(TEAM)                                                                                   \
+  do {                                                                                                     \
+    dim3 grid((max_nm * TEAM + 255) / 256, K);                                                             \
+    if (dim == 3) {                                                                                        \
+      if (plane)                                                                                           \
+        hipLaunchKernelGGL((k_icp_step_cnl<3, true, TEAM>), grid, dim3(256), 0, s, S, probs, states);      \
+      else                                                                                                 \
+        hipLaunchKernelGGL((k_icp_step_cnl<3, false, TEAM>), grid, dim3(256), 0, s, S, probs, states);     \
+    } else {                                                                                               \
+      if (plane)                                                                                           \
+        hipLaunchKernelGGL((k_icp_step_cnl<2, true, TEAM>), grid, dim3(256), 0, s, S, probs, states);      \
+      else                                                                                                 \
+        hipLaunchKernelGGL((k_icp_step_cnl<2, false, TEAM>), grid, dim3(256), 0, s, S, probs, states);     \
+    }                                                                                                      \
+  } while (0)
+  if (team >= 4)
+    CNL_LAUNCH(4);
+  else
+    CNL_LAUNCH(1);
+#undef CNL_LAUNCH
 }
 
 template <int PPT, bool GATHER>
@@ -3815,10 +3878,10 @@ void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* prob
 
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
                      const float* guesses_host, int tsize, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_init, dim3(C.K), dim3(64), 0, s, C, probs_host, probs, states, guesses_host, tsize);
+  hipLaunchKernelGGL(k_icp_init, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(64), 0, s, C, probs_host, probs, states, guesses_host, tsize);
 }
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_control, dim3(C.K), dim3(256), 0, s, C, states, stats);
+  hipLaunchKernelGGL(k_icp_control, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(256), 0, s, C, states, stats);
 }
 void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C, const ProblemDev* probs, ProblemState* states,
                       srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s) {
@@ -3837,15 +3900,15 @@ void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C
 }
 void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
                                srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_control_final, dim3(C.K), dim3(256), 0, s, C, states, stats, outs_host, stats_host,
+  hipLaunchKernelGGL(k_icp_control_final, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(256), 0, s, C, states, stats, outs_host, stats_host,
                      with_post ? 1 : 0);
 }
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_post, dim3((C.K + 63) / 64), dim3(64), 0, s, C, states, stats);
+  hipLaunchKernelGGL(k_icp_post, dim3(((C.nprob > 0 ? C.nprob : C.K) + 63) / 64), dim3(64), 0, s, C, states, stats);
 }
 void launch_icp_finalize(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats,
                          ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_finalize, dim3(C.K), dim3(64), 0, s, C, states, stats, outs_host, stats_host, with_post ? 1 : 0);
+  hipLaunchKernelGGL(k_icp_finalize, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(64), 0, s, C, states, stats, outs_host, stats_host, with_post ? 1 : 0);
 }
 
 }  // namespace srrg2amd

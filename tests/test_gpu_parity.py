@@ -11,16 +11,17 @@ pytestmark = pytest.mark.gpu
 
 # (deferred-search kernel for single alignments?, first iteration run by the converged-pass kernel, points per thread of
 # that kernel, batches hand their failed certificates to the deferred-search kernel?, kept neighbours gathered from the
-# fixed cloud?, search passes over the cell neighbour lists: 0 never / 1 batches / 2 every alignment)
+# fixed cloud?, search passes over the cell neighbour lists: 0 never / 1 batches / 2 every alignment, lanes per moving point
+# of that kernel: None = automatic, 4 for single alignments and 1 for batches)
 _PATHS = {
-    "deferred-search kernel": ("0", None, None, None, None, "1"),
-    "searches finished in the step kernel": ("1000000000", None, None, None, None, "0"),
-    "converged-pass kernel from iteration 1, deferred searches, 4 points per thread": ("0", "1", "4", "1", "0", "0"),
-    "converged-pass kernel from iteration 1, wave-cooperative searches, gathered neighbours": ("1000000000", "1", "1", "0", "1", "1"),
-    "converged-pass kernel from iteration 2, 2 points per thread, streamed neighbours": ("1000000000", "2", "2", "0", "0", "0"),
-    "converged-pass kernel never": ("0", "1000000", None, None, None, "0"),
-    "cell neighbour lists for every search pass": ("0", None, None, None, None, "2"),
-    "cell neighbour lists, converged-pass kernel never, gathered neighbours": ("0", "1000000", None, None, "1", "2"),
+    "deferred-search kernel": ("0", None, None, None, None, "1", None),
+    "searches finished in the step kernel": ("1000000000", None, None, None, None, "0", None),
+    "converged-pass kernel from iteration 1, deferred searches, 4 points per thread": ("0", "1", "4", "1", "0", "0", None),
+    "converged-pass kernel from iteration 1, wave-cooperative searches, gathered neighbours": ("1000000000", "1", "1", "0", "1", "1", "4"),
+    "converged-pass kernel from iteration 2, 2 points per thread, streamed neighbours": ("1000000000", "2", "2", "0", "0", "0", None),
+    "converged-pass kernel never": ("0", "1000000", None, None, None, "0", None),
+    "cell neighbour lists for every search pass": ("0", None, None, None, None, "2", None),
+    "cell neighbour lists with one lane per point, converged-pass kernel never, gathered neighbours": ("0", "1000000", None, None, "1", "2", "1"),
 }
 
 
@@ -33,12 +34,12 @@ def search_path(request, monkeypatch):
     from per-point arrays or gathered from the fixed cloud (SRRG2_AMD_FAST_GATHER); the search passes walk the grid
     (k_icp_step / k_icp_step_tile) or the cell neighbour lists (k_icp_step_cnl, SRRG2_AMD_SEARCH_LISTS).  Every scenario of
     this module runs on all of these paths: they must give the same bits."""
-    qmin, fast_from, ppt, fq, gather, lists = _PATHS[request.param]
+    qmin, fast_from, ppt, fq, gather, lists, team = _PATHS[request.param]
     monkeypatch.setenv("SRRG2_AMD_QUEUE_MIN", qmin)
     monkeypatch.setenv("SRRG2_AMD_FAST_MIN", "0")  # (the converged-pass kernel also on this module's small clouds)
     monkeypatch.setenv("SRRG2_AMD_SMALL_MAX", "1024" if lists != "2" else "0")  # (lists: also the small clouds of this module)
     for name, val in (("SRRG2_AMD_FAST_FROM", fast_from), ("SRRG2_AMD_FAST_PPT", ppt), ("SRRG2_AMD_FAST_QUEUE", fq),
-                      ("SRRG2_AMD_FAST_GATHER", gather), ("SRRG2_AMD_SEARCH_LISTS", lists)):
+                      ("SRRG2_AMD_FAST_GATHER", gather), ("SRRG2_AMD_SEARCH_LISTS", lists), ("SRRG2_AMD_SEARCH_TEAM", team)):
         if val is None:
             monkeypatch.delenv(name, raising=False)
         else:

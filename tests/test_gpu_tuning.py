@@ -18,7 +18,7 @@ def test_tuning_defaults_and_round_trip(product, monkeypatch):
     t = al.tuning()
     assert (t.strategy_mask, t.queue_probe_iteration, t.small_max_points, t.fast_from_iteration) == (0, 1, 1024, 3)
     assert (t.lds_tile, t.fast_gather, t.msort_key_bits, t.queue_min_points) == (-1, -1, 0, 90000)
-    assert t.search_lists == -1
+    assert (t.search_lists, t.search_team, t.batch_pipeline) == (-1, 0, -1)
     assert t.cell_target == pytest.approx(8.0)
     al.set_tuning(lds_tile=2, fast_from_iteration=1, cell_target=6.0)
     t = al.tuning()
@@ -69,7 +69,10 @@ def test_batches_give_the_same_bits_under_every_search_pass_kernel(oracle, produ
                   {"lds_tile": 1, "cell_target": 3.0, "search_lists": 0}, {"lds_tile": 1, "msort_key_bits": -1, "search_lists": 0},
                   {"lds_tile": 1, "fast_from_iteration": 1, "search_lists": 0},
                   {"search_lists": 1}, {"search_lists": 2, "cell_target": 3.0}, {"search_lists": 1, "cell_target": 20.0},
-                  {"search_lists": 1, "fast_from_iteration": 1}, {"search_lists": 1, "fast_from_iteration": 100}):
+                  {"search_lists": 1, "fast_from_iteration": 1}, {"search_lists": 1, "fast_from_iteration": 100},
+                  {"search_lists": 1, "search_team": 4}, {"search_lists": 1, "search_team": 4, "fast_from_iteration": 100},
+                  {"batch_pipeline": 0}, {"batch_pipeline": 1}, {"batch_pipeline": 1, "search_lists": 0},
+                  {"batch_pipeline": 0, "search_lists": 0, "lds_tile": 0}):
         got = run(product.MultiAligner(abi.SE3_QUAT_RIGHT), **knobs)
         for r, g in zip(ref, got):
             assert r["status"] == g["status"], knobs
@@ -95,3 +98,43 @@ def test_single_alignment_on_wave_tiles(oracle, product):
     assert runs[0].status() == abi.SUCCESS
     assert_same_run(runs[0], runs[1])
     assert_same_run(runs[0], runs[2])
+
+
+def test_single_alignments_get_their_lists_from_the_second_compute_on(oracle, product, monkeypatch):
+    """automatic policy (search_lists = -1): the first compute() on a fixed cloud walks the grid (a tracker sets a new fixed
+    cloud every frame and should not pay for lists it uses once), the following ones the cell neighbour lists; a new fixed
+    cloud starts over.  Same bits every time -- and after a pipelined batch on the same handle."""
+    for name in ("SRRG2_AMD_SEARCH_LISTS", "SRRG2_AMD_SEARCH_TEAM", "SRRG2_AMD_BATCH_PIPELINE"):
+        monkeypatch.delenv(name, raising=False)
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=20000, seed=9300)
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.05, 0.8)
+    ref = oracle.OracleAligner(kind)
+    setup_pair(ref, d, cfg)
+    ref.compute()
+    al = product.MultiAligner(kind)
+    setup_pair(al, d, cfg)
+    for _ in range(3):  # grid walk, then lists twice
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+        assert_same_run(ref, al)
+    # a batch of 9 (pipelined: 5 + 4) against the same fixed cloud, then the single alignment again
+    movs = [d["moving"][: 20000 - 777 * k] for k in range(9)]
+    nrms = [d["moving_normals"][: len(m)] for m in movs]
+    got = al.compute_batch(movs, [syn.identity(3)] * 9, nrms)
+    assert got[0]["moving_in_fixed"].tobytes() == ref.moving_in_fixed().tobytes()
+    al.set_moving(0, d["moving"], d["moving_normals"])
+    al.set_moving_in_fixed(syn.identity(3))
+    al.compute()
+    assert_same_run(ref, al)
+    # a new fixed cloud: back to the grid walk, same answer as a fresh handle
+    d2 = syn.cloud_pair_3d(n=15000, seed=9301)
+    ref2 = oracle.OracleAligner(kind)
+    setup_pair(ref2, d2, cfg)
+    ref2.compute()
+    al.set_fixed(0, d2["fixed"], d2["fixed_normals"])
+    al.set_moving(0, d2["moving"], d2["moving_normals"])
+    for _ in range(2):
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+        assert_same_run(ref2, al)
