@@ -214,6 +214,25 @@ def measure(args, init_dist=True):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the driver runs --steps 20, a 5 ms sample of C2.  `value` stays the K timed steps the contract asks for; a
+    # second figure from a loop of >= 50 ms (>= 200 steps) rides beside it with its own min / median / max.
+    long_run = None
+    if world == 1 and args.workload in ("c2", "c3") and args.steps < 200:
+        n_long, long_s = 200, []
+        while True:
+            tl0 = time.perf_counter()
+            for _ in range(n_long):
+                ts = time.perf_counter()
+                step()
+                long_s.append(time.perf_counter() - ts)
+            torch.cuda.synchronize()
+            dt_long = time.perf_counter() - tl0
+            if dt_long >= 0.05 or n_long >= 3200:
+                break
+            n_long, long_s = n_long * 2, []
+        long_run = {"steps": n_long, "seconds": dt_long, "value": units_per_step * n_long / dt_long,
+                    "ms_per_step": dt_long / n_long * 1e3,
+                    "step_ms_min_median_max": [min(long_s) * 1e3, float(np.median(long_s)) * 1e3, max(long_s) * 1e3]}
     gc.enable()
     table = D.exchange_records(records(res), K_total, device=coll_device, mode=args.exchange)
     assert table.shape[0] == K_total
@@ -286,6 +305,7 @@ def measure(args, init_dist=True):
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "step_ms_min_median_max": [min(step_s) * 1e3, float(np.median(step_s)) * 1e3, max(step_s) * 1e3],
+        **({"value_long": long_run["value"], "long_run": long_run} if long_run else {}),
         "higher_is_better": True,
         "scaling": "strong" if (args.workload == "c4" and world > 1) else "weak",
         "vs_baseline": None,
@@ -314,8 +334,8 @@ def measure(args, init_dist=True):
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("k_icp_step<3,true> [+ k_icp_step_queue<3,true>] / k_icp_step_fast<3,true> (one finder+factor pass of the slice)" if args.workload == "c2" else
-                       "k_icp_step_tile<3,true,416> (search passes) / k_icp_step_fast<3,true,1,true> (converged passes): one finder+factor pass over all alignments of the launch" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
+            "kernel": ("k_icp_step_cnl<3,true,4|1> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,false> (converged passes): one finder+factor pass of the slice" if args.workload == "c2" else
+                       "k_icp_step_cnl<3,true,1> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,true> (converged passes): one finder+factor pass over all alignments of the launch" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",
@@ -415,21 +435,49 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
     g = syn.pose_graph_3d(V=V, E=E, seed=5000)
     E = int(g["ij"].shape[0])
     pg = pkg.PoseGraph(abi.SE3_QUAT_RIGHT)
-    best, st = None, None
-    for _ in range(3):  # (the first solve also builds the structure of the multigrid hierarchy on the host)
+    pg.set_tuning(keep_structure=0)  # COLD solves: every one builds the structure of the multigrid hierarchy on the host
+    times, st = [], None
+    for _ in range(4):
         pg.set_graph(g["poses_init"], g["ij"], g["Z"])
         t0 = time.perf_counter()
         st = pg.solve()
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        times.append(time.perf_counter() - t0)
+    times = times[1:]  # (the first solve also pays for first-touch allocations: warm-up; the figure is the MEDIAN of three)
+    best = float(np.median(times))
     pcg = sum(s_["pcg_iterations"] for s_ in st)
     params = pgm.default_params()
     converged = all(s_["solver_status"] == 0 and s_["pcg_iterations"] < params.pcg_max_iterations and
                     s_["pcg_residual"] <= 1.01e-6 for s_ in st)
+    # What MultiGraphSLAM_::optimize() does over and over (multi_graph_slam_impl.cpp:300-317): the same graph again (the
+    # hierarchy's structure is kept while the topology does not change), and the graph after makeNewMap appended one
+    # variable and one factor (:52-90; the structure is rebuilt: that path is not incremental yet)
+    pg.set_tuning(keep_structure=1)
+    warm = []
+    for _ in range(3):
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+        t0 = time.perf_counter()
+        pg.solve()
+        warm.append(time.perf_counter() - t0)
+    vid = pg.add_variable(g["poses_init"][-1])
+    pg.add_factor(V - 1, vid, syn.identity(3))
+    t0 = time.perf_counter()
+    st_app = pg.solve()
+    t_append = time.perf_counter() - t0
     # 94.8 MB per linearisation, 48.8 MB per PCG iteration (float32 spec; the solver stores float64 blocks)
     alg = 94.8e6 * len(st) + 48.8e6 * pcg
+    traffic, traffic_note, dom = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_c5.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic = tj["bytes_per_solve"]
+        dom = {"kernel": tj["dominant_kernel"], "frac": tj["dominant_kernel_frac_of_8TBs"],
+               "note": "FETCH + WRITE bytes of that kernel per launch / its average duration / 8 TB/s (PMC passes)"}
+        traffic_note = "profiles/traffic_c5.json (rocprofv3 --pmc passes of tools/bench_posegraph.py): the multigrid cycle moves ~20x the bytes SURVEY 8d counts for a block-Jacobi PCG iteration"
     out = {
         "value": len(st) / best, "unit": "Gauss-Newton iterations/s", "ms_per_step": best * 1e3,
+        "step_ms_min_median_max": [min(times) * 1e3, best * 1e3, max(times) * 1e3], "steps": len(times),
+        "dtype": "f64", "ms_per_pcg_iteration": best * 1e3 / max(pcg, 1),
         "config": {"workload": "C5: pose-graph GN solve, %d SE(3) poses / %d binary factors, %d Gauss-Newton iterations, PCG "
                                "tolerance 1e-6 (CG preconditioned by a smoothed-aggregation multigrid V-cycle), pose 0 fixed" % (V, E, len(st)),
                    "pcg_iterations": [s_["pcg_iterations"] for s_ in st], "chi_first_last": [st[0]["chi"], st[-1]["chi"]],
@@ -438,7 +486,12 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
                                                "vector kernels; "
                                                "achieved = algorithmic bytes of the whole solve / its wall time",
                      "achieved": alg / best / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / best / 1e9 / 8000.0,
-                     "traffic": None, "algorithmic_bytes": alg},
+                     "traffic": traffic, "traffic_source": traffic_note, "algorithmic_bytes": alg, "dominant_kernel": dom},
+        "warm": {"same_topology_ms": float(np.median(warm)) * 1e3,
+                 "after_appending_one_variable_and_factor_ms": t_append * 1e3,
+                 "pcg_iterations_after_append": [s_["pcg_iterations"] for s_ in st_app],
+                 "note": "ms_per_step is the COLD solve (hierarchy structure built on the host every time); same_topology = "
+                         "set_graph with unchanged edges keeps the structure; an append rebuilds it"},
     }
     if with_cpu:
         # CPU baseline = the oracle's solver (block-Jacobi PCG, one thread) run to CONVERGENCE on a bounded sample: the
@@ -459,7 +512,20 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
                           "block-Jacobi PCG iterations, %.1f s (oracle/o_posegraph.c, one thread)" % (sr[0]["pcg_iterations"], cdt),
                 "converged": bool(sr[0]["pcg_residual"] <= 1.01e-6), "pcg_iterations": sr[0]["pcg_iterations"],
             }
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            # Like for like (VERDICT / ADVICE r3): the two sides run DIFFERENT linear solvers -- the GPU a multigrid-
+            # preconditioned CG (22-51 iterations per solve), the oracle block-Jacobi CG (thousands) -- so the whole-solve
+            # ratio mixes a hardware factor with an algorithmic one.  Reported apart: time per CG iteration on both sides
+            # (same operator, same vectors: the hardware factor) and the iteration counts (the preconditioner's factor).
+            cpu_ms_per_it = cdt * 1e3 / max(sr[0]["pcg_iterations"], 1)
+            gpu_first = st[0]["pcg_iterations"]
+            out["cpu_baseline"].update({
+                "ms_per_pcg_iteration": cpu_ms_per_it,
+                "gpu_ms_per_pcg_iteration": out["ms_per_pcg_iteration"],
+                "speedup_per_pcg_iteration": cpu_ms_per_it / out["ms_per_pcg_iteration"],
+                "pcg_iterations_first_gn_iteration_cpu_vs_gpu": [sr[0]["pcg_iterations"], gpu_first],
+                "note": "cross-algorithm: the per-iteration ratio is the hardware factor, the iteration counts the "
+                        "preconditioner's; their product is not a like-for-like speed-up and is not quoted",
+            })
         except Exception as e:  # (informative: never fail the bench line for it)
             out["cpu_baseline"] = {"error": repr(e)}
     return out
@@ -501,6 +567,9 @@ def main():
             out["c4_32"] = nested("c4", batch=32, steps=20, warmup=3)
             out["c4_8"] = nested("c4", batch=8, steps=20, warmup=3)
             out["c5"] = measure_c5(with_cpu=not args.no_cpu_baseline)
+            # BASELINE's second half asks for >= 6x at 8 GPUs on the 256-alignment job: at 8 GPUs every rank runs 32 per
+            # launch, so the one-GPU figures bound the strong-scaling ratio from above (no collective on the data path)
+            out["projected_8gpu_speedup"] = 8.0 * out["c4_32"]["value"] / out["c4_256"]["value"]
         except Exception as e:  # (the headline must survive a failure of a side configuration; it is reported, not hidden)
             out["nested_error"] = repr(e)
     print(json.dumps(out))

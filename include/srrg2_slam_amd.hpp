@@ -193,6 +193,13 @@ public:
   }
   Status status() const { return _status; }
   const IterationStatsVector& iterationStats() const { return _iteration_stats; }
+  // H = sum w J^T J of the last Gauss-Newton iteration of the last compute() (the solver's system after
+  // multi_aligner_impl.cpp:112-116), D x D row-major, D = 3 (SE2) or 6 (SE3)
+  std::vector<float> information() {
+    std::vector<float> H(36, 0.f);
+    check(srrg2_aligner_get_information(_h, H.data()));
+    return H;
+  }
   int numCorrespondences() {
     int n = 0;
     check(srrg2_aligner_num_correspondences(_h, &n));

@@ -5,7 +5,7 @@ Shared by the product binding (``_capi.py``) and by the test-side oracle binding
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_SLICES = 8
 
 # enum srrg2_variable_kind  (S/registration/aligners/multi_aligner.h:152-158)

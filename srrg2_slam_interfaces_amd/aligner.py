@@ -283,6 +283,13 @@ class MultiAligner:
         self._check(self._b.fn("get_iteration_stats")(self._h, buf, C.byref(n2)))
         return [buf[i].as_dict() for i in range(n2.value)]
 
+    def information(self):
+        """H = sum w J^T J of the last Gauss-Newton iteration of the last compute(), D x D float32 (product backend)"""
+        D = 3 if self.variable_kind == abi.SE2_RIGHT else 6
+        H = np.zeros((D, D), np.float32)
+        self._check(self._b.fn("get_information")(self._h, _fptr(H)))
+        return H
+
     def last_iteration_stats(self):
         """(number of IterationStats of the last compute(), the last one as a dict): what the batch callers' gates read
         (multi_loop_detector_brute_force_impl.cpp:80-91), without building one dict per iteration."""

@@ -144,6 +144,7 @@ struct srrg2_aligner_s {
   int max_stats = 0;
   std::vector<srrg2_iteration_stats> last_stats;  // of problem K-1 (== the only one for compute())
   int last_ncorr[SRRG2_MAX_SLICES]{};
+  float last_H[36]{};  // H of the last Gauss-Newton iteration of the last compute() (problem K - 1)
   bool computed = false;
   // The nearest-neighbour passes do not store correspondence records; they are derived on demand (k_icp_outputs) from
   // the state of the last compute(): 0 = the arrays are current, 1 = to be derived, 2 = lost (the clouds changed since)
@@ -1187,6 +1188,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   int ns    = std::min(o.nstats, slots);
   a->last_stats.assign(a->stats_host + (size_t) (K - 1) * slots, a->stats_host + (size_t) (K - 1) * slots + ns);
   for (int si = 0; si < SRRG2_MAX_SLICES; ++si) a->last_ncorr[si] = o.ncorr[si];
+  std::memcpy(a->last_H, o.H, sizeof(a->last_H));
   a->computed = true;
   a->last_sdev = sdev;
   a->last_nm_max.assign((size_t) nslices, 0);
@@ -1552,6 +1554,13 @@ int srrg2_aligner_get_iteration_stats(srrg2_aligner_h a, srrg2_iteration_stats* 
   const int have = (int) a->last_stats.size();
   if (buf) std::memcpy(buf, a->last_stats.data(), sizeof(srrg2_iteration_stats) * (size_t) std::min(*n, have));
   *n = have;
+  return 0;
+}
+
+int srrg2_aligner_get_information(srrg2_aligner_h a, float* H) {
+  if (!a || !H) return fail(SRRG2_E_INVALID, "get_information: null argument");
+  if (!a->computed) return fail(SRRG2_E_STATE, "get_information: no compute() yet");
+  std::memcpy(H, a->last_H, sizeof(float) * (size_t) a->dof * a->dof);
   return 0;
 }
 

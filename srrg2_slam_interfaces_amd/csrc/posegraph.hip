@@ -1348,7 +1348,8 @@ struct srrg2_posegraph_s {
   DevBuf<MgLevel> levels_dev;
   DevBuf<double> coarse_A, coarse_inv;
   int coarsest_dense = 1;
-  // experiment switches, read from the SRRG2_AMD_PG_* environment ONCE, in srrg2_posegraph_create (DESIGN.md "Strategy knobs")
+  // strategy knobs (srrg2_posegraph_tuning): defaults overridden by the SRRG2_AMD_PG_* environment ONCE, in
+  // srrg2_posegraph_create; srrg2_posegraph_set_tuning replaces them
   struct Switches {
     int match_passes = 3;       // SRRG2_AMD_PG_PASSES
     double omega_p = 0.0;       // SRRG2_AMD_PG_OMEGA_P (set to MG_OMEGA_P at create)
@@ -1357,7 +1358,9 @@ struct srrg2_posegraph_s {
     bool two_phase = true;      // SRRG2_AMD_PG_TWO_PHASE
     bool use_graph = true;      // SRRG2_AMD_PG_GRAPH
     bool debug = false;         // SRRG2_AMD_PG_DEBUG
+    bool keep_structure = true; // the hierarchy's structure survives a set() with the same topology
   } sw;
+  srrg2_posegraph_tuning tuning{};
   bool mg_dirty      = true;
   // host mirrors for the incremental interface (incidence lists are rebuilt lazily from these)
   std::vector<int> h_ij;
@@ -2190,6 +2193,51 @@ int upload_incidence(srrg2_posegraph_s* g) {
 }  // namespace
 extern "C" {
 
+void srrg2_posegraph_default_tuning(srrg2_posegraph_tuning* t) {
+  if (!t) return;
+  std::memset(t, 0, sizeof(*t));
+  t->match_passes   = 3;
+  t->two_phase      = 1;
+  t->use_graph      = 1;
+  t->debug          = 0;
+  t->keep_structure = 1;
+  t->omega_p        = (float) MG_OMEGA_P;
+  t->omega          = (float) MG_OMEGA;
+  t->lag_below      = 0.f;
+}
+
+static void apply_tuning(srrg2_posegraph_s* g, const srrg2_posegraph_tuning& t) {
+  // (the built-in dampings are doubles: a knob left at its float default keeps the exact built-in value)
+  srrg2_posegraph_tuning d;
+  srrg2_posegraph_default_tuning(&d);
+  const bool structure_changes = g->sw.match_passes != t.match_passes || (g->sw.omega_p != 0.0) != (t.omega_p != 0.f);
+  g->sw.match_passes   = t.match_passes;
+  g->sw.omega_p        = t.omega_p == d.omega_p ? (double) MG_OMEGA_P : (double) t.omega_p;
+  g->sw.omega          = t.omega == d.omega ? (double) MG_OMEGA : (double) t.omega;
+  g->sw.lag_below      = (double) t.lag_below;
+  g->sw.two_phase      = t.two_phase != 0;
+  g->sw.use_graph      = t.use_graph != 0;
+  g->sw.debug          = t.debug != 0;
+  g->sw.keep_structure = t.keep_structure != 0;
+  if (structure_changes) g->mg_dirty = true;  // (aggregate sizes / smoothed patterns are part of the structure)
+  g->tuning = t;
+}
+
+int srrg2_posegraph_get_tuning(srrg2_posegraph_h g, srrg2_posegraph_tuning* t) {
+  if (!g || !t) return fail(SRRG2_E_INVALID, "posegraph_get_tuning: null argument");
+  *t = g->tuning;
+  return 0;
+}
+
+int srrg2_posegraph_set_tuning(srrg2_posegraph_h g, const srrg2_posegraph_tuning* t) {
+  if (!g || !t) return fail(SRRG2_E_INVALID, "posegraph_set_tuning: null argument");
+  if (t->match_passes < 1 || t->match_passes > 8 || !(t->omega > 0.f) || !(t->omega < 2.f) || !(t->omega_p >= 0.f) ||
+      !(t->omega_p < 2.f) || !(t->lag_below >= 0.f))
+    return fail(SRRG2_E_INVALID, "posegraph_set_tuning: value out of range");
+  apply_tuning(g, *t);
+  return 0;
+}
+
 int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out) {
   if (!out || (variable_kind != SRRG2_SE2_RIGHT && variable_kind != SRRG2_SE3_QUAT_RIGHT))
     return fail(SRRG2_E_INVALID, "posegraph_create: variable kind must be SE2_RIGHT or SE3_QUAT_RIGHT");
@@ -2202,15 +2250,21 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
   g->D      = variable_kind == SRRG2_SE2_RIGHT ? 3 : 6;
   g->T      = variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
   g->device = device;
-  {  // the experiment switches: environment read once, here
-    auto num = [](const char* name, double dflt) { const char* e = std::getenv(name); return e ? std::atof(e) : dflt; };
-    g->sw.match_passes = std::max(1, (int) num("SRRG2_AMD_PG_PASSES", 3.0));
-    g->sw.omega_p      = num("SRRG2_AMD_PG_OMEGA_P", MG_OMEGA_P);
-    g->sw.omega        = num("SRRG2_AMD_PG_OMEGA", MG_OMEGA);
-    g->sw.lag_below    = num("SRRG2_AMD_PG_LAG", 0.0);
-    g->sw.two_phase    = num("SRRG2_AMD_PG_TWO_PHASE", 1.0) != 0.0;
-    g->sw.use_graph    = num("SRRG2_AMD_PG_GRAPH", 1.0) != 0.0;
-    g->sw.debug        = std::getenv("SRRG2_AMD_PG_DEBUG") != nullptr;
+  {  // the strategy knobs: defaults, overridden by the environment ONCE, here
+    srrg2_posegraph_tuning t;
+    srrg2_posegraph_default_tuning(&t);
+    auto geti = [](const char* name, int32_t& v) { if (const char* e = std::getenv(name)) v = (int32_t) std::atoi(e); };
+    auto getf = [](const char* name, float& v) { if (const char* e = std::getenv(name)) v = (float) std::atof(e); };
+    geti("SRRG2_AMD_PG_PASSES", t.match_passes);
+    geti("SRRG2_AMD_PG_TWO_PHASE", t.two_phase);
+    geti("SRRG2_AMD_PG_GRAPH", t.use_graph);
+    geti("SRRG2_AMD_PG_KEEP_STRUCTURE", t.keep_structure);
+    getf("SRRG2_AMD_PG_OMEGA_P", t.omega_p);
+    getf("SRRG2_AMD_PG_OMEGA", t.omega);
+    getf("SRRG2_AMD_PG_LAG", t.lag_below);
+    if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
+    if (t.match_passes < 1) t.match_passes = 1;
+    apply_tuning(g, t);
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
     delete g;
@@ -2278,8 +2332,18 @@ int srrg2_posegraph_set(srrg2_posegraph_h g, int V, const float* poses, const ui
   HIP_TRY(hipMemcpy(g->Z.p, Z, sizeof(float) * (size_t) E * T, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->omega.p, om.data(), sizeof(double) * om.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->enabled.p, en.data(), (size_t) std::max(E, 1), hipMemcpyHostToDevice));
+  // The hierarchy's STRUCTURE depends on the topology (edges, fixed and enabled masks) and -- through the matching's
+  // nearest-neighbour rule, a quality heuristic -- on the poses at the time it was built; its NUMERICS are recomputed by
+  // every Gauss-Newton iteration.  A set() that only brings new poses / measurements keeps the structure (the case of an
+  // optimize() repeated on an unchanged graph, or of a caller that re-uploads the graph every time).
+  const bool same_topology = g->sw.keep_structure && !g->mg_dirty && g->V == V && g->E == E && (int) g->h_fixed.size() == V &&
+                             (int) g->h_enabled.size() == E && std::memcmp(g->h_ij.data(), ij, sizeof(int32_t) * 2 * (size_t) E) == 0 &&
+                             std::memcmp(g->h_fixed.data(), fx.data(), (size_t) V) == 0 &&
+                             std::memcmp(g->h_enabled.data(), en.data(), (size_t) E) == 0 &&
+                             std::find(g->h_removed.begin(), g->h_removed.end(), (uint8_t) 1) == g->h_removed.end();
   g->V = V;
   g->E = E;
+  if (same_topology) return 0;  // (incidence lists and hierarchy structure are still those of this topology)
   g->h_ij.assign(ij, ij + 2 * (size_t) E);
   g->h_enabled.assign(en.begin(), en.begin() + E);
   g->h_removed.assign((size_t) E, 0);

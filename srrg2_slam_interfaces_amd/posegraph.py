@@ -24,6 +24,13 @@ class PoseGraphStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class PoseGraphTuning(C.Structure):
+    """srrg2_posegraph_tuning: strategy knobs of the solver; every setting solves to the same tolerance"""
+    _fields_ = [("match_passes", C.c_int32), ("two_phase", C.c_int32), ("use_graph", C.c_int32), ("debug", C.c_int32),
+                ("keep_structure", C.c_int32), ("omega_p", C.c_float), ("omega", C.c_float), ("lag_below", C.c_float),
+                ("reserved_", C.c_int32 * 8)]
+
+
 def default_params():
     return PoseGraphParams(10, 600, 1e-6, 0.0)
 
@@ -83,6 +90,20 @@ class PoseGraph:
             en = enabled.ctypes.data_as(bp)
         self._check(self._fn("set")(self._h, C.c_int(self.V), poses.ctypes.data_as(fp), fm, C.c_int(self.E),
                                     ij.ctypes.data_as(C.POINTER(C.c_int32)), Z.ctypes.data_as(fp), om, en))
+
+    def tuning(self):
+        """the handle's strategy knobs (PoseGraphTuning): defaults overridden by the SRRG2_AMD_PG_* environment at creation"""
+        t = PoseGraphTuning()
+        self._check(self._fn("get_tuning")(self._h, C.byref(t)))
+        return t
+
+    def set_tuning(self, **knobs):
+        t = self.tuning()
+        for k, v in knobs.items():
+            if k not in dict(PoseGraphTuning._fields_) or k == "reserved_":
+                raise KeyError(k)
+            setattr(t, k, v)
+        self._check(self._fn("set_tuning")(self._h, C.byref(t)))
 
     def set_enabled(self, enabled):
         enabled = np.ascontiguousarray(enabled, np.uint8)

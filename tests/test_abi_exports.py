@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
-    assert lib.srrg2_amd_abi_version() == 3
+    assert lib.srrg2_amd_abi_version() == 4
 
 
 def test_oracle_mirrors_the_call_surface(oracle):
@@ -72,7 +72,7 @@ def test_headers_compile_with_plain_gxx(tmp_path):
                    'int main() { srrg2_slam_amd::LoopClosure<3> c; return c.source_graph_id + 1; }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
     c_src = tmp_path / "tu.c"  # the C ABI header is C
-    c_src.write_text('#include "srrg2_slam_amd.h"\nint main(void) { return SRRG2_AMD_ABI_VERSION == 3 ? 0 : 1; }\n')
+    c_src.write_text('#include "srrg2_slam_amd.h"\nint main(void) { return SRRG2_AMD_ABI_VERSION == 4 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(c_src)])
 
 

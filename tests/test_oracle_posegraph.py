@@ -116,3 +116,25 @@ def test_oracle_matches_scipy_direct_solve_2k(oracle):
     assert st[0]["solver_status"] == 0 and st[0]["pcg_iterations"] < 20000
     assert abs(st[0]["chi"] - float(G["chi0"])) / float(G["chi0"]) < 1e-6
     assert np.max(np.abs(pg.poses() - G["poses_after_1"])) < 2e-5
+
+
+def test_se2_oracle_matches_scipy_direct_solve(oracle):
+    """SE(2), what srrg2_laser_slam_2d optimises (S/mapping/local_map.h:64): 1 500 poses / ~4 500 factors, two Gauss-Newton
+    steps against the committed result of SciPy's sparse DIRECT solver on an independently assembled system
+    (tests/golden/make_posegraph_golden_se2.py: numpy residual, central-difference Jacobians) -- VERDICT r3 #6"""
+    import os
+
+    from srrg2_slam_interfaces_amd import posegraph as pgm
+
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "posegraph_golden_se2.npz"))
+    g = syn.pose_graph_2d(V=1500, E=4500, seed=5300)
+    p = pgm.default_params()
+    p.pcg_tolerance, p.pcg_max_iterations = 1e-10, 40000
+    for its, key, chi_key in ((1, "poses_after_1", "chi0"), (2, "poses_after_2", "chi1")):
+        pg = oracle.OraclePoseGraph(abi.SE2_RIGHT)
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+        p.max_iterations = its
+        st = pg.solve(p)
+        assert all(s["solver_status"] == 0 and s["pcg_iterations"] < 40000 for s in st)
+        assert abs(st[-1]["chi"] - float(G[chi_key])) / float(G[chi_key]) < 1e-4
+        assert np.max(np.abs(pg.poses() - G[key])) < 2e-5 * max(1.0, float(G["max_abs_dx"][0]))

@@ -9,7 +9,7 @@ import json
 import sqlite3
 import sys
 
-KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_fast<", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")
+KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_fast<", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")
 
 
 def per_kernel(db, counter):
@@ -36,7 +36,7 @@ def main():
         kernels[k] = {"fetch_bytes_corrected": fb, "write_bytes": wb, "dispatches": n}
         total += (fb + wb) * n
         if "queue" not in k and "zbuf" not in k:
-            passes += n  # one step-kernel dispatch (k_icp_step, k_icp_step_tile or k_icp_step_fast) per slice pass; the deferred-search kernel runs in some
+            passes += n  # one step-kernel dispatch (k_icp_step, k_icp_step_tile, k_icp_step_cnl or k_icp_step_fast) per slice pass; the deferred-search kernel runs in some
     total = total / max(passes, 1)
     json.dump({"workload": workload, "bytes_per_slice_pass": total, "slice_passes": passes, "kernels": kernels,
                **({"alignments_per_launch": per_launch} if per_launch else {}),
