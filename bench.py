@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--no-one-gpu-reference", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dump-table", default=None, help="rank 0 saves the exchanged result table of the last step (.npy): tests")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     a.explicit_workload = a.workload is not None
@@ -166,10 +167,16 @@ def measure(args, init_dist=True):
         # fixed (strong scaling); every rank generates the same seeded problems and keeps its shard.
         K_total = args.total_alignments if world > 1 else args.batch
         mine = D.shard(K_total, world, rank)
-        probs = syn.batch_3d(K=K_total, n=args.batch_points, seed=4000, shared_fixed_group=1 << 30)
-        al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
+        # every rank synthesises ITS shard only (problem k is seeded by k: the same clouds as in the full list); the query
+        # map is shared by all alignments of the job and made by every rank (setFixed once per detector call)
+        probs = dict(zip(mine, syn.batch_3d(K=K_total, n=args.batch_points, seed=4000, shared_fixed_group=1 << 30, only=mine)))
+        fixed_of_job = probs[mine[0]] if mine else syn.batch_3d(K=K_total, n=args.batch_points, seed=4000, shared_fixed_group=1 << 30, only=[0])[0]
+        al.set_fixed(0, fixed_of_job["fixed"], fixed_of_job["fixed_normals"])
 
         def resident(indices):
+            missing = [k for k in indices if k not in probs]
+            if missing:  # (rank 0's one-GPU reference of the whole job, after the timed region)
+                probs.update(zip(missing, syn.batch_3d(K=K_total, n=args.batch_points, seed=4000, shared_fixed_group=1 << 30, only=missing)))
             c = torch.from_numpy(np.concatenate([probs[k]["moving"] for k in indices], axis=0)).cuda()
             n = torch.from_numpy(np.concatenate([probs[k]["moving_normals"] for k in indices], axis=0)).cuda()
             o = np.arange(len(indices) + 1, dtype=np.int32) * args.batch_points
@@ -236,6 +243,8 @@ def measure(args, init_dist=True):
     gc.enable()
     table = D.exchange_records(records(res), K_total, device=coll_device, mode=args.exchange)
     assert table.shape[0] == K_total
+    if args.dump_table and rank == 0:
+        np.save(args.dump_table, table)
     all_success = bool(np.all(table[:, 12] == 0)) and bool(np.all(table[:, 13] == args.iterations))
     total_units = args.iterations * K_total if args.workload == "c4" else units_per_step * world
     if world > 1:
@@ -244,6 +253,12 @@ def measure(args, init_dist=True):
         dt = float(t.item())
     status = al.status()
     stats = al.iteration_stats()
+    per_rank = [len(mine)] if args.workload == "c4" else [1]
+    if world > 1:  # how many alignments every rank ran per step (the shard rule made visible on the line)
+        cnt = torch.zeros(world, device=coll_device, dtype=torch.int64)
+        cnt[rank] = per_rank[0]
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        per_rank = [int(v) for v in cnt.cpu().tolist()]
 
     # roofline of the dominant kernel (k_icp_step): HIP events on the launch stream around every launch
     lib = _capi.lib()
@@ -325,6 +340,7 @@ def measure(args, init_dist=True):
             "points": args.points if args.workload == "c2" else (int(data["moving"].shape[0]) if args.workload == "c3" else args.batch_points),
             "iterations_per_step": args.iterations,
             "alignments_per_step_per_gpu": len(mine) if args.workload == "c4" else 1,
+            "alignments_per_step_by_rank": per_rank,
             "alignments_total": K_total,
             "all_success": all_success,
             "last_status": status,

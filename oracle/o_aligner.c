@@ -1270,6 +1270,13 @@ int oracle_aligner_get_last_system(o_aligner* h, double* H, double* b, double* d
   return 0;
 }
 
+/* srrg2_aligner_get_information: H of the last Gauss-Newton iteration as the product hands it out (float32, D x D) */
+int oracle_aligner_get_information(o_aligner* h, float* H) {
+  if (!h || !H) return fail(SRRG2_E_INVALID, "get_information");
+  for (int i = 0; i < h->dof * h->dof; ++i) H[i] = (float) h->last_H[i];
+  return 0;
+}
+
 int oracle_aligner_set_correspondences(o_aligner* h, int si, const srrg2_correspondence* corr, int n) {
   if (!h || si < 0 || si >= h->nslices || n < 0 || (n > 0 && !corr)) return fail(SRRG2_E_INVALID, "set_correspondences");
   o_slice* s = &h->slices[si];

@@ -118,6 +118,8 @@ int oracle_aligner_set_bruteforce(o_aligner* h, int enable);
 int oracle_aligner_linearize_once(o_aligner* h, int slice_idx, int64_t* acc32, int* k_out);
 /* H (DxD row-major), b (D) of the last linearisation as doubles, summed over slices */
 int oracle_aligner_get_last_system(o_aligner* h, double* H, double* b, double* dx);
+/* mirror of srrg2_aligner_get_information: that H as float32 */
+int oracle_aligner_get_information(o_aligner* h, float* H);
 
 #ifdef __cplusplus
 }

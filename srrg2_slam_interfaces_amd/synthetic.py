@@ -139,13 +139,15 @@ def cloud_pair_3d(n=100_000, seed=2000, t=(0.05, -0.03, 0.02), rpy_deg=(1.0, -1.
             "X_gt": f32(X_gt)}
 
 
-def batch_3d(K=256, n=50_000, seed=4000, shared_fixed_group=8, t_max=0.2, rpy_max_deg=5.0):
+def batch_3d(K=256, n=50_000, seed=4000, shared_fixed_group=8, t_max=0.2, rpy_max_deg=5.0, only=None):
     """C4: K alignment problems.  The fixed cloud is shared per group of ``shared_fixed_group``
     problems (setFixed once per query map, multi_loop_detector_brute_force_impl.cpp:63);
-    0 or 1 => all distinct.  Ground truths: t ~ U[-t_max,t_max]^3, rpy ~ U[-rpy_max,rpy_max]^3."""
+    0 or 1 => all distinct.  Ground truths: t ~ U[-t_max,t_max]^3, rpy ~ U[-rpy_max,rpy_max]^3.
+    ``only``: generate just these problems of the K (a rank of a sharded job makes its own shard; every problem is seeded
+    by its index, so the result is the same as picking them out of the full list) -- returns them in the given order."""
     out = []
     fixed_cache = {}
-    for k in range(K):
+    for k in (range(K) if only is None else only):
         grp = k // shared_fixed_group if shared_fixed_group > 1 else k
         if grp not in fixed_cache:
             Pf, Nf = scene_3d(n, seed + 10 * grp)

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -195,6 +196,44 @@ int main() {
       double rec[SRRG2_RECORD_FLOATS];
       ASSERT_TRUE(srrg2_multi_gpu_pack_record((int) k, SRRG2_SE3_QUAT_RIGHT, &one[k], rec) == 0);
       ASSERT_TRUE(std::memcmp(rec, table.data() + k * SRRG2_RECORD_FLOATS, sizeof(rec)) == 0);
+    }
+    // ---- EIGHT handles (the shape of a node: one per GPU, here all on device 0), 64 candidates, 8 per handle: the batch
+    // and its record table equal the one-handle batch byte for byte
+    {
+      std::vector<std::unique_ptr<MultiAligner3DQR>> extra;
+      std::vector<MultiAligner3DQR*> eight = {&aligner, &aligner_b};
+      for (int g = 2; g < 8; ++g) {
+        extra.emplace_back(new MultiAligner3DQR());
+        extra.back()->addSlice(c);
+        extra.back()->param_max_iterations = aligner.param_max_iterations;
+        eight.push_back(extra.back().get());
+      }
+      std::vector<const float*> cl8, nr8;
+      std::vector<int> sz8;
+      std::vector<Isometry3f> gs8;
+      for (int k = 0; k < 64; ++k) {  // the candidates again and again, ragged: candidate k loses its last 37 k points
+        const size_t j = (size_t) k % cl.size();
+        cl8.push_back(cl[j]); nr8.push_back(nr[j]); sz8.push_back(sz[j] - 37 * k); gs8.push_back(gs[j]);
+      }
+      aligner.setFixed(0, pts[(size_t) source].data(), 12, nrm[(size_t) source].data(), 12, N);
+      const std::vector<srrg2_batch_result> one8 = aligner.computeBatch(cl8, sz8, nr8, gs8);
+      ShardedAligners<MultiAligner3DQR> all8(eight);
+      all8.setFixed(0, pts[(size_t) source].data(), 12, nrm[(size_t) source].data(), 12, N);
+      const std::vector<srrg2_batch_result> res8 = all8.computeBatch(cl8, sz8, nr8, gs8);
+      ASSERT_TRUE(one8.size() == 64 && res8.size() == 64);
+      for (size_t k = 0; k < one8.size() && k < res8.size(); ++k)
+        ASSERT_TRUE(std::memcmp(&one8[k], &res8[k], sizeof(srrg2_batch_result)) == 0);
+      const std::vector<double> table8 = all8.recordTable(res8, SRRG2_SE3_QUAT_RIGHT);
+      ASSERT_TRUE(table8.size() == (size_t) 64 * SRRG2_RECORD_FLOATS);
+      for (size_t k = 0; k < one8.size(); ++k) {
+        double rec[SRRG2_RECORD_FLOATS];
+        ASSERT_TRUE(srrg2_multi_gpu_pack_record((int) k, SRRG2_SE3_QUAT_RIGHT, &one8[k], rec) == 0);
+        ASSERT_TRUE(std::memcmp(rec, table8.data() + k * SRRG2_RECORD_FLOATS, sizeof(rec)) == 0);
+      }
+      for (int g = 0; g < 8; ++g) {  // handle g took k = g, g + 8, ...: 8 candidates each
+        int n = 0;
+        ASSERT_TRUE((n = srrg2_multi_gpu_shard_count(64, 8, g)) == 8);
+      }
     }
     detector.param_relocalize_aligners.clear();
     detector.compute(source, hints);  // (back to the one-handle state the checks below read)

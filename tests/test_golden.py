@@ -214,3 +214,71 @@ def test_prior_slice_next_to_a_cue_slice(backend, oracle):
         H, b, dx = al.last_system()
         assert np.max(np.abs(b - GOLD2["p_b"])) / np.max(np.abs(GOLD2["p_b"])) < 1e-4
         assert np.max(np.abs(dx - GOLD2["p_dx"])) < 1e-5
+
+
+# ---- VERDICT r3 #6 (tests/golden/make_golden3.py): C3's two slices summed at 160 x 120; the termination criterion firing
+GOLD3 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icp_golden3.npz"))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_c3_two_projective_slices_summed(backend, oracle):
+    """MultiAligner with a projective point-to-plane slice and a projective reprojection slice (BASELINE config C3, here at
+    160 x 120): H and b of the two factors are ADDED into one system (multi_aligner_impl.cpp:144-160).  Golden: restated
+    finder, matrix-form point-to-plane Jacobian, finite-difference reprojection Jacobian, one Gauss-Newton step."""
+    from helpers import projective_config
+
+    d = syn.rgbd_pair(rows=120, cols=160, seed=3200)
+    al = _aligner(backend, oracle, abi.SE3_QUAT_RIGHT)
+    al.set_params(max_iterations=1, min_num_inliers=10)
+    for sk in (abi.SLICE_P2PLANE, abi.SLICE_REPROJECTION):
+        si = al.add_slice(projective_config(abi.SE3_QUAT_RIGHT, sk, d, gate=0.05))
+        al.set_fixed(si, d["fixed"], d["fixed_normals"])
+        al.set_moving(si, d["moving"], d["moving_normals"])
+    al.set_moving_in_fixed(GOLD3["t_guess"])
+    assert al.compute() == abi.SUCCESS
+    match = GOLD3["t_match"]
+    sel = match >= 0
+    for si in (0, 1):  # both slices run the same finder on the same clouds
+        c = al.correspondences(si)
+        assert np.array_equal(c["moving_idx"], np.nonzero(sel)[0].astype(np.int32))
+        assert np.array_equal(c["fixed_idx"], match[sel])
+        assert c["response"].tobytes() == GOLD3["t_resp"][sel].tobytes()
+    st = al.iteration_stats()
+    assert len(st) == 1 and st[0]["num_inliers"] == int(GOLD3["t_n1"]) + int(GOLD3["t_n2"]) and st[0]["num_outliers"] == 0
+    assert st[0]["num_correspondences"] == 2 * int(sel.sum())
+    assert abs(st[0]["chi_inliers"] - float(GOLD3["t_chi"])) <= 1e-3 * float(GOLD3["t_chi"])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD3["t_X"])) <= 1e-5
+    H = al.last_system()[0] if backend == "oracle" else al.information().astype(np.float64)
+    Hg = GOLD3["t_H"]
+    assert np.max(np.abs(H - Hg)) / np.max(np.abs(Hg)) < 1e-4
+    # (the sum is a sum: either slice alone lands somewhere else -- the reprojection slice's H is 10^4 times the plane
+    # slice's in size, pixel units against metres, so the estimate, not H, is where the plane slice's share shows)
+    assert np.max(np.abs(GOLD3["t_X"] - GOLD3["t_X_plane_only"])) > 1e-4
+    assert np.max(np.abs(GOLD3["t_X"] - GOLD3["t_X_reprojection_only"])) > 1e-4
+    if backend == "oracle":
+        H, b, dx = al.last_system()
+        assert np.max(np.abs(b - GOLD3["t_b"])) / np.max(np.abs(GOLD3["t_b"])) < 1e-3
+        assert np.max(np.abs(dx - GOLD3["t_dx"])) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_termination_criterion_fires_with_its_quirks(backend, oracle):
+    """AlignerTerminationCriteriaStandard_ (aligner_termination_criteria_impl.cpp:24-65), window 5, on a 12-iteration
+    compute(): the golden restates the criterion WITH its quirks -- line 46 holds the outlier window against
+    num_correspondences_range, line 53 the chi window against num_outliers_range -- and picks parameters under which a
+    criterion without them would stop one iteration later.  Iteration count, every IterationStats, the estimate."""
+    d = syn.cloud_pair_3d(n=3000, seed=4400, noise_sigma=0.004)
+    al = _aligner(backend, oracle, abi.SE3_QUAT_RIGHT)
+    al.set_params(max_iterations=12, min_num_inliers=10)
+    t = abi.default_termination_params()
+    t.window_size, t.num_correspondences_range, t.num_inliers_range, t.num_outliers_range = [int(v) for v in GOLD3["c_params"]]
+    t.chi_epsilon = float(GOLD3["c_eps"])
+    al.set_termination_criteria(t)
+    setup_pair(al, d, cue_config(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE, 0.25, abi.ROBUST_CAUCHY, 0.0004), with_moving_normals=False)
+    assert al.compute() == abi.SUCCESS
+    st = al.iteration_stats()
+    stop = int(GOLD3["c_stop"])
+    assert int(GOLD3["c_stop_without_quirks"]) != stop
+    assert len(st) == stop + 1, (len(st), stop)  # (the loop breaks after the iteration at which hasToStop() says so)
+    _check_stats(st, GOLD3["c_stats"])
+    assert np.max(np.abs(al.moving_in_fixed() - GOLD3["c_X"])) <= 1e-5

@@ -181,6 +181,53 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert "cpu_baseline" not in rec  # rank 0 at N = 1 only
 
 
+@pytest.mark.gpu
+def test_bench_eight_ranks_at_the_real_shape_of_the_job(tmp_path):
+    """the N = 8 control flow at the REAL shape of BASELINE's second metric -- 256 alignments, 8 ranks, 32 per
+    rank, ONE exchange -- dry-run on a one-GPU box (SRRG2_BENCH_SHARE_GPU=1: every rank on device 0, gloo for the
+    collective; smaller clouds than the benchmark's so that eight processes share the GPU comfortably).  Every rank
+    synthesises only its shard; the exchanged table must equal, byte for byte, the table of ONE process aligning all 256
+    against the same query map.  No scaling number is claimed: the 8-GPU run is the driver's."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SRRG2_BENCH_SHARE_GPU="1")
+    table_path = str(tmp_path / "table.npy")
+    npts = 6000
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+                          "--gpus", "8", "--steps", "2", "--warmup", "1", "--total-alignments", "256",
+                          "--batch-points", str(npts), "--no-one-gpu-reference", "--dump-table", table_path],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["config"]["all_success"] is True
+    assert rec["config"]["alignments_total"] == 256 and rec["config"]["alignments_per_step_by_rank"] == [32] * 8
+    table = np.load(table_path)
+    # the same job in ONE process: all 256 alignments in one compute_batch against the same query map
+    import srrg2_slam_interfaces_amd as pkg
+    from srrg2_slam_interfaces_amd import _abi as abi
+    from srrg2_slam_interfaces_amd import distributed as D
+    from srrg2_slam_interfaces_amd import synthetic as syn
+
+    sys.path.insert(0, root)
+    import bench
+
+    probs = syn.batch_3d(K=256, n=npts, seed=4000, shared_fixed_group=1 << 30)
+    al = bench.make_aligner(lambda: pkg.MultiAligner(abi.SE3_QUAT_RIGHT, device=0), abi, 10)
+    al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
+    res = al.compute_batch([p["moving"] for p in probs], [syn.identity(3)] * 256, [p["moving_normals"] for p in probs])
+    single = D.all_gather_records([D.pack_record(k, r) for k, r in enumerate(res)], 256)
+    assert table.shape == single.shape == (256, D.RECORD_FLOATS)
+    assert table.tobytes() == single.tobytes()
+    # the shard rule: rank r ran k = r, r + 8, ...; a shard generated on its own equals the pick out of the full list
+    shard3 = syn.batch_3d(K=256, n=npts, seed=4000, shared_fixed_group=1 << 30, only=D.shard(256, 8, 3))
+    assert len(shard3) == 32 and all(np.array_equal(a["moving"], probs[k]["moving"]) for a, k in zip(shard3, D.shard(256, 8, 3)))
+
+
 # ---- ONE alignment sharded by moving points (SURVEY.md 8e, second mode; include/srrg2_slam_amd.h: set_point_shard) ---------
 def _point_shard_problem(n=30_000):
     from srrg2_slam_interfaces_amd import synthetic as syn
