@@ -170,6 +170,13 @@ struct SliceCtl {
   float Sinv[12];                 // robot_in_sensor = sensor_in_robot^-1 (SliceDev::Sinv)
 };
 
+// a single alignment's initial guess and per-slice problem table, carried in k_icp_init's arguments
+struct InitInline {
+  int use;
+  float guess[12];
+  ProblemDev pd[SRRG2_MAX_SLICES];
+};
+
 struct CtlParams {
   int variable_kind;
   int nslices;

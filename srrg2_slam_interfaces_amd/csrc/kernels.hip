@@ -3405,9 +3405,11 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
 // compute() prologue: term_crit->init, stats clear, _preCompute (prior init overrides the guess).  One block per
 // problem.  The initial guesses and the problem tables are read straight from pinned host memory (no staging copies on
 // the stream), the partial-sum slots and queue counters are zeroed here (no memsets on the stream).
+// (inl.use: a single alignment's guess and problem table travel in the kernel arguments -- 116 bytes -- instead of being read
+// from pinned host memory: one PCIe round trip less at the head of every compute(); batches keep the pinned tables)
 __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs_host,
                                                  ProblemDev* __restrict__ probs, ProblemState* __restrict__ states,
-                                                 const float* __restrict__ guesses_host, int tsize) {
+                                                 const float* __restrict__ guesses_host, int tsize, InitInline inl) {
   const int prob = blockIdx.x + C.prob0;
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
@@ -3417,7 +3419,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   }
   if (threadIdx.x != 0) return;
   ProblemState* st = &states[prob];
-  for (int i = 0; i < 12; ++i) st->X[i] = i < tsize ? guesses_host[(size_t) prob * tsize + i] : 0.f;
+  for (int i = 0; i < 12; ++i) st->X[i] = i < tsize ? (inl.use ? inl.guess[i] : guesses_host[(size_t) prob * tsize + i]) : 0.f;
   for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];
   st->status   = SRRG2_FAIL;
   st->done     = 0;
@@ -3431,7 +3433,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     nm_of[s]           = 0;
-    const ProblemDev pd = probs_host[(size_t) s * C.K + prob];
+    const ProblemDev pd = inl.use ? inl.pd[s] : probs_host[(size_t) s * C.K + prob];
     probs[(size_t) s * C.K + prob] = pd;
     st->ncorr[s]       = 0;
     st->ninl[s]        = 0;
@@ -3464,9 +3466,39 @@ __device__ __forceinline__ void state_from_lds(ProblemState* st, const ProblemSt
     reinterpret_cast<int*>(st)[k] = reinterpret_cast<const int*>(lds)[k];
 }
 
+// The slot sets of the first two cue slices, every thread's share, loaded at the very top of the control kernels: in flight
+// TOGETHER with the state record instead of behind it.  (The step was a chain of three dependent round trips -- the `done`
+// word, the state record, the slot sets -- each ~1.5 us on a cold cache behind a kernel boundary: round 4.)
+struct PrePartials {
+  int s0, s1;  // the slices they belong to (-1: none)
+  long long v0, v1;
+};
+__device__ __forceinline__ PrePartials prefetch_partials(const CtlParams& C, int prob) {
+  PrePartials P;
+  P.s0 = P.s1 = -1;
+  P.v0 = P.v1 = 0;
+  for (int s = 0; s < C.nslices; ++s) {  // (uniform: kernel arguments)
+    if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
+    if (P.s0 < 0) P.s0 = s; else if (P.s1 < 0) P.s1 = s;
+  }
+  const int a = threadIdx.x & 31, c = threadIdx.x >> 5;
+  if (P.s0 >= 0) {
+    const long long* p = C.slices[P.s0].partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+#pragma unroll
+    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) P.v0 += p[(size_t) (c + 8 * q) * ACC_N + a];
+  }
+  if (P.s1 >= 0) {
+    const long long* p = C.slices[P.s1].partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+#pragma unroll
+    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) P.v1 += p[(size_t) (c + 8 * q) * ACC_N + a];
+  }
+  return P;
+}
+
 // one 256-thread block per problem: sum the per-block partials of every cue slice (exact integer sums, any
 // order), then thread 0 runs the sequential part of the iteration
-__device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob) {
+__device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_iteration_stats* stats, int prob,
+                                  const PrePartials& pre) {
   __shared__ long long sums[SRRG2_MAX_SLICES][ACC_N];
   __shared__ double scaled[SRRG2_MAX_SLICES][ACC_N];
   __shared__ long long part[8][ACC_N];
@@ -3476,8 +3508,14 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
     if (sc.kind == SRRG2_SLICE_PRIOR) continue;
     long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * PARTIAL_SLOTS * ACC_N;
     long long v  = 0;
+    if (s == pre.s0) {
+      v = pre.v0;
+    } else if (s == pre.s1) {
+      v = pre.v1;
+    } else {
 #pragma unroll
-    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) v += p[(size_t) (c + 8 * q) * ACC_N + a];
+      for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) v += p[(size_t) (c + 8 * q) * ACC_N + a];
+    }
     part[c][a] = v;
     __syncthreads();
     // the slot sets are accumulated with atomics by the step kernels: reset them for the next iteration
@@ -3508,14 +3546,16 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
                                                      srrg2_iteration_stats* __restrict__ stats) {
   const int prob   = blockIdx.x + C.prob0;
   ProblemState* st = &states[prob];
-  if (st->done || st->finished) return;
   // The sequential part reads and writes ~100 words of the state, with stores to other arrays in between that the
   // compiler must assume to alias: in global memory that is a chain of exposed L2 round trips.  The workgroup stages the
-  // record in LDS (one coalesced load), thread 0 works there, the workgroup writes it back.
+  // record in LDS (one coalesced load), thread 0 works there, the workgroup writes it back.  The slot sets are requested
+  // before the record and `done` is read from the staged copy: one round trip for all three.
+  const PrePartials pre = prefetch_partials(C, prob);
   __shared__ ProblemState sst;
   state_to_lds(&sst, st);
   __syncthreads();
-  icp_control_block(C, &sst, stats, prob);
+  if (sst.done || sst.finished) return;  // (uniform: LDS; nothing was modified)
+  icp_control_block(C, &sst, stats, prob, pre);
   __syncthreads();
   state_from_lds(st, &sst);
 }
@@ -3602,10 +3642,11 @@ __global__ __launch_bounds__(256) void k_icp_control_final(CtlParams C, ProblemS
                                                            ProblemOut* __restrict__ outs_host,
                                                            srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
   const int prob = blockIdx.x + C.prob0;
-  __shared__ ProblemState sst;  // (see k_icp_control)
+  const PrePartials pre = prefetch_partials(C, prob);  // (see k_icp_control)
+  __shared__ ProblemState sst;
   state_to_lds(&sst, &states[prob]);
   __syncthreads();
-  if (!sst.done && !sst.finished) icp_control_block(C, &sst, stats, prob);  // (uniform: LDS)
+  if (!sst.done && !sst.finished) icp_control_block(C, &sst, stats, prob, pre);  // (uniform: LDS)
   __threadfence();  // (thread 0's statistics, read by the whole block below)
   __syncthreads();
   icp_finalize_block(C, &sst, stats, outs_host, stats_host, prob, with_post != 0);
@@ -3878,7 +3919,14 @@ void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* prob
 
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
                      const float* guesses_host, int tsize, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_init, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(64), 0, s, C, probs_host, probs, states, guesses_host, tsize);
+  InitInline inl{};
+  if (C.K == 1) {  // (read on the host, sent with the launch)
+    inl.use = 1;
+    for (int i = 0; i < 12; ++i) inl.guess[i] = i < tsize ? guesses_host[i] : 0.f;
+    for (int sl = 0; sl < C.nslices && sl < SRRG2_MAX_SLICES; ++sl) inl.pd[sl] = probs_host[sl];
+  }
+  hipLaunchKernelGGL(k_icp_init, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(64), 0, s, C, probs_host, probs, states, guesses_host,
+                     tsize, inl);
 }
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_control, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(256), 0, s, C, states, stats);
