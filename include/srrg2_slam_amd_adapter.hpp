@@ -236,9 +236,9 @@ namespace srrg2_slam_interfaces {
       if (!param_slice_processors.size()) throw std::runtime_error("MultiAlignerBase_::compute|no slices");  // :49
       this->_status = AlignerBase::Fail;
       this->_iteration_stats.clear();
-      // _preCompute (:131-141): robustifiers are bound by value below; init() per slice -- prior slices compute their
-      // measurement there and override the initial guess through setMovingInFixed()
-      for (size_t i = 0; i < param_slice_processors.size(); ++i) param_slice_processors.value(i)->init(this);
+      // the virtual hook of multi_aligner.h:141: a downstream subclass that overrides it still compiles and still runs
+      // before the registration; the default does what the reference's does (:131-141)
+      _preCompute();
       bindSlices();
       float T[12];
       amd_detail::toRowMajor(this->_moving_in_fixed, T);
@@ -286,6 +286,11 @@ namespace srrg2_slam_interfaces {
         out.reserve(buf.size());
         for (const srrg2_correspondence& c : buf) out.emplace_back(Correspondence(c.fixed_idx, c.moving_idx, c.response));
       }
+      // the virtual hook of multi_aligner.h:143.  The reference runs it inside compute() right after the first solver run
+      // (:71), where its default starts the inlier-only run (:163-181) -- that run has already happened on the device
+      // (enable_inlier_only_runs travels in srrg2_aligner_params), so the default here is empty; an override sees the
+      // final status, estimate, statistics and correspondences.
+      _postCompute();
     }
     // multi_aligner_impl.cpp:275-285
     int numCorrespondences() override {
@@ -308,6 +313,45 @@ namespace srrg2_slam_interfaces {
     }
 
   protected:
+    // ---- the protected surface of multi_aligner.h:108-149, kept so that a downstream subclass written against the
+    // reference compiles and behaves.  What they do in the reference, and here:
+    //   _preCompute()  (virtual, :141 / impl :131-141)  keeps the slices' robustifiers for the inlier-only run and calls
+    //       slice->init(this) on every slice: prior slices compute their measurement there and override the initial guess
+    //       through setMovingInFixed().  Same here (the robustifiers are read by value when the slices are bound).
+    //   _postCompute() (virtual, :143 / impl :163-181)  see compute(): called last, default empty.
+    //   _setupAligner() (:117 / impl :130-161)  rebuilds the one-variable factor graph from the slices: here it (re)binds
+    //       the slices to the device handle, which is what "the graph" is on this side.
+    //   _runSolver(n, criterion) (:121 / impl :98-128)  the iteration loop: on the device, inside srrg2_aligner_compute; a
+    //       subclass cannot interleave host code with its iterations -- calling it runs a whole compute() of n iterations.
+    //   _pruneCorrespondences / _setClampRobustifiers / _restoreRobustifiers (:111-115)  device-side steps of compute()
+    //       (keep_only_inlier_correspondences, enable_inlier_only_runs): nothing left to do on the host, kept as no-ops.
+    //   _graph (:147)  stays null: there is no host-side FactorGraph; _robustifiers_original_per_slice (:149) is filled by
+    //       _preCompute as in the reference.
+    virtual void _preCompute() {
+      const size_t ns = param_slice_processors.size();
+      _robustifiers_original_per_slice.clear();
+      _robustifiers_original_per_slice.reserve(ns);
+      for (size_t i = 0; i < ns; ++i) {
+        AlignerSliceProcessorTypePtr slice = param_slice_processors.value(i);
+        _robustifiers_original_per_slice.push_back(slice->param_robustifier.value());
+        slice->init(this);
+      }
+    }
+    virtual void _postCompute() {}
+    void _setupAligner() { bindSlices(); }
+    void _runSolver(const size_t& number_of_iterations_, const std::shared_ptr<AlignerTerminationCriteriaBase> termination_criterion_) {
+      const int keep_it = this->param_max_iterations.value();
+      auto keep_tc      = this->param_termination_criteria.value();
+      this->param_max_iterations.setValue((int) number_of_iterations_);
+      this->param_termination_criteria.setValue(termination_criterion_);
+      compute();
+      this->param_max_iterations.setValue(keep_it);
+      this->param_termination_criteria.setValue(keep_tc);
+    }
+    void _pruneCorrespondences() {}
+    void _setClampRobustifiers() {}
+    void _restoreRobustifiers() {}
+
     // (re)creates the device-side aligner from the CURRENT slice objects: slice list, PARAMs, bound clouds, prior
     // measurements.  Cheap when nothing changed (the clouds are re-bound only after setFixed / setMoving).
     void bindSlices() {
@@ -382,10 +426,13 @@ namespace srrg2_slam_interfaces {
       for (int k = 0; k < D; ++k) c.prior_information_diag[k] = Om(k, k);
     }
 
-    srrg2_aligner_h _h        = nullptr;
-    int _device               = 0;
-    bool _slices_changed_flag = true;  // multi_aligner.h:37
-    bool _clouds_changed      = true;
+    // multi_aligner.h:146-149
+    FactorGraphPtr _graph     = nullptr;  // (never built: the registration graph lives on the device)
+    bool _slices_changed_flag = true;     // set by PARAM_VECTOR slice_processors (:34-37) and setDevice: the handle is rebuilt
+    std::vector<RobustifierBasePtr> _robustifiers_original_per_slice;
+    srrg2_aligner_h _h   = nullptr;
+    int _device          = 0;
+    bool _clouds_changed = true;
     std::vector<srrg2_slice_config> _bound_configs;
   };
 
