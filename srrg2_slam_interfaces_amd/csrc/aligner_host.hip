@@ -44,6 +44,8 @@ struct Slice {
   DevBuf<int> list_start, list_sums;
   DevBuf<uint2> list_ent;
   DevBuf<int4> list_offs;
+  DevBuf<GridLists> list_hdr;  // the GridLists record the grid points to
+  GridLists lists_host{};      // ... and its host copy (the search-pass kernel takes it by value)
   bool lists_tried = false;  // built, or found not to pay / fit (grid.list_R says which)
   int grid_computes = 0;     // compute() calls on this grid so far (a grid searched a second time gets its lists)
   int nf          = 0;
@@ -97,7 +99,7 @@ struct Slice {
     ms_probs_host_cap = 0;
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
     cell_start.release(); cursor.release(); scan_sums.release(); scalars.release(); pos_of.release();
-    list_start.release(); list_sums.release(); list_ent.release(); list_offs.release();
+    list_start.release(); list_sums.release(); list_ent.release(); list_offs.release(); list_hdr.release();
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
@@ -411,41 +413,41 @@ int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
   std::stable_sort(offs.begin(), offs.end(), [](const Off& p, const Off& q) { return p.cls != q.cls ? p.cls < q.cls : p.c2 < q.c2; });
   std::vector<int4> offs4(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) offs4[k] = make_int4(offs[k].x, offs[k].y, offs[k].z, offs[k].cls);
-  g.lnx = g.nx + 2 * R;
-  g.lny = g.ny + 2 * R;
-  g.lnz = dim == 3 ? g.nz + 2 * R : 1;
-  const long long ncell_ll = (long long) g.lnx * g.lny * g.lnz;
+  GridLists L{};
+  L.R   = R;
+  L.lnx = g.nx + 2 * R;
+  L.lny = g.ny + 2 * R;
+  L.lnz = dim == 3 ? g.nz + 2 * R : 1;
+  const long long ncell_ll = (long long) L.lnx * L.lny * L.lnz;
   if (ncell_ll > (1LL << 28)) return 0;
   const int ncell = (int) ncell_ll;
-  for (int m = 0; m <= CNL_MAX_CLASS; ++m) g.cls_b2[m] = class_bound2(m);
-  g.cls_b2[CNL_MAX_CLASS + 1] = 3.0e38f;
+  for (int m = 0; m <= CNL_MAX_CLASS; ++m) L.cls_b2[m] = class_bound2(m);
+  L.cls_b2[CNL_MAX_CLASS + 1] = 3.0e38f;
   int rc;
   if ((rc = s->list_offs.reserve(offs4.size()))) return rc;
   if ((rc = s->list_start.reserve((size_t) ncell + 1))) return rc;
   if ((rc = s->list_sums.reserve((size_t) srrg2amd::scan_num_blocks(ncell) + 2))) return rc;
+  if ((rc = s->list_hdr.reserve(1))) return rc;
   HIP_TRY(hipMemcpyAsync(s->list_offs.p, offs4.data(), offs4.size() * sizeof(int4), hipMemcpyHostToDevice, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));  // (offs4 is a stack-lifetime host buffer)
-  g.list_R = R;  // (the build kernels read the extended dimensions and R from the grid)
-  srrg2amd::launch_cnl_build(g, s->list_offs.p, (int) offs4.size(), s->list_start.p, nullptr, a->stream);
+  srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, nullptr, a->stream);
   int* total_dev = s->list_sums.p + s->list_sums.cap - 1;
   srrg2amd::launch_exclusive_scan(s->list_start.p, ncell, s->list_sums.p, total_dev, a->stream);
   int total = 0;
   HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(int), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
-  if (total < 0 || (long long) total > max_entries) {
-    g.list_R = 0;
-    return 0;
-  }
-  if ((rc = s->list_ent.reserve((size_t) std::max(total, 1) + 8))) {
-    g.list_R = 0;
-    return rc;
-  }
-  g.list_start = s->list_start.p;
-  g.list_ent   = s->list_ent.p;
-  srrg2amd::launch_cnl_build(g, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_ent.p, a->stream);
+  if (total < 0 || (long long) total > max_entries) return 0;
+  if ((rc = s->list_ent.reserve((size_t) std::max(total, 1) + 8))) return rc;
+  L.start = s->list_start.p;
+  L.ent   = s->list_ent.p;
+  srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_ent.p, a->stream);
+  HIP_TRY(hipMemcpyAsync(s->list_hdr.p, &L, sizeof(L), hipMemcpyHostToDevice, a->stream));
   HIP_TRY(hipGetLastError());
-  // (complete before anybody reads them: the second half of a pipelined batch runs on another stream)
+  // (complete before anybody reads them: the second half of a pipelined batch runs on another stream; L is a local)
   HIP_TRY(hipStreamSynchronize(a->stream));
+  g.lists       = s->list_hdr.p;
+  g.list_R      = R;
+  s->lists_host = L;
   return 0;
 }
 
@@ -1092,7 +1094,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             if (fast)
               srrg2amd::launch_icp_step_fast(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, fast_ppt, fast_gather, hs);
             else if (cnl[(size_t) si] && !sd.queue)
-              srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, pt, a->states.p, Kh, nm_max,
+              srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, s->lists_host, pt, a->states.p, Kh, nm_max,
                                             search_team_knob > 0 ? search_team_knob : ((K <= 4 && slot0 == 0 && it == 0) ? 4 : 1), hs);
             else if (!sd.queue && lds_tile > 0 && !small)
               srrg2amd::launch_icp_step_tile(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, lds_tile == 2 ? 504 : 416, hs);

@@ -37,18 +37,25 @@ struct GridDev {
   const float4* pts;
   const float4* nrm;      // sorted like pts (w unused); null when the cloud has no normals
   const int* pos_of;      // [n] original index -> position in pts (the searches track keys, not positions)
-  // Cell neighbour lists (k_icp_step_cnl; built on demand, kernels_prep.hip: k_cnl_count / k_cnl_fill).  For every cell c of
-  // the grid EXTENDED by list_R cells on every side: the OCCUPIED cells whose points can lie within the extended gate of a
-  // query in c, nearest class first.  An entry = {position of its first point in pts,
-  // byte 0: count - 1 | class << 4, bytes 1 .. 3: dx + R, dy + R, dz + R}; class m = sum_i max(|d_i| - 1, 0)^2 = squared
-  // cell-to-cell separation in cells (entries of a list are sorted by class, then by centre distance); a cell of more than
-  // CNL_ENTRY_MAX points takes several entries (the entries are the work items the lanes of a wave share).  cls_b2[m] = ((sqrt(m) - 0.01) h)^2 * 0.9999: every point of a class-m cell is
-  // farther than that from every query of c (bound2_of generalised to non-integer separations).
-  int list_R;             // 0: no lists
-  int lnx, lny, lnz;      // extended grid: n + 2 R per axis (2-D: lnz = 1)
-  const int* list_start;  // [lnx * lny * lnz + 1]
-  const uint2* list_ent;
-  float cls_b2[14];       // classes 0 .. 12 (R <= 3) + sentinel
+  // Cell neighbour lists (cnl_search; built on demand, kernels_prep.hip: k_cnl_count / k_cnl_fill): GridLists, in device
+  // memory behind a pointer -- carried inline in the kernel arguments their 100 bytes are preloaded into scalar registers by
+  // EVERY kernel that takes a SliceDev, and the converged-pass kernel then spills 30 of them in its hot path.
+  int list_R;                     // 0: no lists
+  const struct GridLists* lists;  // (device)
+};
+// For every cell c of the grid EXTENDED by R cells on every side: the OCCUPIED cells whose points can lie within the
+// extended gate of a query in c, nearest class first.  An entry = {position of its first point in pts,
+// byte 0: count - 1 | class << 4, bytes 1 .. 3: dx + R, dy + R, dz + R}; class m = sum_i max(|d_i| - 1, 0)^2 = squared
+// cell-to-cell separation in cells (entries of a list are sorted by class, then by centre distance); a cell of more than
+// CNL_ENTRY_MAX points takes several entries (the entries are the work items the lanes of a wave share).
+// cls_b2[m] = ((sqrt(m) - 0.01) h)^2 * 0.9999: every point of a class-m cell is farther than that from every query of c
+// (bound2_of generalised to non-integer separations).
+struct GridLists {
+  int R;
+  int lnx, lny, lnz;   // extended grid: n + 2 R per axis (2-D: lnz = 1)
+  const int* start;    // [lnx * lny * lnz + 1]
+  const uint2* ent;
+  float cls_b2[14];    // classes 0 .. 12 (R <= 3) + sentinel
 };
 #define CNL_MAX_R 3
 #define CNL_ENTRY_MAX 16

@@ -670,16 +670,32 @@ struct CnlWave {               // per wave, in LDS
 };
 
 // up to four candidates pts[j .. j + 3], the first `cnt` of them valid; lanes without work issue no load and run no test
-// (reads up to 3 entries past the range, masked out: the sorted array has slack behind it)
+// (reads up to 3 entries past the range, masked out: the sorted array has slack behind it).  Inside the branch everything
+// is straight-line: four loads in flight, four distances, the masks as selects -- written with the ternaries of
+// test_candidate2 the compiler branched around every candidate and sank the second load into its branch (two dependent
+// round trips per group).
 template <int DIM>
 __device__ __forceinline__ void test_group_glb(const float4* __restrict__ pts, int j, int cnt, float qx, float qy, float qz,
                                                unsigned long long& bkey, float& b2) {
   if (cnt > 0) {
     const float4 a0 = pts[j], a1 = pts[j + 1], a2 = pts[j + 2], a3 = pts[j + 3];
-    test_candidate2<DIM>(a0, qx, qy, qz, true, bkey, b2);
-    test_candidate2<DIM>(a1, qx, qy, qz, cnt > 1, bkey, b2);
-    test_candidate2<DIM>(a2, qx, qy, qz, cnt > 2, bkey, b2);
-    test_candidate2<DIM>(a3, qx, qy, qz, cnt > 3, bkey, b2);
+    const float d0 = cand_d2<DIM>(a0, qx, qy, qz);
+    float d1 = cand_d2<DIM>(a1, qx, qy, qz), d2 = cand_d2<DIM>(a2, qx, qy, qz), d3 = cand_d2<DIM>(a3, qx, qy, qz);
+    unsigned i1 = (unsigned) __float_as_int(a1.w), i2 = (unsigned) __float_as_int(a2.w), i3 = (unsigned) __float_as_int(a3.w);
+    d1 = cnt > 1 ? d1 : INFINITY;
+    d2 = cnt > 2 ? d2 : INFINITY;
+    d3 = cnt > 3 ? d3 : INFINITY;
+    i1 = cnt > 1 ? i1 : (unsigned) NO_MATCH;
+    i2 = cnt > 2 ? i2 : (unsigned) NO_MATCH;
+    i3 = cnt > 3 ? i3 : (unsigned) NO_MATCH;
+    b2   = __builtin_amdgcn_fmed3f(__uint_as_float((unsigned) (bkey >> 32)), b2, d0);
+    bkey = key_min(bkey, ((unsigned long long) __float_as_uint(d0) << 32) | (unsigned) __float_as_int(a0.w));
+    b2   = __builtin_amdgcn_fmed3f(__uint_as_float((unsigned) (bkey >> 32)), b2, d1);
+    bkey = key_min(bkey, ((unsigned long long) __float_as_uint(d1) << 32) | i1);
+    b2   = __builtin_amdgcn_fmed3f(__uint_as_float((unsigned) (bkey >> 32)), b2, d2);
+    bkey = key_min(bkey, ((unsigned long long) __float_as_uint(d2) << 32) | i2);
+    b2   = __builtin_amdgcn_fmed3f(__uint_as_float((unsigned) (bkey >> 32)), b2, d3);
+    bkey = key_min(bkey, ((unsigned long long) __float_as_uint(d3) << 32) | i3);
   }
 }
 
@@ -720,10 +736,13 @@ __device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, C
 // Returns, in the first lane of every team with `need`: bkey = the minimum key over the fixed points inside the ball
 // (NO_KEY: none), b2 = squared distance of the runner-up among the points examined, L = squared radius inside which every
 // fixed point was examined (every point not examined is farther than min(L, extended gate)).
+// gl: the grid's list header -- the search-pass kernel gets it by value in its kernel arguments (scalar registers), the
+// converged-pass kernel, which searches rarely, reads it through GridDev::lists.
 template <int DIM, int TEAM>
-__device__ __forceinline__ void cnl_search(const GridDev& g, CnlWave& w, int lane, bool need, float qx, float qy, float qz,
-                                           float r2box, float gfar, unsigned long long& bkey, float& b2, float& L) {
-  const int R  = g.list_R;
+__device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl, CnlWave& w, int lane, bool need, float qx,
+                                           float qy, float qz, float r2box, float gfar, unsigned long long& bkey, float& b2,
+                                           float& L) {
+  const int R  = gl.R;
   const int tl = lane & (TEAM - 1);   // lane within its team
   const int owner_lane = lane - tl;   // the team's slot
   // the query in cell units: cell c + fraction u along every axis
@@ -733,12 +752,12 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, CnlWave& w, int lan
   const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
   const int lx = cx + R, ly = cy + R, lz = DIM == 3 ? cz + R : 0;
   // (a query outside the extended grid is farther than the extended gate from every fixed point: no list, no match)
-  const bool inl = need && lx >= 0 && lx < g.lnx && ly >= 0 && ly < g.lny && lz >= 0 && lz < g.lnz;
+  const bool inl = need && lx >= 0 && lx < gl.lnx && ly >= 0 && ly < gl.lny && lz >= 0 && lz < gl.lnz;
   int e = 0, eend = 0;
   if (inl) {
-    const int lc = (lz * g.lny + ly) * g.lnx + lx;
-    e            = g.list_start[lc];
-    eend         = g.list_start[lc + 1];
+    const int lc = (lz * gl.lny + ly) * gl.lnx + lx;
+    e            = gl.start[lc];
+    eend         = gl.start[lc + 1];
   }
   bkey = NO_KEY;
   b2   = INFINITY;
@@ -747,7 +766,7 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, CnlWave& w, int lan
   {
     const bool p0 = e < eend;
     uint2 h0      = make_uint2(0u, 0u);
-    if (p0) h0 = g.list_ent[e];
+    if (p0) h0 = gl.ent[e];
     int j = (int) h0.x + 4 * tl, cnt = p0 ? (int) (h0.y & 15u) + 1 - 4 * tl : 0;
     while (__any(cnt > 0)) {
       test_group_glb<DIM>(g.pts, j, cnt, qx, qy, qz, bkey, b2);
@@ -786,7 +805,7 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, CnlWave& w, int lan
   const float Lcc = (Lc * g.inv_h) * g.inv_h * 1.0001f;
   int mmax = -1;  // largest class whose cells can reach into the ball
 #pragma unroll
-  for (int m = 0; m <= CNL_MAX_CLASS; ++m) mmax += g.cls_b2[m] <= Lc ? 1 : 0;
+  for (int m = 0; m <= CNL_MAX_CLASS; ++m) mmax += gl.cls_b2[m] <= Lc ? 1 : 0;
   const float fR = (float) R;
   const float mx = 0.011f + fabsf(ux0) * 1e-6f, my = 0.011f + fabsf(uy0) * 1e-6f, mz = 0.011f + fabsf(uz0) * 1e-6f;
   const float ux = ux0 - (float) cx, uy = uy0 - (float) cy, uz = uz0 - (float) cz;
@@ -801,7 +820,7 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, CnlWave& w, int lan
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       hd[k] = make_uint2(0u, 0xf0u);  // (class 15: beyond every ball)
-      if (e + k < eend) hd[k] = g.list_ent[e + k];
+      if (e + k < eend) hd[k] = gl.ent[e + k];
     }
     bool stop = e >= eend;
 #pragma unroll
@@ -2347,7 +2366,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
     if (g.list_R > 0 && __popcll(__ballot(open)) > 4) {
       unsigned long long skey;
       float sb2, sL;
-      cnl_search<DIM, 1>(g, fast_lds[wid].cnl, lane, open, qx, qy, qz, open_ball2[k], gfar, skey, sb2, sL);
+      cnl_search<DIM, 1>(g, *g.lists, fast_lds[wid].cnl, lane, open, qx, qy, qz, open_ball2[k], gfar, skey, sb2, sL);
       if (open) {
         sbest[k] = key_best(skey);
         sidx[k]  = key_idx(skey);
@@ -2437,7 +2456,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
 // The search pass over the cell neighbour lists (cnl_search above): TEAM lanes per moving point.
 // ============================================================================================
 template <int DIM, bool PLANE, int TEAM>
-__global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemDev* __restrict__ probs,
+__global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, const ProblemDev* __restrict__ probs,
                                                       ProblemState* __restrict__ states) {
   constexpr int NW  = 4;
   constexpr int PPB = NW * 64 / TEAM;  // moving points per workgroup
@@ -2533,7 +2552,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, const ProblemD
   if (__any(need)) {
     unsigned long long bkey;
     float b2, L;
-    cnl_search<DIM, TEAM>(g, wlds[wid], lane, need, qx, qy, qz, r2box, gfar, bkey, b2, L);
+    cnl_search<DIM, TEAM>(g, GL, wlds[wid], lane, need, qx, qy, qz, r2box, gfar, bkey, b2, L);
     if (need) {
       best = key_best(bkey);
       bidx = key_idx(bkey);
@@ -3790,22 +3809,22 @@ void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemD
 }
 
 // the search pass over the cell neighbour lists of the grid (S.grid.list_R > 0); team = lanes per moving point (1 or 4)
-void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                         int max_nm, int team, hipStream_t s) {
+void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
+                         ProblemState* states, int K, int max_nm, int team, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
 #define CNL_LAUNCH(TEAM)                                                                                   \
   do {                                                                                                     \
     dim3 grid((max_nm * TEAM + 255) / 256, K);                                                             \
     if (dim == 3) {                                                                                        \
       if (plane)                                                                                           \
-        hipLaunchKernelGGL((k_icp_step_cnl<3, true, TEAM>), grid, dim3(256), 0, s, S, probs, states);      \
+        hipLaunchKernelGGL((k_icp_step_cnl<3, true, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states);  \
       else                                                                                                 \
-        hipLaunchKernelGGL((k_icp_step_cnl<3, false, TEAM>), grid, dim3(256), 0, s, S, probs, states);     \
+        hipLaunchKernelGGL((k_icp_step_cnl<3, false, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states); \
     } else {                                                                                               \
       if (plane)                                                                                           \
-        hipLaunchKernelGGL((k_icp_step_cnl<2, true, TEAM>), grid, dim3(256), 0, s, S, probs, states);      \
+        hipLaunchKernelGGL((k_icp_step_cnl<2, true, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states);  \
       else                                                                                                 \
-        hipLaunchKernelGGL((k_icp_step_cnl<2, false, TEAM>), grid, dim3(256), 0, s, S, probs, states);     \
+        hipLaunchKernelGGL((k_icp_step_cnl<2, false, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states); \
     }                                                                                                      \
   } while (0)
   if (team >= 4)

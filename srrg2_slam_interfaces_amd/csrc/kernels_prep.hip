@@ -256,10 +256,10 @@ __global__ void k_grid_scatter(GridDev g, const float4* __restrict__ pts, const 
 // (class, centre distance)) and emits one entry per CNL_ENTRY_MAX points of every occupied target cell -- k_cnl_count counts them,
 // an exclusive scan places the lists, k_cnl_fill writes them.  Once per set_fixed, and only when a compute() wants them.
 // ============================================================================================
-__device__ __forceinline__ int cnl_target_cell(const GridDev& g, int lc, const int4 o, int& cnt) {
-  const int lx = lc % g.lnx, ly = (lc / g.lnx) % g.lny, lz = lc / (g.lnx * g.lny);
-  const int Rz = g.lnz > 1 ? g.list_R : 0;
-  const int X = lx - g.list_R + o.x, Y = ly - g.list_R + o.y, Z = lz - Rz + o.z;
+__device__ __forceinline__ int cnl_target_cell(const GridDev& g, const GridLists& L, int lc, const int4 o, int& cnt) {
+  const int lx = lc % L.lnx, ly = (lc / L.lnx) % L.lny, lz = lc / (L.lnx * L.lny);
+  const int Rz = L.lnz > 1 ? L.R : 0;
+  const int X = lx - L.R + o.x, Y = ly - L.R + o.y, Z = lz - Rz + o.z;
   cnt = 0;
   if (X < 0 || X >= g.nx || Y < 0 || Y >= g.ny || Z < 0 || Z >= g.nz) return -1;
   const int c = (Z * g.ny + Y) * g.nx + X;
@@ -267,29 +267,29 @@ __device__ __forceinline__ int cnl_target_cell(const GridDev& g, int lc, const i
   return c;
 }
 
-__global__ __launch_bounds__(256) void k_cnl_count(GridDev g, const int4* __restrict__ offs, int noffs, int ncell,
+__global__ __launch_bounds__(256) void k_cnl_count(GridDev g, GridLists L, const int4* __restrict__ offs, int noffs, int ncell,
                                                    int* __restrict__ counts) {
   const int lc = blockIdx.x * blockDim.x + threadIdx.x;
   if (lc >= ncell) return;
   int total = 0;
   for (int k = 0; k < noffs; ++k) {
     int cnt;
-    (void) cnl_target_cell(g, lc, offs[k], cnt);
+    (void) cnl_target_cell(g, L, lc, offs[k], cnt);
     total += (cnt + CNL_ENTRY_MAX - 1) / CNL_ENTRY_MAX;
   }
   counts[lc] = total;
 }
 
-__global__ __launch_bounds__(256) void k_cnl_fill(GridDev g, const int4* __restrict__ offs, int noffs, int ncell,
+__global__ __launch_bounds__(256) void k_cnl_fill(GridDev g, GridLists L, const int4* __restrict__ offs, int noffs, int ncell,
                                                   const int* __restrict__ list_start, uint2* __restrict__ ent) {
   const int lc = blockIdx.x * blockDim.x + threadIdx.x;
   if (lc >= ncell) return;
   int at       = list_start[lc];
-  const int R  = g.list_R;
+  const int R  = L.R;
   for (int k = 0; k < noffs; ++k) {
     const int4 o = offs[k];
     int cnt;
-    const int c = cnl_target_cell(g, lc, o, cnt);
+    const int c = cnl_target_cell(g, L, lc, o, cnt);
     if (cnt <= 0) continue;
     const unsigned code = ((unsigned) o.w << 4) | ((unsigned) (o.x + R) << 8) | ((unsigned) (o.y + R) << 16) |
                           ((unsigned) (o.z + R) << 24);
@@ -714,13 +714,14 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
 }
 
 // counts (ent == null: per-cell entry counts into list_start[0 .. ncell)) or fills the cell neighbour lists
-void launch_cnl_build(const GridDev& g, const int4* offs, int noffs, int* list_start, uint2* ent, hipStream_t s) {
-  const int ncell = g.lnx * g.lny * g.lnz;
+void launch_cnl_build(const GridDev& g, const GridLists& L, const int4* offs, int noffs, int* list_start, uint2* ent,
+                      hipStream_t s) {
+  const int ncell = L.lnx * L.lny * L.lnz;
   if (ncell <= 0 || noffs <= 0) return;
   if (!ent)
-    hipLaunchKernelGGL(k_cnl_count, dim3((ncell + 255) / 256), dim3(256), 0, s, g, offs, noffs, ncell, list_start);
+    hipLaunchKernelGGL(k_cnl_count, dim3((ncell + 255) / 256), dim3(256), 0, s, g, L, offs, noffs, ncell, list_start);
   else
-    hipLaunchKernelGGL(k_cnl_fill, dim3((ncell + 255) / 256), dim3(256), 0, s, g, offs, noffs, ncell, list_start, ent);
+    hipLaunchKernelGGL(k_cnl_fill, dim3((ncell + 255) / 256), dim3(256), 0, s, g, L, offs, noffs, ncell, list_start, ent);
 }
 
 // false: the key space does not fit in LDS (the caller takes the ingest + global-histogram path)
