@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--no-one-gpu-reference", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--c3-own-clouds", action="store_true", help="c3: every slice uploads its own copy of the clouds (round <= 3)")
     ap.add_argument("--dump-table", default=None, help="rank 0 saves the exchanged result table of the last step (.npy): tests")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,8 +149,13 @@ def measure(args, init_dist=True):
             c.image_rows, c.image_cols = data["rows"], data["cols"]
             c.depth_min, c.depth_max = data["depth_min"], data["depth_max"]
             si = al.add_slice(c)
-            al.set_fixed(si, data["fixed"], data["fixed_normals"])
-            al.set_moving(si, data["moving"], data["moving_normals"])
+            if si == 0 or args.c3_own_clouds:
+                al.set_fixed(si, data["fixed"], data["fixed_normals"])
+                al.set_moving(si, data["moving"], data["moving_normals"])
+            else:
+                # both slices read the SAME depth cloud: in the reference they would name the same scene properties
+                # (fixed_slice_name / moving_slice_name, aligner_slice_processor_base.h:41-53) and bind to the same objects
+                al.share_clouds(si, 0)
         K_total = world
         units_per_step = args.iterations
         nm, nf = data["moving"].shape[0], data["fixed"].shape[0]
@@ -351,7 +357,7 @@ def measure(args, init_dist=True):
         "roofline": {
             "bound": "hbm",
             "kernel": ("k_icp_step_cnl<3,true,4|1> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,false> (converged passes): one finder+factor pass of the slice" if args.workload == "c2" else
-                       "k_icp_step_cnl<3,true,1> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,true> (converged passes): one finder+factor pass over all alignments of the launch" if args.workload == "c4" else "k_proj_zbuf_pack + k_icp_step_proj_pack (both slices of the aligner in one launch pair)"),
+                       "k_icp_step_cnl<3,true,1> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,true> (converged passes): one finder+factor pass over all alignments of the launch" if args.workload == "c4" else "k_proj_zbuf + k_icp_step_proj_fused (both slices share their clouds and their association: one z-buffer pass, one step launch)"),
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",

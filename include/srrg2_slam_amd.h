@@ -314,6 +314,15 @@ int srrg2_multi_gpu_shard_indices(int K, int world, int rank, int32_t* indices_o
 int srrg2_multi_gpu_pack_record(int k, int variable_kind, const srrg2_batch_result* r, double* record_out);
 int srrg2_multi_gpu_unpack_record(const double* record, int variable_kind, int* k_out, srrg2_batch_result* r_out);
 
+/* Two cue slices that read the SAME clouds: slice `slice_idx` shares the fixed and the moving cloud of slice
+ * `source_slice_idx` (no copy; -1 gives it clouds of its own again, to be set).  In the reference a slice finds its clouds
+ * BY NAME in the scene (fixed_slice_name / moving_slice_name, aligner_slice_processor_base.h:41-53,
+ * aligner_slice_processor_base_impl.cpp:27-50): two slices with the same names bind to the same cloud objects, which is
+ * what this call says.  set_fixed / set_moving on the source then serve both; on the sharing slice they are an error.
+ * Slices with the projective finder only.  When, on top, their finder parameters agree (camera matrix, image size, depth
+ * range, gate, sensor pose) they share ONE association pass per iteration: same results, half the traffic (ABI v4). */
+int srrg2_aligner_share_clouds(srrg2_aligner_h h, int slice_idx, int source_slice_idx);
+
 /* ---- one alignment sharded by moving points (second mode; no reference counterpart) ---------
  * For clouds of millions of points one alignment can be spread over G GPUs: the fixed cloud is set on every rank, rank g
  * sets ITS share of the moving points, and every Gauss-Newton iteration adds the ranks' partial sums before the control

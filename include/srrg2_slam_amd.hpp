@@ -191,6 +191,9 @@ public:
                                         offsets.data(), SRRG2_MEM_HOST, g.data(), results.data()));
     return results;
   }
+  // slice `slice` reads the clouds of slice `source` (two slices with the same fixed_slice_name / moving_slice_name bind to
+  // the same clouds of the scene: aligner_slice_processor_base_impl.cpp:27-50); -1: clouds of its own again
+  void shareClouds(int slice, int source) { check(srrg2_aligner_share_clouds(_h, slice, source)); }
   Status status() const { return _status; }
   const IterationStatsVector& iterationStats() const { return _iteration_stats; }
   // H = sum w J^T J of the last Gauss-Newton iteration of the last compute() (the solver's system after

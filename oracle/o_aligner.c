@@ -298,6 +298,7 @@ typedef struct {
   int k;
   double prior_H[36], prior_b[6], prior_chi;
   int prior_status;
+  int shares; /* 1 + index of the slice whose clouds this one reads (srrg2_aligner_share_clouds); 0: its own */
 } o_slice;
 
 typedef struct {
@@ -459,12 +460,46 @@ static float max_abs_finite(const float* v, int n, int dim, int per_point) {
   return m;
 }
 
+static int set_fixed_one(o_aligner* h, int si, const float* coords, int cs, const float* normals, int ns, int n);
+static int set_moving_one(o_aligner* h, int si, const float* coords, int cs, const float* normals, int ns, int n);
+
+/* srrg2_aligner_share_clouds: in the reference two slices with the same fixed_slice_name / moving_slice_name bind to the same
+ * cloud objects of the scene (aligner_slice_processor_base_impl.cpp:27-50).  The oracle stays literal: every slice keeps
+ * its OWN finder and its own copy of the clouds (the reference's slices each run their finder); sharing only means that
+ * what is set on the source is set on the sharing slices too. */
+int oracle_aligner_share_clouds(o_aligner* h, int si, int source) {
+  if (!h || si < 0 || si >= h->nslices) return fail(SRRG2_E_INVALID, "share_clouds");
+  o_slice* s = &h->slices[si];
+  if (source == -1) {
+    s->shares = 0;
+    return 0;
+  }
+  if (source < 0 || source >= h->nslices || source == si) return fail(SRRG2_E_INVALID, "share_clouds: two different cue slices");
+  o_slice* o = &h->slices[source];
+  if (s->cfg.kind == SRRG2_SLICE_PRIOR || o->cfg.kind == SRRG2_SLICE_PRIOR || o->shares)
+    return fail(SRRG2_E_INVALID, "share_clouds: bad source");
+  if (s->cfg.finder != SRRG2_FINDER_PROJECTIVE || o->cfg.finder != SRRG2_FINDER_PROJECTIVE)
+    return fail(SRRG2_E_UNSUPPORTED, "share_clouds: both slices must use the projective finder");
+  s->shares = source + 1;
+  if (o->fixed) set_fixed_one(h, si, o->fixed, h->dim * 4, o->fixed_n, h->dim * 4, o->nf);
+  if (o->moving) set_moving_one(h, si, o->moving, h->dim * 4, o->moving_n, h->dim * 4, o->nm);
+  return 0;
+}
+
 int oracle_aligner_set_fixed(o_aligner* h, int si, const float* coords, int cs, const float* normals, int ns, int n,
                              int mem) {
   if (!h || si < 0 || si >= h->nslices || n < 0 || (n > 0 && !coords)) return fail(SRRG2_E_INVALID, "set_fixed");
   if (mem != SRRG2_MEM_HOST) return fail(SRRG2_E_UNSUPPORTED, "oracle takes host memory only");
+  if (h->slices[si].cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_fixed on a prior slice");
+  if (h->slices[si].shares) return fail(SRRG2_E_STATE, "set_fixed: this slice shares the clouds of another slice");
+  int rc = set_fixed_one(h, si, coords, cs, normals, ns, n);
+  for (int t = 0; t < h->nslices && !rc; ++t)
+    if (h->slices[t].shares == si + 1) rc = set_fixed_one(h, t, coords, cs, normals, ns, n);
+  return rc;
+}
+
+static int set_fixed_one(o_aligner* h, int si, const float* coords, int cs, const float* normals, int ns, int n) {
   o_slice* s = &h->slices[si];
-  if (s->cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_fixed on a prior slice");
   free(s->fixed);
   free(s->fixed_n);
   s->fixed   = gather(coords, cs, n, h->dim);
@@ -480,8 +515,16 @@ int oracle_aligner_set_moving(o_aligner* h, int si, const float* coords, int cs,
                               int mem) {
   if (!h || si < 0 || si >= h->nslices || n < 0 || (n > 0 && !coords)) return fail(SRRG2_E_INVALID, "set_moving");
   if (mem != SRRG2_MEM_HOST) return fail(SRRG2_E_UNSUPPORTED, "oracle takes host memory only");
+  if (h->slices[si].cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_moving on a prior slice");
+  if (h->slices[si].shares) return fail(SRRG2_E_STATE, "set_moving: this slice shares the clouds of another slice");
+  int rc = set_moving_one(h, si, coords, cs, normals, ns, n);
+  for (int t = 0; t < h->nslices && !rc; ++t)
+    if (h->slices[t].shares == si + 1) rc = set_moving_one(h, t, coords, cs, normals, ns, n);
+  return rc;
+}
+
+static int set_moving_one(o_aligner* h, int si, const float* coords, int cs, const float* normals, int ns, int n) {
   o_slice* s = &h->slices[si];
-  if (s->cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_moving on a prior slice");
   free(s->moving);
   free(s->moving_n);
   s->moving   = gather(coords, cs, n, h->dim);

@@ -72,6 +72,7 @@ int oracle_aligner_set_termination(o_aligner* h, const srrg2_termination_params*
 int oracle_aligner_add_slice(o_aligner* h, const srrg2_slice_config* c, int* slice_idx_out);
 int oracle_aligner_clear_slices(o_aligner* h);
 int oracle_aligner_set_robustifier(o_aligner* h, int slice_idx, int kind, float chi_threshold);
+int oracle_aligner_share_clouds(o_aligner* h, int slice_idx, int source_slice_idx);
 int oracle_aligner_set_fixed(o_aligner* h, int slice_idx, const float* coords, int coord_stride_bytes,
                              const float* normals, int normal_stride_bytes, int n, int mem);
 int oracle_aligner_set_moving(o_aligner* h, int slice_idx, const float* coords, int coord_stride_bytes,

@@ -165,6 +165,12 @@ class MultiAligner:
         self._check(self._b.fn("get_tuning")(self._h, C.byref(t)))
         return t
 
+    def share_clouds(self, slice_idx, source_slice_idx):
+        """slice ``slice_idx`` reads the fixed and moving clouds of ``source_slice_idx`` (no copy; -1: its own again): the
+        reference's slices find their clouds by name in the scene, two slices with the same names bind to the same clouds
+        (aligner_slice_processor_base_impl.cpp:27-50)"""
+        self._check(self._b.fn("share_clouds")(self._h, C.c_int(slice_idx), C.c_int(source_slice_idx)))
+
     def set_tuning(self, **knobs):
         """change strategy knobs by name (fields of srrg2_aligner_tuning); results do not depend on them"""
         t = self.tuning()

@@ -53,6 +53,7 @@ struct Slice {
   int probe_n   = 0;
   bool has_fixed  = false;
   bool fixed_has_normals = false;
+  int alias_of = -1;  // this slice reads the clouds of that slice (srrg2_aligner_share_clouds); -1: its own
   // moving cloud(s)
   DevBuf<float4> moving, moving_nrm;          // Morton-sorted per problem, .w = caller's index
   DevBuf<float4> moving_raw, moving_nrm_raw;  // ingest order
@@ -644,6 +645,24 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // aligner_slice_processor_prior_impl.cpp:11-22)
   int max_nm = 0;
   std::vector<ProblemDev> probs((size_t) K);
+  for (int si = 0; si < nslices; ++si) {  // slices that share another slice's clouds: views of its buffers, its sizes
+    Slice* s = a->slices[si];
+    if (s->alias_of < 0) continue;
+    if (s->alias_of >= nslices || a->slices[s->alias_of]->alias_of >= 0 || a->slices[s->alias_of]->cfg.kind == SRRG2_SLICE_PRIOR)
+      return fail(SRRG2_E_STATE, "compute: a slice shares the clouds of a slice that is gone");
+    Slice* o = a->slices[s->alias_of];
+    if (s->cfg.finder != SRRG2_FINDER_PROJECTIVE || o->cfg.finder != SRRG2_FINDER_PROJECTIVE)
+      return fail(SRRG2_E_UNSUPPORTED, "compute: shared clouds are for slices with the projective finder");
+    s->fixed_raw.borrow(o->fixed_raw);   s->fixed_nrm_raw.borrow(o->fixed_nrm_raw);
+    s->moving.borrow(o->moving);         s->moving_nrm.borrow(o->moving_nrm);
+    s->moving_raw.borrow(o->moving_raw); s->moving_nrm_raw.borrow(o->moving_nrm_raw);
+    s->pinf.borrow(o->pinf);             s->scalars.borrow(o->scalars);
+    s->nf = o->nf; s->nm_total = o->nm_total; s->has_fixed = o->has_fixed; s->has_moving = o->has_moving;
+    s->fixed_has_normals = o->fixed_has_normals; s->moving_has_normals = o->moving_has_normals;
+    s->moving_is_batch = o->moving_is_batch;
+    const size_t n = (size_t) std::max(s->nm_total, 1);
+    if ((rc = s->corr_fixed.reserve(n)) || (rc = s->corr_resp.reserve(n)) || (rc = s->corr_stat.reserve(n))) return rc;
+  }
   for (int si = 0; si < nslices; ++si) {
     Slice* s = a->slices[si];
     if (s->cfg.kind == SRRG2_SLICE_PRIOR) {
@@ -970,6 +989,18 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     if (!all_proj || proj_group.size() < 2 || proj_group.size() > 4 || (C.tune & 131072)) proj_group.clear();
   }
+  // ... and when they all read the SAME clouds (srrg2_aligner_share_clouds) through the same finder parameters, their
+  // associations are identical: one z-buffer pass and one step launch serve all of them (k_icp_step_proj_fused)
+  bool proj_fused = !proj_group.empty() && K >= 1;
+  for (size_t z = 1; z < proj_group.size() && proj_fused; ++z) {
+    const Slice* s0 = a->slices[proj_group[0]];
+    const Slice* sz = a->slices[proj_group[z]];
+    const srrg2_slice_config &c0 = s0->cfg, &cz = sz->cfg;
+    proj_fused = sz->alias_of == proj_group[0] && s0->alias_of < 0 && cz.image_rows == c0.image_rows && cz.image_cols == c0.image_cols &&
+                 cz.depth_min == c0.depth_min && cz.depth_max == c0.depth_max && cz.finder_max_distance == c0.finder_max_distance &&
+                 std::memcmp(cz.camera_matrix, c0.camera_matrix, sizeof(c0.camera_matrix)) == 0 &&
+                 std::memcmp(cz.sensor_in_robot, c0.sensor_in_robot, sizeof(c0.sensor_in_robot)) == 0;
+  }
   // Adaptive use of the deferred-search kernel.  After iteration `probe_it` the control kernel looks at what that
   // iteration deferred: few entries, none of them far (a far entry is a whole-wave scan: expensive when a wave has to do
   // several in a row) => it clears st->qmode and the step kernels finish their open points themselves from then on; it
@@ -1042,8 +1073,13 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           a->prof_used++;
           HIP_TRY(hipEventRecord(e0, a->stream));
         }
-        srrg2amd::launch_proj_step_pack(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
-        for (int si : proj_group) sdev[si].zbuf_parity ^= 1;
+        if (proj_fused) {
+          srrg2amd::launch_proj_step_fused(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
+          sdev[proj_group[0]].zbuf_parity ^= 1;  // (the one z-buffer that is used)
+        } else {
+          srrg2amd::launch_proj_step_pack(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
+          for (int si : proj_group) sdev[si].zbuf_parity ^= 1;
+        }
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
         control(it, last_phase, 0);
         continue;
@@ -1438,6 +1474,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   if (n < 0 || (n > 0 && !coords)) return fail(SRRG2_E_INVALID, "set_fixed: bad cloud");
   Slice* s = a->slices[si];
   if (s->cfg.kind == SRRG2_SLICE_PRIOR) return fail(SRRG2_E_INVALID, "set_fixed on a prior slice: use set_prior_measurement");
+  if (s->alias_of >= 0) return fail(SRRG2_E_STATE, "set_fixed: this slice shares the clouds of another slice (share_clouds): set them there");
   if ((rc = set_device(a))) return rc;
   if ((rc = quiesce_stream2(a))) return rc;
   if (a->records_state == 1) a->records_state = 2;
@@ -1472,9 +1509,44 @@ int srrg2_aligner_set_moving(srrg2_aligner_h a, int si, const float* coords, int
   if (n < 0 || (n > 0 && !coords)) return fail(SRRG2_E_INVALID, "set_moving: bad cloud");
   if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR)
     return fail(SRRG2_E_INVALID, "set_moving on a prior slice: use set_prior_measurement");
+  if (a->slices[si]->alias_of >= 0)
+    return fail(SRRG2_E_STATE, "set_moving: this slice shares the clouds of another slice (share_clouds): set them there");
   if ((rc = set_device(a))) return rc;
   const int32_t offsets[2] = {0, n};
   return upload_moving(a, si, coords, cs, normals, ns, offsets, 1, mem);
+}
+
+int srrg2_aligner_share_clouds(srrg2_aligner_h a, int si, int source) {
+  int rc = check_slice(a, si, "share_clouds");
+  if (rc) return rc;
+  if (source == -1) {  // back to clouds of its own (to be set again)
+    Slice* s = a->slices[si];
+    if (s->alias_of >= 0) {
+      s->alias_of = -1;
+      s->fixed_raw.release(); s->fixed_nrm_raw.release(); s->moving.release(); s->moving_nrm.release();
+      s->moving_raw.release(); s->moving_nrm_raw.release(); s->pinf.release(); s->scalars.release();
+      s->has_fixed = s->has_moving = false;
+      s->nf = s->nm_total = 0;
+    }
+    return 0;
+  }
+  if ((rc = check_slice(a, source, "share_clouds"))) return rc;
+  Slice *s = a->slices[si], *o = a->slices[source];
+  if (si == source || s->cfg.kind == SRRG2_SLICE_PRIOR || o->cfg.kind == SRRG2_SLICE_PRIOR)
+    return fail(SRRG2_E_INVALID, "share_clouds: two different cue slices");
+  if (o->alias_of >= 0) return fail(SRRG2_E_INVALID, "share_clouds: the source slice shares another slice's clouds itself");
+  for (Slice* t : a->slices)
+    if (t->alias_of == si) return fail(SRRG2_E_INVALID, "share_clouds: other slices share this slice's clouds");
+  if (s->cfg.finder != SRRG2_FINDER_PROJECTIVE || o->cfg.finder != SRRG2_FINDER_PROJECTIVE)
+    return fail(SRRG2_E_UNSUPPORTED, "share_clouds: both slices must use the projective finder");
+  if ((rc = set_device(a)) || (rc = quiesce_stream2(a))) return rc;
+  HIP_TRY(hipStreamSynchronize(a->stream));
+  s->alias_of = source;
+  // (its own copies, if any, are dropped: from now on it views the source's buffers, re-borrowed at every compute())
+  s->fixed_raw.release(); s->fixed_nrm_raw.release(); s->moving.release(); s->moving_nrm.release();
+  s->moving_raw.release(); s->moving_nrm_raw.release(); s->pinf.release(); s->scalars.release();
+  if (a->records_state == 1) a->records_state = 2;
+  return 0;
 }
 
 int srrg2_aligner_set_point_shard(srrg2_aligner_h a, srrg2_reduce_fn fn, void* user, int64_t total_moving_points) {
@@ -1590,6 +1662,11 @@ static int fetch_dense(srrg2_aligner* a, int si, std::vector<int>& cf, std::vect
     return 0;
   }
   if ((rc = materialize_records(a))) return rc;
+  if (s->alias_of >= 0 && s->alias_of < (int) a->slices.size()) {  // (the owner may have re-allocated its clouds since)
+    Slice* o = a->slices[s->alias_of];
+    s->moving.borrow(o->moving);
+    s->nm_total = std::min(s->nm_total, o->nm_total);
+  }
   // problem K-1 of the last run
   int moff = 0, nm = s->nm_total;
   if (a->K > 1) {

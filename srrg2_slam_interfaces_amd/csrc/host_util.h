@@ -13,9 +13,22 @@ int fail(int code, const std::string& msg);
 
 template <typename T>
 struct DevBuf {
-  T* p       = nullptr;
-  size_t cap = 0;  // elements
+  T* p          = nullptr;
+  size_t cap    = 0;      // elements
+  bool borrowed = false;  // p belongs to another DevBuf (a slice that shares the clouds of another slice)
+  // view of another buffer: no ownership; the lender must outlive the use (re-borrowed at every compute())
+  void borrow(const DevBuf<T>& o) {
+    if (!borrowed) release();
+    p        = o.p;
+    cap      = o.cap;
+    borrowed = o.p != nullptr;
+  }
   int reserve(size_t n) {
+    if (borrowed) {
+      p        = nullptr;
+      cap      = 0;
+      borrowed = false;
+    }
     if (n <= cap) return 0;
     if (p) (void) hipFree(p);
     p   = nullptr;
@@ -27,9 +40,10 @@ struct DevBuf {
     return 0;
   }
   void release() {
-    if (p) (void) hipFree(p);
-    p   = nullptr;
-    cap = 0;
+    if (p && !borrowed) (void) hipFree(p);
+    p        = nullptr;
+    cap      = 0;
+    borrowed = false;
   }
 };
 

@@ -47,6 +47,9 @@ int icp_queue_blocks(int max_nm, int K);
 // projective slices: z-buffer reset + z-buffer kernel + step kernel (one ICP iteration of the slice)
 void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
                            int max_nm, hipStream_t s);
+// ... sharing clouds and finder parameters: one z-buffer pass and one step launch for all of them
+void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
+                            int max_nm, hipStream_t s);
 void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                       int max_ncorr, hipStream_t s);
 void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,

@@ -3102,6 +3102,133 @@ __device__ __forceinline__ void step_proj_body(const SliceDev& S, const ProblemD
   block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, 1);
 }
 
+// Projective slices that SHARE their clouds and their finder parameters (srrg2_aligner_share_clouds: in the reference two
+// slices with the same fixed_slice_name / moving_slice_name read the same cloud objects of the scene,
+// aligner_slice_processor_base_impl.cpp:27-50) also share their association: every slice's finder would project the same
+// points with the same transform into an identical z-buffer.  ONE z-buffer pass (the first slice's) and ONE step launch:
+// a thread projects its point, reads the z-buffer and the matched pixel once and evaluates every slice's factor rows in
+// turn (own robustifier, own normal gate, own exponent), each reduced into that slice's slot sets.  Same pixel, same
+// gates, same rows per slice => the same bits as the slices run one by one; C3 moves 36 instead of 68 MB per iteration.
+__global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int nslices, ProblemState* __restrict__ states) {
+  constexpr int D     = 6;
+  const SliceDev& S0  = P.s[0];  // the association is the first slice's
+  const int prob      = blockIdx.y;
+  ProblemState* st    = &states[prob];
+  {  // ping-pong reset of the (one) z-buffer, as in step_proj_body
+    const size_t npix        = (size_t) S0.rows * S0.cols;
+    unsigned long long* next = S0.zbuf + ((size_t) (1 - S0.zbuf_parity) * gridDim.y + prob) * npix;
+    for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < npix; k += (size_t) gridDim.x * blockDim.x)
+      next[k] = ~0ull;
+  }
+  if (st->done || st->finished) return;
+  const ProblemDev pd = P.probs[0][prob];
+  float T[12];
+  finder_transform3(S0, st, T);
+  const unsigned long long* zcur = S0.zbuf + ((size_t) S0.zbuf_parity * gridDim.y + prob) * S0.rows * S0.cols;
+  const float kk = S0.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
+  const int i    = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inr = i < pd.nm;
+  const int gi   = pd.moff + (inr ? i : 0);
+  float4 p       = make_float4(NAN, 0.f, 0.f, 0.f);
+  if (inr) p = S0.mpts[gi];
+  const int ci      = __float_as_int(p.w);
+  const bool active = inr && finite3(p.x, p.y, p.z);
+  const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+  const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+  const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+  float u, v;
+  int pix = -1;
+  if (active) pix = project_point(S0, qx, qy, qz, u, v);
+  const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) ci;
+  bool found0 = false;
+  float4 f    = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pix >= 0 && zcur[pix] == key) {
+    f      = S0.fixed_org[pix];
+    found0 = finite3(f.x, f.y, f.z);
+  }
+  const float dd = fabsf(f.z - qz);
+  {
+    const float dx = f.x - qx, dy = f.y - qy, dz = f.z - qz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    const float g2 = (2.f * S0.gate) * (2.f * S0.gate);
+    found0         = found0 && dd <= S0.gate && d2 <= g2;
+  }
+  // the matched pixel's normal and the point's own normal: loaded once if any slice wants them
+  bool want_nf = false, want_nm = false;
+#pragma unroll
+  for (int z = 0; z < 4; ++z)
+    if (z < nslices) {
+      want_nf = want_nf || P.s[z].factor != SRRG2_SLICE_REPROJECTION || P.s[z].use_normal_gate;
+      want_nm = want_nm || P.s[z].use_normal_gate;
+    }
+  float4 nf = make_float4(0.f, 0.f, 0.f, 0.f), nm = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (found0 && want_nf && S0.fixed_org_nrm) nf = S0.fixed_org_nrm[pix];
+  if (found0 && want_nm && S0.mnrm) nm = S0.mnrm[gi];
+  float ndot = 0.f;
+  {
+    const float rx = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
+    const float ry = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
+    const float rz = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
+    ndot           = (nf.x * rx + nf.y * ry) + nf.z * rz;
+  }
+#pragma unroll
+  for (int z = 0; z < 4; ++z) {
+    if (z >= nslices) break;  // (uniform)
+    const SliceDev& S  = P.s[z];
+    const bool repro   = S.factor == SRRG2_SLICE_REPROJECTION;
+    const double scale = dm::pow2(st->kexp[S.slice_idx]);
+    const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+    bool found         = found0;
+    // (a slice without normals of its own kind sees zeros, as step_proj_body does)
+    const float4 nfz = (!repro || S.use_normal_gate) ? nf : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (S.use_normal_gate) found = found && ndot > S.normal_cos;
+    long long acc[ACC_N];
+    uint8_t fstat;
+    if (repro) {
+      float J[2][D], e[2], m[2][3];
+      bool valid     = f.z > 0.f;
+      const float uq = (S.K[0] * qx) / qz + S.K[2], vq = (S.K[4] * qy) / qz + S.K[5];
+      const float uf = (S.K[0] * f.x) / f.z + S.K[2], vf = (S.K[4] * f.y) / f.z + S.K[5];
+      e[0]           = valid ? uq - uf : 0.f;
+      e[1]           = valid ? vq - vf : 0.f;
+      if (!(fabsf(e[0]) <= PIX_BOUND) || !(fabsf(e[1]) <= PIX_BOUND)) valid = false;
+      const float iz = 1.0f / qz;
+      const float g[2][3] = {{S.K[0] * iz, 0.f, -(((S.K[0] * qx) * iz) * iz)},
+                             {0.f, S.K[4] * iz, -(((S.K[4] * qy) * iz) * iz)}};
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m[r][k] = (T[0 * 4 + k] * g[r][0] + T[1 * 4 + k] * g[r][1]) + T[2 * 4 + k] * g[r][2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        J[r][0] = m[r][0]; J[r][1] = m[r][1]; J[r][2] = m[r][2];
+        J[r][3] = kk * (p.y * m[r][2] - p.z * m[r][1]);
+        J[r][4] = kk * (p.z * m[r][0] - p.x * m[r][2]);
+        J[r][5] = kk * (p.x * m[r][1] - p.y * m[r][0]);
+      }
+      fstat = factor_accumulate_flat<D, 2, true>(J, e, found, rk, S.robust_thr, scale, acc, valid);
+    } else {
+      float J[1][D], e[1], m[3];
+      e[0] = (nfz.x * (qx - f.x) + nfz.y * (qy - f.y)) + nfz.z * (qz - f.z);
+      m[0] = (T[0] * nfz.x + T[4] * nfz.y) + T[8] * nfz.z;
+      m[1] = (T[1] * nfz.x + T[5] * nfz.y) + T[9] * nfz.z;
+      m[2] = (T[2] * nfz.x + T[6] * nfz.y) + T[10] * nfz.z;
+      J[0][0] = m[0]; J[0][1] = m[1]; J[0][2] = m[2];
+      J[0][3] = kk * (p.y * m[2] - p.z * m[1]);
+      J[0][4] = kk * (p.z * m[0] - p.x * m[2]);
+      J[0][5] = kk * (p.x * m[1] - p.y * m[0]);
+      fstat = factor_accumulate_flat<D, 1, true>(J, e, found, rk, S.robust_thr, scale, acc, true);
+    }
+    if (inr) {
+      S.corr_fixed[gi] = found ? pix : -1;
+      S.corr_resp[gi]  = found ? dd : 0.f;
+      S.corr_stat[gi]  = fstat;
+    }
+    if (z > 0) __syncthreads();  // (the reduction's scratch in LDS is the previous slice's until every thread has left it)
+    block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, 1);
+  }
+}
+
 template <bool REPRO>
 __global__ __launch_bounds__(256) void k_icp_step_proj(SliceDev S, const ProblemDev* __restrict__ probs,
                                                        ProblemState* __restrict__ states) {
@@ -3934,6 +4061,20 @@ void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* prob
   dim3 grid(icp_step_blocks(max_nm), K, nslices);
   hipLaunchKernelGGL(k_proj_zbuf_pack, grid, dim3(256), 0, s, P, states);
   hipLaunchKernelGGL(k_icp_step_proj_pack, grid, dim3(256), 0, s, P, states);
+}
+
+// the projective slices of one aligner that share clouds and finder parameters: ONE z-buffer pass, ONE step launch
+void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
+                            int max_nm, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0 || nslices <= 0 || nslices > 4) return;
+  SlicePack P;
+  for (int z = 0; z < 4; ++z) {
+    P.s[z]     = slices[z < nslices ? z : 0];
+    P.probs[z] = probs[z < nslices ? z : 0];
+  }
+  dim3 grid(icp_step_blocks(max_nm), K);
+  hipLaunchKernelGGL(k_proj_zbuf, grid, dim3(256), 0, s, P.s[0], P.probs[0], states);
+  hipLaunchKernelGGL(k_icp_step_proj_fused, grid, dim3(256), 0, s, P, nslices, states);
 }
 
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,

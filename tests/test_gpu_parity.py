@@ -264,6 +264,67 @@ def test_c3_full_resolution_two_slices(oracle, product):
     assert runs[1].iteration_stats()[-1]["num_correspondences"] > 400000  # both slices count
 
 
+@pytest.mark.parametrize("variant", ["c3", "three slices, normal gate, robust kernels, inlier-only run", "different gates"])
+def test_projective_slices_sharing_their_clouds(oracle, product, variant):
+    """srrg2_aligner_share_clouds: two slices that read the same clouds (in the reference: the same fixed_slice_name /
+    moving_slice_name, aligner_slice_processor_base_impl.cpp:27-50) and agree on their finder parameters share ONE
+    association pass per iteration (k_icp_step_proj_fused).  The oracle runs every slice's own finder, as the reference
+    does: same correspondences, statistics and estimate, bit for bit -- also with a third slice, a normal gate on one of
+    them, different robustifiers and the inlier-only second run; slices with different gates share the clouds but not
+    the association (the unfused launch pair)."""
+    from helpers import projective_config
+
+    kind = abi.SE3_QUAT_RIGHT
+    rows, cols = (480, 640) if variant == "c3" else (120, 160)
+    d = syn.rgbd_pair(rows=rows, cols=cols, seed=3000 if variant == "c3" else 3300)
+    if variant == "c3":
+        cfgs = [projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05), projective_config(kind, abi.SLICE_REPROJECTION, d, gate=0.05)]
+        params = dict(max_iterations=10)
+    elif variant == "different gates":
+        cfgs = [projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05), projective_config(kind, abi.SLICE_REPROJECTION, d, gate=0.08)]
+        params = dict(max_iterations=5)
+    else:
+        cfgs = [projective_config(kind, abi.SLICE_REPROJECTION, d, gate=0.05, robust=abi.ROBUST_CAUCHY, thr=2.0),
+                projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05, robust=abi.ROBUST_SATURATED, thr=1e-4, normal_cos=0.9),
+                projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05)]
+        params = dict(max_iterations=4, min_num_inliers=10, enable_inlier_only_runs=True, keep_only_inlier_correspondences=True)
+    runs = []
+    for al in _pair(oracle, product, kind):
+        al.set_params(**params)
+        for k, c in enumerate(cfgs):
+            si = al.add_slice(c)
+            if k == 0:
+                al.set_fixed(si, d["fixed"], d["fixed_normals"])
+                al.set_moving(si, d["moving"], d["moving_normals"])
+            else:
+                al.share_clouds(si, 0)
+                with pytest.raises(Exception):  # (the clouds are the source's to set)
+                    al.set_moving(si, d["moving"], d["moving_normals"])
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+        runs.append(al)
+    assert runs[0].status() == abi.SUCCESS
+    assert_same_run(runs[0], runs[1], slices=tuple(range(len(cfgs))))
+    # ... and the same bits as a product aligner whose slices each hold their own copy of the clouds
+    own = product.MultiAligner(kind)
+    own.set_params(**params)
+    for c in cfgs:
+        si = own.add_slice(c)
+        own.set_fixed(si, d["fixed"], d["fixed_normals"])
+        own.set_moving(si, d["moving"], d["moving_normals"])
+    own.set_moving_in_fixed(syn.identity(3))
+    own.compute()
+    assert own.moving_in_fixed().tobytes() == runs[1].moving_in_fixed().tobytes()
+    assert own.information().tobytes() == runs[1].information().tobytes()
+    # a new moving cloud on the source serves the sharing slices too
+    runs[1].set_moving(0, d["moving"][::2], d["moving_normals"][::2])
+    runs[0].set_moving(0, d["moving"][::2], d["moving_normals"][::2])
+    for al in runs:
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+    assert_same_run(runs[0], runs[1], slices=tuple(range(len(cfgs))))
+
+
 @pytest.mark.parametrize("offset", [0.0, 900.0, -7000.0])
 @pytest.mark.parametrize("cell", [0.0, 0.05, 0.4])
 def test_ball_trimmed_search_is_exact(oracle, product, offset, cell):

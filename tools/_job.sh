@@ -2,18 +2,17 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$R/gpurun_out/r4q; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_tuning.py -x -q -m gpu > $O/pytest_gpu.txt 2>&1
-tail -3 $O/pytest_gpu.txt
-bash tools/ab_env.sh $O/ab.txt "--workload c4 --batch 256 --steps 10 --warmup 2" "-" "-"
-bash tools/ab_env.sh $O/ab.txt "--workload c4 --batch 32 --steps 30 --warmup 3" "-" "-"
-bash tools/ab_env.sh $O/ab.txt "--workload c4 --batch 8 --steps 30 --warmup 3" "-"
-bash tools/ab_env.sh $O/ab.txt "--workload c2 --steps 200 --warmup 20" "-" "-"
-cat $O/ab.txt
+O=$R/gpurun_out/r4r; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sharing or c3 or projective" > $O/pytest_gpu.txt 2>&1
+tail -5 $O/pytest_gpu.txt
+python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline --c3-own-clouds | cut -c1-160
+python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline | cut -c1-160
+python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline --c3-own-clouds | cut -c1-160
+python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-baseline | cut -c1-160
 cd /tmp
-B="--workload c4 --batch 256 --steps 1 --warmup 1 --no-cpu-baseline"
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d /tmp/p256a -o p -- python $R/bench.py $B > /dev/null 2>&1
-python $R/tools/iter_durations.py $(find /tmp/p256a -name '*.db' | head -1) 10 > $O/c4_256_passes.txt
-SRRG2_AMD_BATCH_PIPELINE=0 timeout 600 rocprofv3 --kernel-trace -d /tmp/tr256 -o t -- python $R/bench.py --workload c4 --batch 256 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-python $R/tools/iter_durations.py $(find /tmp/tr256 -name '*.db' | head -1) 10 >> $O/c4_256_passes.txt
-cat $O/c4_256_passes.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c3_$c -o p -- python $R/bench.py --workload c3 --steps 205 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+done
+python $R/tools/traffic_from_pmc.py $O/traffic_c3.json c3 $(find /tmp/pmc_c3_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c3_WRITE_SIZE -name '*.db' | head -1) | head -30
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c3 -o t -- python $R/bench.py --workload c3 --steps 205 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/rocpd_summary.py $O/rocprofv3_c3_summary.txt kernel_trace_stats=$(find /tmp/tr_c3 -name '*.db' | head -1); head -8 $O/rocprofv3_c3_summary.txt | cut -c1-140

@@ -9,7 +9,7 @@ import json
 import sqlite3
 import sys
 
-KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_fast<", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")
+KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_fast<", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")  # (k_icp_step_proj_fused matches k_icp_step_proj)
 
 
 def per_kernel(db, counter):
