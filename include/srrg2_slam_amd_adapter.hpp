@@ -411,6 +411,20 @@ namespace srrg2_slam_interfaces {
           amd_detail::check(srrg2_aligner_set_prior_measurement(_h, (int) i, Z));
         } else if (_clouds_changed) {
           const CueBinding& b = cues[i];
+          // two slices bound to the SAME cloud objects of the scene (same fixed_slice_name / moving_slice_name,
+          // aligner_slice_processor_base_impl.cpp:27-50): the later one reads the earlier one's device copy (projective
+          // finders; with equal finder parameters they then share one association pass per iteration)
+          int shares = -1;
+          for (size_t j = 0; j < i && shares < 0; ++j)
+            if (configs[j].kind != SRRG2_SLICE_PRIOR && configs[j].finder == SRRG2_FINDER_PROJECTIVE &&
+                configs[i].finder == SRRG2_FINDER_PROJECTIVE && cues[j].fixed_coords == b.fixed_coords &&
+                cues[j].moving_coords == b.moving_coords && cues[j].fixed_size == b.fixed_size && cues[j].moving_size == b.moving_size)
+              shares = (int) j;
+          if (shares >= 0) {
+            amd_detail::check(srrg2_aligner_share_clouds(_h, (int) i, shares));
+            continue;
+          }
+          amd_detail::check(srrg2_aligner_share_clouds(_h, (int) i, -1));
           amd_detail::check(srrg2_aligner_set_fixed(_h, (int) i, b.fixed_coords, b.fixed_stride, b.fixed_normals, b.fixed_stride,
                                                     b.fixed_size, SRRG2_MEM_HOST));
           amd_detail::check(srrg2_aligner_set_moving(_h, (int) i, b.moving_coords, b.moving_stride, b.moving_normals,

@@ -27,6 +27,8 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c4_256 -o t -- python $R
 python $R/tools/rocpd_summary.py $O/rocprofv3_c4_256_summary.txt kernel_trace_stats=$(find /tmp/tr_c4_256 -name '*.db' | head -1)
 SRRG2_AMD_PG_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c5 -o t -- python $R/tools/bench_posegraph.py > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $O/rocprofv3_c5_summary.txt kernel_trace_stats=$(find /tmp/tr_c5 -name '*.db' | head -1)
+timeout 600 rocprofv3 --kernel-trace -d /tmp/tr32 -o t -- python $R/bench.py --workload c4 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/batch_timeline.py $(find /tmp/tr32 -name '*.db' | head -1) > $O/timeline_c4_32_pipelined.txt
 python $R/tools/trace_steps.py $(find /tmp/tr_c2 -name '*.db' | head -1) > $O/trace_c2_steps.txt 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c3_$c -o p -- python $R/bench.py --workload c3 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -38,6 +40,13 @@ python $R/tools/traffic_from_pmc.py $O/traffic_c3.json c3 $(find /tmp/pmc_c3_FET
 python $R/tools/traffic_from_pmc.py $O/traffic_c2.json c2 $(find /tmp/pmc_c2_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c2_WRITE_SIZE -name '*.db' | head -1)
 python $R/tools/traffic_from_pmc.py $O/traffic_c4.json c4 $(find /tmp/pmc_c4_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c4_WRITE_SIZE -name '*.db' | head -1) 32
 python $R/tools/traffic_from_pmc.py $O/traffic_c4_256.json c4 $(find /tmp/pmc_c4_256_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c4_256_WRITE_SIZE -name '*.db' | head -1) 256
+# C5: the pose-graph kernels' counters (HIP graph off: every kernel a dispatch of its own)
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES"; do
+  n=$(echo $c | tr ' ' '_')
+  SRRG2_AMD_PG_GRAPH=0 timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_c5_$n -o p -- python $R/tools/bench_posegraph.py > /dev/null 2>&1
+  python $R/tools/rocpd_summary.py $O/pmc_c5_$n.txt $n=$(find /tmp/pmc_c5_$n -name '*.db' | head -1)
+done
+python $R/tools/traffic_c5_from_pmc.py $O/traffic_c5.json $O/pmc_c5_FETCH_SIZE.txt $O/pmc_c5_WRITE_SIZE.txt $O/pmc_c5_SQ_INSTS_VALU_SQ_WAVES.txt $O/rocprofv3_c5_summary.txt 3 10 381 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_valu -o p -- python $R/bench.py --workload c4 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $O/rocprofv3_c4_valu_pmc_summary.txt valu=$(find /tmp/pmc_valu -name '*.db' | head -1)
 # the search passes of the 256-alignment batch, pass by pass: durations, instructions, texture-path and LDS activity
