@@ -312,6 +312,36 @@ struct MgLevel {  // device view of one level (level 0 = the pose graph without 
   double *x, *r, *res;          // [n][D] work vectors of the cycle
 };
 
+// A level and the next coarser one, BY VALUE in the kernel's arguments: pointers that come out of the argument segment are
+// global pointers to the compiler (global_load / global_store); a pointer loaded from a record in device memory is a GENERIC
+// one, every access through it a flat_load / flat_store -- issued to the LDS path as well and counted in both wait counters
+// (round 4: 1 981 flat against 376 global accesses in this file) -- and the record itself a dependent load in front of the
+// kernel's first useful one.
+struct MgPair {
+  MgLevel L, C;
+};
+
+// (k_mg_coarse_cycle walks several small levels inside one workgroup and reads their records from device memory)
+template <typename T>
+__device__ __forceinline__ T* mg_glob(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the builtins exist in the device pass only)
+  __builtin_assume(!__builtin_amdgcn_is_shared((const void*) p) & !__builtin_amdgcn_is_private((const void*) p));
+#endif
+  return p;
+}
+__device__ __forceinline__ MgLevel mg_level(const MgLevel* __restrict__ levels, int l) {
+  MgLevel L = levels[l];
+  L.eij = mg_glob(L.eij); L.inc_start = mg_glob(L.inc_start); L.inc_adj = mg_glob(L.inc_adj);
+  L.agg = mg_glob(L.agg); L.rep0 = mg_glob(L.rep0); L.prow_start = mg_glob(L.prow_start); L.pcol = mg_glob(L.pcol);
+  L.prow_of = mg_glob(L.prow_of); L.pcsc_start = mg_glob(L.pcsc_start); L.pcsc_ent = mg_glob(L.pcsc_ent);
+  L.qrow_start = mg_glob(L.qrow_start); L.qcol = mg_glob(L.qcol); L.qrow_of = mg_glob(L.qrow_of);
+  L.Hd = mg_glob(L.Hd); L.Ho = mg_glob(L.Ho); L.P = mg_glob(L.P); L.Ps = mg_glob(L.Ps); L.Q = mg_glob(L.Q); L.Dinv = mg_glob(L.Dinv);
+  L.Hdf = mg_glob(L.Hdf); L.Hof = mg_glob(L.Hof); L.Dinvf = mg_glob(L.Dinvf); L.Psf = mg_glob(L.Psf); L.Qf = mg_glob(L.Qf);
+  L.qcsc_start = mg_glob(L.qcsc_start); L.qcsc_ent = mg_glob(L.qcsc_ent); L.pcsc2 = mg_glob(L.pcsc2); L.qcsc2 = mg_glob(L.qcsc2);
+  L.x = mg_glob(L.x); L.r = mg_glob(L.r); L.res = mg_glob(L.res);
+  return L;
+}
+
 // sum of w over the `parts` adjacent lanes that share an output (fixed butterfly: deterministic; every lane gets the sum)
 template <int D>
 __device__ __forceinline__ void mg_group_sum(double (&w)[D], int parts) {
@@ -436,8 +466,10 @@ __device__ __forceinline__ void mg_residual(const MgLevel& L, int tid, int nth) 
 }
 
 // r_coarse = Ps^T res   (`col_parts` adjacent lanes share a column of Ps: a coarse node interpolates to 30-250 fine ones)
-template <int D>
-__device__ __forceinline__ void mg_restrict(const MgLevel& L, double* __restrict__ rc, int tid, int nth) {
+// (BT: the float32 copy of Ps wherever the level has one -- the same copy in the restriction and the prolongation, so the
+// cycle stays symmetric; level 0's two passes over Ps were 2 x 58 MB of float64 blocks per cycle on C5)
+template <int D, typename BT>
+__device__ __forceinline__ void mg_restrict_t(const MgLevel& L, const BT* __restrict__ Ps, double* __restrict__ rc, int tid, int nth) {
   const int parts = L.col_parts;
   for (int t = tid; t < L.nc * D * parts; t += nth) {
     const int part = t & (parts - 1), u = t / parts;
@@ -445,32 +477,42 @@ __device__ __forceinline__ void mg_restrict(const MgLevel& L, double* __restrict
     double s = 0.0;
     for (int m = L.pcsc_start[I] + part; m < L.pcsc_start[I + 1]; m += parts) {
       const int e = L.pcsc_ent[m], i = L.prow_of[e];
-      const double* B = L.Ps + (size_t) e * D * D;
+      const BT* B = Ps + (size_t) e * D * D;
 #pragma unroll
-      for (int b = 0; b < D; ++b) s = s + B[b * D + a] * L.res[(size_t) i * D + b];
+      for (int b = 0; b < D; ++b) s = s + (double) B[b * D + a] * L.res[(size_t) i * D + b];
     }
     for (int off = parts >> 1; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
     if (part == 0) rc[u] = s;
   }
 }
+template <int D>
+__device__ __forceinline__ void mg_restrict(const MgLevel& L, double* __restrict__ rc, int tid, int nth) {
+  if (L.Psf) mg_restrict_t<D, float>(L, L.Psf, rc, tid, nth);
+  else mg_restrict_t<D, double>(L, L.Ps, rc, tid, nth);
+}
 
 // x += Ps x_coarse   (`prow_parts` adjacent lanes share a row of Ps)
-template <int D>
-__device__ __forceinline__ void mg_prolong(const MgLevel& L, const double* __restrict__ xc, int tid, int nth) {
+template <int D, typename BT>
+__device__ __forceinline__ void mg_prolong_t(const MgLevel& L, const BT* __restrict__ Ps, const double* __restrict__ xc, int tid, int nth) {
   const int parts = L.prow_parts;
   for (int t = tid; t < L.n * D * parts; t += nth) {
     const int part = t & (parts - 1), u = t / parts;
     const int v = u / D, row = u - v * D;
     double s = 0.0;
     for (int e = L.prow_start[v] + part; e < L.prow_start[v + 1]; e += parts) {
-      const double* B  = L.Ps + (size_t) e * D * D;
+      const BT* B      = Ps + (size_t) e * D * D;
       const double* xo = xc + (size_t) L.pcol[e] * D;
 #pragma unroll
-      for (int a = 0; a < D; ++a) s = s + B[row * D + a] * xo[a];
+      for (int a = 0; a < D; ++a) s = s + (double) B[row * D + a] * xo[a];
     }
     for (int off = parts >> 1; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
     if (part == 0) L.x[u] = L.x[u] + s;
   }
+}
+template <int D>
+__device__ __forceinline__ void mg_prolong(const MgLevel& L, const double* __restrict__ xc, int tid, int nth) {
+  if (L.Psf) mg_prolong_t<D, float>(L, L.Psf, xc, tid, nth);
+  else mg_prolong_t<D, double>(L, L.Ps, xc, tid, nth);
 }
 
 // x += omega Dinv res   (res = r - H x computed by mg_residual beforehand: Jacobi, no race)
@@ -500,15 +542,15 @@ enum { MG_OP_SMOOTH0 = 0, MG_OP_RESIDUAL = 1, MG_OP_RESTRICT = 2, MG_OP_PROLONG 
 
 // one phase of the cycle on one (large) level
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_op(int op, const MgLevel* __restrict__ levels, int l,
+__global__ __launch_bounds__(PG_THREADS) void k_mg_op(int op, MgPair LV,
                                                       const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const MgLevel L = levels[l];
+  const MgLevel L = LV.L;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
   if (op == MG_OP_SMOOTH0) mg_smooth0<D>(L, tid, nth);
   else if (op == MG_OP_RESIDUAL) mg_residual<D>(L, tid, nth);
-  else if (op == MG_OP_RESTRICT) mg_restrict<D>(L, levels[l + 1].r, tid, nth);
-  else if (op == MG_OP_PROLONG) mg_prolong<D>(L, levels[l + 1].x, tid, nth);
+  else if (op == MG_OP_RESTRICT) mg_restrict<D>(L, LV.C.r, tid, nth);
+  else if (op == MG_OP_PROLONG) mg_prolong<D>(L, LV.C.x, tid, nth);
   else mg_update<D>(L, tid, nth);
 }
 
@@ -581,11 +623,11 @@ __device__ __forceinline__ void mg_down2_column(const MgLevel& L, int I, int tid
 }
 
 template <int D>
-__global__ __launch_bounds__(MG_DOWN2_THREADS) void k_mg_down2(const MgLevel* __restrict__ levels, int l,
+__global__ __launch_bounds__(MG_DOWN2_THREADS) void k_mg_down2(MgPair LV,
                                                                const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const MgLevel L = levels[l];
-  const MgLevel C = levels[l + 1];
+  const MgLevel L = LV.L;
+  const MgLevel C = LV.C;
   const int I     = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NW = MG_DOWN2_THREADS / 64;
@@ -625,11 +667,11 @@ __global__ __launch_bounds__(MG_DOWN2_THREADS) void k_mg_down2(const MgLevel* __
 // and load latency per cycle (profiles/r3p_*).  A wave per coarsest node, the waves meet in LDS, 8 lanes share a row of
 // the dense inverse.
 template <int D>
-__global__ __launch_bounds__(1024) void k_mg_down2_coarsest(const MgLevel* __restrict__ levels, int l, const double* __restrict__ Cinv,
+__global__ __launch_bounds__(1024) void k_mg_down2_coarsest(MgPair LV, const double* __restrict__ Cinv,
                                                             const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const MgLevel L = levels[l];
-  const MgLevel C = levels[l + 1];
+  const MgLevel L = LV.L;
+  const MgLevel C = LV.C;
   __shared__ double rc[MG_FUSE_LAST_NODES * D];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = C.n * D;
@@ -702,11 +744,11 @@ __device__ __forceinline__ void mg_block_mul(const float* __restrict__ B, const 
 // A node owns NL = 8 * parts adjacent lanes; every lane takes WHOLE blocks of the node's rows of H, Q and Ps (all D rows
 // of the result from one 144-byte load, two blocks in flight), the lanes of a node meet by shuffles.
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_up2(const MgLevel* __restrict__ levels, int l, int parts, int xc_in_res,
+__global__ __launch_bounds__(PG_THREADS) void k_mg_up2(MgPair LV, int parts, int xc_in_res,
                                                        const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const MgLevel L = levels[l];
-  const double* __restrict__ xc = xc_in_res ? levels[l + 1].res : levels[l + 1].x;
+  const MgLevel L = LV.L;
+  const double* __restrict__ xc = xc_in_res ? LV.C.res : LV.C.x;
   const int t  = blockIdx.x * blockDim.x + threadIdx.x;
   const int NL = 8 * parts;
   const int k = t & (NL - 1), v = t / NL;
@@ -758,11 +800,11 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_up2(const MgLevel* __restrict
 
 // x += Ps x_coarse with the coarse correction taken from the coarse level's `res` (a two-phase level below a six-phase one)
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_prolong_res(const MgLevel* __restrict__ levels, int l,
+__global__ __launch_bounds__(PG_THREADS) void k_mg_prolong_res(MgPair LV,
                                                                const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const MgLevel L = levels[l];
-  mg_prolong<D>(L, levels[l + 1].res, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  const MgLevel L = LV.L;
+  mg_prolong<D>(L, LV.C.res, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // levels lf .. nl-1 (small) + the coarsest level nl in ONE workgroup: down, coarsest solve, up
@@ -773,16 +815,16 @@ __global__ __launch_bounds__(1024) void k_mg_coarse_cycle(const MgLevel* __restr
   if (sc->done || sc->bad) return;
   const int tid = threadIdx.x, nth = blockDim.x;
   for (int l = lf; l < nl; ++l) {
-    const MgLevel L = levels[l];
+    const MgLevel L = mg_level(levels, l);
     mg_smooth0<D>(L, tid, nth);
     __syncthreads();
     mg_residual<D>(L, tid, nth);
     __syncthreads();
-    mg_restrict<D>(L, levels[l + 1].r, tid, nth);
+    mg_restrict<D>(L, mg_glob(levels[l + 1].r), tid, nth);
     __syncthreads();
   }
   {
-    const MgLevel L = levels[nl];
+    const MgLevel L = mg_level(levels, nl);
     if (coarsest_dense) {
       mg_coarsest<D>(L, Cinv, tid, nth);
     } else {  // (coarsening stalled above the dense limit: smoothing only)
@@ -797,8 +839,8 @@ __global__ __launch_bounds__(1024) void k_mg_coarse_cycle(const MgLevel* __restr
     __syncthreads();
   }
   for (int l = nl - 1; l >= lf; --l) {
-    const MgLevel L = levels[l];
-    mg_prolong<D>(L, levels[l + 1].x, tid, nth);
+    const MgLevel L = mg_level(levels, l);
+    mg_prolong<D>(L, mg_glob(levels[l + 1].x), tid, nth);
     __syncthreads();
     mg_residual<D>(L, tid, nth);
     __syncthreads();
@@ -823,9 +865,9 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_pack0(int V, int ne, const in
 
 // P_i = Ad(X_i^-1 X_I): the aggregate's rigid motion seen from member i (right perturbations, rotation part = quaternion vector)
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_interp(const MgLevel* __restrict__ levels, int l, int T,
+__global__ __launch_bounds__(PG_THREADS) void k_mg_interp(MgPair LV, int T,
                                                           const float* __restrict__ poses) {
-  const MgLevel L = levels[l];
+  const MgLevel L = LV.L;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L.n) return;
   float* P = L.P + (size_t) i * D * D;
@@ -834,7 +876,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_interp(const MgLevel* __restr
   for (int k = 0; k < D * D; ++k) P[k] = 0.f;
   if (I < 0) return;
   const float* Xi = poses + (size_t) L.rep0[i] * T;
-  const float* XI = poses + (size_t) levels[l + 1].rep0[I] * T;  // (the pose of the aggregate's first member)
+  const float* XI = poses + (size_t) LV.C.rep0[I] * T;  // (the pose of the aggregate's first member)
   float Xi_inv[12], A[12];
   if (D == 6) {
     dm::se3_inverse(Xi, Xi_inv);
@@ -883,9 +925,9 @@ __device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* _
 // Piecewise-rigid interpolation alone leaves the V-cycle's convergence dependent on the number of levels (C5: 151-415 CG
 // iterations per solve); one Jacobi sweep on the interpolation removes its high-energy part (C5: ~30 iterations).
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(const MgLevel* __restrict__ levels, int l, double omega_p) {
+__global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(MgPair LV, double omega_p) {
   // one thread per (entry of Ps, part): every H block of the row is read once for the whole D x D block of the entry
-  const MgLevel L = levels[l];
+  const MgLevel L = LV.L;
   const int parts = L.row_parts;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= L.np * parts) return;  // (whole groups: the bound is a multiple of `parts`)
@@ -896,9 +938,28 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(const MgLevel* __rest
   for (int k = 0; k < D * D; ++k) w[k] = 0.0;
   const bool own = L.agg[i] == A;
   if (own && part == 0) mg_block_mac<D, false>(w, L.Hd + (size_t) i * D * D, L.P + (size_t) i * D * D);
-  for (int q = L.inc_start[i] + part; q < L.inc_start[i + 1]; q += parts) {
+  // (which incidences contribute is found first, as a bit mask: the block products then run once per CONTRIBUTING incidence of
+  // the wave's busiest lane -- inside the search loop a lane sat through the product of every incidence any lane needed)
+  const int q0 = L.inc_start[i] + part, q1 = L.inc_start[i + 1];
+  unsigned long long todo = 0;
+  for (int q = q0, b = 0; q < q1; q += parts, ++b) {
     const int2 adj = L.inc_adj[q];
     if (L.agg[adj.x] != A) continue;
+    if (b < 64) {
+      todo |= 1ull << b;
+      continue;
+    }
+    const float* Tj = L.P + (size_t) adj.x * D * D;
+    const double* B = L.Ho + (size_t) (adj.y >> 1) * D * D;
+    if (adj.y & 1)
+      mg_block_mac<D, true>(w, B, Tj);
+    else
+      mg_block_mac<D, false>(w, B, Tj);
+  }
+  while (todo) {
+    const int b = __ffsll((long long) todo) - 1;
+    todo &= todo - 1;
+    const int2 adj  = L.inc_adj[q0 + b * parts];
     const float* Tj = L.P + (size_t) adj.x * D * D;
     const double* B = L.Ho + (size_t) (adj.y >> 1) * D * D;
     if (adj.y & 1)
@@ -921,8 +982,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(const MgLevel* __rest
 // expensive part (a binary search each), so a thread does them once for the whole D x D block; `row_parts` adjacent
 // lanes share the incidences and add their blocks with the fixed butterfly.
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_hp(const MgLevel* __restrict__ levels, int l) {
-  const MgLevel L = levels[l];
+__global__ __launch_bounds__(PG_THREADS) void k_mg_hp(MgPair LV) {
+  const MgLevel L = LV.L;
   const int parts = L.row_parts;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= L.nq * parts) return;  // (whole groups: the bound is a multiple of `parts`)
@@ -956,9 +1017,9 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_hp(const MgLevel* __restrict_
 // Galerkin product, second half: Hc[A, B] = sum_i Ps[i, A]^T Q[i, B] over the rows of column A; the diagonal blocks
 // and the blocks of the coarse edges (A < B).  One thread per (coarse block, part); fixed lists, fixed order: deterministic.
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(const MgLevel* __restrict__ levels, int l) {
-  const MgLevel L = levels[l];
-  const MgLevel C = levels[l + 1];
+__global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(MgPair LV) {
+  const MgLevel L = LV.L;
+  const MgLevel C = LV.C;
   const int parts = L.col_parts;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (L.nc + L.nce) * parts) return;
@@ -991,8 +1052,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(const MgLevel* __res
 
 // inverse diagonal blocks of level l (the smoother)
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(const MgLevel* __restrict__ levels, int l, PgScalars* __restrict__ sc) {
-  const MgLevel L = levels[l];
+__global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(MgPair LV, PgScalars* __restrict__ sc) {
+  const MgLevel L = LV.L;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= L.n) return;
   double H[D * D], Mi[D * D];
@@ -1020,8 +1081,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(const MgLevel* __restric
 
 // the V-cycle's float32 copies of one level's blocks (see MgLevel)
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_to_float(const MgLevel* __restrict__ levels, int l) {
-  const MgLevel L = levels[l];
+__global__ __launch_bounds__(PG_THREADS) void k_mg_to_float(MgPair LV, int with_p, int with_q) {
+  const MgLevel L = LV.L;
   const size_t nd = (size_t) L.n * D * D, no = (size_t) L.ne * D * D;
   for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < nd || k < no; k += (size_t) gridDim.x * blockDim.x) {
     if (k < nd) {
@@ -1030,8 +1091,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_to_float(const MgLevel* __res
     }
     if (k < no) L.Hof[k] = (float) L.Ho[k];
   }
-  if (L.Psf) {
-    const size_t np = (size_t) L.np * D * D, nq = (size_t) L.nq * D * D;
+  if (L.Psf && with_p) {  // (Qf is read by the two-phase levels only: level 0's Q is 2.7 x its Ps)
+    const size_t np = (size_t) L.np * D * D, nq = with_q ? (size_t) L.nq * D * D : 0;
     for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < np || k < nq; k += (size_t) gridDim.x * blockDim.x) {
       if (k < np) L.Psf[k] = (float) L.Ps[k];
       if (k < nq) L.Qf[k] = (float) L.Q[k];
@@ -1041,13 +1102,13 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_to_float(const MgLevel* __res
 
 // dense inverse of the coarsest operator: assemble, Cholesky in place, then one thread per column solves for the inverse
 template <int D>
-__global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(const MgLevel* __restrict__ levels, int l, double* __restrict__ Aglobal,
+__global__ __launch_bounds__(1024) void k_mg_coarsest_inverse(MgPair LV, double* __restrict__ Aglobal,
                                                               double* __restrict__ Cinv, PgScalars* __restrict__ sc, int in_lds) {
   // (the factorisation is a chain of N column steps with three barriers each: with the matrix in LDS a step costs
   // ~2 us instead of ~12; the host asks for it when N x N doubles fit)
   extern __shared__ double A_lds[];
   double* __restrict__ A = in_lds ? A_lds : Aglobal;
-  const MgLevel L = levels[l];
+  const MgLevel L = LV.L;
   const int N = L.n * D, tid = threadIdx.x, nth = blockDim.x;
   for (int k = tid; k < N * N; k += nth) A[k] = 0.0;
   __syncthreads();
@@ -1233,11 +1294,11 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_update_p(int n, int nblocks, 
 
 // Ap = H p on level 0 (float32 blocks, float64 accumulation); partial p.Ap
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(const MgLevel* __restrict__ levels, const double* __restrict__ p,
+__global__ __launch_bounds__(PG_THREADS) void k_pg_spmv(MgPair LV, const double* __restrict__ p,
                                                         double* __restrict__ Ap, double* __restrict__ part_pAp,
                                                         const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
-  const MgLevel L = levels[0];
+  const MgLevel L = LV.L;
   double pap = 0.0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < L.n * D; t += gridDim.x * blockDim.x) {
     const int v = t / D, row = t - v * D;
@@ -1346,6 +1407,7 @@ struct srrg2_posegraph_s {
   std::set<int> pg_force_tentative;      // levels whose smoothed interpolation exceeded the fill limit (this build)
   std::vector<MgLevelBufs*> level_pool;  // level objects with their device buffers, kept across rebuilds
   DevBuf<MgLevel> levels_dev;
+  std::vector<MgLevel> level_views;      // host copies of the records in levels_dev (kernel arguments: MgPair)
   DevBuf<double> coarse_A, coarse_inv;
   int coarsest_dense = 1;
   // strategy knobs (srrg2_posegraph_tuning): defaults overridden by the SRRG2_AMD_PG_* environment ONCE, in
@@ -1354,7 +1416,7 @@ struct srrg2_posegraph_s {
     int match_passes = 3;       // SRRG2_AMD_PG_PASSES
     double omega_p = 0.0;       // SRRG2_AMD_PG_OMEGA_P (set to MG_OMEGA_P at create)
     double omega = 0.0;         // SRRG2_AMD_PG_OMEGA   (set to MG_OMEGA at create)
-    double lag_below = 0.0;     // SRRG2_AMD_PG_LAG
+    double lag_below = 0.05;    // SRRG2_AMD_PG_LAG
     bool two_phase = true;      // SRRG2_AMD_PG_TWO_PHASE
     bool use_graph = true;      // SRRG2_AMD_PG_GRAPH
     bool debug = false;         // SRRG2_AMD_PG_DEBUG
@@ -1876,6 +1938,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   }
   if ((rc = g->levels_dev.reserve((size_t) nl))) return rc;
   HIP_TRY(hipMemcpy(g->levels_dev.p, views.data(), sizeof(MgLevel) * (size_t) nl, hipMemcpyHostToDevice));
+  g->level_views = views;
   const size_t N = (size_t) g->levels.back()->n * D;
   if (g->coarsest_dense) {
     if ((rc = g->coarse_A.reserve(std::max<size_t>(N * N, 1))) || (rc = g->coarse_inv.reserve(std::max<size_t>(N * N, 1)))) return rc;
@@ -1910,6 +1973,12 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   const int cstride = (int) (sizeof(EdgeContrib<D>) / sizeof(double));
   const int chi_off = (int) (offsetof(EdgeContrib<D>, chi) / sizeof(double));
   MgLevelBufs* L0 = g->levels[0];
+  auto pair = [&](int l) {  // level l and the next coarser one (the coarsest level's partner is itself: never read)
+    MgPair P;
+    P.L = g->level_views[(size_t) l];
+    P.C = g->level_views[(size_t) std::min(l + 1, (int) g->level_views.size() - 1)];
+    return P;
+  };
   // first level that runs inside the single-workgroup launch
   int lf = nl;
   for (int l = 0; l < nl; ++l)  // (a small but dense level -- C5: 100 nodes, 4950 blocks -- is 1.4 MB of blocks: not for one workgroup)
@@ -1928,21 +1997,21 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   auto vcycle2 = [&]() {
     const MgLevelBufs* L0b = g->levels[0];
     const int bl0 = blocks_for(L0b->n * D), bc0 = blocks_for(L0b->nc * D * L0b->col_parts), br0 = blocks_for(L0b->n * D * L0b->row_parts);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, g->levels_dev.p, 0, g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, 0, g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(bc0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, g->levels_dev.p, 0, g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, pair(0), g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(0), g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(bc0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, pair(0), g->sc.p);
     if (lf > 1)  // x1 of level 1 (the levels below get theirs from k_mg_down2)
       hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(g->levels[1]->n * D)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0,
-                         g->levels_dev.p, 1, g->sc.p);
+                         pair(1), g->sc.p);
     // (the last two-phase level's down phase and the dense coarsest solve share a launch when the coarsest level is tiny)
     const bool fuse_last = g->coarsest_dense && lf == nl && lf >= 2 && g->levels[(size_t) nl]->n <= MG_FUSE_LAST_NODES &&
                            g->levels[(size_t) nl]->n == g->levels[(size_t) nl - 1]->nc;
     for (int l = 1; l < lf; ++l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
       if (l == lf - 1 && fuse_last)
-        hipLaunchKernelGGL(k_mg_down2_coarsest<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, l, g->coarse_inv.p, g->sc.p);
+        hipLaunchKernelGGL(k_mg_down2_coarsest<D>, dim3(1), dim3(1024), 0, g->stream, pair(l), g->coarse_inv.p, g->sc.p);
       else if (Lb->nc > 0)
-        hipLaunchKernelGGL(k_mg_down2<D>, dim3((unsigned) Lb->nc), dim3(MG_DOWN2_THREADS), 0, g->stream, g->levels_dev.p, l, g->sc.p);
+        hipLaunchKernelGGL(k_mg_down2<D>, dim3((unsigned) Lb->nc), dim3(MG_DOWN2_THREADS), 0, g->stream, pair(l), g->sc.p);
     }
     if (!fuse_last)
       hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
@@ -1950,16 +2019,16 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     for (int l = lf - 1; l >= 1; --l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
       const int pp = parts2(Lb, false);
-      hipLaunchKernelGGL(k_mg_up2<D>, dim3((unsigned) (((size_t) Lb->n * 8 * pp + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l, pp,
+      hipLaunchKernelGGL(k_mg_up2<D>, dim3((unsigned) (((size_t) Lb->n * 8 * pp + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream, pair(l), pp,
                          l + 1 < lf ? 1 : 0, g->sc.p);
     }
     const int bp0 = blocks_for(L0b->n * D * L0b->prow_parts);
     if (lf > 1)
-      hipLaunchKernelGGL(k_mg_prolong_res<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, 0, g->sc.p);
+      hipLaunchKernelGGL(k_mg_prolong_res<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, pair(0), g->sc.p);
     else
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, g->levels_dev.p, 0, g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, 0, g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, g->levels_dev.p, 0, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, pair(0), g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(0), g->sc.p);
+    hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, pair(0), g->sc.p);
   };
   auto vcycle = [&]() {
     if (two_phase && lf >= 1 && nl >= 1) {
@@ -1969,18 +2038,18 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     for (int l = 0; l < lf; ++l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
       const int bl = blocks_for(Lb->n * D), bc = blocks_for(Lb->nc * D * Lb->col_parts), br = blocks_for(Lb->n * D * Lb->row_parts);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, g->levels_dev.p, l, g->sc.p);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(br), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bc), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, pair(l), g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(br), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(l), g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bc), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, pair(l), g->sc.p);
     }
     hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
                        g->coarsest_dense, g->sc.p);
     for (int l = lf - 1; l >= 0; --l) {
       const int bl = blocks_for(g->levels[(size_t) l]->n * D), br = blocks_for(g->levels[(size_t) l]->n * D * g->levels[(size_t) l]->row_parts);
       const int bp = blocks_for(g->levels[(size_t) l]->n * D * g->levels[(size_t) l]->prow_parts);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bp), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, g->levels_dev.p, l, g->sc.p);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(br), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, g->levels_dev.p, l, g->sc.p);
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, g->levels_dev.p, l, g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bp), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, pair(l), g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(br), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(l), g->sc.p);
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bl), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, pair(l), g->sc.p);
     }
   };
   // SRRG2_AMD_PG_LAG: largest step (max |dx| over all variables) below which the next iteration keeps the hierarchy; 0 = never
@@ -2018,18 +2087,18 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       // always the fresh ones).  Lagging it while the poses still move does not precondition at all.
       const bool reuse = lag_below > 0.0 && it > 0 && hierarchy_fresh && prev_max_dx < lag_below;
       if (reuse)
-        hipLaunchKernelGGL(k_mg_to_float<D>, dim3(4096), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, 0);
+        hipLaunchKernelGGL(k_mg_to_float<D>, dim3(4096), dim3(PG_THREADS), 0, g->stream, pair(0), 0, 0);
       for (int l = 0; l < nl && !reuse; ++l) {
         MgLevelBufs* L = g->levels[(size_t) l];
         auto grid_of = [](size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); };
-        hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l, T, g->poses.p);
+        hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, pair(l), T, g->poses.p);
         hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * L->row_parts), dim3(PG_THREADS), 0, g->stream,
-                           g->levels_dev.p, l, L->smoothed ? omega_p : 0.0);
-        hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * L->row_parts), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
+                           pair(l), L->smoothed ? omega_p : 0.0);
+        hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * L->row_parts), dim3(PG_THREADS), 0, g->stream, pair(l));
         hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
-                           g->levels_dev.p, l);
+                           pair(l));
         hipLaunchKernelGGL(k_mg_dinv<D>, dim3((unsigned) ((L->nc + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
-                           g->levels_dev.p, l + 1, g->sc.p);
+                           pair(l + 1), g->sc.p);
       }
       if (g->coarsest_dense && !reuse) {
         const size_t Nc       = (size_t) g->levels[(size_t) nl]->n * D;
@@ -2039,8 +2108,8 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         // 2: factor and L^-1 in LDS (row-sweep inverse); 1: factor in LDS; 0: everything in global memory
         const int in_lds = !lds_ok ? 0 : (2 * lds_need <= 150 * 1024 ? 2 : (lds_need <= 150 * 1024 ? 1 : 0));
         if (!lds_ok) (void) hipGetLastError();
-        hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), (size_t) in_lds * lds_need, g->stream, g->levels_dev.p,
-                           nl, g->coarse_A.p, g->coarse_inv.p, g->sc.p, in_lds);
+        hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), (size_t) in_lds * lds_need, g->stream, pair(nl),
+                           g->coarse_A.p, g->coarse_inv.p, g->sc.p, in_lds);
       }
       hierarchy_fresh = true;
       // the V-cycle's float32 copies of every level's blocks (the coarsest level is inverted, not cycled through)
@@ -2048,7 +2117,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         const MgLevelBufs* L = g->levels[(size_t) l];
         const size_t items   = std::max((size_t) L->n, (size_t) L->ne) * D * D;
         hipLaunchKernelGGL(k_mg_to_float<D>, dim3((unsigned) std::min<size_t>(std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1), 4096)),
-                           dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, l);
+                           dim3(PG_THREADS), 0, g->stream, pair(l), 1, (two_phase && l >= 1 && l < lf) ? 1 : 0);
       }
     }
     // PCG: r lives in level 0's r (the cycle's input), z = level 0's x (its output)
@@ -2065,7 +2134,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       for (int k = 0; k < count; ++k) {
         double* rz_cur = ((first + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
         double* rz_nxt = ((first + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
-        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, g->levels_dev.p, g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
+        hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, pair(0), g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_update_xr, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance, g->p.p,
                            g->Ap.p, g->x.p, r, rz_cur, g->part_pAp.p, g->part_rr.p, g->part_bb.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_converged, dim3(1), dim3(PG_THREADS), 0, g->stream, nb, (double) p->pcg_tolerance, g->part_rr.p,
@@ -2203,7 +2272,7 @@ void srrg2_posegraph_default_tuning(srrg2_posegraph_tuning* t) {
   t->keep_structure = 1;
   t->omega_p        = (float) MG_OMEGA_P;
   t->omega          = (float) MG_OMEGA;
-  t->lag_below      = 0.f;
+  t->lag_below      = 0.05f;
 }
 
 static void apply_tuning(srrg2_posegraph_s* g, const srrg2_posegraph_tuning& t) {
