@@ -517,7 +517,7 @@ typedef struct srrg2_aligner_tuning {
                                    deferred-search launch is kept (default 1; -1 = never drop it)                      */
   int32_t small_max_points;     /* SRRG2_AMD_SMALL_MAX: largest moving cloud run by the one-workgroup kernel (1024)    */
   int32_t fast_from_iteration;  /* SRRG2_AMD_FAST_FROM: first iteration the converged-pass kernel takes (3)           */
-  int32_t fast_points_per_thread; /* SRRG2_AMD_FAST_PPT: 1, 2 or 4 (1)                                                */
+  int32_t fast_points_per_thread; /* SRRG2_AMD_FAST_PPT: 1, 2 or 4; 0 (default) = 2 for launches of 64 alignments or more, else 1 */
   int32_t fast_min_points;      /* SRRG2_AMD_FAST_MIN: smallest moving cloud using the converged-pass kernel (0)       */
   int32_t fast_gather;          /* SRRG2_AMD_FAST_GATHER: kept neighbours gathered from the fixed cloud (1) or streamed
                                    from per-point arrays (0); -1 = batches of more than 4 alignments gather            */

@@ -153,6 +153,7 @@ struct srrg2_aligner_s {
   // the state of the last compute(): 0 = the arrays are current, 1 = to be derived, 2 = lost (the clouds changed since)
   int records_state = 0;
   std::vector<SliceDev> last_sdev;
+  std::vector<int> last_proj_owner;  // projective slices of the last compute(): the slice whose z-buffer held their association (-1: their own)
   std::vector<int> last_nm_max;
   // strategy knobs: defaults overridden by the SRRG2_AMD_* environment ONCE, at create; srrg2_aligner_set_tuning replaces them
   srrg2_aligner_tuning tuning{};
@@ -479,7 +480,7 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
   getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
   // (the environment bypasses srrg2_aligner_set_tuning's range check: clamp to what that check accepts)
-  if (t->fast_points_per_thread < 1) t->fast_points_per_thread = 1;
+  if (t->fast_points_per_thread < 0) t->fast_points_per_thread = 0;
   if (t->fast_from_iteration < 1) t->fast_from_iteration = 1;  // (iteration 0 has no previous neighbours to certify)
   if (t->msort_key_bits > 18) t->msort_key_bits = 18;
   if (t->msort_key_bits < -1) t->msort_key_bits = -1;
@@ -506,7 +507,7 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     int rcq = quiesce_stream2(a);
     if (rcq) return rcq;
   }
-  if (a->records_state == 1) a->records_state = 2;  // (the records of the last compute() can no longer be derived)
+  if (a->computed) a->records_state = 2;  // (the records of the last compute() can no longer be derived)
   const int n = offsets[K] - offsets[0];
   int rc;
   if ((rc = s->moving.reserve((size_t) std::max(n, 1)))) return rc;
@@ -752,7 +753,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // (measured on C4, 32 x 50k, profiles/r2c: one point per thread with the failed certificates searched by their own wave
   // 37.7 us per pass / 268.8 k it/s; two points per thread 45 us -- the accumulators stay live across the search, 181
   // registers -- ; with a queue the nearly idle deferred-search launch costs 15 us per iteration: 31 + 15 us, 254 k it/s)
-  const int fast_ppt  = tn.fast_points_per_thread;
+  // (0 = automatic: two points per thread share one reduction once a launch holds 64 alignments or more -- C4-256 575 -> 595 k it/s;
+  // smaller launches and single alignments lose the waves they need to fill the chip: C4-32 unchanged, C2 45.1 -> 42.6 k it/s)
+  const int fast_ppt  = tn.fast_points_per_thread > 0 ? tn.fast_points_per_thread : (K >= 64 ? 2 : 1);
   // batches gather the kept neighbour from the cache-resident fixed cloud (36 -> 8 streamed bytes per point); single
   // alignments read it from per-point arrays (no dependent load on the chain of a latency-bound launch)
   // (smallest moving cloud that uses the converged-pass kernel.  Sparse clouds of a few thousand points leave a larger
@@ -1229,6 +1232,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   std::memcpy(a->last_H, o.H, sizeof(a->last_H));
   a->computed = true;
   a->last_sdev = sdev;
+  a->last_proj_owner.assign((size_t) nslices, -1);
+  if (proj_fused)
+    for (int si : proj_group) a->last_proj_owner[(size_t) si] = proj_group[0];
   a->last_nm_max.assign((size_t) nslices, 0);
   for (int si = 0; si < nslices; ++si)
     for (int k = 0; k < K; ++k) a->last_nm_max[(size_t) si] = std::max(a->last_nm_max[(size_t) si], all[(size_t) si * K + k].nm);
@@ -1242,9 +1248,20 @@ int materialize_records(srrg2_aligner* a) {
   int rc;
   if ((rc = set_device(a))) return rc;
   if ((rc = quiesce_stream2(a))) return rc;
+  std::vector<char> rebuilt(a->slices.size(), 0);
   for (size_t si = 0; si < a->slices.size() && si < a->last_sdev.size(); ++si) {
     Slice* s = a->slices[si];
-    if (s->cfg.kind == SRRG2_SLICE_PRIOR || s->cfg.finder != SRRG2_FINDER_NN_GATED) continue;
+    if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+    if (s->cfg.finder == SRRG2_FINDER_PROJECTIVE) {
+      // (the association belongs to the slice itself, or to the first slice of a group that shared clouds and finder)
+      const int owner = si < a->last_proj_owner.size() && a->last_proj_owner[si] >= 0 ? a->last_proj_owner[si] : (int) si;
+      srrg2amd::launch_proj_records(a->last_sdev[(size_t) owner], a->last_sdev[si], a->probs.p + (size_t) owner * a->K,
+                                    a->probs.p + si * (size_t) a->K, a->states.p, a->K, a->last_nm_max[si],
+                                    !rebuilt[(size_t) owner], a->stream);
+      rebuilt[(size_t) owner] = 1;
+      continue;
+    }
+    if (s->cfg.finder != SRRG2_FINDER_NN_GATED) continue;
     srrg2amd::launch_icp_outputs(a->dim, s->cfg.kind == SRRG2_SLICE_P2PLANE, a->last_sdev[si], a->probs.p + si * (size_t) a->K,
                                  a->states.p, a->K, a->last_nm_max[si], a->stream);
   }
@@ -1291,7 +1308,7 @@ void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t) {
   t->queue_probe_iteration  = 1;
   t->small_max_points       = 1024;
   t->fast_from_iteration    = 3;
-  t->fast_points_per_thread = 1;
+  t->fast_points_per_thread = 0;
   t->fast_min_points        = 0;
   t->fast_gather            = -1;
   t->fast_batch_queue       = 0;
@@ -1316,7 +1333,7 @@ int srrg2_aligner_set_tuning(srrg2_aligner_h a, const srrg2_aligner_tuning* t) {
   if (!a || !t) return fail(SRRG2_E_INVALID, "set_tuning: null argument");
   // (fast_from_iteration >= 1: the converged-pass kernel certifies against the neighbours the PREVIOUS pass of this
   // compute() left behind; at iteration 0 there are none -- ADVICE r3)
-  if (t->fast_points_per_thread < 1 || t->fast_from_iteration < 1 || !(t->cell_target > 0.f) || t->msort_key_bits > 18 ||
+  if (t->fast_points_per_thread < 0 || t->fast_from_iteration < 1 || !(t->cell_target > 0.f) || t->msort_key_bits > 18 ||
       t->msort_key_bits < -1 || t->msort_segments < 0 || t->search_team < 0)
     return fail(SRRG2_E_INVALID, "set_tuning: value out of range");
   a->tuning = *t;
@@ -1477,7 +1494,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   if (s->alias_of >= 0) return fail(SRRG2_E_STATE, "set_fixed: this slice shares the clouds of another slice (share_clouds): set them there");
   if ((rc = set_device(a))) return rc;
   if ((rc = quiesce_stream2(a))) return rc;
-  if (a->records_state == 1) a->records_state = 2;
+  if (a->computed) a->records_state = 2;
   if ((rc = s->fixed_raw.reserve((size_t) std::max(n, 1)))) return rc;
   if (normals && (rc = s->fixed_nrm_raw.reserve((size_t) std::max(n, 1)))) return rc;
   if ((rc = s->scalars.reserve(16))) return rc;
@@ -1545,7 +1562,7 @@ int srrg2_aligner_share_clouds(srrg2_aligner_h a, int si, int source) {
   // (its own copies, if any, are dropped: from now on it views the source's buffers, re-borrowed at every compute())
   s->fixed_raw.release(); s->fixed_nrm_raw.release(); s->moving.release(); s->moving_nrm.release();
   s->moving_raw.release(); s->moving_nrm_raw.release(); s->pinf.release(); s->scalars.release();
-  if (a->records_state == 1) a->records_state = 2;
+  if (a->computed) a->records_state = 2;
   return 0;
 }
 
@@ -1656,7 +1673,7 @@ static int fetch_dense(srrg2_aligner* a, int si, std::vector<int>& cf, std::vect
   int rc;
   if ((rc = set_device(a))) return rc;
   if (!a->computed || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving ||
-      (a->records_state == 2 && s->cfg.finder == SRRG2_FINDER_NN_GATED)) {
+      (a->records_state == 2 && (s->cfg.finder == SRRG2_FINDER_NN_GATED || s->cfg.finder == SRRG2_FINDER_PROJECTIVE))) {
     cf.clear(); cr.clear(); cst.clear();
     *moff_out = 0;
     return 0;

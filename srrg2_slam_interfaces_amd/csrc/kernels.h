@@ -48,6 +48,8 @@ int icp_queue_blocks(int max_nm, int K);
 void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
                            int max_nm, hipStream_t s);
 // ... sharing clouds and finder parameters: one z-buffer pass and one step launch for all of them
+void launch_proj_records(const SliceDev& S0, const SliceDev& S, const ProblemDev* probs0, const ProblemDev* probs,
+                         ProblemState* states, int K, int max_nm, bool rebuild, hipStream_t s);
 void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
                             int max_nm, hipStream_t s);
 void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,

@@ -2963,16 +2963,22 @@ struct SlicePack {
   const ProblemDev* probs[4];
 };
 
+// LAST: the z-buffer of the last EXECUTED pass again (ProblemState::Tlast), into buffer 0, whatever the alignment's flags
+// say: the correspondence records of the projective slices are derived on demand (k_proj_records)
+template <bool LAST = false>
 __device__ __forceinline__ void proj_zbuf_body(const SliceDev& S, const ProblemDev* __restrict__ probs,
                                                ProblemState* __restrict__ states) {
   const int prob   = blockIdx.y;
   ProblemState* st = &states[prob];
-  if (st->done || st->finished) return;
+  if (LAST ? st->npasses <= 0 : (st->done || st->finished)) return;
   const ProblemDev pd = probs[prob];
   const int i         = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pd.nm) return;
   float T[12];
-  finder_transform3(S, st, T);
+  if (LAST)
+    load_T(st->Tlast[S.slice_idx], T);
+  else
+    finder_transform3(S, st, T);
   const float4 p = S.mpts[pd.moff + i];
   if (!finite3(p.x, p.y, p.z)) return;
   const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
@@ -2982,7 +2988,7 @@ __device__ __forceinline__ void proj_zbuf_body(const SliceDev& S, const ProblemD
   const int pix = project_point(S, qx, qy, qz, u, v);
   if (pix < 0) return;
   const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
-  atomicMin(&S.zbuf[((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols + pix], key);
+  atomicMin(&S.zbuf[((size_t) (LAST ? 0 : S.zbuf_parity) * gridDim.y + prob) * S.rows * S.cols + pix], key);
 }
 
 __global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev* __restrict__ probs,
@@ -2991,6 +2997,88 @@ __global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev*
 }
 __global__ __launch_bounds__(256) void k_proj_zbuf_pack(SlicePack P, ProblemState* __restrict__ states) {
   proj_zbuf_body(P.s[blockIdx.z], P.probs[blockIdx.z], states);
+}
+__global__ __launch_bounds__(256) void k_proj_zbuf_last(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                        ProblemState* __restrict__ states) {
+  proj_zbuf_body<true>(S, probs, states);
+}
+
+// Correspondence records {matched pixel, |dz|, factor status} of a projective slice, derived on demand from the z-buffer of
+// the last executed pass (k_proj_zbuf_last has rebuilt it in buffer 0 of the slice that OWNS the association: S0 = S, or
+// the first slice of a group that shares clouds and finder parameters) with the arithmetic of the pass: the same bits the
+// pass used to store every iteration (9 bytes per point and slice: C3 wrote 5.5 of its 39.8 MB per iteration for them).
+__global__ __launch_bounds__(256) void k_proj_records(SliceDev S0, SliceDev S, const ProblemDev* __restrict__ probs,
+                                                      const ProblemState* __restrict__ states) {
+  const int prob         = blockIdx.y;
+  const ProblemState* st = &states[prob];
+  const ProblemDev pd    = probs[prob];
+  const int i            = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pd.nm) return;
+  const int gi  = pd.moff + i;
+  int match     = -1;
+  float resp    = 0.f;
+  uint8_t fstat = SRRG2_FACTOR_SUPPRESSED;
+  const float4 p = S0.mpts[gi];
+  if (st->npasses > 0 && finite3(p.x, p.y, p.z)) {
+    float T[12];
+    load_T(st->Tlast[S0.slice_idx], T);
+    const unsigned long long* zcur = S0.zbuf + (size_t) prob * S0.rows * S0.cols;
+    const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+    const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+    const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+    float u, v;
+    const int pix = project_point(S0, qx, qy, qz, u, v);
+    const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
+    bool found = false;
+    float4 f   = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pix >= 0 && zcur[pix] == key) {
+      f     = S0.fixed_org[pix];
+      found = finite3(f.x, f.y, f.z);
+    }
+    const float dd = fabsf(f.z - qz);
+    {
+      const float dx = f.x - qx, dy = f.y - qy, dz = f.z - qz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const float g2 = (2.f * S0.gate) * (2.f * S0.gate);
+      found          = found && dd <= S0.gate && d2 <= g2;
+    }
+    const bool repro = S.factor == SRRG2_SLICE_REPROJECTION;
+    float4 nf        = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (found && (!repro || S.use_normal_gate) && S0.fixed_org_nrm) nf = S0.fixed_org_nrm[pix];
+    if (S.use_normal_gate) {
+      float4 nm = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (found && S0.mnrm) nm = S0.mnrm[gi];
+      const float rx  = (T[0] * nm.x + T[1] * nm.y) + T[2] * nm.z;
+      const float ry  = (T[4] * nm.x + T[5] * nm.y) + T[6] * nm.z;
+      const float rz  = (T[8] * nm.x + T[9] * nm.y) + T[10] * nm.z;
+      const float dot = (nf.x * rx + nf.y * ry) + nf.z * rz;
+      found           = found && dot > S.normal_cos;
+    }
+    if (found) {
+      match = pix;
+      resp  = dd;
+      bool valid = true;
+      float chi;
+      if (repro) {
+        valid          = f.z > 0.f;
+        const float uq = (S.K[0] * qx) / qz + S.K[2], vq = (S.K[4] * qy) / qz + S.K[5];
+        const float uf = (S.K[0] * f.x) / f.z + S.K[2], vf = (S.K[4] * f.y) / f.z + S.K[5];
+        const float e0 = valid ? uq - uf : 0.f, e1 = valid ? vq - vf : 0.f;
+        if (!(fabsf(e0) <= PIX_BOUND) || !(fabsf(e1) <= PIX_BOUND)) valid = false;
+        chi = e0 * e0;
+        chi = chi + e1 * e1;
+      } else {
+        const float e0 = (nf.x * (qx - f.x) + nf.y * (qy - f.y)) + nf.z * (qz - f.z);
+        chi            = e0 * e0;
+      }
+      const int rk = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+      if (valid && isfinite(chi))
+        fstat = (rk != SRRG2_ROBUST_NONE && !(chi < S.robust_thr)) ? SRRG2_FACTOR_KERNELIZED : SRRG2_FACTOR_INLIER;
+    }
+  }
+  S.corr_fixed[gi] = match;
+  S.corr_resp[gi]  = resp;
+  S.corr_stat[gi]  = fstat;
 }
 
 template <bool REPRO>
@@ -3092,13 +3180,9 @@ __device__ __forceinline__ void step_proj_body(const SliceDev& S, const ProblemD
     J[r][4] = kk * (p.z * m[r][0] - p.x * m[r][2]);
     J[r][5] = kk * (p.x * m[r][1] - p.y * m[r][0]);
   }
-  const uint8_t fstat = factor_accumulate_flat<D, ROWS, true>(J, e, found, rk, S.robust_thr, scale, acc, valid);
-  if (inr) {
-    // (stored in the sorted order of the moving cloud: coalesced; the host API maps back to the caller's order)
-    S.corr_fixed[gi] = found ? pix : -1;
-    S.corr_resp[gi]  = found ? dd : 0.f;
-    S.corr_stat[gi]  = fstat;
-  }
+  // (the correspondence record {pixel, |dz|, status} is not stored: k_proj_records derives it on demand)
+  (void) factor_accumulate_flat<D, ROWS, true>(J, e, found, rk, S.robust_thr, scale, acc, valid);
+  (void) dd;
   block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, 1);
 }
 
@@ -3183,7 +3267,6 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int ns
     const float4 nfz = (!repro || S.use_normal_gate) ? nf : make_float4(0.f, 0.f, 0.f, 0.f);
     if (S.use_normal_gate) found = found && ndot > S.normal_cos;
     long long acc[ACC_N];
-    uint8_t fstat;
     if (repro) {
       float J[2][D], e[2], m[2][3];
       bool valid     = f.z > 0.f;
@@ -3206,7 +3289,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int ns
         J[r][4] = kk * (p.z * m[r][0] - p.x * m[r][2]);
         J[r][5] = kk * (p.x * m[r][1] - p.y * m[r][0]);
       }
-      fstat = factor_accumulate_flat<D, 2, true>(J, e, found, rk, S.robust_thr, scale, acc, valid);
+      (void) factor_accumulate_flat<D, 2, true>(J, e, found, rk, S.robust_thr, scale, acc, valid);
     } else {
       float J[1][D], e[1], m[3];
       e[0] = (nfz.x * (qx - f.x) + nfz.y * (qy - f.y)) + nfz.z * (qz - f.z);
@@ -3217,13 +3300,9 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int ns
       J[0][3] = kk * (p.y * m[2] - p.z * m[1]);
       J[0][4] = kk * (p.z * m[0] - p.x * m[2]);
       J[0][5] = kk * (p.x * m[1] - p.y * m[0]);
-      fstat = factor_accumulate_flat<D, 1, true>(J, e, found, rk, S.robust_thr, scale, acc, true);
+      (void) factor_accumulate_flat<D, 1, true>(J, e, found, rk, S.robust_thr, scale, acc, true);
     }
-    if (inr) {
-      S.corr_fixed[gi] = found ? pix : -1;
-      S.corr_resp[gi]  = found ? dd : 0.f;
-      S.corr_stat[gi]  = fstat;
-    }
+    // (no correspondence records: k_proj_records derives them on demand)
     if (z > 0) __syncthreads();  // (the reduction's scratch in LDS is the previous slice's until every thread has left it)
     block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, 1);
   }
@@ -4075,6 +4154,19 @@ void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* pro
   dim3 grid(icp_step_blocks(max_nm), K);
   hipLaunchKernelGGL(k_proj_zbuf, grid, dim3(256), 0, s, P.s[0], P.probs[0], states);
   hipLaunchKernelGGL(k_icp_step_proj_fused, grid, dim3(256), 0, s, P, nslices, states);
+}
+
+// the correspondence records of projective slice S after a compute(): the z-buffer of the last executed pass is rebuilt in
+// buffer 0 of the slice that owns the association (S0; once per owner: `rebuild`), then read by k_proj_records
+void launch_proj_records(const SliceDev& S0, const SliceDev& S, const ProblemDev* probs0, const ProblemDev* probs,
+                         ProblemState* states, int K, int max_nm, bool rebuild, hipStream_t s) {
+  if (K <= 0 || max_nm <= 0 || !S0.zbuf) return;
+  dim3 grid(icp_step_blocks(max_nm), K);
+  if (rebuild) {
+    (void) hipMemsetAsync(S0.zbuf, 0xff, (size_t) K * S0.rows * S0.cols * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_proj_zbuf_last, grid, dim3(256), 0, s, S0, probs0, states);
+  }
+  hipLaunchKernelGGL(k_proj_records, grid, dim3(256), 0, s, S0, S, probs, (const ProblemState*) states);
 }
 
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,

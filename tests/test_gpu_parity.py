@@ -325,6 +325,46 @@ def test_projective_slices_sharing_their_clouds(oracle, product, variant):
     assert_same_run(runs[0], runs[1], slices=tuple(range(len(cfgs))))
 
 
+def test_projective_correspondences_are_derived_on_demand(oracle, product):
+    """The projective passes no longer store their correspondence records (9 bytes per point, slice and iteration): they are
+    derived when asked for, from the z-buffer of the last executed pass (k_proj_zbuf_last / k_proj_records).  Asking twice
+    gives the same records, asking for the second slice of a sharing pair first gives the same records, a run that stops
+    on its termination criterion before max_iterations reports the records of the pass it stopped after (the oracle's), and
+    once a cloud has been replaced the records of the previous run are gone (as for the nearest-neighbour slices)."""
+    from helpers import projective_config
+
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.rgbd_pair(rows=120, cols=160, seed=3400)
+    cfgs = [projective_config(kind, abi.SLICE_P2PLANE, d, gate=0.05, robust=abi.ROBUST_CAUCHY, thr=1e-3),
+            projective_config(kind, abi.SLICE_REPROJECTION, d, gate=0.05)]
+    runs = []
+    for al in _pair(oracle, product, kind):
+        al.set_params(max_iterations=12)
+        tc = abi.TerminationParams()
+        tc.window_size, tc.num_correspondences_range, tc.num_inliers_range, tc.num_outliers_range = 3, 100000, 100000, 1000000
+        tc.chi_epsilon = 0.5
+        al.set_termination_criteria(tc)
+        for k, c in enumerate(cfgs):
+            si = al.add_slice(c)
+            if k == 0:
+                al.set_fixed(si, d["fixed"], d["fixed_normals"])
+                al.set_moving(si, d["moving"], d["moving_normals"])
+            else:
+                al.share_clouds(si, 0)
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+        runs.append(al)
+    assert len(runs[0].iteration_stats()) < 12  # (stopped by the criterion: the last pass is not the last possible one)
+    second_first = [runs[1].correspondences(1), runs[1].correspondences(0)]
+    assert_same_run(runs[0], runs[1], slices=(0, 1))
+    again = [runs[1].correspondences(1), runs[1].correspondences(0)]
+    for a, b in zip(second_first, again):
+        assert a.tobytes() == b.tobytes()
+    assert len(second_first[0]) > 1000
+    runs[1].set_moving(0, d["moving"][::2], d["moving_normals"][::2])
+    assert len(runs[1].correspondences(0)) == 0
+
+
 @pytest.mark.parametrize("offset", [0.0, 900.0, -7000.0])
 @pytest.mark.parametrize("cell", [0.0, 0.05, 0.4])
 def test_ball_trimmed_search_is_exact(oracle, product, offset, cell):

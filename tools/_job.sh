@@ -2,8 +2,6 @@
 # scratch job for gpurun
 R=$GRAFT_REPO_ROOT
 cd $R
-O=$R/gpurun_out/t14; mkdir -p $O
-python -m pytest tests/test_gpu_posegraph.py -x -q 2>&1 | tail -3 > $O/pytest_pg.txt
-for lag in 0 0.05 0.2; do
-SRRG2_AMD_PG_LAG=$lag python bench.py --workload c5 > $O/bench_c5_lag$lag.json 2>$O/bench_c5.err
-done
+O=$R/gpurun_out/t17; mkdir -p $O
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_tuning.py tests/test_gpu_full_size.py -x -q 2>&1 | tail -5 > $O/pytest.txt
+python bench.py --workload c4 --batch 256 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('c4_256', d['value'], d['ms_per_step'])" >> $O/ab.txt
