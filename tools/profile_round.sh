@@ -27,6 +27,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c4_256 -o t -- python $R
 python $R/tools/rocpd_summary.py $O/rocprofv3_c4_256_summary.txt kernel_trace_stats=$(find /tmp/tr_c4_256 -name '*.db' | head -1)
 SRRG2_AMD_PG_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/tr_c5 -o t -- python $R/tools/bench_posegraph.py > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $O/rocprofv3_c5_summary.txt kernel_trace_stats=$(find /tmp/tr_c5 -name '*.db' | head -1)
+python $R/tools/pg_trace.py $(find /tmp/tr_c5 -name '*.db' | head -1) > $O/trace_c5_per_grid.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace -d /tmp/tr32 -o t -- python $R/bench.py --workload c4 --batch 32 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/batch_timeline.py $(find /tmp/tr32 -name '*.db' | head -1) > $O/timeline_c4_32_pipelined.txt
 python $R/tools/trace_steps.py $(find /tmp/tr_c2 -name '*.db' | head -1) > $O/trace_c2_steps.txt 2>/dev/null
@@ -46,7 +47,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES"; do
   SRRG2_AMD_PG_GRAPH=0 timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_c5_$n -o p -- python $R/tools/bench_posegraph.py > /dev/null 2>&1
   python $R/tools/rocpd_summary.py $O/pmc_c5_$n.txt $n=$(find /tmp/pmc_c5_$n -name '*.db' | head -1)
 done
-python $R/tools/traffic_c5_from_pmc.py $O/traffic_c5.json $O/pmc_c5_FETCH_SIZE.txt $O/pmc_c5_WRITE_SIZE.txt $O/pmc_c5_SQ_INSTS_VALU_SQ_WAVES.txt $O/rocprofv3_c5_summary.txt 3 10 381 > /dev/null 2>&1
+python $R/tools/traffic_c5_from_pmc.py $O/traffic_c5.json $O/pmc_c5_FETCH_SIZE.txt $O/pmc_c5_WRITE_SIZE.txt $O/pmc_c5_SQ_INSTS_VALU_SQ_WAVES.txt $O/rocprofv3_c5_summary.txt 3 10 384 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_valu -o p -- python $R/bench.py --workload c4 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $O/rocprofv3_c4_valu_pmc_summary.txt valu=$(find /tmp/pmc_valu -name '*.db' | head -1)
 # the search passes of the 256-alignment batch, pass by pass: durations, instructions, texture-path and LDS activity
