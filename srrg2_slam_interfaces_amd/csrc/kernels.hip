@@ -102,9 +102,12 @@ __device__ __forceinline__ void test_candidate2(const float4 f, float qx, float 
 #endif
 // margin of a trimmed scan beyond the previous neighbour's distance: 2 |q - q'| capped at PAD_CAP cells + 2% of a
 // cell.  A margin that turns out too small only means one more (trimmed) scan next iteration; measured on C2 / C4:
-// no cap 27.4k / 196k, 0.25: 28.1k / 199k, 0.1: 28.7k / 202k it/s.
+// no cap 27.4k / 196k, 0.25: 28.1k / 199k, 0.1: 28.7k / 202k it/s (round 2, grid scans).  Round 4, searches over the cell
+// neighbour lists (a search is cheaper, a candidate is not): C4-256 0.4 / 0.2 / 0.1 / 0.05 / 0.025 / 0: 539 / 575 / 596 / 611 /
+// 612 / 615 k it/s, C4-32 423 / 444 / 458 / 457 / 464 / 470 k, C2 43.2 / 44.8 / 45.4 / 45.9 / 45.7 / 45.5 k; tracker cycle, small
+// clouds and the 60 % overlap unchanged (profiles/r4w_ab_scan_margin.txt): the margin is the 2 % of a cell alone.
 #ifndef PAD_CAP
-#define PAD_CAP 0.1f
+#define PAD_CAP 0.0f
 #endif
 #ifndef SCAN_W0
 #define SCAN_W0 1
