@@ -109,6 +109,9 @@ __device__ __forceinline__ void test_candidate2(const float4 f, float qx, float 
 #ifndef PAD_CAP
 #define PAD_CAP 0.0f
 #endif
+#ifndef PAD_MIN
+#define PAD_MIN 0.02f  // the part of the margin that does not depend on the motion, in cells
+#endif
 #ifndef SCAN_W0
 #define SCAN_W0 1
 #endif
@@ -196,7 +199,7 @@ __device__ __forceinline__ void scan_radius1(const GridDev& g, float qx, float q
   rs[RC] = re[RC] = 0;
   complete2 = r2box;
   if (key_idx(bkey) != NO_MATCH) {
-    const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+    const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + PAD_MIN) * g.h) * 1.00001f;
     complete2      = fminf(complete2, rb * rb);
   }
   if (complete2 < 3.0e38f) {
@@ -787,7 +790,7 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
     if (p0) {
       ++e;
       if (key_idx(bkey) != NO_MATCH) {
-        const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+        const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + PAD_MIN) * g.h) * 1.00001f;
         L              = fminf(L, rb * rb);
       }
     }
@@ -1059,7 +1062,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
   float ball2  = INFINITY;  // ... and the wider scans
   bool skipped = false;     // the previous nearest neighbour is provably still the nearest
   float excl_wide = 0.f;
-  float pad       = 0.02f * g.h;  // margin of the scans beyond the nearest neighbour (grows with the motion)
+  float pad       = PAD_MIN * g.h;  // margin of the scans beyond the nearest neighbour (grows with the motion)
   __shared__ int coop_lds[NW][288];  // (64-lane scans need 264 ints, four 16-lane teams 4 x 72)
   STAMP(tl, 1);  // moving point + prior loaded
   if (active && !KNOB(S.tune, 16)) {
@@ -1090,7 +1093,7 @@ __device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDe
         // made its whole wave pay a search)
         excl    = pm * 0.9999999f - dl * 1.00001f;
       } else {
-        pad            = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+        pad            = fminf(2.f * dl, PAD_CAP * g.h) + PAD_MIN * g.h;
         const float rr = (d1 + pad) * 1.00001f;
         r2box          = fminf(rr * rr, gfar);
       }
@@ -1693,7 +1696,7 @@ __device__ __forceinline__ void scan_radius1_tile(const GridDev& g, WaveTile<CAP
     row_range(RC, rs, re);
     scan_range_lds<DIM>(t.pts, rs, re, qx, qy, qz, bkey, b2);
     if (key_idx(bkey) != NO_MATCH) {
-      const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+      const float rb = (sqrtf(key_best(bkey)) + (PAD_CAP + PAD_MIN) * g.h) * 1.00001f;
       complete2      = fminf(complete2, rb * rb);
     }
   }
@@ -1835,7 +1838,7 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
   int r2 = 0;
   float excl = 0.f, r2box = INFINITY, ball2 = INFINITY, excl_wide = 0.f;
   bool skipped = false;
-  float pad    = 0.02f * g.h;
+  float pad    = PAD_MIN * g.h;
   if (active) {
     transform_point<DIM>(T, p, qx, qy, qz);
     // temporal coherence, exactly as in icp_step_body: (a) the previous neighbour is provably still the nearest,
@@ -1854,7 +1857,7 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
         bidx    = key_idx(k1);
         excl    = pm * 0.9999999f - dl * 1.00001f;
       } else {
-        pad            = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+        pad            = fminf(2.f * dl, PAD_CAP * g.h) + PAD_MIN * g.h;
         const float rr = (d1 + pad) * 1.00001f;
         r2box          = fminf(rr * rr, gfar);
       }
@@ -2303,7 +2306,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
     const bool cc   = !hasp && cert_c && pm[k] > 0.f && (gate_r * 1.00001f + dl * 1.00001f < rhs);
     const bool have = active && (ca || cc);
     const float excl = pm[k] * 0.9999999f - dl * 1.00001f;
-    const float pad  = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+    const float pad  = fminf(2.f * dl, PAD_CAP * g.h) + PAD_MIN * g.h;
     const float rr   = (d1 + pad) * 1.00001f;
     const float r2box = hasp ? fminf(rr * rr, gfar) : gfar;
     open_ball2[k]     = (active && !have) ? r2box : -1.f;
@@ -2536,7 +2539,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
         bidx    = key_idx(k1);
         excl    = pm * 0.9999999f - dl * 1.00001f;
       } else {
-        const float pad = fminf(2.f * dl, PAD_CAP * g.h) + 0.02f * g.h;
+        const float pad = fminf(2.f * dl, PAD_CAP * g.h) + PAD_MIN * g.h;
         const float rr  = (d1 + pad) * 1.00001f;
         r2box           = fminf(rr * rr, gfar);
       }
@@ -2806,7 +2809,7 @@ __global__ __launch_bounds__(256) void k_icp_step_queue(SliceDev S, const Proble
         const float b2 = fminf(bound2_of(r, g.h), q.ball2);
         coop_scan<DIM, 64>(g, lane, coop_lds[wid], q.qx, q.qy, q.qz, cx, cy, cz, r, b2, wbest, widx, wpos, wexcl2);
         if (widx != NO_MATCH) {  // (wave-uniform: every lane gets the same result)
-          const float rr = (sqrtf(wbest) + (PAD_CAP + 0.02f) * g.h) * 1.00001f;
+          const float rr = (sqrtf(wbest) + (PAD_CAP + PAD_MIN) * g.h) * 1.00001f;
           ball2          = fminf(rr * rr, q.ball2);
           sr             = 1;
           while (sr < q.r2 && bound2_of(sr, g.h) < ball2) ++sr;
