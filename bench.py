@@ -208,15 +208,16 @@ def measure(args, init_dist=True):
     for _ in range(args.warmup):
         res = step()
     D.exchange_records(records(res), K_total, device=coll_device, mode=args.exchange)  # (warms the group up, untimed)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
     # (a collection of the interpreter inside the timed loop -- the clouds of a 256-alignment batch are hundreds of numpy
-    # arrays -- shows up as a multi-millisecond step: collect before, keep the collector off while the steps are timed)
+    # arrays -- shows up as a multi-millisecond step: collect before, keep the collector off while the steps are timed;
+    # collected BEFORE the barrier + synchronize that open the timed region, not between them and the first step)
     import gc
 
     gc.collect()
     gc.disable()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
