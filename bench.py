@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the aligner hot path (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; a bare
+   `python bench.py --gpus N` launches those N ranks itself.  `n_gpus` on the line is the size of the process group that
+   ran, and that group must have N ranks on N distinct devices over RCCL -- anything else fails loudly, never N = 1 quietly)
 
 BASELINE.json's metric has two halves and the default workload follows N:
   N = 1  "ICP iterations/sec (100k-pt SE(3) point-to-plane) @1 GPU": config C2.  One step = set the guess + one blocking
@@ -50,8 +52,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--c3-own-clouds", action="store_true", help="c3: every slice uploads its own copy of the clouds (round <= 3)")
     ap.add_argument("--dump-table", default=None, help="rank 0 saves the exchanged result table of the last step (.npy): tests")
+    ap.add_argument("--print-launch", action="store_true", help="N > 1 without a launcher: print the command that would be run, and exit")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and world != a.gpus:
+        # (a launcher started `world` ranks for a command line that says --gpus N: the line would claim the wrong N)
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     a.explicit_workload = a.workload is not None
     if a.workload is None:
         a.workload = "c2" if world == 1 else "c4"
@@ -64,6 +72,32 @@ def fill_defaults(a, world):
         a.steps = 200 if a.workload == "c2" else (100 if a.workload == "c3" else 20)
     if a.warmup is None:
         a.warmup = 20 if a.workload != "c4" else 3
+
+
+def launch_command(gpus, argv, port):
+    """`python bench.py --gpus N ...` without a launcher: the command that starts the N ranks (one per GPU, RCCL)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 and no WORLD_SIZE in the environment: start the N ranks (the driver may run the multi-GPU points the way
+    it runs N = 1).  Returns the exit code of the launcher; rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [x for x in sys.argv[1:] if x != "--print-launch"]
+    cmd = launch_command(args.gpus, argv, port)
+    if args.print_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return subprocess.call(cmd, env=env)
 
 
 def make_aligner(pkg_or_oracle_ctor, abi, iterations, cell_size=0.0):
@@ -95,6 +129,9 @@ def measure(args, init_dist=True):
     share = os.environ.get("SRRG2_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible: one rank per GPU (a one-GPU dry run of the "
+                         "control flow needs SRRG2_BENCH_SHARE_GPU=1 and says so on its line)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     coll_device = "cpu" if share else "cuda"
@@ -107,6 +144,11 @@ def measure(args, init_dist=True):
                 dist.init_process_group(backend="gloo")
             else:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # the line says n_gpus = N only when N ranks really ran, over RCCL unless this is the one-GPU dry run
+        if dist.get_world_size() != args.gpus or world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
+        if not share and dist.get_backend() != "nccl":
+            raise SystemExit("bench.py: the %d-rank run must use RCCL (backend nccl), got %s" % (world, dist.get_backend()))
 
     import srrg2_slam_interfaces_amd as pkg
     from srrg2_slam_interfaces_amd import _abi as abi
@@ -323,6 +365,8 @@ def measure(args, init_dist=True):
         "value": total_units * args.steps / dt,
         "unit": "iterations/s",
         "n_gpus": world,
+        **({"shared_gpu_dry_run": True, "collective_backend": "gloo"} if (share and world > 1) else
+           ({"collective_backend": "nccl (RCCL)"} if world > 1 else {})),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -556,6 +600,8 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     explicit = args.explicit_workload
     if args.workload == "c5":  # (replicas only: the pose graph does not shard)

@@ -537,9 +537,9 @@ typedef struct srrg2_aligner_tuning {
                                    2 = every alignment; -1 = automatic (carved out of reserved_: same struct size)        */
   int32_t search_team;          /* SRRG2_AMD_SEARCH_TEAM: lanes per moving point of that kernel, 1 or 4; 0 = automatic (4 for up
                                    to four alignments per launch, 1 for batches)                                         */
-  int32_t batch_pipeline;       /* SRRG2_AMD_BATCH_PIPELINE: compute_batch runs its alignments as two halves on two streams (one
-                                   half's control steps and sort under the other half's passes): 0 = never, 1 = every batch,
-                                   -1 = automatic (from 8 alignments per call on)                                        */
+  int32_t batch_pipeline;       /* SRRG2_AMD_BATCH_PIPELINE: compute_batch runs its alignments as P parts on P streams (one
+                                   part's control steps and sort under the other parts' passes): 0 = never, 1 = two halves
+                                   for every batch, 2 .. 8 = that many parts, -1 = automatic                             */
   int32_t reserved_[7];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */

@@ -113,13 +113,15 @@ struct Slice {
 struct srrg2_aligner_s {
   int kind = 0, dim = 3, dof = 6, tsize = 12, device = 0;
   hipStream_t stream = nullptr;
-  // Batches run as TWO half-batches on two streams (run_compute, "pipelined"): while one half's control step -- one
-  // workgroup per alignment, ~10 us of an otherwise idle chip per iteration -- and kernel boundary pass, the other half's
-  // pass kernel has the chip.  The halves share nothing but read-only data (fixed cloud, grid, lists).
-  hipStream_t stream2   = nullptr;
-  hipEvent_t ev_staged  = nullptr;  // the staging copies of a batch upload (stream) before the second half's sort (stream2)
-  bool stream2_dirty    = false;    // stream2 may still be running the tail of the last pipelined batch
-  int batch_split       = 0;        // upload_moving -> run_compute: the batch at hand is split at this alignment (0: not)
+  // Batches run as up to MAX_PARTS sub-batches on as many streams (run_compute, "pipelined"): while one part's control
+  // step -- one workgroup per alignment, ~10 us of an otherwise idle chip per iteration -- and kernel boundary pass, the
+  // other parts' pass kernels have the chip.  The parts share nothing but read-only data (fixed cloud, grid, lists).
+  static constexpr int MAX_PARTS = 8;
+  hipStream_t pstream[MAX_PARTS]{};  // pstream[0] == stream
+  hipEvent_t ev_staged  = nullptr;   // the staging copies of a batch upload (stream) before the other parts' sorts
+  int parts_dirty       = 0;         // pstream[1 .. parts_dirty) may still be running the tail of the last pipelined batch
+  int batch_parts       = 0;         // upload_moving -> run_compute: the batch at hand runs as this many parts (0: one)
+  int part_begin[MAX_PARTS + 1]{};   // ... part p = alignments [part_begin[p], part_begin[p + 1])
   srrg2_aligner_params params{10, 10, 0, 0};
   // point-sharded alignment (srrg2_aligner_set_point_shard): the host side's reduction and the global point count
   srrg2_reduce_fn reduce_fn = nullptr;
@@ -189,10 +191,9 @@ int set_device(srrg2_aligner* a) {
 // Everything outside a pipelined batch runs on `stream` alone: before it touches state the second half of the last pipelined
 // batch wrote, that half's stream must have retired (its results were seen by the host long ago: the wait is a formality).
 int quiesce_stream2(srrg2_aligner* a) {
-  if (a->stream2_dirty) {
-    a->stream2_dirty = false;
-    HIP_TRY(hipStreamSynchronize(a->stream2));
-  }
+  const int n    = a->parts_dirty;
+  a->parts_dirty = 0;
+  for (int p = 1; p < n; ++p) HIP_TRY(hipStreamSynchronize(a->pstream[p]));
   return 0;
 }
 
@@ -500,9 +501,9 @@ int check_slice(srrg2_aligner* a, int si, const char* what) {
 // return).  compute_batch passes false: it returns after the compute() that follows on the same stream has delivered
 // its results, and the launches of that compute() overlap the sort instead of waiting behind it.
 int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const float* normals, int ns,
-                  const int32_t* offsets, int K, int mem, bool wait = true, int split = 0) {
+                  const int32_t* offsets, int K, int mem, bool wait = true, int nparts = 0, const int* pbegin = nullptr) {
   Slice* s    = a->slices[si];
-  a->batch_split = 0;
+  a->batch_parts = 0;
   {
     int rcq = quiesce_stream2(a);
     if (rcq) return rcq;
@@ -560,24 +561,25 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
     s->ms_pending = false;
     std::memcpy(s->ms_probs_host, pd.data(), (size_t) K * sizeof(ProblemDev));
     bool sorted = false;
-    if (split > 0 && split < K && a->stream2) {
-      // pipelined batch: the second half is sorted on the second stream (behind the staging copies of this call), under the
-      // first half's first pass
+    if (nparts >= 2 && nparts <= srrg2_aligner::MAX_PARTS && pbegin) {
+      // pipelined batch: every part is sorted on its own stream (behind the staging copies of this call), the later parts
+      // under the first part's first pass
       if (mem == SRRG2_MEM_HOST) {
         HIP_TRY(hipEventRecord(a->ev_staged, a->stream));
-        HIP_TRY(hipStreamWaitEvent(a->stream2, a->ev_staged, 0));
+        for (int p = 1; p < nparts; ++p) HIP_TRY(hipStreamWaitEvent(a->pstream[p], a->ev_staged, 0));
       }
-      int nmA = 0, nmB = 0;
-      for (int k = 0; k < K; ++k) (k < split ? nmA : nmB) = std::max(k < split ? nmA : nmB, pd[k].nm);
-      sorted = srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, split, a->dim, kbits, aniso,
-                                            a->tuning.msort_segments, nmA, s->moving.p, normals ? s->moving_nrm.p : nullptr,
-                                            s->pinf.p, a->stream) &&
-               srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host + split, K - split, a->dim, kbits, aniso,
-                                            a->tuning.msort_segments, nmB, s->moving.p, normals ? s->moving_nrm.p : nullptr,
-                                            s->pinf.p + split, a->stream2);
+      sorted = true;
+      for (int p = 0; p < nparts && sorted; ++p) {
+        int nmp = 0;
+        for (int k = pbegin[p]; k < pbegin[p + 1]; ++k) nmp = std::max(nmp, pd[k].nm);
+        sorted = srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host + pbegin[p], pbegin[p + 1] - pbegin[p], a->dim,
+                                              kbits, aniso, a->tuning.msort_segments, nmp, s->moving.p,
+                                              normals ? s->moving_nrm.p : nullptr, s->pinf.p + pbegin[p], a->pstream[p]);
+        if (p > 0) a->parts_dirty = std::max(a->parts_dirty, p + 1);
+      }
       if (sorted) {
-        a->batch_split   = split;
-        a->stream2_dirty = true;
+        a->batch_parts = nparts;
+        for (int p = 0; p <= nparts; ++p) a->part_begin[p] = pbegin[p];
       }
     } else {
       sorted = srrg2amd::launch_msort_local(dsrc, sf, nsrc, nsf, s->ms_probs_host, K, a->dim, kbits, aniso, a->tuning.msort_segments,
@@ -588,7 +590,7 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
       // the caller may reuse its buffer on return (host or device memory: the ingest has finished reading it)
       if (wait) {
         HIP_TRY(hipStreamSynchronize(a->stream));
-        if (a->batch_split) HIP_TRY(hipStreamSynchronize(a->stream2));
+        for (int p = 1; p < a->batch_parts; ++p) HIP_TRY(hipStreamSynchronize(a->pstream[p]));
       }
       s->ms_pending         = !wait;  // (the sort reads the pinned problem table: the compute() that follows drains the stream)
       s->nm_total           = n;
@@ -638,8 +640,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   int rc;
   if ((rc = set_device(a))) return rc;
   // (a pipelined batch: upload_moving has already put the second half's sort on the second stream)
-  const int split = (K > 1 && a->batch_split > 0 && a->batch_split < K) ? a->batch_split : 0;
-  a->batch_split  = 0;
+  const int split = (K > 1 && a->batch_parts >= 2 && a->part_begin[a->batch_parts] == K) ? a->batch_parts : 0;  // parts (0: one)
+  a->batch_parts  = 0;
   if (!split && (rc = quiesce_stream2(a))) return rc;
   const int nslices = (int) a->slices.size();
   // sanity checks (reference: sanityCheck throws, aligner_slice_processor_impl.cpp:8-17;
@@ -755,7 +757,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // registers -- ; with a queue the nearly idle deferred-search launch costs 15 us per iteration: 31 + 15 us, 254 k it/s)
   // (0 = automatic: two points per thread share one reduction once a launch holds 64 alignments or more -- C4-256 575 -> 595 k it/s;
   // smaller launches and single alignments lose the waves they need to fill the chip: C4-32 unchanged, C2 45.1 -> 42.6 k it/s)
-  const int fast_ppt  = tn.fast_points_per_thread > 0 ? tn.fast_points_per_thread : (K >= 64 ? 2 : 1);
+  // (decided per LAUNCH: a part of a pipelined batch is its own launch)
+  auto fast_ppt_of = [&](int k_launch) { return tn.fast_points_per_thread > 0 ? tn.fast_points_per_thread : (k_launch >= 64 ? 2 : 1); };
   // batches gather the kept neighbour from the cache-resident fixed cloud (36 -> 8 streamed bytes per point); single
   // alignments read it from per-point arrays (no dependent load on the chain of a latency-bound launch)
   // (smallest moving cloud that uses the converged-pass kernel.  Sparse clouds of a few thousand points leave a larger
@@ -960,12 +963,16 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   }
   // k_icp_init sizes the fixed-point exponents from the per-slice problem tables ([slice][K])
   auto t_prep = std::chrono::steady_clock::now();
-  // the halves of a pipelined batch: problems [0, split) on `stream`, [split, K) on `stream2`; otherwise one range
-  const int nhalves = split ? 2 : 1;
-  const int h0[2] = {0, split}, hn[2] = {split ? split : K, K - split};
-  hipStream_t hstream[2] = {a->stream, a->stream2};
-  CtlParams Ch[2] = {C, C};
+  // the parts of a pipelined batch: problems [part_begin[p], part_begin[p + 1]) on pstream[p]; otherwise one range
+  constexpr int MP  = srrg2_aligner::MAX_PARTS;
+  const int nhalves = split ? split : 1;
+  int h0[MP], hn[MP];
+  hipStream_t hstream[MP];
+  std::vector<CtlParams> Ch((size_t) nhalves, C);
   for (int h = 0; h < nhalves; ++h) {
+    h0[h]       = split ? a->part_begin[h] : 0;
+    hn[h]       = split ? a->part_begin[h + 1] - a->part_begin[h] : K;
+    hstream[h]  = a->pstream[h];
     Ch[h].prob0 = h0[h];
     Ch[h].nprob = hn[h];
   }
@@ -1131,7 +1138,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             hipStream_t hs = hstream[h];
             const int Kh   = hn[h];
             if (fast)
-              srrg2amd::launch_icp_step_fast(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, fast_ppt, fast_gather, hs);
+              srrg2amd::launch_icp_step_fast(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, fast_ppt_of(Kh), fast_gather, hs);
             else if (cnl[(size_t) si] && !sd.queue)
               srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, s->lists_host, pt, a->states.p, Kh, nm_max,
                                             search_team_knob > 0 ? search_team_knob : ((K <= 4 && slot0 == 0 && it == 0) ? 4 : 1), hs);
@@ -1163,7 +1170,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     for (int h = 0; h < nhalves; ++h)
       srrg2amd::launch_icp_finalize(Ch[h], a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                     !a->params.enable_inlier_only_runs /* post step inside */, hstream[h]);
-  if (split) a->stream2_dirty = true;
+  if (split) a->parts_dirty = std::max(a->parts_dirty, split);
   HIP_TRY(hipGetLastError());
   const bool hosttime = a->hosttime;
   auto t_enq = std::chrono::steady_clock::now();
@@ -1175,7 +1182,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   for (int k = 0; k < K && seen; ++k) {
     volatile int* flag = &a->outs_host[k].seq;
     int spins          = 0;
-    hipStream_t qs = (split && k >= split) ? a->stream2 : a->stream;
+    hipStream_t qs = a->stream;
+    for (int h = 1; h < nhalves; ++h)
+      if (k >= h0[h]) qs = hstream[h];
     while (*flag != C.seq)
       if ((++spins & 4095) == 0 && hipStreamQuery(qs) != hipErrorNotReady) {
         seen = *flag == C.seq;  // (drained: either the flag has just arrived or a launch failed)
@@ -1184,7 +1193,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   }
   if (!seen || a->profile || !a->timeline_path.empty()) {
     HIP_TRY(hipStreamSynchronize(a->stream));
-    if (split) HIP_TRY(hipStreamSynchronize(a->stream2));
+    for (int h = 1; h < nhalves; ++h) HIP_TRY(hipStreamSynchronize(hstream[h]));
   }
   if (hook_failed) return fail(SRRG2_E_INVALID, "the reduction hook of the point-sharded alignment failed");
   if (hosttime) {
@@ -1382,11 +1391,14 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
   tuning_from_environment(&a->tuning);
   if (const char* tl = std::getenv("SRRG2_AMD_TIMELINE")) a->timeline_path = tl;
   a->hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&a->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming) != hipSuccess) {
-    if (a->stream) (void) hipStreamDestroy(a->stream);
-    if (a->stream2) (void) hipStreamDestroy(a->stream2);
+  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess;
+  a->pstream[0] = a->stream;
+  for (int p = 1; ok && p < srrg2_aligner::MAX_PARTS; ++p)
+    ok = hipStreamCreateWithFlags(&a->pstream[p], hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    for (int p = 0; p < srrg2_aligner::MAX_PARTS; ++p)
+      if (a->pstream[p]) (void) hipStreamDestroy(a->pstream[p]);
     delete a;
     return fail(SRRG2_E_HIP, "create: cannot create stream");
   }
@@ -1397,8 +1409,8 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
 int srrg2_aligner_destroy(srrg2_aligner_h a) {
   if (!a) return 0;
   (void) hipSetDevice(a->device);
-  if (a->stream) (void) hipStreamSynchronize(a->stream);
-  if (a->stream2) (void) hipStreamSynchronize(a->stream2);
+  for (int p = 0; p < srrg2_aligner::MAX_PARTS; ++p)
+    if (a->pstream[p]) (void) hipStreamSynchronize(a->pstream[p]);
   for (Slice* s : a->slices) {
     s->release();
     delete s;
@@ -1414,8 +1426,8 @@ int srrg2_aligner_destroy(srrg2_aligner_h a) {
     (void) hipEventDestroy(ev.second);
   }
   if (a->ev_staged) (void) hipEventDestroy(a->ev_staged);
-  if (a->stream2) (void) hipStreamDestroy(a->stream2);
-  if (a->stream) (void) hipStreamDestroy(a->stream);
+  for (int p = srrg2_aligner::MAX_PARTS - 1; p >= 0; --p)
+    if (a->pstream[p]) (void) hipStreamDestroy(a->pstream[p]);
   delete a;
   return 0;
 }
@@ -1848,11 +1860,11 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
   int rc;
   if ((rc = set_device(a))) return rc;
   const auto t_up0 = std::chrono::steady_clock::now();
-  // Pipelined batches: the alignments are independent, so the batch runs as two halves on two streams -- while one half's
+  // Pipelined batches: the alignments are independent, so the batch runs as P parts on P streams -- while one part's
   // control step (one workgroup per alignment on an otherwise idle chip, ~10 us per iteration, + the kernel boundaries) and
-  // Morton sort pass, the other half's pass kernel has the chip.  Same kernels on the same data: the same bits.
-  // tuning.batch_pipeline: 0 = never, 1 = every batch of >= 2, -1 = automatic (from 8 alignments per launch on)
-  int split = 0;
+  // Morton sort pass, the other parts' pass kernels have the chip.  Same kernels on the same data: the same bits.
+  // tuning.batch_pipeline: 0 = never, 1 = two halves for every batch of >= 2, P >= 2: P parts (batches of >= P), -1 = automatic
+  int nparts = 0, pbegin[srrg2_aligner::MAX_PARTS + 1] = {0};
   {
     const srrg2_aligner_tuning& tn = a->tuning;
     int max_nm = 0;
@@ -1860,12 +1872,15 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
     bool one_cue = true;
     for (size_t si = 1; si < a->slices.size(); ++si)
       if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR) one_cue = false;
-    const int min_k = tn.batch_pipeline == 0 ? (1 << 30) : (tn.batch_pipeline > 0 ? 2 : 8);
-    if (K >= min_k && one_cue && a->slices[0]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm > tn.small_max_points &&
-        !tn.fast_batch_queue && !a->reduce_fn && !a->profile && a->timeline_path.empty() && a->stream2)
-      split = (K + 1) / 2;
+    int want = tn.batch_pipeline == 0 ? 1 : (tn.batch_pipeline == 1 ? 2 : (tn.batch_pipeline > 1 ? tn.batch_pipeline : (K >= 8 ? 2 : 1)));
+    want     = std::min(std::min(want, (int) srrg2_aligner::MAX_PARTS), K);
+    if (want >= 2 && one_cue && a->slices[0]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm > tn.small_max_points &&
+        !tn.fast_batch_queue && !a->reduce_fn && !a->profile && a->timeline_path.empty()) {
+      nparts = want;
+      for (int p = 0; p <= nparts; ++p) pbegin[p] = (int) ((long long) K * p / nparts);  // (contiguous, sizes differ by <= 1)
+    }
   }
-  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false, split))) return rc;
+  if ((rc = upload_moving(a, 0, coords, cs, normals, ns, offsets, K, mem, /*wait=*/false, nparts, pbegin))) return rc;
   if (a->hosttime)
     std::fprintf(stderr, "compute_batch: upload_moving (enqueue) %.1f us\n",
                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_up0).count());

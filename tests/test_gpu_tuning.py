@@ -72,6 +72,7 @@ def test_batches_give_the_same_bits_under_every_search_pass_kernel(oracle, produ
                   {"search_lists": 1, "fast_from_iteration": 1}, {"search_lists": 1, "fast_from_iteration": 100},
                   {"search_lists": 1, "search_team": 4}, {"search_lists": 1, "search_team": 4, "fast_from_iteration": 100},
                   {"batch_pipeline": 0}, {"batch_pipeline": 1}, {"batch_pipeline": 1, "search_lists": 0},
+                  {"batch_pipeline": 3}, {"batch_pipeline": 4}, {"batch_pipeline": 8}, {"batch_pipeline": 5, "search_lists": 0},
                   {"batch_pipeline": 0, "search_lists": 0, "lds_tile": 0}):
         got = run(product.MultiAligner(abi.SE3_QUAT_RIGHT), **knobs)
         for r, g in zip(ref, got):
