@@ -540,7 +540,12 @@ typedef struct srrg2_aligner_tuning {
   int32_t batch_pipeline;       /* SRRG2_AMD_BATCH_PIPELINE: compute_batch runs its alignments as P parts on P streams (one
                                    part's control steps and sort under the other parts' passes): 0 = never, 1 = two halves
                                    for every batch, 2 .. 8 = that many parts, -1 = automatic                             */
-  int32_t reserved_[7];
+  int32_t fused_control;        /* SRRG2_AMD_FUSED_CONTROL: the control step of an ICP iteration (sums, Gauss-Newton step, update,
+                                   statistics, termination) runs on one wave in the prologue of the next iteration's first
+                                   pass kernel instead of as a launch of its own: 0 = never, 1 = whenever the aligner is ONE
+                                   nearest-neighbour cue slice searched over cell neighbour lists, -1 = automatic (as 1, for
+                                   launches of up to 1600 workgroups; carved out of reserved_)                            */
+  int32_t reserved_[6];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */
 void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t);

@@ -116,7 +116,8 @@ class AlignerTuning(C.Structure):
         ("search_lists", C.c_int32),
         ("search_team", C.c_int32),
         ("batch_pipeline", C.c_int32),
-        ("reserved_", C.c_int32 * 7),
+        ("fused_control", C.c_int32),
+        ("reserved_", C.c_int32 * 6),
     ]
 
 

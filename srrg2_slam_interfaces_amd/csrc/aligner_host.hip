@@ -139,6 +139,11 @@ struct srrg2_aligner_s {
   DevBuf<ProblemOut> outs;
   DevBuf<srrg2_iteration_stats> stats;
   DevBuf<float> guesses;
+  // fused control steps (FusedCtl, device_types.h): the records the passes read, their poll words, the device copies of the
+  // control parameters (one per part of a pipelined batch)
+  DevBuf<unsigned long long> pub;
+  DevBuf<unsigned> pub_epoch;
+  DevBuf<CtlParams> ctl_dev;
   DevBuf<char> staging;  // raw strided input staged on the device
   // pinned host mirrors
   ProblemOut* outs_host = nullptr; size_t outs_host_cap = 0;
@@ -478,6 +483,7 @@ void tuning_from_environment(srrg2_aligner_tuning* t) {
   geti("SRRG2_AMD_SEARCH_LISTS", t->search_lists);
   geti("SRRG2_AMD_SEARCH_TEAM", t->search_team);
   geti("SRRG2_AMD_BATCH_PIPELINE", t->batch_pipeline);
+  geti("SRRG2_AMD_FUSED_CONTROL", t->fused_control);
   getf("SRRG2_AMD_CELL_TARGET", t->cell_target);
   getf("SRRG2_AMD_RMAX_CAP", t->rmax_cap);
   // (the environment bypasses srrg2_aligner_set_tuning's range check: clamp to what that check accepts)
@@ -836,7 +842,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     const bool fast_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && K > 4 && !small && fast_batch_queue;
     s->fast_queue_only = fast_queue && !use_queue;
     const int nblocks    = PARTIAL_SLOTS;
-    if ((rc = s->partials.reserve((size_t) K * nblocks * ACC_N))) return rc;
+    if ((rc = s->partials.reserve((size_t) 2 * K * nblocks * ACC_N))) return rc;  // (two buffers: fused control steps)
     if (use_queue || fast_queue) {
       if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 10))) return rc;  // QEntry = 10 x 4 bytes
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
@@ -946,6 +952,37 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR && si != first_cue)
         return fail(SRRG2_E_UNSUPPORTED, "compute_batch supports one cue slice (plus prior slices)");
   }
+  // Fused control steps (FusedCtl): the control step of iteration i runs in the prologue of the first pass kernel of
+  // iteration i + 1 -- no control launch between the passes of a run.  For aligners whose slices are all nearest-neighbour
+  // cue slices on the list / converged-pass kernels; everything else keeps one control launch per iteration.
+  // tuning.fused_control: 0 = never, 1 = whenever the configuration allows it, -1 = automatic: launches whose workgroups
+  // are all resident at once (<= 1600 per launch: C2 391, a half of a 16-alignment C4 batch 1568).  There the step's
+  // latency is paid once, by everybody in parallel, and the saved launch + boundary count: C2 45.8 -> 48.9 k it/s, C4 with
+  // 4 / 8 / 12 / 16 alignments +6 / +12 / +5 / +4 %.  A launch of several rounds of workgroups pays an agent-scope read of
+  // the record in every workgroup and gets slower: C4-24 -4 %, C4-32 -8 %, C4-256 -13 % (profiles/r5e, r5f).
+  bool fuse = tn.fused_control != 0 && !small && !a->reduce_fn && a->timeline_path.empty() && first_cue >= 0 &&
+              a->params.max_iterations >= 2;
+  fuse = fuse && nslices == 1;  // (one cue slice, no prior slices: the step finds everything in that slice's record)
+  if (fuse && tn.fused_control < 0) {
+    long long worst = 0;
+    for (int h = 0; h < (split ? split : 1); ++h) {
+      long long wg = 0;
+      for (int k = (split ? a->part_begin[h] : 0); k < (split ? a->part_begin[h + 1] : K); ++k) wg += (all[(size_t) k].nm + 255) / 256;
+      worst = std::max(worst, wg);
+    }
+    fuse = worst <= 1600;
+  }
+  for (int si = 0; si < nslices && fuse; ++si) {
+    const Slice* s = a->slices[si];
+    fuse = s->cfg.kind != SRRG2_SLICE_PRIOR && s->cfg.finder == SRRG2_FINDER_NN_GATED && cnl[(size_t) si] && !sdev[si].queue;
+  }
+  if (fuse) {
+    if ((rc = a->pub.reserve((size_t) K * SRRG2_MAX_SLICES * PUB_SLICE_GRANULES))) return rc;
+    if ((rc = a->pub_epoch.reserve((size_t) K * PUB_EPOCH_REPLICAS * PUB_EPOCH_STRIDE))) return rc;
+    if ((rc = a->ctl_dev.reserve((size_t) srrg2_aligner::MAX_PARTS))) return rc;
+    C.pub       = a->pub.p;
+    C.pub_epoch = a->pub_epoch.p;
+  }
   bool hook_failed = false;
   if (a->reduce_fn) {
     // point-sharded alignment: one nearest-neighbour cue slice, K = 1; max |coordinate| over all ranks before the
@@ -975,7 +1012,18 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     hstream[h]  = a->pstream[h];
     Ch[h].prob0 = h0[h];
     Ch[h].nprob = hn[h];
+    if (fuse) Ch[h].ctl_dev = a->ctl_dev.p + h;
   }
+  int epoch = 0;  // control steps applied (or scheduled inside a pass) so far: what the next passes build on
+  if (fuse)
+    for (int si = 0; si < nslices; ++si) {
+      sdev[si].fc.pub       = a->pub.p;
+      sdev[si].fc.pub_epoch = a->pub_epoch.p;
+      sdev[si].fc.stats     = a->stats.p;
+      sdev[si].fc.min_num_correspondences = a->slices[si]->cfg.min_num_correspondences;
+      sdev[si].fc.max_stats = slots;
+      sdev[si].fc.has_term  = a->has_term ? 1 : 0;
+    }
   if (split && (small || a->reduce_fn || a->profile || !a->timeline_path.empty()))
     return fail(SRRG2_E_STATE, "internal: a pipelined batch on a path that cannot be split");
   for (int h = 0; h < nhalves; ++h)
@@ -1031,7 +1079,15 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if (a->reduce_fn(a->reduce_user, SRRG2_REDUCE_SUM_I64, s->partials.p, (size_t) K * PARTIAL_SLOTS * ACC_N, (void*) a->stream))
         hook_failed = true;
     }
-    if (last_phase && it == a->params.max_iterations - 1) {
+    const bool last_it = it == a->params.max_iterations - 1;
+    if (fuse) {
+      // (the passes of this iteration added into slot-set buffer epoch & 1; its control step produces epoch + 1: inside the
+      // first pass of the next iteration, or -- the last iteration of a run -- as a launch)
+      Ch[h].parity = epoch & 1;
+      Ch[h].epoch  = epoch + 1;
+      if (!last_it) return;
+    }
+    if (last_phase && last_it) {
       srrg2amd::launch_icp_control_final(Ch[h], a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                          !a->params.enable_inlier_only_runs /* post step inside */, hstream[h]);
       final_launched = true;
@@ -1134,6 +1190,13 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           for (int h = 0; h < nhalves; ++h) {
             // (a pipelined batch has one cue slice: each half's pass is followed by that half's control step on its stream)
             sd.prob0 = h0[h];
+            if (fuse) {
+              sd.fc.ctl   = a->ctl_dev.p + h;
+              sd.fc.epoch = epoch;
+              sd.partials = s->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
+              sd.fc.prev_partials = s->partials.p + (size_t) ((epoch + 1) & 1) * K * PARTIAL_SLOTS * ACC_N;
+              sd.fc.prior         = (slot0 > 0 || it > 0) ? 1 : 0;
+            }
             const ProblemDev* pt = a->probs.p + (size_t) si * K;
             hipStream_t hs = hstream[h];
             const int Kh   = hn[h];
@@ -1152,6 +1215,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
       }
       if (!split) control(it, last_phase, 0);
+      ++epoch;
     }
     return 0;
   };
@@ -1160,7 +1224,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   } else {
     if ((rc = run_phase(0, !a->params.enable_inlier_only_runs))) return rc;
     if (a->params.enable_inlier_only_runs) {
-      for (int h = 0; h < nhalves; ++h) srrg2amd::launch_icp_post(Ch[h], a->states.p, a->stats.p, hstream[h]);
+      for (int h = 0; h < nhalves; ++h) {
+        Ch[h].epoch = epoch + 1;  // (the post step changes flags the passes read: it republishes the records)
+        srrg2amd::launch_icp_post(Ch[h], a->states.p, a->stats.p, hstream[h]);
+      }
+      ++epoch;
       if ((rc = run_phase(a->params.max_iterations, true))) return rc;
     }
   }
@@ -1328,6 +1396,7 @@ void srrg2_aligner_default_tuning(srrg2_aligner_tuning* t) {
   t->search_lists           = -1;
   t->search_team            = 0;
   t->batch_pipeline         = -1;
+  t->fused_control          = -1;
   t->cell_target            = 8.0f;
   t->rmax_cap               = 0.f;
 }
@@ -1416,6 +1485,7 @@ int srrg2_aligner_destroy(srrg2_aligner_h a) {
     delete s;
   }
   a->probs.release(); a->states.release(); a->outs.release(); a->stats.release(); a->guesses.release();
+  a->pub.release(); a->pub_epoch.release(); a->ctl_dev.release();
   a->staging.release();
   if (a->outs_host) (void) hipHostFree(a->outs_host);
   if (a->stats_host) (void) hipHostFree(a->stats_host);

@@ -61,6 +61,40 @@ struct GridLists {
 #define CNL_ENTRY_MAX 16
 #define CNL_MAX_CLASS 12
 
+// Fused control steps (round 5; tuning.fused_control).  The control step of iteration i -- sum the slot sets, one
+// Gauss-Newton step, X <- X [+] dx, statistics, termination: k_icp_control's work -- runs in the PROLOGUE of the first pass
+// kernel of iteration i + 1, on ONE wave (wave 0 of workgroup (0, problem), which the dispatcher starts before its
+// siblings): no launch and no kernel boundary between the passes of two iterations.  What the passes need of the state
+// (finder transforms, exponent, flags) travels in a per-(problem, slice) RECORD of 8-byte granules {value, epoch tag}, each
+// written by one store and read by one load per lane: a wave that finds every tag at the epoch of its launch proceeds; a
+// stale record means the control step has not been applied yet -- the designated wave applies it, the others poll
+// replicated epoch words.  pub == nullptr: legacy path (the passes read ProblemState, every control step is a launch).
+#define PUB_SLICE_GRANULES 64  // per (problem, slice), one granule per lane of a wave: [0, 12) Tf, [12, 24) Tfprev, ...
+#define PUB_G_KEXP 24
+#define PUB_G_FLAGS 25
+#define PUB_G_NSTATS 26
+#define PUB_G_WCOUNT 27
+#define PUB_G_NPASSES 28
+#define PUB_G_X 32             //   ... [32, 44) X: with these the control step reads nothing of ProblemState
+#define PUB_FLAG_STOP 1u       //   flags: done | finished
+#define PUB_FLAG_PHASE1 2u     //          inlier-only run (Clamp robustifiers)
+#define PUB_FLAG_PRIOR 4u      //          nstats > 0 (neighbours of a previous pass exist)
+#define PUB_EPOCH_REPLICAS 8   // poll words per problem, 128 bytes apart
+#define PUB_EPOCH_STRIDE 32    // (in 4-byte words)
+struct CtlParams;
+struct FusedCtl {
+  unsigned long long* pub;     // [K][SRRG2_MAX_SLICES][PUB_SLICE_GRANULES]
+  unsigned* pub_epoch;         // [K][PUB_EPOCH_REPLICAS][PUB_EPOCH_STRIDE]
+  const CtlParams* ctl;        // device copy of this compute()'s control parameters (written by k_icp_init): termination criterion
+  srrg2_iteration_stats* stats;
+  long long* prev_partials;    // the slot sets the control step of this launch's epoch consumes: buffer (epoch - 1) & 1, [K][32][32]
+  int epoch;                   // control steps the passes of this launch build on
+  int min_num_correspondences; // of the (one) cue slice
+  int max_stats;
+  int has_term;
+  int prior;                   // neighbours of a previous pass of this compute() exist (every pass but the first of the first run)
+};
+
 // One cue slice (AlignerSliceProcessor_) as the step kernel sees it.
 struct SliceDev {
   GridDev grid;
@@ -111,6 +145,7 @@ struct SliceDev {
   int prob0;            // first problem of the launch (blockIdx.y = 0): a launch may cover a sub-range of the batch (the two
                         // halves of a pipelined batch run on two streams)
   float Sinv[12];       // robot_in_sensor = sensor_in_robot^-1
+  FusedCtl fc;          // fused control steps (fc.pub == nullptr: off)
 };
 
 struct ProblemDev {
@@ -169,7 +204,7 @@ struct SliceCtl {
   int* qprobe_host;         // pinned host copy of the counters of iteration probe_it ([problem][near, far]), or null
   const ProblemDev* probs;  // [problem] table of the slice (device): point counts for the decision threshold
   int nm_global;            // > 0: moving points of the alignment over ALL ranks (point-sharded alignment: sizes the exponent)
-  const long long* partials;  // [problem][PARTIAL_SLOTS][ACC_N] (null for priors)
+  const long long* partials;  // [2][problem][PARTIAL_SLOTS][ACC_N] (null for priors; the second buffer is used by fused control steps)
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
   const unsigned* finf_bits;      // [1] max |coordinate| of the fixed cloud (given-correspondences slices)
@@ -196,5 +231,12 @@ struct CtlParams {
   int probe_it;   // iteration after which the use of the deferred-search queue is decided (-1: never)
   int seq;        // sequence number of this compute() (completion flag in ProblemOut)
   int prob0, nprob;  // the problems [prob0, prob0 + nprob) of the batch are this launch's (nprob = 0: all K)
+  // fused control steps (FusedCtl): the records, the epoch THIS control step produces (0: k_icp_init) and which of the two
+  // slot-set buffers it consumes (pass e adds into buffer e & 1; SliceCtl::partials is the base of both: [2][K][32][32])
+  unsigned long long* pub;  // null: legacy
+  unsigned* pub_epoch;
+  CtlParams* ctl_dev;       // k_icp_init stores this record there for the fused control steps
+  int epoch;
+  int parity;
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

@@ -2025,6 +2025,427 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
 //     k_icp_step, or -- without a queue -- searched here by the whole wave (coop_scan), one at a time.
 // Same per-point arithmetic, same exact integer sums: bit-identical results.
 // ============================================================================================
+// ============================================================================================
+// Fused control steps (FusedCtl, device_types.h): the control step of an ICP iteration on ONE wave, in the prologue of the
+// first pass kernel of the next iteration.  wave_control() is k_icp_control's body (control_body below: the reference's
+// multi_aligner_impl.cpp:106-126) for aligners whose slices are all cue slices with a nearest-neighbour or projective finder
+// (no prior factors, no given correspondences, no deferred-search queue: those keep the control launch), written so that it
+// can live inside a pass kernel: no LDS, no barrier, and matrices spread over the LANES of the wave (H(r, c) in lane
+// r D + c, vectors in lanes 0 .. D - 1) instead of over 238 registers of one thread.  Every arithmetic statement is the one
+// of control_body / dm::solve / dm::box_plus / dm::se3_compose with the same operands in the same order, executed by the
+// lane that owns the result (operands fetched by v_readlane / ds_bpermute): the same bits.
+// ============================================================================================
+namespace {
+
+__device__ __forceinline__ double rl_d(double v, int k) {  // lane k's value, k wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ long long rl_ll(long long v, int k) {
+  const int lo = __builtin_amdgcn_readlane((int) (unsigned) v, k);
+  const int hi = __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) v >> 32), k);
+  return (long long) (((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
+}
+__device__ __forceinline__ float rl_f(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v              = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v              = o < v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long pub_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pub_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the granule of lane `lane` of the record of (problem, slice s), from the state
+__device__ __forceinline__ unsigned pub_granule_of(const CtlParams& C, const ProblemState* st, int s, int lane) {
+  unsigned v = 0u;
+  if (lane < 12) v = __float_as_uint(st->Tf[s][lane]);
+  else if (lane < 24) v = __float_as_uint(st->Tfprev[s][lane - 12]);
+  else if (lane == PUB_G_KEXP) v = (unsigned) st->kexp[s];
+  else if (lane == PUB_G_FLAGS)
+    v = ((st->done || st->finished) ? PUB_FLAG_STOP : 0u) | (st->phase == 1 ? PUB_FLAG_PHASE1 : 0u) |
+        ((st->nstats > 0 || st->phase == 1) ? PUB_FLAG_PRIOR : 0u);
+  else if (lane == PUB_G_NSTATS) v = (unsigned) st->nstats;
+  else if (lane == PUB_G_WCOUNT) v = (unsigned) st->w_count;
+  else if (lane == PUB_G_NPASSES) v = (unsigned) st->npasses;
+  else if (lane >= PUB_G_X && lane < PUB_G_X + 12) v = __float_as_uint(st->X[lane - PUB_G_X]);
+  return v;
+}
+__device__ __forceinline__ void pub_write_epoch(unsigned* pub_epoch, int prob, int lane, unsigned epoch) {
+  if (lane < PUB_EPOCH_REPLICAS)
+    __hip_atomic_store(pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + lane) * PUB_EPOCH_STRIDE, epoch, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// all records of a problem from its state, by the lanes 0 .. 63 of one wave (the control / init / post kernels)
+__device__ __forceinline__ void pub_publish_state(const CtlParams& C, const ProblemState* st, int prob, int lane, unsigned epoch) {
+  for (int s = 0; s < C.nslices; ++s) {
+    if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
+    pub_store(C.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane,
+              ((unsigned long long) epoch << 32) | pub_granule_of(C, st, s, lane));
+  }
+}
+
+// The control step on one wave, for an aligner with ONE cue slice (the slice of the calling pass kernel).  Everything it
+// reads arrives in ONE round trip: the record of the previous epoch (`g`: this lane's granule, already loaded by the caller)
+// carries the state the step needs, the slot sets are addressed from the kernel arguments.  Nothing waits for its plain stores
+// (state, statistics, zeroed slot sets: read after the next kernel boundary); the new record and the epoch words are
+// self-contained 8-byte stores.  D = 3 | 6.
+template <int D>
+__device__ __forceinline__ void wave_control(const SliceDev& S, ProblemState* __restrict__ states, int prob, unsigned long long g) {
+  const FusedCtl& F  = S.fc;
+  const int lane     = threadIdx.x & 63;
+  const int s        = S.slice_idx;
+  ProblemState* st   = &states[prob];
+  const unsigned epoch = (unsigned) F.epoch;
+  unsigned long long* rec = F.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane;
+  constexpr int TS   = D == 3 ? 9 : 12;  // words of X
+  // ---- the slot sets of the passes of the previous epoch (buffer (epoch - 1) & 1): requested first
+  long long* p = F.prev_partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+  long long v  = 0;
+#pragma unroll
+  for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) v += p[q * 64 + lane];
+  const int w          = (int) (unsigned) g;  // the value of this lane's granule
+  const float told     = __int_as_float(w);   // lanes [0, 12): Tf of the passes just run
+  float Xl             = __int_as_float(__shfl(w, (PUB_G_X + lane) & 63));  // lanes [0, 12): X
+  const int kexp       = __builtin_amdgcn_readlane(w, PUB_G_KEXP);
+  const unsigned fl0   = (unsigned) __builtin_amdgcn_readlane(w, PUB_G_FLAGS);
+  const int nstats0    = __builtin_amdgcn_readlane(w, PUB_G_NSTATS);
+  const int wc         = __builtin_amdgcn_readlane(w, PUB_G_WCOUNT);
+  const int npasses0   = __builtin_amdgcn_readlane(w, PUB_G_NPASSES);
+  if (fl0 & PUB_FLAG_STOP) {  // (the passes return at their first instruction; the record only moves to the new epoch)
+    pub_store(rec, ((unsigned long long) epoch << 32) | (unsigned) w);
+    pub_write_epoch(F.pub_epoch, prob, lane, epoch);
+    return;
+  }
+  // (termination criterion: the windows, one entry per lane, in flight with the slot sets)
+  double wo = 0.0, wi = 0.0, wx = 0.0;
+  int W = 1;
+  if (F.has_term) {
+    W = F.ctl->term.window_size;
+    if (lane < W) {
+      wo = st->w_out[lane];
+      wi = st->w_inl[lane];
+      wx = st->w_chi[lane];
+    }
+  }
+  v += __shfl_xor(v, 32);  // the total of entry (lane & 31)
+  // the slot sets are accumulated with atomics by the passes: this buffer is added to again two passes from now
+#pragma unroll
+  for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+  const double scaled = (double) v * dm::pow2(-kexp);
+  const int nc = (int) rl_ll(v, ACC_N_CORR), num_in = (int) rl_ll(v, ACC_N_IN), num_out = (int) rl_ll(v, ACC_N_OUT);
+  const int num_sup = nc - num_in - num_out, num_corr = nc >= 0 ? nc : 0;
+  const double chi_in = 0.0 + rl_d(scaled, ACC_CHI_IN), chi_out = 0.0 + rl_d(scaled, ACC_CHI_OUT);
+  const int hr = lane / D, hc = lane - hr * D;
+  const double Hl = 0.0 + __shfl(scaled, hidx(hr < hc ? hr : hc, hr < hc ? hc : hr) & 31);  // H(r, c) in lane r D + c
+  const double bl = 0.0 + __shfl(scaled, (ACC_B + lane) & 31);                              // b(a) in lane a
+  if (lane == 0) {
+    st->ncorr[s] = nc;
+    st->ninl[s]  = num_in;
+    st->npasses  = npasses0 + 1;
+  }
+  if (lane < 12) st->Tlast[s][lane] = told;  // the transforms the passes of this iteration ran with
+  if (!(nc > F.min_num_correspondences)) {  // aligner_slice_processor_impl.cpp:77-79; multi_aligner_impl.cpp:107-111
+    if (lane == 0) {
+      st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;
+      st->done   = 1;
+    }
+    unsigned nv = (unsigned) w;
+    if (lane == PUB_G_FLAGS) nv = fl0 | PUB_FLAG_STOP;
+    if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
+    pub_store(rec, ((unsigned long long) epoch << 32) | nv);
+    pub_write_epoch(F.pub_epoch, prob, lane, epoch);
+    return;
+  }
+  // ---- dm::solve<D>: L D L^T, statement for statement; L(i, j) in lane i D + j (i > j), d(j) in lane j D + j of Dv,
+  //      1 / d(j) in the same lane of Iv
+  double Lv = 0.0, Dv = 0.0, Iv = 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double sj = rl_d(Hl, j * D + j);
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      const double ljk = rl_d(Lv, j * D + k);
+      sj               = sj - (ljk * ljk) * rl_d(Dv, k * D + k);
+    }
+    if (!(sj > 0.0)) {
+      bad = true;
+      break;
+    }
+    const double inv = 1.0 / sj;
+    if (lane == j * D + j) {
+      Dv = sj;
+      Iv = inv;
+    }
+    double t = Hl;  // lane (i, j): H(i, j) - sum_k (L(i, k) L(j, k)) d(k)
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      const double lik = __shfl(Lv, (hr * D + k) & 63);
+      const double ljk = rl_d(Lv, j * D + k);
+      t                = t - (lik * ljk) * rl_d(Dv, k * D + k);
+    }
+    if (hc == j && hr > j && lane < D * D) Lv = t * inv;
+  }
+  double yv = 0.0, dxv = 0.0;  // y(i), dx(i) in lane i
+  if (!bad) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      double t = -rl_d(bl, i);
+#pragma unroll
+      for (int k = 0; k < i; ++k) t = t - rl_d(Lv, i * D + k) * rl_d(yv, k);
+      if (lane == i) yv = t;
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+      double t = rl_d(yv, i) * rl_d(Iv, i * D + i);
+#pragma unroll
+      for (int k = i + 1; k < D; ++k) t = t - rl_d(Lv, k * D + i) * rl_d(dxv, k);
+      if (lane == i) dxv = t;
+    }
+    const bool nf = lane < D && (!(dxv == dxv) || dxv > 1e300 || dxv < -1e300);
+    bad           = __any(nf);
+  }
+  // ---- what get_information / the batch records read: H, b, dx of this Gauss-Newton iteration
+  if (lane < D * D) st->last_H[lane] = Hl;
+  if (lane < D) {
+    st->last_b[lane]  = bl;
+    st->last_dx[lane] = bad ? 0.0 : dxv;
+  }
+  if (lane < 12) st->Xprev[lane] = Xl;
+  // ---- X <- X * v2t(dx) (dm::box_plus), the element of lane l < TS
+  if (!bad) {
+    if constexpr (D == 3) {
+      double sn, cs;
+      dm::sincos(rl_d(dxv, 2), sn, cs);
+      const int i = lane / 3, j = lane - i * 3;
+      const double a0 = (double) __shfl(Xl, (i * 3 + 0) & 63), a1 = (double) __shfl(Xl, (i * 3 + 1) & 63),
+                   a2 = (double) __shfl(Xl, (i * 3 + 2) & 63);
+      const double o0 = a0 * cs + a1 * sn;
+      const double o1 = a0 * (-sn) + a1 * cs;
+      const double o2 = (a0 * rl_d(dxv, 0) + a1 * rl_d(dxv, 1)) + a2;
+      float out       = (float) (j == 0 ? o0 : (j == 1 ? o1 : o2));
+      if (lane >= 6) out = lane == 8 ? 1.f : 0.f;
+      if (lane < 9) Xl = out;
+    } else {
+      // dm::se3_v2t on named scalars (through its arrays, filled on three control-flow paths, the compiler keeps part of R on
+      // the stack: a kernel that owns scratch memory pays for it in every wave)
+      const double v0 = rl_d(dxv, 0), v1 = rl_d(dxv, 1), v2 = rl_d(dxv, 2), v3 = rl_d(dxv, 3), v4 = rl_d(dxv, 4), v5 = rl_d(dxv, 5);
+      double R0, R1, R2, R3, R4, R5, R6, R7, R8;
+      if (S.variable_kind == 2) {
+        const double n2  = (v3 * v3 + v4 * v4) + v5 * v5;
+        const bool small = n2 < 1.0;
+        const double qw  = sqrt(small ? 1.0 - n2 : 1.0);
+        // dm::quat_to_R(qw, v3, v4, v5)
+        const double xx = v3 * v3, yy = v4 * v4, zz = v5 * v5;
+        const double xy = v3 * v4, xz = v3 * v5, yz = v4 * v5;
+        const double wx_ = qw * v3, wy_ = qw * v4, wz_ = qw * v5;
+        R0 = small ? 1.0 - 2.0 * (yy + zz) : 1.0; R1 = small ? 2.0 * (xy - wz_) : 0.0;      R2 = small ? 2.0 * (xz + wy_) : 0.0;
+        R3 = small ? 2.0 * (xy + wz_) : 0.0;      R4 = small ? 1.0 - 2.0 * (xx + zz) : 1.0; R5 = small ? 2.0 * (yz - wx_) : 0.0;
+        R6 = small ? 2.0 * (xz - wy_) : 0.0;      R7 = small ? 2.0 * (yz + wx_) : 0.0;      R8 = small ? 1.0 - 2.0 * (xx + yy) : 1.0;
+      } else {
+        double sa, ca, sb, cb, sc, cc;
+        dm::sincos(v3, sa, ca);
+        dm::sincos(v4, sb, cb);
+        dm::sincos(v5, sc, cc);
+        R0 = cb * cc;                   R1 = -(cb * sc);                R2 = sb;
+        R3 = ca * sc + (sa * sb) * cc;  R4 = ca * cc - (sa * sb) * sc;  R5 = -(sa * cb);
+        R6 = sa * sc - (ca * sb) * cc;  R7 = sa * cc + (ca * sb) * sc;  R8 = ca * cb;
+      }
+      const int i = lane >> 2, j = lane & 3;
+      const double a0 = (double) __shfl(Xl, (i * 4 + 0) & 63), a1 = (double) __shfl(Xl, (i * 4 + 1) & 63),
+                   a2 = (double) __shfl(Xl, (i * 4 + 2) & 63), a3 = (double) __shfl(Xl, (i * 4 + 3) & 63);
+      double r0 = v0, r1 = v1, r2 = v2;  // (t = the translation part of dx)
+      if (j == 0) { r0 = R0; r1 = R3; r2 = R6; }
+      if (j == 1) { r0 = R1; r1 = R4; r2 = R7; }
+      if (j == 2) { r0 = R2; r1 = R5; r2 = R8; }
+      double o = (a0 * r0 + a1 * r1) + a2 * r2;
+      if (j == 3) o = o + a3;
+      if (lane < 12) Xl = (float) o;
+    }
+    if (lane < TS) st->X[lane] = Xl;
+  }
+  // ---- IterationStats of this iteration (multi_aligner_impl.cpp:113-115): one 4-byte word of the record per lane
+  const float chi_in_f = (float) chi_in, chi_out_f = (float) chi_out;
+  if (nstats0 < F.max_stats && lane < 8) {
+    static_assert(sizeof(srrg2_iteration_stats) == 32, "eight words");
+    const int sw = lane == 0 ? nstats0 : lane == 1 ? num_in : lane == 2 ? num_out : lane == 3 ? num_sup : lane == 4 ? num_corr
+                 : lane == 5 ? (bad ? 1 : 0) : lane == 6 ? __float_as_int(chi_in_f) : __float_as_int(chi_out_f);
+    reinterpret_cast<int*>(F.stats + (size_t) prob * F.max_stats + nstats0)[lane] = sw;
+  }
+  if (lane == 0) st->nstats = nstats0 + 1;
+  // ---- AlignerTerminationCriteriaStandard_::hasToStop (aligner_termination_criteria_impl.cpp:24-65, has_to_stop below)
+  bool stop = false;
+  int wc1   = wc;
+  if (F.has_term && num_in != 0) {
+    const srrg2_termination_params& tp = F.ctl->term;
+    const float chi = chi_in_f / (float) num_in;
+    const int slot  = wc % W;
+    const int n     = wc + 1 < W ? wc + 1 : W;
+    wc1             = wc + 1;
+    if (n >= W) {  // (W <= TERM_WINDOW_MAX = 64: one entry per lane; the entry of this iteration comes from the registers)
+      const bool in = lane < n;
+      if (lane == slot) {
+        wo = (double) num_out;
+        wi = (double) num_in;
+        wx = (double) chi;
+      }
+      const double first_o = rl_d(wo, 0), first_i = rl_d(wi, 0), first_x = rl_d(wx, 0);
+      const double omax = wave_max_d(in ? wo : first_o), omin = wave_min_d(in ? wo : first_o);
+      const double imax = wave_max_d(in ? wi : first_i), imin = wave_min_d(in ? wi : first_i);
+      const double xmax = wave_max_d(in ? wx : first_x), xmin = wave_min_d(in ? wx : first_x);
+      stop = true;
+      if (omax - omin > (double) tp.num_correspondences_range) stop = false;  // :46
+      if (imax - imin > (double) tp.num_inliers_range) stop = false;
+      const float chi_range = (float) (xmax - xmin);
+      if (chi_range > (float) tp.num_outliers_range) stop = false;  // :53
+      if (chi_range / (float) xmax > tp.chi_epsilon) stop = false;
+    }
+    if (lane == 0) {
+      st->w_corr[slot] = num_corr;
+      st->w_inl[slot]  = num_in;
+      st->w_out[slot]  = num_out;
+      st->w_chi[slot]  = (double) chi;
+      st->w_count      = wc + 1;
+    }
+  }
+  if (stop && lane == 0) st->done = 1;  // :124-126
+  // ---- finder transform robot_in_sensor * X (finder_transform_of), the previous one kept
+  float tnew = told;
+  if (!bad) {
+    const float* A = S.Sinv;
+    const int i = (lane >> 2) % 3, j = lane & 3;  // slot (i, j) of the 3 x 4 layout
+    const float A0 = i == 0 ? A[0] : (i == 1 ? A[D == 6 ? 4 : 3] : A[D == 6 ? 8 : 6]);
+    const float A1 = i == 0 ? A[1] : (i == 1 ? A[D == 6 ? 5 : 4] : A[D == 6 ? 9 : 7]);
+    const float A2 = i == 0 ? A[2] : (i == 1 ? A[D == 6 ? 6 : 5] : A[D == 6 ? 10 : 8]);
+    if constexpr (D == 6) {
+      const float A3  = i == 0 ? A[3] : (i == 1 ? A[7] : A[11]);
+      const double b0 = (double) __shfl(Xl, (0 * 4 + j) & 63), b1 = (double) __shfl(Xl, (1 * 4 + j) & 63),
+                   b2 = (double) __shfl(Xl, (2 * 4 + j) & 63);
+      double o = ((double) A0 * b0 + (double) A1 * b1) + (double) A2 * b2;
+      if (j == 3) o = o + (double) A3;
+      tnew = (float) o;
+    } else {
+      // se2_compose into t9, spread into the 3 x 4 slots: T = [t0 t1 0 t2; t3 t4 0 t5; 0 0 1 0]
+      const int jj = j == 3 ? 2 : j;  // column of the 3 x 3 product the slot holds (j = 2: none)
+      const double b0 = (double) __shfl(Xl, (0 * 3 + jj) & 63), b1 = (double) __shfl(Xl, (1 * 3 + jj) & 63);
+      double o = (double) A0 * b0 + (double) A1 * b1;  // (rows i < 2; row 2 is overwritten below)
+      if (j == 3) o = o + (double) A2;
+      float f = (float) o;
+      if (j == 2) f = 0.f;
+      if (i == 2) f = j == 2 ? 1.f : 0.f;
+      tnew = f;
+    }
+    if (lane < 12) st->Tf[s][lane] = tnew;
+  }
+  if (lane < 12) st->Tfprev[s][lane] = told;
+  // ---- the record of the new epoch, then the epoch words
+  unsigned nv = 0u;
+  if (lane < 12) nv = __float_as_uint(tnew);
+  else if (lane < 24) nv = __float_as_uint(__shfl(told, (lane - 12) & 63));
+  {
+    const unsigned told_up = __float_as_uint(__shfl(told, (lane - 12) & 63));  // (every lane takes part in the shuffle)
+    const unsigned x_up    = __float_as_uint(__shfl(Xl, (lane - PUB_G_X) & 63));
+    if (lane >= 12 && lane < 24) nv = told_up;
+    if (lane == PUB_G_KEXP) nv = (unsigned) kexp;
+    if (lane == PUB_G_FLAGS) nv = (stop ? PUB_FLAG_STOP : 0u) | (fl0 & PUB_FLAG_PHASE1) | PUB_FLAG_PRIOR;
+    if (lane == PUB_G_NSTATS) nv = (unsigned) (nstats0 + 1);
+    if (lane == PUB_G_WCOUNT) nv = (unsigned) wc1;
+    if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
+    if (lane >= PUB_G_X && lane < PUB_G_X + 12) nv = x_up;
+  }
+  pub_store(rec, ((unsigned long long) epoch << 32) | nv);
+  pub_write_epoch(F.pub_epoch, prob, lane, epoch);
+}
+
+// What a pass kernel needs of the state.  Legacy (FUSED = false: its own kernel instantiations, the code of round 4): read from
+// ProblemState.  Fused control steps: from the record of (problem, slice).  ONE wave per workgroup reads it (agent-scope
+// loads: the record changes during the launch and other XCDs' L2s are not coherent) and hands the values to the others
+// through LDS; a stale record => the control step is applied here (designated wave) or waited for.  Called AFTER the
+// workgroup has requested its points: those loads do not depend on the state and are in flight while the record arrives.
+struct PassView {
+  float T[12], Tprev[12];
+  int kexp;
+  bool stop, phase1, prior;
+};
+
+__device__ __forceinline__ void pass_view_legacy(const SliceDev& S, const ProblemState* __restrict__ st, PassView& v) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.T[i] = st->Tf[S.slice_idx][i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.Tprev[i] = st->Tfprev[S.slice_idx][i];
+  v.kexp   = st->kexp[S.slice_idx];
+  v.stop   = st->done || st->finished;
+  v.phase1 = st->phase == 1;
+  v.prior  = st->nstats > 0 || st->phase == 1;
+}
+
+// Top of a fused pass kernel: wave 0 of workgroup (0, problem) applies the control step of the previous iteration if the
+// record still stands at the previous epoch (this wave is the only writer of the record during the launch).  Before the
+// workgroup requests its points: the step's registers are free again when the pass needs its own.
+template <int DIM>
+__device__ __forceinline__ void fused_control_if_due(const SliceDev& S, ProblemState* __restrict__ states, int prob) {
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const unsigned long long g =
+    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63));
+  if (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) wave_control<DIM == 3 ? 6 : 3>(S, states, prob, g);
+}
+
+template <int DIM>
+__device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState* __restrict__ states, int prob, PassView& v) {
+  __shared__ unsigned rec_lds[PUB_SLICE_GRANULES];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    const unsigned long long* rec = S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + lane;
+    unsigned long long g = pub_load(rec);
+    if (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) {
+      // (workgroup (0, problem) applied the control step at its very top -- fused_control_if_due -- before it came here)
+      const unsigned* ep = S.fc.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.x & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
+      int spins = 0;
+      while ((int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S.fc.epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 24)) __builtin_trap();  // (never: workgroup (0, problem) is dispatched before its siblings)
+      }
+      g     = pub_load(rec);
+      spins = 0;
+      while (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) {  // (the epoch words are written after the record)
+        __builtin_amdgcn_s_sleep(2);
+        g = pub_load(rec);
+        if (++spins > (1 << 24)) __builtin_trap();
+      }
+    }
+    rec_lds[lane] = (unsigned) g;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.T[i] = __int_as_float(__builtin_amdgcn_readfirstlane((int) rec_lds[i]));
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.Tprev[i] = __int_as_float(__builtin_amdgcn_readfirstlane((int) rec_lds[12 + i]));
+  v.kexp = __builtin_amdgcn_readfirstlane((int) rec_lds[PUB_G_KEXP]);
+  const unsigned fl = (unsigned) __builtin_amdgcn_readfirstlane((int) rec_lds[PUB_G_FLAGS]);
+  v.stop   = (fl & PUB_FLAG_STOP) != 0;
+  v.phase1 = (fl & PUB_FLAG_PHASE1) != 0;
+  v.prior  = (fl & PUB_FLAG_PRIOR) != 0;
+}
+
+}  // namespace
+
 namespace {
 
 // NW = waves that reduce together (through LDS); NW == 1: every wave on its own, no barrier (the rare second phase of
@@ -2191,21 +2612,33 @@ __device__ __forceinline__ void point_rows(const float* T, float kk, const float
 // GATHER: the previous neighbour and its normal are gathered from the fixed cloud through prev_pos (batches: the cloud
 // is shared by all alignments and stays in L2; 8 instead of 36 streamed bytes per point) instead of read from prev_f / prev_n
 // (single alignments: no dependent load on the chain).
-template <int DIM, bool PLANE, int PPT, bool GATHER>
+template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
 __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const ProblemDev* __restrict__ probs,
                                                        ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   const int prob     = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   const ProblemState* st = &states[prob];
-  if (st->done || st->finished) return;
+  PassView pv;
+  if constexpr (!FUSED) {
+    pass_view_legacy(S, st, pv);
+    if (pv.stop) return;
+  } else {
+    fused_control_if_due<DIM>(S, states, prob);
+  }
   const ProblemDev pd = probs[prob];
-  if ((int) blockIdx.x * (256 * PPT) >= pd.nm) return;  // (batches of unequal clouds)
+  // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
+  // iteration whatever its share of the points)
+  if ((int) blockIdx.x * (256 * PPT) >= pd.nm && (!FUSED || blockIdx.x != 0)) return;
   float T[12], Tprev[12];
-  load_T(st->Tf[S.slice_idx], T);
-  load_T(st->Tfprev[S.slice_idx], Tprev);
-  const double scale = dm::pow2(st->kexp[S.slice_idx]);
-  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  double scale;
+  int rk;
+  if constexpr (!FUSED) {
+    load_T(pv.T, T);
+    load_T(pv.Tprev, Tprev);
+    scale = dm::pow2(pv.kexp);
+    rk    = (pv.phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  }
   const float thr    = S.robust_thr;
   const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
   const GridDev& g   = S.grid;
@@ -2214,7 +2647,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   const int rfar     = ext ? g.rmax : g.rfar_gate;
   const float gate_r = S.gate * 1.000001f;  // (>= sqrt(gate2))
   const bool ngate   = S.use_normal_gate != 0;
-  const bool use_q   = S.queue != nullptr && st->qmode[S.slice_idx] != 0;
+  const bool use_q   = !FUSED && S.queue != nullptr && st->qmode[S.slice_idx] != 0;  // (fused control steps: no queue)
   const bool cert_a  = !(S.tune & 4096), cert_c = !(S.tune & (4096 | 65536));
   const int lane     = threadIdx.x & 63;
   const int wid      = threadIdx.x >> 6;
@@ -2279,6 +2712,14 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       pf[k] = g.pts[ppos];
       if (PLANE || ngate) pn[k] = g.nrm[ppos];
     }
+  }
+  if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
+    pass_view_fused<DIM>(S, states, prob, pv);
+    if (pv.stop || (int) blockIdx.x * (256 * PPT) >= pd.nm) return;
+    load_T(pv.T, T);
+    load_T(pv.Tprev, Tprev);
+    scale = dm::pow2(pv.kexp);
+    rk    = (pv.phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
   }
 
   // Phase 1: the certificates; points that keep their neighbour are linearised.  A failed certificate leaves the squared
@@ -2461,28 +2902,41 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
 // ============================================================================================
 // The search pass over the cell neighbour lists (cnl_search above): TEAM lanes per moving point.
 // ============================================================================================
-template <int DIM, bool PLANE, int TEAM>
+template <int DIM, bool PLANE, int TEAM, bool FUSED>
 __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, const ProblemDev* __restrict__ probs,
                                                       ProblemState* __restrict__ states) {
   constexpr int NW  = 4;
   constexpr int PPB = NW * 64 / TEAM;  // moving points per workgroup
   const int prob    = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
-  const ProblemState* st = &states[prob];
-  if (st->done || st->finished) return;
+  PassView pv;
+  if constexpr (!FUSED) {
+    pass_view_legacy(S, &states[prob], pv);
+    if (pv.stop) return;
+  } else {
+    fused_control_if_due<DIM>(S, states, prob);
+  }
   const ProblemDev pd = probs[prob];
   const int tile      = blockIdx.x;
-  if (tile * PPB >= pd.nm) return;  // (batches of unequal clouds)
-  float T[12];
-  load_T(st->Tf[S.slice_idx], T);
-  const double scale = dm::pow2(st->kexp[S.slice_idx]);
-  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
+  // iteration whatever its share of the points)
+  if (tile * PPB >= pd.nm && (!FUSED || tile != 0)) return;
+  float T[12], Tprev[12];
+  double scale;
+  int rk;
+  bool use_prior;
+  if constexpr (!FUSED) {
+    load_T(pv.T, T);
+    load_T(pv.Tprev, Tprev);
+    scale     = dm::pow2(pv.kexp);
+    rk        = (pv.phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+    use_prior = pv.prior && !(S.tune & 4);
+  } else {
+    use_prior = S.fc.prior != 0 && !(S.tune & 4);  // (the host knows: every pass but the first of the first run)
+  }
   const float thr    = S.robust_thr;
   const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
   const GridDev& g   = S.grid;
-  const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
   const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
-  float Tprev[12];
-  load_T(st->Tfprev[S.slice_idx], Tprev);
 
   __shared__ CnlWave wlds[NW];
 
@@ -2513,6 +2967,14 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
         if (PLANE || S.use_normal_gate) pn = S.prev_n[gi];
       }
     }
+  }
+  if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
+    pass_view_fused<DIM>(S, states, prob, pv);
+    if (pv.stop || tile * PPB >= pd.nm) return;
+    load_T(pv.T, T);
+    load_T(pv.Tprev, Tprev);
+    scale = dm::pow2(pv.kexp);
+    rk    = (pv.phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
   }
   const bool has_prev = __float_as_int(pf.w) != NO_MATCH;
   const bool active   = inrange && finite3(p.x, p.y, p.z);
@@ -3645,8 +4107,16 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
-    long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * PARTIAL_SLOTS * ACC_N;
-    for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += blockDim.x) p[k] = 0;
+    for (int buf = 0; buf < 2; ++buf) {  // (the second buffer: fused control steps, pass e adds into buffer e & 1)
+      long long* p = const_cast<long long*>(sc.partials) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
+      for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += blockDim.x) p[k] = 0;
+    }
+  }
+  if (C.ctl_dev && blockIdx.x == 0) {  // the control parameters where the fused control steps find them
+    static_assert(sizeof(CtlParams) % sizeof(int) == 0, "copied word-wise");
+    const int* src = reinterpret_cast<const int*>(&C);
+    int* dst       = reinterpret_cast<int*>(C.ctl_dev);
+    for (int k = threadIdx.x; k < (int) (sizeof(CtlParams) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
   }
   if (threadIdx.x != 0) return;
   ProblemState* st = &states[prob];
@@ -3684,6 +4154,10 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
     finder_transform_of(C.slices[s].Sinv, C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3, st->X, st->Tf[s]);
     for (int i = 0; i < 12; ++i) st->Tfprev[s][i] = st->Tf[s][i];
   }
+  if (C.pub) {  // fused control steps: the records of epoch 0 (one thread: the state is its own)
+    for (int l = 0; l < PUB_SLICE_GRANULES; ++l) pub_publish_state(C, st, prob, l, 0u);  // (64 x 8-byte stores per cue slice)
+    for (int l = 0; l < PUB_EPOCH_REPLICAS; ++l) pub_write_epoch(C.pub_epoch, prob, l, 0u);
+  }
 }
 
 constexpr int STATE_WORDS = (int) (sizeof(ProblemState) / sizeof(int));
@@ -3714,12 +4188,12 @@ __device__ __forceinline__ PrePartials prefetch_partials(const CtlParams& C, int
   }
   const int a = threadIdx.x & 31, c = threadIdx.x >> 5;
   if (P.s0 >= 0) {
-    const long long* p = C.slices[P.s0].partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+    const long long* p = C.slices[P.s0].partials + ((size_t) C.parity * C.K + prob) * PARTIAL_SLOTS * ACC_N;
 #pragma unroll
     for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) P.v0 += p[(size_t) (c + 8 * q) * ACC_N + a];
   }
   if (P.s1 >= 0) {
-    const long long* p = C.slices[P.s1].partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+    const long long* p = C.slices[P.s1].partials + ((size_t) C.parity * C.K + prob) * PARTIAL_SLOTS * ACC_N;
 #pragma unroll
     for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) P.v1 += p[(size_t) (c + 8 * q) * ACC_N + a];
   }
@@ -3737,7 +4211,7 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     if (sc.kind == SRRG2_SLICE_PRIOR) continue;
-    long long* p = const_cast<long long*>(sc.partials) + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+    long long* p = const_cast<long long*>(sc.partials) + ((size_t) C.parity * C.K + prob) * PARTIAL_SLOTS * ACC_N;
     long long v  = 0;
     if (s == pre.s0) {
       v = pre.v0;
@@ -3785,10 +4259,20 @@ __global__ __launch_bounds__(256) void k_icp_control(CtlParams C, ProblemState* 
   __shared__ ProblemState sst;
   state_to_lds(&sst, st);
   __syncthreads();
-  if (sst.done || sst.finished) return;  // (uniform: LDS; nothing was modified)
+  if (sst.done || sst.finished) {  // (uniform: LDS; nothing was modified)
+    if (C.pub && threadIdx.x < 64) {  // (fused control steps: the records still move to this step's epoch)
+      pub_publish_state(C, &sst, prob, threadIdx.x, (unsigned) C.epoch);
+      pub_write_epoch(C.pub_epoch, prob, threadIdx.x, (unsigned) C.epoch);
+    }
+    return;
+  }
   icp_control_block(C, &sst, stats, prob, pre);
   __syncthreads();
   state_from_lds(st, &sst);
+  if (C.pub && threadIdx.x < 64) {
+    pub_publish_state(C, &sst, prob, threadIdx.x, (unsigned) C.epoch);
+    pub_write_epoch(C.pub_epoch, prob, threadIdx.x, (unsigned) C.epoch);
+  }
 }
 
 // after the main _runSolver: multi_aligner_impl.cpp:75-85 and the start of _postCompute (:165-171)
@@ -3815,6 +4299,10 @@ __global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const
   if (prob >= (C.nprob > 0 ? C.nprob : C.K)) return;
   prob += C.prob0;
   icp_post_one(C, &states[prob], stats, prob);
+  if (C.pub) {  // (fused control steps: phase / done changed; one thread per problem)
+    for (int l = 0; l < PUB_SLICE_GRANULES; ++l) pub_publish_state(C, &states[prob], prob, l, (unsigned) C.epoch);
+    for (int l = 0; l < PUB_EPOCH_REPLICAS; ++l) pub_write_epoch(C.pub_epoch, prob, l, (unsigned) C.epoch);
+  }
 }
 
 // end of compute(): _pruneCorrespondences bookkeeping, fixTransform, Success (:88-94).  One block per problem; the
@@ -4024,63 +4512,82 @@ void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemD
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
                          ProblemState* states, int K, int max_nm, int team, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
-#define CNL_LAUNCH(TEAM)                                                                                   \
-  do {                                                                                                     \
-    dim3 grid((max_nm * TEAM + 255) / 256, K);                                                             \
-    if (dim == 3) {                                                                                        \
-      if (plane)                                                                                           \
-        hipLaunchKernelGGL((k_icp_step_cnl<3, true, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states);  \
-      else                                                                                                 \
-        hipLaunchKernelGGL((k_icp_step_cnl<3, false, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states); \
-    } else {                                                                                               \
-      if (plane)                                                                                           \
-        hipLaunchKernelGGL((k_icp_step_cnl<2, true, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states);  \
-      else                                                                                                 \
-        hipLaunchKernelGGL((k_icp_step_cnl<2, false, TEAM>), grid, dim3(256), 0, s, S, GL, probs, states); \
-    }                                                                                                      \
+#define CNL_LAUNCH(TEAM, FUSED)                                                                                   \
+  do {                                                                                                            \
+    dim3 grid((max_nm * TEAM + 255) / 256, K);                                                                    \
+    if (dim == 3) {                                                                                               \
+      if (plane)                                                                                                  \
+        hipLaunchKernelGGL((k_icp_step_cnl<3, true, TEAM, FUSED>), grid, dim3(256), 0, s, S, GL, probs, states);  \
+      else                                                                                                        \
+        hipLaunchKernelGGL((k_icp_step_cnl<3, false, TEAM, FUSED>), grid, dim3(256), 0, s, S, GL, probs, states); \
+    } else {                                                                                                      \
+      if (plane)                                                                                                  \
+        hipLaunchKernelGGL((k_icp_step_cnl<2, true, TEAM, FUSED>), grid, dim3(256), 0, s, S, GL, probs, states);  \
+      else                                                                                                        \
+        hipLaunchKernelGGL((k_icp_step_cnl<2, false, TEAM, FUSED>), grid, dim3(256), 0, s, S, GL, probs, states); \
+    }                                                                                                             \
   } while (0)
-  if (team >= 4)
-    CNL_LAUNCH(4);
-  else
-    CNL_LAUNCH(1);
+  // (fused control steps -- S.fc.pub: the instantiations that read the state from the published record)
+  if (S.fc.pub) {
+    if (team >= 4)
+      CNL_LAUNCH(4, true);
+    else
+      CNL_LAUNCH(1, true);
+  } else {
+    if (team >= 4)
+      CNL_LAUNCH(4, false);
+    else
+      CNL_LAUNCH(1, false);
+  }
 #undef CNL_LAUNCH
 }
-
-template <int PPT, bool GATHER>
+template <int PPT, bool GATHER, bool FUSED>
 static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                             int max_nm, hipStream_t s) {
   dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
   if (dim == 3) {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step_fast<3, false, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<3, false, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
   } else {
     if (plane)
-      hipLaunchKernelGGL((k_icp_step_fast<2, true, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<2, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
     else
-      hipLaunchKernelGGL((k_icp_step_fast<2, false, PPT, GATHER>), grid, dim3(256), 0, s, S, probs, states);
+      hipLaunchKernelGGL((k_icp_step_fast<2, false, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
   }
 }
-
-// the converged pass (k_icp_step_fast) + the deferred-search kernel for the points whose certificate failed (S.queue)
 void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                           int max_nm, int ppt, bool gather, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
+  if (S.fc.pub) {  // fused control steps (one or two points per thread)
+    if (gather) {
+      if (ppt >= 2)
+        launch_fast_ppt<2, true, true>(dim, plane, S, probs, states, K, max_nm, s);
+      else
+        launch_fast_ppt<1, true, true>(dim, plane, S, probs, states, K, max_nm, s);
+    } else {
+      if (ppt >= 2)
+        launch_fast_ppt<2, false, true>(dim, plane, S, probs, states, K, max_nm, s);
+      else
+        launch_fast_ppt<1, false, true>(dim, plane, S, probs, states, K, max_nm, s);
+    }
+    return;
+  }
   if (gather) {
     if (ppt >= 4)
-      launch_fast_ppt<4, true>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<4, true, false>(dim, plane, S, probs, states, K, max_nm, s);
     else if (ppt >= 2)
-      launch_fast_ppt<2, true>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<2, true, false>(dim, plane, S, probs, states, K, max_nm, s);
     else
-      launch_fast_ppt<1, true>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<1, true, false>(dim, plane, S, probs, states, K, max_nm, s);
   } else {
     if (ppt >= 4)
-      launch_fast_ppt<4, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<4, false, false>(dim, plane, S, probs, states, K, max_nm, s);
     else if (ppt >= 2)
-      launch_fast_ppt<2, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<2, false, false>(dim, plane, S, probs, states, K, max_nm, s);
     else
-      launch_fast_ppt<1, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<1, false, false>(dim, plane, S, probs, states, K, max_nm, s);
   }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }

@@ -18,7 +18,7 @@ def test_tuning_defaults_and_round_trip(product, monkeypatch):
     t = al.tuning()
     assert (t.strategy_mask, t.queue_probe_iteration, t.small_max_points, t.fast_from_iteration) == (0, 1, 1024, 3)
     assert (t.lds_tile, t.fast_gather, t.msort_key_bits, t.queue_min_points) == (-1, -1, 0, 90000)
-    assert (t.search_lists, t.search_team, t.batch_pipeline) == (-1, 0, -1)
+    assert (t.search_lists, t.search_team, t.batch_pipeline, t.fused_control) == (-1, 0, -1, -1)
     assert t.cell_target == pytest.approx(8.0)
     al.set_tuning(lds_tile=2, fast_from_iteration=1, cell_target=6.0)
     t = al.tuning()
@@ -73,6 +73,9 @@ def test_batches_give_the_same_bits_under_every_search_pass_kernel(oracle, produ
                   {"search_lists": 1, "search_team": 4}, {"search_lists": 1, "search_team": 4, "fast_from_iteration": 100},
                   {"batch_pipeline": 0}, {"batch_pipeline": 1}, {"batch_pipeline": 1, "search_lists": 0},
                   {"batch_pipeline": 3}, {"batch_pipeline": 4}, {"batch_pipeline": 8}, {"batch_pipeline": 5, "search_lists": 0},
+                  {"fused_control": 0}, {"fused_control": 1}, {"fused_control": 1, "batch_pipeline": 0},
+                  {"fused_control": 1, "fast_from_iteration": 1}, {"fused_control": 1, "fast_from_iteration": 100},
+                  {"fused_control": 0, "batch_pipeline": 0},
                   {"batch_pipeline": 0, "search_lists": 0, "lds_tile": 0}):
         got = run(product.MultiAligner(abi.SE3_QUAT_RIGHT), **knobs)
         for r, g in zip(ref, got):
