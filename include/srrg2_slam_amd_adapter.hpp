@@ -68,6 +68,8 @@
 
 #include <cstring>
 #include <functional>
+#include <iostream>
+#include <typeinfo>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -113,7 +115,35 @@ namespace srrg2_slam_interfaces {
       c.robustifier               = dynamic_cast<RobustifierCauchy*>(rob)      ? SRRG2_ROBUST_CAUCHY
                                     : dynamic_cast<RobustifierSaturated*>(rob) ? SRRG2_ROBUST_SATURATED
                                     : dynamic_cast<RobustifierClamp*>(rob)     ? SRRG2_ROBUST_CLAMP
-                                                                               : SRRG2_ROBUST_NONE;
+                                                                               : -1;
+      // (a robustifier the device does not evaluate must not silently become "none" -- the alignment would
+      // run without the kernel the configuration asked for)
+      if (c.robustifier < 0)
+        throw std::runtime_error("MultiAlignerBase_|robustifier type [" + rob->className() +
+                                 "] is not evaluated on the device (Cauchy, Saturated, Clamp or none)");
+    }
+    // PARAM `solver` (multi_aligner.h:39-43).  The registration solver of the reference runs ONE Gauss-Newton iteration per
+    // ICP iteration on a one-variable graph (its constructor forces max_iterations = [1], multi_aligner.h:61-62); that step
+    // is fixed on the device (dense L D L^T, no damping).  A configuration that swaps the solver for a subclass or asks for
+    // another iteration count would behave differently there: refuse it instead of ignoring it.  Everything else the Solver
+    // exposes (linear solver, termination criteria, robustifier policies: [EXT] srrg2_solver, not under the reference tree)
+    // cannot change a single dense 3 x 3 / 6 x 6 solve and is not consulted -- said once on stderr when the object is not
+    // the one the aligner constructed.
+    inline void checkSolver(const std::shared_ptr<Solver>& solver, const Solver* constructed) {
+      if (!solver) throw std::runtime_error("MultiAlignerBase_|no solver");  // multi_aligner_impl.cpp:29,39,48
+      if (typeid(*solver) != typeid(Solver))
+        throw std::runtime_error("MultiAlignerBase_|PARAM solver holds a [" + solver->className() +
+                                 "]: the registration step runs on the device and cannot host a Solver subclass");
+      const auto& its = solver->param_max_iterations.value();
+      if (its.size() != 1 || its[0] != 1)
+        throw std::runtime_error("MultiAlignerBase_|PARAM solver: max_iterations must stay [1] (multi_aligner.h:61-62): one "
+                                 "Gauss-Newton step per ICP iteration is what the device runs");
+      static bool told = false;
+      if (solver.get() != constructed && !told) {
+        told = true;
+        std::cerr << "MultiAlignerBase_|PARAM solver was replaced by the configuration: only its class and max_iterations are "
+                     "checked; its other PARAMs are not consulted (the Gauss-Newton step of the registration runs on the device)\n";
+      }
     }
   }  // namespace amd_detail
 
@@ -202,7 +232,12 @@ namespace srrg2_slam_interfaces {
           false,
           nullptr);
 
-    MultiAlignerBase_() = default;
+    MultiAlignerBase_() {
+      // multi_aligner.h:61-62: the registration solver runs ONE iteration per call
+      param_solver->param_max_iterations.value().clear();
+      param_solver->param_max_iterations.pushBack(1);
+      _constructed_solver = param_solver.value().get();
+    }
     virtual ~MultiAlignerBase_() {
       if (_h) srrg2_aligner_destroy(_h);
     }
@@ -234,11 +269,29 @@ namespace srrg2_slam_interfaces {
     // multi_aligner_impl.cpp:47-95: blocking; status, estimate and iteration statistics are host visible on return
     void compute() override {
       if (!param_slice_processors.size()) throw std::runtime_error("MultiAlignerBase_::compute|no slices");  // :49
-      this->_status = AlignerBase::Fail;
-      this->_iteration_stats.clear();
+      amd_detail::checkSolver(param_solver.value(), _constructed_solver);
+      // (an override of _preCompute / _postCompute written like the reference's default calls _runSolver; that
+      // must run the iterations, not compute() with its hooks again)
+      if (_in_compute) throw std::runtime_error("MultiAlignerBase_::compute|re-entered from one of its own hooks: call _runSolver there");
+      struct Guard { bool& f; explicit Guard(bool& f_) : f(f_) { f = true; } ~Guard() { f = false; } } guard(_in_compute);
       // the virtual hook of multi_aligner.h:141: a downstream subclass that overrides it still compiles and still runs
       // before the registration; the default does what the reference's does (:131-141)
       _preCompute();
+      runOnDevice();
+      // the virtual hook of multi_aligner.h:143.  The reference reaches it only when the first run left statistics and
+      // enough inliers (multi_aligner_impl.cpp:73-88: it returns before it on Fail and on NotEnoughInliers), and its default
+      // starts the inlier-only run (:163-181) -- that run has already happened on the device (enable_inlier_only_runs
+      // travels in srrg2_aligner_params), so the default here is empty; an override sees the final status, estimate,
+      // statistics and correspondences.
+      if (this->_status == AlignerBase::Success && !this->_iteration_stats.empty()) _postCompute();
+    }
+
+  protected:
+    // one blocking registration on the device with the CURRENT PARAMs, slices, clouds and guess: no hooks (compute() and
+    // _runSolver() both end up here)
+    void runOnDevice() {
+      this->_status = AlignerBase::Fail;
+      this->_iteration_stats.clear();
       bindSlices();
       float T[12];
       amd_detail::toRowMajor(this->_moving_in_fixed, T);
@@ -286,12 +339,9 @@ namespace srrg2_slam_interfaces {
         out.reserve(buf.size());
         for (const srrg2_correspondence& c : buf) out.emplace_back(Correspondence(c.fixed_idx, c.moving_idx, c.response));
       }
-      // the virtual hook of multi_aligner.h:143.  The reference runs it inside compute() right after the first solver run
-      // (:71), where its default starts the inlier-only run (:163-181) -- that run has already happened on the device
-      // (enable_inlier_only_runs travels in srrg2_aligner_params), so the default here is empty; an override sees the
-      // final status, estimate, statistics and correspondences.
-      _postCompute();
     }
+
+  public:
     // multi_aligner_impl.cpp:275-285
     int numCorrespondences() override {
       int n = 0;
@@ -344,7 +394,7 @@ namespace srrg2_slam_interfaces {
       auto keep_tc      = this->param_termination_criteria.value();
       this->param_max_iterations.setValue((int) number_of_iterations_);
       this->param_termination_criteria.setValue(termination_criterion_);
-      compute();
+      runOnDevice();  // (the iterations only: no _preCompute / _postCompute, as in the reference)
       this->param_max_iterations.setValue(keep_it);
       this->param_termination_criteria.setValue(keep_tc);
     }
@@ -447,6 +497,8 @@ namespace srrg2_slam_interfaces {
     srrg2_aligner_h _h   = nullptr;
     int _device          = 0;
     bool _clouds_changed = true;
+    bool _in_compute     = false;               // compute() is running its hooks (re-entrancy guard)
+    const Solver* _constructed_solver = nullptr;  // the solver this aligner built itself (checkSolver)
     std::vector<srrg2_slice_config> _bound_configs;
   };
 
