@@ -390,6 +390,7 @@ def measure(args, init_dist=True):
                          (K_total, args.batch_points, world, len(mine), args.iterations)),
             "points": args.points if args.workload == "c2" else (int(data["moving"].shape[0]) if args.workload == "c3" else args.batch_points),
             "iterations_per_step": args.iterations,
+            **({"shared_clouds": not args.c3_own_clouds} if args.workload == "c3" else {}),
             "alignments_per_step_per_gpu": len(mine) if args.workload == "c4" else 1,
             "alignments_per_step_by_rank": per_rank,
             "alignments_total": K_total,

@@ -261,7 +261,13 @@ int srrg2_aligner_get_information(srrg2_aligner_h h, float* H_out);
 /* MultiAlignerBase_::numCorrespondences() (multi_aligner_impl.cpp:275-285): priors count 1 */
 int srrg2_aligner_num_correspondences(srrg2_aligner_h h, int* n_out);
 /* slice->correspondences() (aligner_slice_processor.h:92-98), after pruning if enabled;
- * ascending moving_idx. */
+ * ascending moving_idx.
+ * LIFETIME: the passes do not store per-point records; this call (and get_factor_status, the scene merge)
+ * DERIVES them from the state the last compute() left on the device -- the clouds, the neighbour of every moving point, the
+ * transform of the last executed pass.  They stay derivable until a cloud of the aligner is replaced: after the next
+ * set_fixed / set_moving / share_clouds / compute_batch upload the correspondences of the earlier compute() are gone (n = 0),
+ * because their indices would refer to the new cloud.  A tracker reads (or stores) them before it binds the next frame,
+ * as the reference's does (multi_tracker_impl.cpp:105-108: compute(), then storeCorrespondences()). */
 int srrg2_aligner_get_correspondences(srrg2_aligner_h h, int slice_idx, srrg2_correspondence* buf,
                                       int* n_inout);
 /* solver->measurementStats() of the last iteration for one cue slice

@@ -418,6 +418,10 @@ int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
         if (m > CNL_MAX_CLASS || class_bound2(m) > g.gate2_ext) continue;
         offs.push_back(Off{x, y, z, m, x * x + y * y + z * z});
       }
+  // (the entry counts are scanned in 32 bits.  A fixed cell of c points puts ceil(c / 16) entries into at most
+  // |offs| lists, so the total is below |offs| (nf + nf / 16): refuse the lists where that bound does not fit an int --
+  // a wrapped sum could land back inside [0, max_entries] and under-allocate the entry array)
+  if ((long long) offs.size() * ((long long) s->nf + s->nf / CNL_ENTRY_MAX + 1) >= (1LL << 31)) return 0;
   std::stable_sort(offs.begin(), offs.end(), [](const Off& p, const Off& q) { return p.cls != q.cls ? p.cls < q.cls : p.c2 < q.c2; });
   std::vector<int4> offs4(offs.size());
   for (size_t k = 0; k < offs.size(); ++k) offs4[k] = make_int4(offs[k].x, offs[k].y, offs[k].z, offs[k].cls);
