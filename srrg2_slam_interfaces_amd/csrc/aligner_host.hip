@@ -956,6 +956,29 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if (a->slices[si]->cfg.kind != SRRG2_SLICE_PRIOR && si != first_cue)
         return fail(SRRG2_E_UNSUPPORTED, "compute_batch supports one cue slice (plus prior slices)");
   }
+  // all cue slices projective (RGB-D: point-to-plane + reprojection): one launch pair per iteration for all of them
+  std::vector<int> proj_group;
+  {
+    bool all_proj = true;
+    for (int si = 0; si < nslices; ++si) {
+      if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+      if (a->slices[si]->cfg.finder != SRRG2_FINDER_PROJECTIVE) all_proj = false;
+      proj_group.push_back(si);
+    }
+    if (!all_proj || proj_group.size() < 2 || proj_group.size() > 4 || (C.tune & 131072)) proj_group.clear();
+  }
+  // ... and when they all read the SAME clouds (srrg2_aligner_share_clouds) through the same finder parameters, their
+  // associations are identical: one z-buffer pass and one step launch serve all of them (k_icp_step_proj_fused)
+  bool proj_fused = !proj_group.empty() && K >= 1;
+  for (size_t z = 1; z < proj_group.size() && proj_fused; ++z) {
+    const Slice* s0 = a->slices[proj_group[0]];
+    const Slice* sz = a->slices[proj_group[z]];
+    const srrg2_slice_config &c0 = s0->cfg, &cz = sz->cfg;
+    proj_fused = sz->alias_of == proj_group[0] && s0->alias_of < 0 && cz.image_rows == c0.image_rows && cz.image_cols == c0.image_cols &&
+                 cz.depth_min == c0.depth_min && cz.depth_max == c0.depth_max && cz.finder_max_distance == c0.finder_max_distance &&
+                 std::memcmp(cz.camera_matrix, c0.camera_matrix, sizeof(c0.camera_matrix)) == 0 &&
+                 std::memcmp(cz.sensor_in_robot, c0.sensor_in_robot, sizeof(c0.sensor_in_robot)) == 0;
+  }
   // Fused control steps (FusedCtl): the control step of iteration i runs in the prologue of the first pass kernel of
   // iteration i + 1 -- no control launch between the passes of a run.  For aligners whose slices are all nearest-neighbour
   // cue slices on the list / converged-pass kernels; everything else keeps one control launch per iteration.
@@ -966,7 +989,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // the record in every workgroup and gets slower: C4-24 -4 %, C4-32 -8 %, C4-256 -13 % (profiles/r5e, r5f).
   bool fuse = tn.fused_control != 0 && !small && !a->reduce_fn && a->timeline_path.empty() && first_cue >= 0 &&
               a->params.max_iterations >= 2;
-  fuse = fuse && nslices == 1;  // (one cue slice, no prior slices: the step finds everything in that slice's record)
+  // (one nearest-neighbour cue slice, or projective slices that share one association -- k_proj_zbuf_fz --; no prior slices:
+  // the step finds everything in the slices' records)
+  const bool fuse_proj = proj_fused && (int) proj_group.size() == nslices && K == 1;
+  fuse = fuse && (nslices == 1 || fuse_proj);
   if (fuse && tn.fused_control < 0) {
     long long worst = 0;
     for (int h = 0; h < (split ? split : 1); ++h) {
@@ -978,7 +1004,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   }
   for (int si = 0; si < nslices && fuse; ++si) {
     const Slice* s = a->slices[si];
-    fuse = s->cfg.kind != SRRG2_SLICE_PRIOR && s->cfg.finder == SRRG2_FINDER_NN_GATED && cnl[(size_t) si] && !sdev[si].queue;
+    fuse = s->cfg.kind != SRRG2_SLICE_PRIOR &&
+           (fuse_proj ? s->cfg.finder == SRRG2_FINDER_PROJECTIVE
+                      : (s->cfg.finder == SRRG2_FINDER_NN_GATED && cnl[(size_t) si] && !sdev[si].queue));
   }
   if (fuse) {
     if ((rc = a->pub.reserve((size_t) K * SRRG2_MAX_SLICES * PUB_SLICE_GRANULES))) return rc;
@@ -1039,29 +1067,6 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     srrg2amd::launch_icp_small(a->dim, s->cfg.kind == SRRG2_SLICE_P2PLANE, sdev[first_cue], C,
                                a->probs.p + (size_t) first_cue * K, a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                a->stream);
-  }
-  // all cue slices projective (RGB-D: point-to-plane + reprojection): one launch pair per iteration for all of them
-  std::vector<int> proj_group;
-  {
-    bool all_proj = true;
-    for (int si = 0; si < nslices; ++si) {
-      if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR) continue;
-      if (a->slices[si]->cfg.finder != SRRG2_FINDER_PROJECTIVE) all_proj = false;
-      proj_group.push_back(si);
-    }
-    if (!all_proj || proj_group.size() < 2 || proj_group.size() > 4 || (C.tune & 131072)) proj_group.clear();
-  }
-  // ... and when they all read the SAME clouds (srrg2_aligner_share_clouds) through the same finder parameters, their
-  // associations are identical: one z-buffer pass and one step launch serve all of them (k_icp_step_proj_fused)
-  bool proj_fused = !proj_group.empty() && K >= 1;
-  for (size_t z = 1; z < proj_group.size() && proj_fused; ++z) {
-    const Slice* s0 = a->slices[proj_group[0]];
-    const Slice* sz = a->slices[proj_group[z]];
-    const srrg2_slice_config &c0 = s0->cfg, &cz = sz->cfg;
-    proj_fused = sz->alias_of == proj_group[0] && s0->alias_of < 0 && cz.image_rows == c0.image_rows && cz.image_cols == c0.image_cols &&
-                 cz.depth_min == c0.depth_min && cz.depth_max == c0.depth_max && cz.finder_max_distance == c0.finder_max_distance &&
-                 std::memcmp(cz.camera_matrix, c0.camera_matrix, sizeof(c0.camera_matrix)) == 0 &&
-                 std::memcmp(cz.sensor_in_robot, c0.sensor_in_robot, sizeof(c0.sensor_in_robot)) == 0;
   }
   // Adaptive use of the deferred-search kernel.  After iteration `probe_it` the control kernel looks at what that
   // iteration deferred: few entries, none of them far (a far entry is a whole-wave scan: expensive when a wave has to do
@@ -1143,6 +1148,15 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           a->prof_used++;
           HIP_TRY(hipEventRecord(e0, a->stream));
         }
+        if (fuse)
+          for (size_t z = 0; z < proj_group.size(); ++z) {
+            Slice* sz              = a->slices[proj_group[z]];
+            pack[z].fc.ctl         = a->ctl_dev.p;
+            pack[z].fc.epoch       = epoch;
+            pack[z].partials       = sz->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
+            pack[z].fc.prev_partials = sz->partials.p + (size_t) ((epoch + 1) & 1) * K * PARTIAL_SLOTS * ACC_N;
+            pack[z].fc.prior       = (slot0 > 0 || it > 0) ? 1 : 0;
+          }
         if (proj_fused) {
           srrg2amd::launch_proj_step_fused(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
           sdev[proj_group[0]].zbuf_parity ^= 1;  // (the one z-buffer that is used)
@@ -1152,6 +1166,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         }
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
         control(it, last_phase, 0);
+        ++epoch;
         continue;
       }
       for (int si = 0; si < nslices; ++si) {

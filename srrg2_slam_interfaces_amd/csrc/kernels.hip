@@ -2101,35 +2101,50 @@ __device__ __forceinline__ void pub_publish_state(const CtlParams& C, const Prob
   }
 }
 
-// The control step on one wave, for an aligner with ONE cue slice (the slice of the calling pass kernel).  Everything it
-// reads arrives in ONE round trip: the record of the previous epoch (`g`: this lane's granule, already loaded by the caller)
-// carries the state the step needs, the slot sets are addressed from the kernel arguments.  Nothing waits for its plain stores
-// (state, statistics, zeroed slot sets: read after the next kernel boundary); the new record and the epoch words are
-// self-contained 8-byte stores.  D = 3 | 6.
-template <int D>
-__device__ __forceinline__ void wave_control(const SliceDev& S, ProblemState* __restrict__ states, int prob, unsigned long long g) {
-  const FusedCtl& F  = S.fc;
+// The control step on one wave, for an aligner of `ns` <= MAXS cue slices and no prior slices (Sv: their SliceDev records in
+// slice order -- the calling pass kernel's own argument, or the pack of the projective kernels).  Everything it reads
+// arrives in ONE round trip: the records of the previous epoch (`g[z]`: this lane's granule of slice z's record, already
+// loaded by the caller) carry the state the step needs, the slot sets are addressed from the kernel arguments.  Nothing waits
+// for its plain stores (state, statistics, zeroed slot sets: read after the next kernel boundary); the new records and the
+// epoch words are self-contained 8-byte stores.  D = 3 | 6.
+template <int D, int MAXS>
+__device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, int ns, ProblemState* __restrict__ states, int prob,
+                                             const unsigned long long (&g)[MAXS]) {
+  const FusedCtl& F  = Sv[0].fc;
   const int lane     = threadIdx.x & 63;
-  const int s        = S.slice_idx;
   ProblemState* st   = &states[prob];
   const unsigned epoch = (unsigned) F.epoch;
-  unsigned long long* rec = F.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane;
   constexpr int TS   = D == 3 ? 9 : 12;  // words of X
-  // ---- the slot sets of the passes of the previous epoch (buffer (epoch - 1) & 1): requested first
-  long long* p = F.prev_partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
-  long long v  = 0;
+  // ---- the slot sets of the passes of the previous epoch (buffer (epoch - 1) & 1) of every slice: requested first
+  long long v[MAXS];
 #pragma unroll
-  for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) v += p[q * 64 + lane];
-  const int w          = (int) (unsigned) g;  // the value of this lane's granule
-  const float told     = __int_as_float(w);   // lanes [0, 12): Tf of the passes just run
+  for (int z = 0; z < MAXS; ++z) {
+    v[z] = 0;
+    if (z < ns) {
+      const long long* p = Sv[z].fc.prev_partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+#pragma unroll
+      for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) v[z] += p[q * 64 + lane];
+    }
+  }
+  const int w          = (int) (unsigned) g[0];  // the value of this lane's granule (slice 0: the shared part of the state)
   float Xl             = __int_as_float(__shfl(w, (PUB_G_X + lane) & 63));  // lanes [0, 12): X
-  const int kexp       = __builtin_amdgcn_readlane(w, PUB_G_KEXP);
   const unsigned fl0   = (unsigned) __builtin_amdgcn_readlane(w, PUB_G_FLAGS);
   const int nstats0    = __builtin_amdgcn_readlane(w, PUB_G_NSTATS);
   const int wc         = __builtin_amdgcn_readlane(w, PUB_G_WCOUNT);
   const int npasses0   = __builtin_amdgcn_readlane(w, PUB_G_NPASSES);
-  if (fl0 & PUB_FLAG_STOP) {  // (the passes return at their first instruction; the record only moves to the new epoch)
-    pub_store(rec, ((unsigned long long) epoch << 32) | (unsigned) w);
+  float told[MAXS];  // lanes [0, 12): Tf of the passes just run, per slice
+  int kexp[MAXS];
+#pragma unroll
+  for (int z = 0; z < MAXS; ++z) {
+    told[z] = __int_as_float((int) (unsigned) g[z]);
+    kexp[z] = __builtin_amdgcn_readlane((int) (unsigned) g[z], PUB_G_KEXP);
+  }
+  if (fl0 & PUB_FLAG_STOP) {  // (the passes return at their first instruction; the records only move to the new epoch)
+#pragma unroll
+    for (int z = 0; z < MAXS; ++z)
+      if (z < ns)
+        pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane,
+                  ((unsigned long long) epoch << 32) | (unsigned) g[z]);
     pub_write_epoch(F.pub_epoch, prob, lane, epoch);
     return;
   }
@@ -2144,32 +2159,53 @@ __device__ __forceinline__ void wave_control(const SliceDev& S, ProblemState* __
       wx = st->w_chi[lane];
     }
   }
-  v += __shfl_xor(v, 32);  // the total of entry (lane & 31)
-  // the slot sets are accumulated with atomics by the passes: this buffer is added to again two passes from now
-#pragma unroll
-  for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
-  const double scaled = (double) v * dm::pow2(-kexp);
-  const int nc = (int) rl_ll(v, ACC_N_CORR), num_in = (int) rl_ll(v, ACC_N_IN), num_out = (int) rl_ll(v, ACC_N_OUT);
-  const int num_sup = nc - num_in - num_out, num_corr = nc >= 0 ? nc : 0;
-  const double chi_in = 0.0 + rl_d(scaled, ACC_CHI_IN), chi_out = 0.0 + rl_d(scaled, ACC_CHI_OUT);
   const int hr = lane / D, hc = lane - hr * D;
-  const double Hl = 0.0 + __shfl(scaled, hidx(hr < hc ? hr : hc, hr < hc ? hc : hr) & 31);  // H(r, c) in lane r D + c
-  const double bl = 0.0 + __shfl(scaled, (ACC_B + lane) & 31);                              // b(a) in lane a
-  if (lane == 0) {
-    st->ncorr[s] = nc;
-    st->ninl[s]  = num_in;
-    st->npasses  = npasses0 + 1;
+  const int hsrc = hidx(hr < hc ? hr : hc, hr < hc ? hc : hr) & 31;
+  double Hl = 0.0, bl = 0.0;  // H(r, c) in lane r D + c; b(a) in lane a
+  int num_in = 0, num_out = 0, num_sup = 0, num_corr = 0;
+  double chi_in = 0.0, chi_out = 0.0;
+  bool good = false;
+#pragma unroll
+  for (int z = 0; z < MAXS; ++z) {
+    if (z >= ns) break;  // (uniform)
+    v[z] += __shfl_xor(v[z], 32);  // the total of entry (lane & 31)
+    // the slot sets are accumulated with atomics by the passes: this buffer is added to again two passes from now
+    long long* p = Sv[z].fc.prev_partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+#pragma unroll
+    for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+    const double scaled = (double) v[z] * dm::pow2(-kexp[z]);
+    const int nc = (int) rl_ll(v[z], ACC_N_CORR), n_in = (int) rl_ll(v[z], ACC_N_IN), n_out = (int) rl_ll(v[z], ACC_N_OUT);
+    good |= nc > Sv[z].fc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
+    Hl = Hl + __shfl(scaled, hsrc);
+    bl = bl + __shfl(scaled, (ACC_B + lane) & 31);
+    num_in += n_in;
+    num_out += n_out;
+    num_sup += nc - n_in - n_out;
+    num_corr += nc >= 0 ? nc : 0;
+    chi_in  = chi_in + rl_d(scaled, ACC_CHI_IN);
+    chi_out = chi_out + rl_d(scaled, ACC_CHI_OUT);
+    const int s = Sv[z].slice_idx;
+    if (lane == 0) {
+      st->ncorr[s] = nc;
+      st->ninl[s]  = n_in;
+    }
+    if (lane < 12) st->Tlast[s][lane] = told[z];  // the transforms the passes of this iteration ran with
   }
-  if (lane < 12) st->Tlast[s][lane] = told;  // the transforms the passes of this iteration ran with
-  if (!(nc > F.min_num_correspondences)) {  // aligner_slice_processor_impl.cpp:77-79; multi_aligner_impl.cpp:107-111
+  if (lane == 0) st->npasses = npasses0 + 1;
+  if (!good) {  // multi_aligner_impl.cpp:107-111
     if (lane == 0) {
       st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;
       st->done   = 1;
     }
-    unsigned nv = (unsigned) w;
-    if (lane == PUB_G_FLAGS) nv = fl0 | PUB_FLAG_STOP;
-    if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
-    pub_store(rec, ((unsigned long long) epoch << 32) | nv);
+#pragma unroll
+    for (int z = 0; z < MAXS; ++z) {
+      if (z >= ns) break;
+      unsigned nv = (unsigned) g[z];
+      if (lane == PUB_G_FLAGS) nv = fl0 | PUB_FLAG_STOP;
+      if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
+      pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane,
+                ((unsigned long long) epoch << 32) | nv);
+    }
     pub_write_epoch(F.pub_epoch, prob, lane, epoch);
     return;
   }
@@ -2248,7 +2284,7 @@ __device__ __forceinline__ void wave_control(const SliceDev& S, ProblemState* __
       // the stack: a kernel that owns scratch memory pays for it in every wave)
       const double v0 = rl_d(dxv, 0), v1 = rl_d(dxv, 1), v2 = rl_d(dxv, 2), v3 = rl_d(dxv, 3), v4 = rl_d(dxv, 4), v5 = rl_d(dxv, 5);
       double R0, R1, R2, R3, R4, R5, R6, R7, R8;
-      if (S.variable_kind == 2) {
+      if (Sv[0].variable_kind == 2) {
         const double n2  = (v3 * v3 + v4 * v4) + v5 * v5;
         const bool small = n2 < 1.0;
         const double qw  = sqrt(small ? 1.0 - n2 : 1.0);
@@ -2326,51 +2362,53 @@ __device__ __forceinline__ void wave_control(const SliceDev& S, ProblemState* __
     }
   }
   if (stop && lane == 0) st->done = 1;  // :124-126
-  // ---- finder transform robot_in_sensor * X (finder_transform_of), the previous one kept
-  float tnew = told;
-  if (!bad) {
-    const float* A = S.Sinv;
-    const int i = (lane >> 2) % 3, j = lane & 3;  // slot (i, j) of the 3 x 4 layout
-    const float A0 = i == 0 ? A[0] : (i == 1 ? A[D == 6 ? 4 : 3] : A[D == 6 ? 8 : 6]);
-    const float A1 = i == 0 ? A[1] : (i == 1 ? A[D == 6 ? 5 : 4] : A[D == 6 ? 9 : 7]);
-    const float A2 = i == 0 ? A[2] : (i == 1 ? A[D == 6 ? 6 : 5] : A[D == 6 ? 10 : 8]);
-    if constexpr (D == 6) {
-      const float A3  = i == 0 ? A[3] : (i == 1 ? A[7] : A[11]);
-      const double b0 = (double) __shfl(Xl, (0 * 4 + j) & 63), b1 = (double) __shfl(Xl, (1 * 4 + j) & 63),
-                   b2 = (double) __shfl(Xl, (2 * 4 + j) & 63);
-      double o = ((double) A0 * b0 + (double) A1 * b1) + (double) A2 * b2;
-      if (j == 3) o = o + (double) A3;
-      tnew = (float) o;
-    } else {
-      // se2_compose into t9, spread into the 3 x 4 slots: T = [t0 t1 0 t2; t3 t4 0 t5; 0 0 1 0]
-      const int jj = j == 3 ? 2 : j;  // column of the 3 x 3 product the slot holds (j = 2: none)
-      const double b0 = (double) __shfl(Xl, (0 * 3 + jj) & 63), b1 = (double) __shfl(Xl, (1 * 3 + jj) & 63);
-      double o = (double) A0 * b0 + (double) A1 * b1;  // (rows i < 2; row 2 is overwritten below)
-      if (j == 3) o = o + (double) A2;
-      float f = (float) o;
-      if (j == 2) f = 0.f;
-      if (i == 2) f = j == 2 ? 1.f : 0.f;
-      tnew = f;
+  // ---- finder transforms robot_in_sensor * X (finder_transform_of) of the slices, the previous ones kept; the records of
+  //      the new epoch, then the epoch words
+  const unsigned x_up = __float_as_uint(__shfl(Xl, (lane - PUB_G_X) & 63));
+#pragma unroll
+  for (int z = 0; z < MAXS; ++z) {
+    if (z >= ns) break;  // (uniform)
+    const int s = Sv[z].slice_idx;
+    float tnew  = told[z];
+    if (!bad) {
+      const float* A = Sv[z].Sinv;
+      const int i = (lane >> 2) % 3, j = lane & 3;  // slot (i, j) of the 3 x 4 layout
+      const float A0 = i == 0 ? A[0] : (i == 1 ? A[D == 6 ? 4 : 3] : A[D == 6 ? 8 : 6]);
+      const float A1 = i == 0 ? A[1] : (i == 1 ? A[D == 6 ? 5 : 4] : A[D == 6 ? 9 : 7]);
+      const float A2 = i == 0 ? A[2] : (i == 1 ? A[D == 6 ? 6 : 5] : A[D == 6 ? 10 : 8]);
+      if constexpr (D == 6) {
+        const float A3  = i == 0 ? A[3] : (i == 1 ? A[7] : A[11]);
+        const double b0 = (double) __shfl(Xl, (0 * 4 + j) & 63), b1 = (double) __shfl(Xl, (1 * 4 + j) & 63),
+                     b2 = (double) __shfl(Xl, (2 * 4 + j) & 63);
+        double o = ((double) A0 * b0 + (double) A1 * b1) + (double) A2 * b2;
+        if (j == 3) o = o + (double) A3;
+        tnew = (float) o;
+      } else {
+        // se2_compose into t9, spread into the 3 x 4 slots: T = [t0 t1 0 t2; t3 t4 0 t5; 0 0 1 0]
+        const int jj = j == 3 ? 2 : j;  // column of the 3 x 3 product the slot holds (j = 2: none)
+        const double b0 = (double) __shfl(Xl, (0 * 3 + jj) & 63), b1 = (double) __shfl(Xl, (1 * 3 + jj) & 63);
+        double o = (double) A0 * b0 + (double) A1 * b1;  // (rows i < 2; row 2 is overwritten below)
+        if (j == 3) o = o + (double) A2;
+        float f = (float) o;
+        if (j == 2) f = 0.f;
+        if (i == 2) f = j == 2 ? 1.f : 0.f;
+        tnew = f;
+      }
+      if (lane < 12) st->Tf[s][lane] = tnew;
     }
-    if (lane < 12) st->Tf[s][lane] = tnew;
-  }
-  if (lane < 12) st->Tfprev[s][lane] = told;
-  // ---- the record of the new epoch, then the epoch words
-  unsigned nv = 0u;
-  if (lane < 12) nv = __float_as_uint(tnew);
-  else if (lane < 24) nv = __float_as_uint(__shfl(told, (lane - 12) & 63));
-  {
-    const unsigned told_up = __float_as_uint(__shfl(told, (lane - 12) & 63));  // (every lane takes part in the shuffle)
-    const unsigned x_up    = __float_as_uint(__shfl(Xl, (lane - PUB_G_X) & 63));
+    if (lane < 12) st->Tfprev[s][lane] = told[z];
+    const unsigned told_up = __float_as_uint(__shfl(told[z], (lane - 12) & 63));  // (every lane takes part in the shuffle)
+    unsigned nv = 0u;
+    if (lane < 12) nv = __float_as_uint(tnew);
     if (lane >= 12 && lane < 24) nv = told_up;
-    if (lane == PUB_G_KEXP) nv = (unsigned) kexp;
+    if (lane == PUB_G_KEXP) nv = (unsigned) kexp[z];
     if (lane == PUB_G_FLAGS) nv = (stop ? PUB_FLAG_STOP : 0u) | (fl0 & PUB_FLAG_PHASE1) | PUB_FLAG_PRIOR;
     if (lane == PUB_G_NSTATS) nv = (unsigned) (nstats0 + 1);
     if (lane == PUB_G_WCOUNT) nv = (unsigned) wc1;
     if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
     if (lane >= PUB_G_X && lane < PUB_G_X + 12) nv = x_up;
+    pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane, ((unsigned long long) epoch << 32) | nv);
   }
-  pub_store(rec, ((unsigned long long) epoch << 32) | nv);
   pub_write_epoch(F.pub_epoch, prob, lane, epoch);
 }
 
@@ -2402,9 +2440,9 @@ __device__ __forceinline__ void pass_view_legacy(const SliceDev& S, const Proble
 template <int DIM>
 __device__ __forceinline__ void fused_control_if_due(const SliceDev& S, ProblemState* __restrict__ states, int prob) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-  const unsigned long long g =
-    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63));
-  if (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) wave_control<DIM == 3 ? 6 : 3>(S, states, prob, g);
+  const unsigned long long g[1] = {
+    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
+  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<DIM == 3 ? 6 : 3, 1>(&S, 1, states, prob, g);
 }
 
 template <int DIM>
@@ -2439,6 +2477,77 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
   for (int i = 0; i < 12; ++i) v.Tprev[i] = __int_as_float(__builtin_amdgcn_readfirstlane((int) rec_lds[12 + i]));
   v.kexp = __builtin_amdgcn_readfirstlane((int) rec_lds[PUB_G_KEXP]);
   const unsigned fl = (unsigned) __builtin_amdgcn_readfirstlane((int) rec_lds[PUB_G_FLAGS]);
+  v.stop   = (fl & PUB_FLAG_STOP) != 0;
+  v.phase1 = (fl & PUB_FLAG_PHASE1) != 0;
+  v.prior  = (fl & PUB_FLAG_PRIOR) != 0;
+}
+
+// Several slices (the projective kernels: a pack of up to four slices that share one association): the control step of all
+// of them at the top of the iteration's first kernel, and the records of `ns` slices staged in LDS by wave 0.
+template <int MAXS>
+__device__ __forceinline__ void fused_control_if_due_multi(const SliceDev* __restrict__ Sv, int ns, ProblemState* __restrict__ states,
+                                                           int prob) {
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  unsigned long long g[MAXS];
+  bool stale = false;
+#pragma unroll
+  for (int z = 0; z < MAXS; ++z) {
+    g[z] = 0ull;
+    if (z < ns) {
+      g[z]  = pub_load(Sv[0].fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63));
+      stale = stale || (unsigned) (g[z] >> 32) != (unsigned) Sv[0].fc.epoch;
+    }
+  }
+  if (__any(stale)) wave_control<6, MAXS>(Sv, ns, states, prob, g);  // (projective finders: SE(3))
+}
+template <int MAXS>
+__device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, int ns, int prob,
+                                              unsigned (&rec)[MAXS][PUB_SLICE_GRANULES]) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    const FusedCtl& F = Sv[0].fc;
+    unsigned long long g[MAXS];
+    bool stale = false;
+#pragma unroll
+    for (int z = 0; z < MAXS; ++z) {
+      g[z] = 0ull;
+      if (z < ns) {
+        g[z]  = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+        stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
+      }
+    }
+    if (__any(stale)) {
+      const unsigned* ep = F.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.x & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
+      int spins = 0;
+      while ((int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < F.epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 24)) __builtin_trap();  // (never: workgroup (0, problem) is dispatched before its siblings)
+      }
+      spins = 0;
+      do {  // (the epoch words are written after the records)
+        stale = false;
+#pragma unroll
+        for (int z = 0; z < MAXS; ++z)
+          if (z < ns) {
+            g[z]  = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+            stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
+          }
+        if (++spins > (1 << 24)) __builtin_trap();
+      } while (__any(stale));
+    }
+#pragma unroll
+    for (int z = 0; z < MAXS; ++z)
+      if (z < ns) rec[z][lane] = (unsigned) g[z];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void view_of_record(const unsigned* rec, PassView& v) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.T[i] = __int_as_float(__builtin_amdgcn_readfirstlane((int) rec[i]));
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.Tprev[i] = __int_as_float(__builtin_amdgcn_readfirstlane((int) rec[12 + i]));
+  v.kexp = __builtin_amdgcn_readfirstlane((int) rec[PUB_G_KEXP]);
+  const unsigned fl = (unsigned) __builtin_amdgcn_readfirstlane((int) rec[PUB_G_FLAGS]);
   v.stop   = (fl & PUB_FLAG_STOP) != 0;
   v.phase1 = (fl & PUB_FLAG_PHASE1) != 0;
   v.prior  = (fl & PUB_FLAG_PRIOR) != 0;
@@ -3466,6 +3575,34 @@ __global__ __launch_bounds__(256) void k_proj_zbuf(SliceDev S, const ProblemDev*
 __global__ __launch_bounds__(256) void k_proj_zbuf_pack(SlicePack P, ProblemState* __restrict__ states) {
   proj_zbuf_body(P.s[blockIdx.z], P.probs[blockIdx.z], states);
 }
+// Fused control steps (projective slices that share their association): the z-buffer pass is the first kernel of an
+// iteration -- wave 0 of workgroup (0, problem) applies the control step of ALL slices of the previous iteration at its top;
+// the transform comes from the record of the first slice.
+__global__ __launch_bounds__(256) void k_proj_zbuf_fz(SlicePack P, int nslices, ProblemState* __restrict__ states) {
+  const SliceDev& S = P.s[0];
+  const int prob    = blockIdx.y;
+  fused_control_if_due_multi<4>(P.s, nslices, states, prob);
+  const ProblemDev pd = P.probs[0][prob];
+  const int i         = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inr      = i < pd.nm;
+  float4 p            = make_float4(NAN, 0.f, 0.f, 0.f);
+  if (inr) p = S.mpts[pd.moff + i];  // (requested before the record: it does not depend on the state)
+  __shared__ unsigned rec[1][PUB_SLICE_GRANULES];
+  records_fused<1>(P.s, 1, prob, rec);
+  PassView pv;
+  view_of_record(rec[0], pv);
+  if (pv.stop || !inr) return;
+  const float (&T)[12] = pv.T;
+  if (!finite3(p.x, p.y, p.z)) return;
+  const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+  const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+  const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+  float u, v;
+  const int pix = project_point(S, qx, qy, qz, u, v);
+  if (pix < 0) return;
+  const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
+  atomicMin(&S.zbuf[((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols + pix], key);
+}
 __global__ __launch_bounds__(256) void k_proj_zbuf_last(SliceDev S, const ProblemDev* __restrict__ probs,
                                                         ProblemState* __restrict__ states) {
   proj_zbuf_body<true>(S, probs, states);
@@ -3661,21 +3798,32 @@ __device__ __forceinline__ void step_proj_body(const SliceDev& S, const ProblemD
 // a thread projects its point, reads the z-buffer and the matched pixel once and evaluates every slice's factor rows in
 // turn (own robustifier, own normal gate, own exponent), each reduced into that slice's slot sets.  Same pixel, same
 // gates, same rows per slice => the same bits as the slices run one by one; C3 moves 36 instead of 68 MB per iteration.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int nslices, ProblemState* __restrict__ states) {
   constexpr int D     = 6;
   const SliceDev& S0  = P.s[0];  // the association is the first slice's
   const int prob      = blockIdx.y;
   ProblemState* st    = &states[prob];
+  // (fused control steps: the state comes from the slices' records -- current: the z-buffer kernel ran before this one)
+  __shared__ unsigned rec[FUSED ? 4 : 1][PUB_SLICE_GRANULES];
+  PassView pv0;
+  if constexpr (FUSED) {
+    records_fused<4>(P.s, nslices, prob, rec);
+    view_of_record(rec[0], pv0);
+  }
   {  // ping-pong reset of the (one) z-buffer, as in step_proj_body
     const size_t npix        = (size_t) S0.rows * S0.cols;
     unsigned long long* next = S0.zbuf + ((size_t) (1 - S0.zbuf_parity) * gridDim.y + prob) * npix;
     for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < npix; k += (size_t) gridDim.x * blockDim.x)
       next[k] = ~0ull;
   }
-  if (st->done || st->finished) return;
+  if (FUSED ? pv0.stop : (st->done || st->finished)) return;
   const ProblemDev pd = P.probs[0][prob];
   float T[12];
-  finder_transform3(S0, st, T);
+  if constexpr (FUSED)
+    load_T(pv0.T, T);
+  else
+    finder_transform3(S0, st, T);
   const unsigned long long* zcur = S0.zbuf + ((size_t) S0.zbuf_parity * gridDim.y + prob) * S0.rows * S0.cols;
   const float kk = S0.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
   const int i    = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3728,8 +3876,10 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int ns
     if (z >= nslices) break;  // (uniform)
     const SliceDev& S  = P.s[z];
     const bool repro   = S.factor == SRRG2_SLICE_REPROJECTION;
-    const double scale = dm::pow2(st->kexp[S.slice_idx]);
-    const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+    const int kexp_z   = FUSED ? __builtin_amdgcn_readfirstlane((int) rec[FUSED ? z : 0][PUB_G_KEXP]) : st->kexp[S.slice_idx];
+    const bool phase1  = FUSED ? pv0.phase1 : st->phase == 1;
+    const double scale = dm::pow2(kexp_z);
+    const int rk       = (phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
     bool found         = found0;
     // (a slice without normals of its own kind sees zeros, as step_proj_body does)
     const float4 nfz = (!repro || S.use_normal_gate) ? nf : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -4153,15 +4303,23 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   }
   for (int s = 0; s < C.nslices; ++s) {  // (after the loop: a prior slice may have replaced the initial guess)
     if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
-    st->kexp[s] = slice_exponent(C, C.slices[s], prob, nm_of[s], st->X);
-    finder_transform_of(C.slices[s].Sinv, C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3, st->X, st->Tf[s]);
-    for (int i = 0; i < 12; ++i) st->Tfprev[s][i] = st->Tf[s][i];
-  }
-  if (C.pub)  // fused control steps: the records of epoch 0, staged for the wave
-    for (int s = 0; s < C.nslices; ++s) {
-      if (C.slices[s].kind == SRRG2_SLICE_PRIOR) continue;
-      for (int l = 0; l < PUB_SLICE_GRANULES; ++l) init_gran[s][l] = pub_granule_of(C, st, s, l);
+    float Xloc[12], Tloc[12];
+    for (int i = 0; i < 12; ++i) Xloc[i] = st->X[i];
+    const int kx = slice_exponent(C, C.slices[s], prob, nm_of[s], Xloc);
+    finder_transform_of(C.slices[s].Sinv, C.variable_kind == SRRG2_SE2_RIGHT ? 2 : 3, Xloc, Tloc);
+    st->kexp[s] = kx;
+    for (int i = 0; i < 12; ++i) st->Tf[s][i] = st->Tfprev[s][i] = Tloc[i];
+    if (C.pub) {  // fused control steps: the record of epoch 0, staged for the wave (from the registers: read back from the
+                  // state just stored, 64 dependent loads took the kernel from 7 to 17 us)
+      for (int l = 0; l < PUB_SLICE_GRANULES; ++l) init_gran[s][l] = 0u;  // (flags, nstats, w_count, npasses: 0)
+      for (int i = 0; i < 12; ++i) {
+        init_gran[s][i]           = __float_as_uint(Tloc[i]);
+        init_gran[s][12 + i]      = __float_as_uint(Tloc[i]);
+        init_gran[s][PUB_G_X + i] = __float_as_uint(Xloc[i]);
+      }
+      init_gran[s][PUB_G_KEXP] = (unsigned) kx;
     }
+  }
   }  // (thread 0)
   if (!C.pub) return;
   __syncthreads();
@@ -4676,8 +4834,13 @@ void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* pro
     P.probs[z] = probs[z < nslices ? z : 0];
   }
   dim3 grid(icp_step_blocks(max_nm), K);
+  if (P.s[0].fc.pub) {  // fused control steps
+    hipLaunchKernelGGL(k_proj_zbuf_fz, grid, dim3(256), 0, s, P, nslices, states);
+    hipLaunchKernelGGL(k_icp_step_proj_fused<true>, grid, dim3(256), 0, s, P, nslices, states);
+    return;
+  }
   hipLaunchKernelGGL(k_proj_zbuf, grid, dim3(256), 0, s, P.s[0], P.probs[0], states);
-  hipLaunchKernelGGL(k_icp_step_proj_fused, grid, dim3(256), 0, s, P, nslices, states);
+  hipLaunchKernelGGL(k_icp_step_proj_fused<false>, grid, dim3(256), 0, s, P, nslices, states);
 }
 
 // the correspondence records of projective slice S after a compute(): the z-buffer of the last executed pass is rebuilt in
