@@ -982,26 +982,17 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // Fused control steps (FusedCtl): the control step of iteration i runs in the prologue of the first pass kernel of
   // iteration i + 1 -- no control launch between the passes of a run.  For aligners whose slices are all nearest-neighbour
   // cue slices on the list / converged-pass kernels; everything else keeps one control launch per iteration.
-  // tuning.fused_control: 0 = never, 1 = whenever the configuration allows it, -1 = automatic: launches whose workgroups
-  // are all resident at once (<= 1600 per launch: C2 391, a half of a 16-alignment C4 batch 1568).  There the step's
-  // latency is paid once, by everybody in parallel, and the saved launch + boundary count: C2 45.8 -> 48.9 k it/s, C4 with
-  // 4 / 8 / 12 / 16 alignments +6 / +12 / +5 / +4 %.  A launch of several rounds of workgroups pays an agent-scope read of
-  // the record in every workgroup and gets slower: C4-24 -4 %, C4-32 -8 %, C4-256 -13 % (profiles/r5e, r5f).
+  // tuning.fused_control: 0 = never, 1 / -1 = whenever the configuration allows it.  Measured (profiles/r5m): C2 45.5 -> 52.4 k
+  // it/s, C4 with 8 / 16 / 24 / 32 / 64 / 256 alignments per call +17 / +12 / +11 / +8 / +3 / +0 %.  (A first version read the record
+  // with an agent-scope load in EVERY workgroup and lost 8 - 13 % from 24 alignments on, profiles/r5e, r5f: the launch now
+  // walks the problems first, so the control steps of all problems run in its first workgroups, and the workgroups of the
+  // later rounds read the published records through the L2.)
   bool fuse = tn.fused_control != 0 && !small && !a->reduce_fn && a->timeline_path.empty() && first_cue >= 0 &&
               a->params.max_iterations >= 2;
   // (one nearest-neighbour cue slice, or projective slices that share one association -- k_proj_zbuf_fz --; no prior slices:
   // the step finds everything in the slices' records)
   const bool fuse_proj = proj_fused && (int) proj_group.size() == nslices && K == 1;
   fuse = fuse && (nslices == 1 || fuse_proj);
-  if (fuse && tn.fused_control < 0) {
-    long long worst = 0;
-    for (int h = 0; h < (split ? split : 1); ++h) {
-      long long wg = 0;
-      for (int k = (split ? a->part_begin[h] : 0); k < (split ? a->part_begin[h + 1] : K); ++k) wg += (all[(size_t) k].nm + 255) / 256;
-      worst = std::max(worst, wg);
-    }
-    fuse = worst <= 1600;
-  }
   for (int si = 0; si < nslices && fuse; ++si) {
     const Slice* s = a->slices[si];
     fuse = s->cfg.kind != SRRG2_SLICE_PRIOR &&
@@ -1055,6 +1046,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       sdev[si].fc.min_num_correspondences = a->slices[si]->cfg.min_num_correspondences;
       sdev[si].fc.max_stats = slots;
       sdev[si].fc.has_term  = a->has_term ? 1 : 0;
+      sdev[si].fc.first_round = 1536;  // (256 CUs x 6 workgroups: nothing beyond them is resident when a launch starts)
     }
   if (split && (small || a->reduce_fn || a->profile || !a->timeline_path.empty()))
     return fail(SRRG2_E_STATE, "internal: a pipelined batch on a path that cannot be split");

@@ -92,6 +92,7 @@ struct FusedCtl {
   int min_num_correspondences; // of the (one) cue slice
   int max_stats;
   int has_term;
+  int first_round;             // workgroups (linear index, problem fastest) that may start before the control steps have published
   int prior;                   // neighbours of a previous pass of this compute() exist (every pass but the first of the first run)
 };
 

@@ -2439,7 +2439,7 @@ __device__ __forceinline__ void pass_view_legacy(const SliceDev& S, const Proble
 // workgroup requests its points: the step's registers are free again when the pass needs its own.
 template <int DIM>
 __device__ __forceinline__ void fused_control_if_due(const SliceDev& S, ProblemState* __restrict__ states, int prob) {
-  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  if (blockIdx.y != 0 || threadIdx.x >= 64) return;  // (fused launches: x = problem, y = tile)
   const unsigned long long g[1] = {
     pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
   if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<DIM == 3 ? 6 : 3, 1>(&S, 1, states, prob, g);
@@ -2451,10 +2451,15 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
     const unsigned long long* rec = S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + lane;
-    unsigned long long g = pub_load(rec);
+    // A workgroup of the first round of the launch starts before the control steps have published: agent-scope load
+    // (no copy of the stale record left in this XCD's L2).  A later one starts when a first-round workgroup has retired,
+    // i.e. after the control steps (they all run in the first K workgroups of the launch): an ordinary cached load finds the
+    // new record -- and if it ever does not, the tags say so and the agent-scope path below takes over.
+    const bool late      = (int) (blockIdx.y * gridDim.x + blockIdx.x) >= S.fc.first_round;
+    unsigned long long g = late ? *rec : pub_load(rec);
     if (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) {
       // (workgroup (0, problem) applied the control step at its very top -- fused_control_if_due -- before it came here)
-      const unsigned* ep = S.fc.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.x & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
+      const unsigned* ep = S.fc.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.y & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
       int spins = 0;
       while ((int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S.fc.epoch) {
         __builtin_amdgcn_s_sleep(4);
@@ -2726,7 +2731,10 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
                                                        ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
-  const int prob     = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
+  // (a launch may cover a sub-range of the batch: SliceDev::prob0.  Fused control steps: x = problem, y = tile -- the
+  // dispatcher walks x first, so the workgroups (problem, tile 0) that carry the control steps of ALL problems start first)
+  const int prob     = (FUSED ? blockIdx.x : blockIdx.y) + S.prob0;
+  const int tile     = FUSED ? (int) blockIdx.y : (int) blockIdx.x;
   const ProblemState* st = &states[prob];
   PassView pv;
   if constexpr (!FUSED) {
@@ -2738,7 +2746,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   const ProblemDev pd = probs[prob];
   // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
   // iteration whatever its share of the points)
-  if ((int) blockIdx.x * (256 * PPT) >= pd.nm && (!FUSED || blockIdx.x != 0)) return;
+  if (tile * (256 * PPT) >= pd.nm && (!FUSED || tile != 0)) return;
   float T[12], Tprev[12];
   double scale;
   int rk;
@@ -2801,7 +2809,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   bool inr[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    const int i = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
+    const int i = (tile * PPT + k) * 256 + (int) threadIdx.x;
     inr[k]      = i < pd.nm;
     gi_[k]      = pd.moff + (inr[k] ? i : 0);  // (out of range: the loads below read point 0 of the problem, masked out later)
     int ppos    = -1;
@@ -2824,7 +2832,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
   }
   if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
     pass_view_fused<DIM>(S, states, prob, pv);
-    if (pv.stop || (int) blockIdx.x * (256 * PPT) >= pd.nm) return;
+    if (pv.stop || tile * (256 * PPT) >= pd.nm) return;
     load_T(pv.T, T);
     load_T(pv.Tprev, Tprev);
     scale = dm::pow2(pv.kexp);
@@ -2887,7 +2895,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       if (open) {
         const unsigned long long below = (1ull << lane) - 1ull;
         QEntry q;
-        q.i = ((int) blockIdx.x * PPT + k) * 256 + (int) threadIdx.x;
+        q.i = (tile * PPT + k) * 256 + (int) threadIdx.x;
         q.r2 = r2; q.best = INFINITY; q.bidx = NO_MATCH; q.bpos = 0;
         transform_point<DIM>(T, p[k], q.qx, q.qy, q.qz);
         q.ball2 = open_ball2[k]; q.pad_ = 0;
@@ -2899,7 +2907,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       }
     }
   }
-  block_reduce_store_biased<4>(acc, S.partials, prob, blockIdx.x, PPT);
+  block_reduce_store_biased<4>(acc, S.partials, prob, tile, PPT);
   if (use_q || !__any(any_open)) return;
 
   // Phase 2 (waves with a failed certificate and no queue; rare once the estimate has settled): the whole wave searches
@@ -3005,7 +3013,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
       }
     }
   }
-  block_reduce_store_biased<1>(acc2, S.partials, prob, blockIdx.x, PPT);
+  block_reduce_store_biased<1>(acc2, S.partials, prob, tile, PPT);
 }
 
 // ============================================================================================
@@ -3016,7 +3024,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
                                                       ProblemState* __restrict__ states) {
   constexpr int NW  = 4;
   constexpr int PPB = NW * 64 / TEAM;  // moving points per workgroup
-  const int prob    = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
+  const int prob    = (FUSED ? blockIdx.x : blockIdx.y) + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   PassView pv;
   if constexpr (!FUSED) {
     pass_view_legacy(S, &states[prob], pv);
@@ -3025,7 +3033,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     fused_control_if_due<DIM>(S, states, prob);
   }
   const ProblemDev pd = probs[prob];
-  const int tile      = blockIdx.x;
+  const int tile      = FUSED ? blockIdx.y : blockIdx.x;
   // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
   // iteration whatever its share of the points)
   if (tile * PPB >= pd.nm && (!FUSED || tile != 0)) return;
@@ -4684,6 +4692,7 @@ void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists
 #define CNL_LAUNCH(TEAM, FUSED)                                                                                   \
   do {                                                                                                            \
     dim3 grid((max_nm * TEAM + 255) / 256, K);                                                                    \
+    if (FUSED) grid = dim3(K, (max_nm * TEAM + 255) / 256); /* x = problem, y = tile */                            \
     if (dim == 3) {                                                                                               \
       if (plane)                                                                                                  \
         hipLaunchKernelGGL((k_icp_step_cnl<3, true, TEAM, FUSED>), grid, dim3(256), 0, s, S, GL, probs, states);  \
@@ -4714,6 +4723,7 @@ template <int PPT, bool GATHER, bool FUSED>
 static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                             int max_nm, hipStream_t s) {
   dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
+  if (FUSED) grid = dim3(K, (max_nm + 256 * PPT - 1) / (256 * PPT));  // (x = problem, y = tile)
   if (dim == 3) {
     if (plane)
       hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
