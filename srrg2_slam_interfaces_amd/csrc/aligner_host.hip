@@ -42,7 +42,8 @@ struct Slice {
   GridDev grid{};
   // cell neighbour lists of the grid (GridDev::list_*), built by the first compute() that wants them after a set_fixed
   DevBuf<int> list_start, list_sums;
-  DevBuf<uint2> list_ent;
+  DevBuf<uint4> list_ent;
+  DevBuf<uint2> list_box;  // scratch of the build: tight box per chunk of 16 points, by the position of its first point
   DevBuf<int4> list_offs;
   DevBuf<GridLists> list_hdr;  // the GridLists record the grid points to
   GridLists lists_host{};      // ... and its host copy (the search-pass kernel takes it by value)
@@ -100,7 +101,7 @@ struct Slice {
     ms_probs_host_cap = 0;
     fixed_raw.release(); fixed_nrm_raw.release(); fixed_sorted.release(); fixed_nrm_sorted.release();
     cell_start.release(); cursor.release(); scan_sums.release(); scalars.release(); pos_of.release();
-    list_start.release(); list_sums.release(); list_ent.release(); list_offs.release(); list_hdr.release();
+    list_start.release(); list_sums.release(); list_ent.release(); list_box.release(); list_offs.release(); list_hdr.release();
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
@@ -442,7 +443,7 @@ int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
   if ((rc = s->list_hdr.reserve(1))) return rc;
   HIP_TRY(hipMemcpyAsync(s->list_offs.p, offs4.data(), offs4.size() * sizeof(int4), hipMemcpyHostToDevice, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));  // (offs4 is a stack-lifetime host buffer)
-  srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, nullptr, a->stream);
+  srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, nullptr, nullptr, a->stream);
   int* total_dev = s->list_sums.p + s->list_sums.cap - 1;
   srrg2amd::launch_exclusive_scan(s->list_start.p, ncell, s->list_sums.p, total_dev, a->stream);
   int total = 0;
@@ -450,9 +451,10 @@ int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
   HIP_TRY(hipStreamSynchronize(a->stream));
   if (total < 0 || (long long) total > max_entries) return 0;
   if ((rc = s->list_ent.reserve((size_t) std::max(total, 1) + 8))) return rc;
+  if ((rc = s->list_box.reserve((size_t) std::max(s->nf, 1) + 8))) return rc;
   L.start = s->list_start.p;
   L.ent   = s->list_ent.p;
-  srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_ent.p, a->stream);
+  srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_box.p, s->list_ent.p, a->stream);
   HIP_TRY(hipMemcpyAsync(s->list_hdr.p, &L, sizeof(L), hipMemcpyHostToDevice, a->stream));
   HIP_TRY(hipGetLastError());
   // (complete before anybody reads them: the second half of a pipelined batch runs on another stream; L is a local)
@@ -835,8 +837,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
                             (search_lists < 0 && (K > 4 || s->grid_computes >= 1 || s->lists_tried));
     s->grid_computes++;
     if (s->cfg.finder == SRRG2_FINDER_NN_GATED && !small && want_lists) {
-      // (the lists are built once per grid; 32 Mi entries = 256 MB: far above C2 / C4, a guard for dense clouds)
-      if ((rc = ensure_lists(a, s, 32LL << 20))) return rc;
+      // (the lists are built once per grid; 16 Mi entries = 256 MB: far above C2 / C4, a guard for dense clouds)
+      if ((rc = ensure_lists(a, s, 16LL << 20))) return rc;
       cnl[(size_t) si] = s->grid.list_R > 0 ? 1 : 0;
     }
     const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small &&

@@ -45,7 +45,8 @@ struct GridDev {
 };
 // For every cell c of the grid EXTENDED by R cells on every side: the OCCUPIED cells whose points can lie within the
 // extended gate of a query in c, nearest class first.  An entry = {position of its first point in pts,
-// byte 0: count - 1 | class << 4, bytes 1 .. 3: dx + R, dy + R, dz + R}; class m = sum_i max(|d_i| - 1, 0)^2 = squared
+// byte 0: count - 1 | class << 4, bytes 1 .. 3: dx + R, dy + R, dz + R; the tight box of its points, lower and upper corner:
+// one byte per axis, (d + R) * 16 + sixteenths of the cell (k_cnl_boxes)}; class m = sum_i max(|d_i| - 1, 0)^2 = squared
 // cell-to-cell separation in cells (entries of a list are sorted by class, then by centre distance); a cell of more than
 // CNL_ENTRY_MAX points takes several entries (the entries are the work items the lanes of a wave share).
 // cls_b2[m] = ((sqrt(m) - 0.01) h)^2 * 0.9999: every point of a class-m cell is farther than that from every query of c
@@ -54,7 +55,7 @@ struct GridLists {
   int R;
   int lnx, lny, lnz;   // extended grid: n + 2 R per axis (2-D: lnz = 1)
   const int* start;    // [lnx * lny * lnz + 1]
-  const uint2* ent;
+  const uint4* ent;
   float cls_b2[14];    // classes 0 .. 12 (R <= 3) + sentinel
 };
 #define CNL_MAX_R 3

@@ -16,8 +16,9 @@ void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, 
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
                          float4* out_nrm, int* pos_of, hipStream_t s);
 // cell neighbour lists of the grid (GridDev::list_*): ent == null counts the entries per cell into list_start, else fills
-void launch_cnl_build(const GridDev& g, const GridLists& L, const int4* offs, int noffs, int* list_start, uint2* ent,
-                      hipStream_t s);
+// (box_at: [fixed points] scratch of the fill pass -- the tight box of every entry, by the position of its first point)
+void launch_cnl_build(const GridDev& g, const GridLists& L, const int4* offs, int noffs, int* list_start, uint2* box_at,
+                      uint4* ent, hipStream_t s);
 // search pass over the cell neighbour lists (any number of alignments per launch; no deferred-search queue)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
                          ProblemState* states, int K, int max_nm, int team, hipStream_t s);

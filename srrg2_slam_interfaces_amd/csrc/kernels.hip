@@ -771,7 +771,7 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
   // ---- phase 0: the first entry of the list; its best candidate (+ pad) bounds the rest
   {
     const bool p0 = e < eend;
-    uint2 h0      = make_uint2(0u, 0u);
+    uint4 h0      = make_uint4(0u, 0u, 0u, 0u);
     if (p0) h0 = gl.ent[e];
     int j = (int) h0.x + 4 * tl, cnt = p0 ? (int) (h0.y & 15u) + 1 - 4 * tl : 0;
     while (__any(cnt > 0)) {
@@ -802,30 +802,31 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
     w.q[1][lane] = qy;
     if (DIM == 3) w.q[2][lane] = qz;
   }
-  // ---- phase A: the headers.  Distances in cell units: with u = the query's fraction of its own cell, the cell at offset d
-  // along an axis spans [d - u, d - u + 1] around the query, so it is max(d - u, u - d - 1, 0) away -- shrunk by
-  // m = 1.1 % of a cell + 1e-6 of the coordinate, which covers the float32 rounding of cell assignments (a point's cell is
-  // floor(fl(fl(x - o) * inv_h))) and of these expressions.  The header carries d + R as a byte: one conversion
-  // (v_cvt_f32_ubyte), two subtractions from per-lane constants, one v_max3 per axis.
+  // ---- phase A: the headers.  Every entry carries the box of ITS points in sixteenths of a cell, as bytes (offset + R) * 16 +
+  // sixteenths per axis (k_cnl_boxes): lower corner lo, upper corner hi.  With u = the query's fraction of its own cell the box
+  // is max(lo / 16 - (R + u), (R + u) - hi / 16, 0) away along an axis -- shrunk by m = 1.1 % of a cell + 1e-6 of the
+  // coordinate, which covers the float32 rounding of cell assignments (a point's cell is floor(fl(fl(x - o) * inv_h))) and of
+  // these expressions; the box itself is rounded outwards.  Two conversions (v_cvt_f32_ubyte), two subtractions from
+  // per-lane constants, one v_max3 per axis; everything in sixteenths (squared distances x 256).
   const float Lc  = L * 1.00002f;
-  const float Lcc = (Lc * g.inv_h) * g.inv_h * 1.0001f;
+  const float Lcc = ((Lc * g.inv_h) * g.inv_h * 1.0001f) * 256.f;
   int mmax = -1;  // largest class whose cells can reach into the ball
 #pragma unroll
   for (int m = 0; m <= CNL_MAX_CLASS; ++m) mmax += gl.cls_b2[m] <= Lc ? 1 : 0;
   const float fR = (float) R;
   const float mx = 0.011f + fabsf(ux0) * 1e-6f, my = 0.011f + fabsf(uy0) * 1e-6f, mz = 0.011f + fabsf(uz0) * 1e-6f;
   const float ux = ux0 - (float) cx, uy = uy0 - (float) cy, uz = uz0 - (float) cz;
-  // t = max(s - ca, cb - s, 0) with s = d + R:  d - u - m = s - (R + u + m),  u - d - 1 - m = (R + u - 1 - m) - s
-  const float cax = (fR + ux) + mx, cbx = ((fR + ux) - 1.f) - mx;
-  const float cay = (fR + uy) + my, cby = ((fR + uy) - 1.f) - my;
-  const float caz = (fR + uz) + mz, cbz = ((fR + uz) - 1.f) - mz;
+  // t = max(lo - ca, cb - hi, 0):  lo / 16 - (R + u + m),  (R + u - m) - hi / 16, in sixteenths
+  const float cax = ((fR + ux) + mx) * 16.f, cbx = ((fR + ux) - mx) * 16.f;
+  const float cay = ((fR + uy) + my) * 16.f, cby = ((fR + uy) - my) * 16.f;
+  const float caz = ((fR + uz) + mz) * 16.f, cbz = ((fR + uz) - mz) * 16.f;
   int pool_n = 0;  // (wave-uniform)
   e += 4 * tl;     // the lanes of a team take the headers four at a time, in turn
   while (__any(e < eend)) {
-    uint2 hd[4];
+    uint4 hd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      hd[k] = make_uint2(0u, 0xf0u);  // (class 15: beyond every ball)
+      hd[k] = make_uint4(0u, 0xf0u, 0u, 0u);  // (class 15: beyond every ball)
       if (e + k < eend) hd[k] = gl.ent[e + k];
     }
     bool stop = e >= eend;
@@ -834,14 +835,16 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
       const unsigned code = hd[k].y;
       // (sorted by class: nothing behind the first entry of a class beyond the ball can reach into it)
       stop = stop || (int) ((code >> 4) & 15u) > mmax;
-      const float sx = (float) ((code >> 8) & 255u), sy = (float) ((code >> 16) & 255u);
-      const float tx = fmaxf(fmaxf(sx - cax, cbx - sx), 0.f);
-      const float ty = fmaxf(fmaxf(sy - cay, cby - sy), 0.f);
+      const unsigned blo = hd[k].z, bhi = hd[k].w;
+      const float lx_ = (float) (blo & 255u), ly_ = (float) ((blo >> 8) & 255u);
+      const float hx_ = (float) (bhi & 255u), hy_ = (float) ((bhi >> 8) & 255u);
+      const float tx = fmaxf(fmaxf(lx_ - cax, cbx - hx_), 0.f);
+      const float ty = fmaxf(fmaxf(ly_ - cay, cby - hy_), 0.f);
       float d2c      = __fmaf_rn(ty, ty, tx * tx);
       if (DIM == 3) {
-        const float sz = (float) (code >> 24);
-        const float tz = fmaxf(fmaxf(sz - caz, cbz - sz), 0.f);
-        d2c            = __fmaf_rn(tz, tz, d2c);
+        const float lz_ = (float) ((blo >> 16) & 255u), hz_ = (float) ((bhi >> 16) & 255u);
+        const float tz  = fmaxf(fmaxf(lz_ - caz, cbz - hz_), 0.f);
+        d2c             = __fmaf_rn(tz, tz, d2c);
       }
       const bool surv             = !stop && !(d2c > Lcc);
       const unsigned long long bm = __ballot(surv);
