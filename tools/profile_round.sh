@@ -3,7 +3,7 @@
 # passes (separate --pmc runs, never together with a trace).  Everything lands under gpurun_out/$1/; copy what is to be
 # judged into profiles/.      usage: gpurun -- 'bash tools/profile_round.sh r2final'
 TAG=${1:-round}
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-/root/repo}; GRAFT_REPO_ROOT=$(pwd)
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 R=$GRAFT_REPO_ROOT
@@ -34,13 +34,13 @@ python $R/tools/trace_steps.py $(find /tmp/tr_c2 -name '*.db' | head -1) > $O/tr
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c3_$c -o p -- python $R/bench.py --workload c3 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c2_$c -o p -- python $R/bench.py --workload c2 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c4_$c -o p -- python $R/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-  timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c4_256_$c -o p -- python $R/bench.py --workload c4 --batch 256 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  SRRG2_AMD_BATCH_PIPELINE=0 timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c4_$c -o p -- python $R/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  SRRG2_AMD_BATCH_PIPELINE=0 timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_c4_256_$c -o p -- python $R/bench.py --workload c4 --batch 256 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python $R/tools/traffic_from_pmc.py $O/traffic_c3.json c3 $(find /tmp/pmc_c3_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c3_WRITE_SIZE -name '*.db' | head -1)
 python $R/tools/traffic_from_pmc.py $O/traffic_c2.json c2 $(find /tmp/pmc_c2_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c2_WRITE_SIZE -name '*.db' | head -1)
-python $R/tools/traffic_from_pmc.py $O/traffic_c4.json c4 $(find /tmp/pmc_c4_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c4_WRITE_SIZE -name '*.db' | head -1) 32
-python $R/tools/traffic_from_pmc.py $O/traffic_c4_256.json c4 $(find /tmp/pmc_c4_256_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c4_256_WRITE_SIZE -name '*.db' | head -1) 256
+python $R/tools/traffic_from_pmc.py $O/traffic_c4.json c4 $(find /tmp/pmc_c4_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c4_WRITE_SIZE -name '*.db' | head -1) 32 76800000
+python $R/tools/traffic_from_pmc.py $O/traffic_c4_256.json c4 $(find /tmp/pmc_c4_256_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_c4_256_WRITE_SIZE -name '*.db' | head -1) 256 614400000
 # C5: the pose-graph kernels' counters (HIP graph off: every kernel a dispatch of its own)
 for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES"; do
   n=$(echo $c | tr ' ' '_')
