@@ -6,7 +6,7 @@ scattered stores and taken as is; Infinity-Cache hits are counted (memory-side o
 
 A PASS is one finder + factor pass over ALL alignments of a compute_batch.  A pipelined batch runs a pass as several
 dispatches (one per part, on its own stream: aligner_host.hip), so dispatches are weighted by the share of the batch they
-cover (grid_size_y / alignments per launch) -- round 4 averaged per DISPATCH and mixed half- with whole-batch dispatches
+cover (its problem dimension of the grid / alignments per launch) -- round 4 averaged per DISPATCH and mixed half- with whole-batch dispatches
 (VERDICT r4 "weak" #2: 0.91x algorithmic reported where the per-pass file said 1.37x).  With the alignments per launch given
 (C4) the output also lists the passes of the LAST compute() one by one when every dispatch of it covers the whole batch
 (profile with SRRG2_AMD_BATCH_PIPELINE=0).
@@ -23,10 +23,14 @@ def dispatches(db, counter):
     """[(short kernel name, value, grid_size_y)] of the step kernels, in dispatch order"""
     cur = sqlite3.connect(db).cursor()
     out = []
-    for name, val, gy in cur.execute("select kernel_name, value, grid_size_y from counters_collection where "
-                                     "counter_name = ? order by dispatch_id", (counter,)):
+    for name, val, gx, gy, wx in cur.execute("select kernel_name, value, grid_size_x, grid_size_y, workgroup_size_x from "
+                                             "counters_collection where counter_name = ? order by dispatch_id", (counter,)):
         if any(k in name for k in KERNELS):
-            out.append((name.split("(")[0].replace("void ", ""), float(val), int(gy)))
+            short = name.split("(")[0].replace("void ", "")
+            # alignments the dispatch covers: grid y -- or grid x (in workgroups) for the launches with fused control steps, which
+            # walk the problems first (k_icp_step_cnl<..., true> / k_icp_step_fast<..., true>: x = problem, y = tile)
+            fused = short.startswith(("k_icp_step_cnl<", "k_icp_step_fast<")) and short.rstrip().endswith(", true>")
+            out.append((short, float(val), int(gx) // max(int(wx), 1) if fused else int(gy)))
     return out
 
 
