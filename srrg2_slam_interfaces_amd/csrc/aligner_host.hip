@@ -770,7 +770,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // (0 = automatic: two points per thread share one reduction once a launch holds 64 alignments or more -- C4-256 575 -> 595 k it/s;
   // smaller launches and single alignments lose the waves they need to fill the chip: C4-32 unchanged, C2 45.1 -> 42.6 k it/s)
   // (decided per LAUNCH: a part of a pipelined batch is its own launch)
-  auto fast_ppt_of = [&](int k_launch) { return tn.fast_points_per_thread > 0 ? tn.fast_points_per_thread : (k_launch >= 64 ? 2 : 1); };
+  // (round 5, launches with fused control steps: two points per thread from 16 alignments per launch on -- C4-32 556 -> 567 k it/s,
+  // C4-48 587 -> 597 k, profiles/r5s: half as many workgroups read the record and share a reduction)
+  bool fuse = false;  // (decided below, before the first launch)
+  auto fast_ppt_of = [&](int k_launch) {
+    return tn.fast_points_per_thread > 0 ? tn.fast_points_per_thread : (k_launch >= (fuse ? 16 : 64) ? 2 : 1);
+  };
   // batches gather the kept neighbour from the cache-resident fixed cloud (36 -> 8 streamed bytes per point); single
   // alignments read it from per-point arrays (no dependent load on the chain of a latency-bound launch)
   // (smallest moving cloud that uses the converged-pass kernel.  Sparse clouds of a few thousand points leave a larger
@@ -989,8 +994,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // with an agent-scope load in EVERY workgroup and lost 8 - 13 % from 24 alignments on, profiles/r5e, r5f: the launch now
   // walks the problems first, so the control steps of all problems run in its first workgroups, and the workgroups of the
   // later rounds read the published records through the L2.)
-  bool fuse = tn.fused_control != 0 && !small && !a->reduce_fn && a->timeline_path.empty() && first_cue >= 0 &&
-              a->params.max_iterations >= 2;
+  fuse = tn.fused_control != 0 && !small && !a->reduce_fn && a->timeline_path.empty() && first_cue >= 0 &&
+         a->params.max_iterations >= 2;
   // (one nearest-neighbour cue slice, or projective slices that share one association -- k_proj_zbuf_fz --; no prior slices:
   // the step finds everything in the slices' records)
   const bool fuse_proj = proj_fused && (int) proj_group.size() == nslices && K == 1;
