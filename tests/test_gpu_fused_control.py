@@ -1,0 +1,149 @@
+"""Fused control steps (round 5): the control step of an ICP iteration -- slot-set sums, one Gauss-Newton
+step (multi_aligner_impl.cpp:112-121), statistics, termination criterion (aligner_termination_criteria_impl.cpp:24-65) --
+runs on one wave inside the next iteration's first pass kernel, with matrices spread over lanes.  Every outcome of the state
+machine through that path, against the oracle AND against the same library with one control launch per iteration."""
+import numpy as np
+import pytest
+
+from helpers import assert_same_run, cue_config, setup_pair
+from srrg2_slam_interfaces_amd import _abi as abi
+from srrg2_slam_interfaces_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _runs(oracle, product, kind, build, knobs_list):
+    out = []
+    for make, knobs in [(lambda: oracle.OracleAligner(kind), None)] + [(lambda: product.MultiAligner(kind), k) for k in knobs_list]:
+        al = make()
+        if knobs:
+            al.set_tuning(**knobs)
+        build(al)
+        out.append(al)
+    return out
+
+
+FUSED = {"search_lists": 2, "fused_control": 1}    # lists (hence the fused launches) from the first compute() on
+UNFUSED = {"search_lists": 2, "fused_control": 0}
+
+
+@pytest.mark.parametrize("kind,slice_kind", [(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE), (abi.SE3_EULER_RIGHT, abi.SLICE_P2P),
+                                             (abi.SE2_RIGHT, abi.SLICE_P2P), (abi.SE2_RIGHT, abi.SLICE_P2PLANE)])
+def test_termination_criterion_inlier_only_run_and_pruning(oracle, product, kind, slice_kind):
+    if kind == abi.SE2_RIGHT:
+        d = syn.scan_pair_2d(beams=3000, sigma=0.01, seed=1234)
+        gate, thr = 0.5, 0.002
+        if slice_kind == abi.SLICE_P2PLANE:  # (a 2-D "plane" factor needs normals: the scans' own, from neighbouring beams)
+            for which in ("fixed", "moving"):
+                p = d[which]
+                t = np.roll(p, -1, axis=0) - np.roll(p, 1, axis=0)
+                n = np.stack([-t[:, 1], t[:, 0]], axis=1)
+                d[which + "_normals"] = (n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+    else:
+        d = syn.cloud_pair_3d(n=15000, seed=2200, noise_sigma=0.01)
+        gate, thr = 0.25, 0.0005
+    cfg = cue_config(kind, slice_kind, gate, abi.ROBUST_CAUCHY, thr)
+
+    def build(al):
+        al.set_params(max_iterations=12, min_num_inliers=10, enable_inlier_only_runs=True, keep_only_inlier_correspondences=True)
+        al.set_termination_criteria(abi.default_termination_params())
+        setup_pair(al, d, cfg)
+        al.compute()
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()  # (a second compute() on the same clouds: the same path again, from a used handle)
+
+    ref, fused, unfused = _runs(oracle, product, kind, build, [FUSED, UNFUSED])
+    assert ref.status() == abi.SUCCESS
+    if kind != abi.SE2_RIGHT or slice_kind == abi.SLICE_P2PLANE:
+        assert len(ref.iteration_stats()) < 24  # (the criterion fired)
+    assert_same_run(ref, fused)
+    assert_same_run(ref, unfused)
+    assert fused.information().tobytes() == unfused.information().tobytes()
+
+
+def test_every_way_an_alignment_of_a_batch_can_end(oracle, product):
+    """One launch, five fates: converges; empty cloud (Fail: no statistics, multi_aligner_impl.cpp:75-78); a guess so far off
+    that iteration 0 finds nothing (Fail); few points and a large min_num_inliers (NotEnoughInliers, :81-85); a cloud that loses
+    its correspondences after a few iterations is not constructible on purpose -- instead min_num_correspondences above what a
+    partial overlap offers, which ends NotEnoughCorrespondences at iteration 0 -> Fail as well (the quirk of :75-78)."""
+    kind = abi.SE3_QUAT_RIGHT
+    probs = syn.batch_3d(K=6, n=9000, seed=8800, shared_fixed_group=64, t_max=0.1, rpy_max_deg=2.0)
+    fixed, fixed_n = probs[0]["fixed"], probs[0]["fixed_normals"]
+    far = syn.se3(np.array([30.0, 0.0, 0.0]), np.zeros(3)).astype(np.float32)
+    movs = [probs[0]["moving"], probs[1]["moving"][:0], probs[2]["moving"], probs[3]["moving"][::110][:80], probs[4]["moving"][:2500],
+            probs[5]["moving"]]
+    nrms = [probs[0]["moving_normals"], probs[1]["moving_normals"][:0], probs[2]["moving_normals"], probs[3]["moving_normals"][::110][:80],
+            probs[4]["moving_normals"][:2500], probs[5]["moving_normals"]]
+    guesses = [syn.identity(3), syn.identity(3), far, syn.identity(3), syn.identity(3), syn.identity(3)]
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.3, abi.ROBUST_CAUCHY, 0.05, 0.7)
+
+    def run(al):
+        al.set_params(max_iterations=7, min_num_inliers=100)
+        al.add_slice(cfg)
+        al.set_fixed(0, fixed, fixed_n)
+        return al.compute_batch(movs, guesses, nrms)
+
+    ref = run(oracle.OracleAligner(kind))
+    assert [r["status"] for r in ref] == [abi.SUCCESS, abi.FAIL, abi.FAIL, abi.NOT_ENOUGH_INLIERS, abi.SUCCESS, abi.SUCCESS]
+    for knobs in (FUSED, UNFUSED, dict(FUSED, batch_pipeline=0), dict(FUSED, batch_pipeline=3)):
+        al = product.MultiAligner(kind)
+        al.set_tuning(**knobs)
+        got = run(al)
+        for r, g in zip(ref, got):
+            assert r["status"] == g["status"] and r["num_iterations"] == g["num_iterations"], knobs
+            assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes(), knobs
+            assert r["last"] == g["last"] and r["num_correspondences"] == g["num_correspondences"], knobs
+            assert np.asarray(r["information"]).tobytes() == np.asarray(g["information"]).tobytes(), knobs
+
+
+def test_a_solver_failure_keeps_the_estimate(oracle, product):
+    """All moving points on one line seen through a point-to-plane factor with parallel normals: H is singular, the L D L^T
+    meets a pivot <= 0, solver status != Success and the estimate stays (multi_aligner_impl.cpp:118-121) -- through the
+    lane-distributed factorisation too."""
+    kind = abi.SE3_QUAT_RIGHT
+    n = 4000
+    x = np.linspace(-3, 3, n, dtype=np.float32)
+    fixed = np.stack([x, np.zeros(n, np.float32), np.zeros(n, np.float32)], axis=1)
+    fn = np.tile(np.array([[0, 0, 1]], np.float32), (n, 1))
+    moving = fixed + np.array([0.01, 0.0, 0.02], np.float32)
+    d = {"fixed": fixed, "fixed_normals": fn, "moving": moving, "moving_normals": fn.copy()}
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.25)
+
+    def build(al):
+        al.set_params(max_iterations=4, min_num_inliers=10)
+        setup_pair(al, d, cfg)
+        al.compute()
+
+    ref, fused, unfused = _runs(oracle, product, kind, build, [FUSED, UNFUSED])
+    assert all(s_["solver_status"] != 0 for s_ in ref.iteration_stats())
+    assert_same_run(ref, fused)
+    assert_same_run(ref, unfused)
+
+
+def test_projective_slices_sharing_one_association(oracle, product):
+    """C3's shape at a quarter of the resolution: the control step of BOTH slices in the z-buffer kernel's prologue"""
+    kind = abi.SE3_QUAT_RIGHT
+    r = syn.rgbd_pair(rows=120, cols=160, seed=3100)
+
+    def build(al):
+        al.set_params(max_iterations=8, min_num_inliers=10, enable_inlier_only_runs=True)
+        for sk in (abi.SLICE_P2PLANE, abi.SLICE_REPROJECTION):
+            c = abi.default_slice_config(kind)
+            c.kind, c.finder, c.finder_max_distance = sk, abi.FINDER_PROJECTIVE, 0.05
+            c.robustifier, c.robustifier_chi_threshold = abi.ROBUST_CAUCHY, 0.05 if sk == abi.SLICE_P2PLANE else 4.0
+            for i, v in enumerate(r["K"].reshape(-1)):
+                c.camera_matrix[i] = v
+            c.image_rows, c.image_cols, c.depth_min, c.depth_max = r["rows"], r["cols"], r["depth_min"], r["depth_max"]
+            si = al.add_slice(c)
+            if si == 0 or not hasattr(al, "share_clouds") or isinstance(al, oracle.OracleAligner):
+                al.set_fixed(si, r["fixed"], r["fixed_normals"])
+                al.set_moving(si, r["moving"], r["moving_normals"])
+            else:
+                al.share_clouds(si, 0)
+        al.set_moving_in_fixed(syn.identity(3))
+        al.compute()
+
+    ref, fused, unfused = _runs(oracle, product, kind, build, [{"fused_control": 1}, {"fused_control": 0}])
+    assert ref.status() == abi.SUCCESS
+    assert_same_run(ref, fused, slices=(0, 1))
+    assert_same_run(ref, unfused, slices=(0, 1))
