@@ -622,6 +622,9 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
   // (any monotone cell assignment gives a valid sort: the keys only order the points)
   const KeySpec ks = kspec;
   auto key_of = [&](const float4 p) -> unsigned { return key_of_point(p, ks, kbits); };
+#if defined(SRRG2_MSORT_EXPERIMENT) && SRRG2_MSORT_EXPERIMENT == 3
+  if (kbits > 0) return;  // (timing experiment: bounding box pass only)
+#endif
   // ---- pass 2: histogram
   for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
     float4 q[NPT];
@@ -657,6 +660,9 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
     for (int c = wid * seg + lane; c < min((wid + 1) * seg, ncell); c += 64) hist[c] += before;
   }
   __syncthreads();
+#if defined(SRRG2_MSORT_EXPERIMENT) && SRRG2_MSORT_EXPERIMENT == 2
+  if (kbits > 0) return;  // (timing experiment: no scatter pass at all)
+#endif
   // ---- pass 3: scatter (the caller's index travels in .w; the order inside a cell does not matter: see above)
   const float* nbase = nsrc ? nsrc + (size_t) pd.moff * nsf : nullptr;
   for (int i0 = tid; i0 < pd.nm; i0 += NPT * 1024) {
@@ -677,8 +683,14 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
       if (i >= pd.nm) continue;
       const int pos = atomicAdd(&hist[key_of(q[j])], 1);
       q[j].w        = __int_as_float(seg0 + i);  // the caller's index within its problem
+#if defined(SRRG2_MSORT_EXPERIMENT) && SRRG2_MSORT_EXPERIMENT == 1
+      if (pos < 0) {  // (timing experiment: the scatter without its stores; wrong results)
+#endif
       out_pts[pd.moff + pos] = q[j];
       if (nbase) out_nrm[pd.moff + pos] = nq[j];
+#if defined(SRRG2_MSORT_EXPERIMENT) && SRRG2_MSORT_EXPERIMENT == 1
+      }
+#endif
     }
   }
 }
