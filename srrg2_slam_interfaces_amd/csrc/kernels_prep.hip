@@ -529,7 +529,10 @@ __global__ __launch_bounds__(1024) void k_msort_local(const float* __restrict__ 
                                                       int nsf, const ProblemDev* __restrict__ probs, int dim, int kbits, int aniso,
                                                       float4* __restrict__ out_pts, float4* __restrict__ out_nrm,
                                                       unsigned* __restrict__ maxabs_bits /* [K] */) {
-  constexpr int NPT = 8;  // points in flight per thread and round
+#ifndef SRRG2_MSORT_NPT
+#define SRRG2_MSORT_NPT 8
+#endif
+  constexpr int NPT = SRRG2_MSORT_NPT;  // points in flight per thread and round
   extern __shared__ int hist[];  // 1 << kbits counters, then cursors
   __shared__ unsigned red[16][6];
   __shared__ unsigned bbs[6];
