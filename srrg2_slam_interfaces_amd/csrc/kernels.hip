@@ -2730,8 +2730,8 @@ __device__ __forceinline__ void point_rows(const float* T, float kk, const float
 // is shared by all alignments and stays in L2; 8 instead of 36 streamed bytes per point) instead of read from prev_f / prev_n
 // (single alignments: no dependent load on the chain).
 template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
-__global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                       ProblemState* __restrict__ states) {
+__device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const ProblemDev* __restrict__ probs,
+                                                   ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
   constexpr int ROWS = PLANE ? 1 : DIM;
   // (a launch may cover a sub-range of the batch: SliceDev::prob0.  Fused control steps: x = problem, y = tile -- the
@@ -3017,6 +3017,19 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
     }
   }
   block_reduce_store_biased<1>(acc2, S.partials, prob, tile, PPT);
+}
+
+template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
+__global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                       ProblemState* __restrict__ states) {
+  icp_step_fast_body<DIM, PLANE, PPT, GATHER, FUSED>(S, probs, states);
+}
+// The two-points-per-thread pass held to 128 registers = four waves per SIMD (it needs 133: five spilled words); the default
+// for SE(3) point-to-plane batches with fused control steps, SRRG2_AMD_TUNE bit 24 switches back to the 133-register kernel.
+template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
+__global__ __launch_bounds__(256, 4) void k_icp_step_fast_occ4(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                                ProblemState* __restrict__ states) {
+  icp_step_fast_body<DIM, PLANE, PPT, GATHER, FUSED>(S, probs, states);
 }
 
 // ============================================================================================
@@ -4727,6 +4740,12 @@ static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const Proble
                             int max_nm, hipStream_t s) {
   dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
   if (FUSED) grid = dim3(K, (max_nm + 256 * PPT - 1) / (256 * PPT));  // (x = problem, y = tile)
+  if constexpr (PPT == 2 && GATHER && FUSED) {
+    if (dim == 3 && plane && !(S.tune & (1 << 24))) {  // (C4-256 650 -> 658 k it/s, C4-64 +1 %, C4-32 neutral: profiles/r5z)
+      hipLaunchKernelGGL((k_icp_step_fast_occ4<3, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
+      return;
+    }
+  }
   if (dim == 3) {
     if (plane)
       hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
