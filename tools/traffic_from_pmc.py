@@ -16,7 +16,7 @@ import json
 import sqlite3
 import sys
 
-KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_fast<", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")  # (k_icp_step_proj_fused matches k_icp_step_proj)
+KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_fast", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")  # (k_icp_step_proj_fused matches k_icp_step_proj)
 
 
 def dispatches(db, counter):
@@ -29,7 +29,7 @@ def dispatches(db, counter):
             short = name.split("(")[0].replace("void ", "")
             # alignments the dispatch covers: grid y -- or grid x (in workgroups) for the launches with fused control steps, which
             # walk the problems first (k_icp_step_cnl<..., true> / k_icp_step_fast<..., true>: x = problem, y = tile)
-            fused = short.startswith(("k_icp_step_cnl<", "k_icp_step_fast<")) and short.rstrip().endswith(", true>")
+            fused = short.startswith(("k_icp_step_cnl<", "k_icp_step_fast")) and short.rstrip().endswith(", true>")
             out.append((short, float(val), int(gx) // max(int(wx), 1) if fused else int(gy)))
     return out
 
