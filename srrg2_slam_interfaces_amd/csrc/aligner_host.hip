@@ -1096,8 +1096,21 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if (!last_it) return;
     }
     if (last_phase && last_it) {
-      srrg2amd::launch_icp_control_final(Ch[h], a->states.p, a->stats.p, a->outs_host, a->stats_host,
-                                         !a->params.enable_inlier_only_runs /* post step inside */, hstream[h]);
+      // (the last step on one wave too -- k_icp_final_wave -- measured SLOWER than the 256-thread kernel on C2, 0.191 against
+      // 0.188 ms, neutral on batches (profiles/r6a): the finalize part reads the state back from memory where the big kernel
+      // has it staged in LDS.  Off; SRRG2_AMD_TUNE bit 25 switches it on)
+      if (fuse && !fuse_proj && (C.tune & (1 << 25))) {
+        SliceDev sd          = sdev[first_cue];
+        sd.prob0             = h0[h];
+        sd.fc.ctl            = a->ctl_dev.p + h;
+        sd.fc.epoch          = epoch + 1;
+        sd.fc.prev_partials  = a->slices[first_cue]->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
+        srrg2amd::launch_icp_final_wave(Ch[h], sd, a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                        !a->params.enable_inlier_only_runs, hstream[h]);
+      } else {
+        srrg2amd::launch_icp_control_final(Ch[h], a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                           !a->params.enable_inlier_only_runs /* post step inside */, hstream[h]);
+      }
       final_launched = true;
     } else {
       srrg2amd::launch_icp_control(Ch[h], a->states.p, a->stats.p, hstream[h]);

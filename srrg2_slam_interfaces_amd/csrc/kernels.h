@@ -62,6 +62,9 @@ void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDe
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s);
 void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C, const ProblemDev* probs, ProblemState* states,
                       srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s);
+// the last control step of a compute() with fused control steps (one nearest-neighbour cue slice): one wave per problem
+void launch_icp_final_wave(const CtlParams& C, const SliceDev& S, ProblemState* states, srrg2_iteration_stats* stats,
+                           ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s);
 void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
                                srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s);
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s);

@@ -4917,6 +4917,30 @@ void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C
       hipLaunchKernelGGL((k_icp_small<2, false>), dim3(C.K), dim3(512), 0, s, S, C, probs, states, stats, outs_host, stats_host);
   }
 }
+// The LAST control step of a compute() with fused control steps, on one wave (wave_control) with the post / finalize steps
+// behind it: the 256-thread k_icp_control_final stages the 3.4 KB state through LDS around a 238-register body; this one reads
+// the record + the slot sets, runs the lane-distributed step and lets icp_finalize_block read the state back (its stores are
+// complete behind the fence; this kernel has not loaded those lines before, so no stale copy can be hit).
+template <int D>
+__global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, ProblemState* __restrict__ states,
+                                                        srrg2_iteration_stats* __restrict__ stats,
+                                                        ProblemOut* __restrict__ outs_host,
+                                                        srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
+  const int prob = blockIdx.x + C.prob0;
+  const unsigned long long g[1] = {
+    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
+  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1>(&S, 1, states, prob, g);
+  __threadfence();
+  icp_finalize_block(C, &states[prob], stats, outs_host, stats_host, prob, with_post != 0);
+}
+void launch_icp_final_wave(const CtlParams& C, const SliceDev& S, ProblemState* states, srrg2_iteration_stats* stats,
+                           ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
+  const dim3 grid(C.nprob > 0 ? C.nprob : C.K);
+  if (C.variable_kind == SRRG2_SE2_RIGHT)
+    hipLaunchKernelGGL(k_icp_final_wave<3>, grid, dim3(64), 0, s, C, S, states, stats, outs_host, stats_host, with_post ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_icp_final_wave<6>, grid, dim3(64), 0, s, C, S, states, stats, outs_host, stats_host, with_post ? 1 : 0);
+}
 void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
                                srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
   hipLaunchKernelGGL(k_icp_control_final, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(256), 0, s, C, states, stats, outs_host, stats_host,
