@@ -666,6 +666,25 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
 // ============================================================================================
 namespace {
 
+// -DSRRG2_CNL_REDEAL=1: the search pass re-deals the queries of a workgroup by the estimated length of their header walk
+// (k_icp_step_cnl).  An experiment, OFF: exact, but 2-6 % slower per search pass on C4 (profiles/r6b_*): the walk lengths
+// are spread evenly between 4 and 28 headers rather than in two groups, the estimate ranks them poorly (6.98 -> 6.26 steps
+// per wave where a perfect sort would reach ~4.8) and the exchange costs what that saves.
+#ifndef SRRG2_CNL_REDEAL
+#define SRRG2_CNL_REDEAL 0
+#endif
+// -DSRRG2_CNL_STATS: census of the lane utilisation of the list search per iteration (tools/cnl_stats.py); compiled out of the
+// product build
+#ifdef SRRG2_CNL_STATS
+__device__ unsigned long long g_cnl_stats[4 * 16];
+#define CNL_STAT(k, v)                                                                                   \
+  do {                                                                                                   \
+    const unsigned long long v_ = (unsigned long long) (v); /* (by every lane: v may hold a ballot) */   \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_cnl_stats[(stat_it < 3 ? stat_it : 3) * 16 + (k)], v_);    \
+  } while (0)
+#else
+#define CNL_STAT(k, v) do { } while (0)
+#endif
 constexpr int CNL_POOL = 512;  // survivor entries of a wave between two rounds of phase B (a step of phase A adds <= 256)
 
 struct CnlWave {               // per wave, in LDS
@@ -707,9 +726,11 @@ __device__ __forceinline__ void test_group_glb(const float4* __restrict__ pts, i
 
 // Phase B: the wave works off the n pooled survivors; results are merged into the owners' slots.
 template <int DIM>
-__device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, CnlWave& w, int lane, int n) {
+__device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, CnlWave& w, int lane, int n, int stat_it = 3) {
   wave_lds_sync();  // (pool entries, queries and slots written by other lanes)
+  CNL_STAT(6, n);
   for (int s0 = 0; s0 < n; s0 += 64) {
+    CNL_STAT(7, 1);
     const int s     = s0 + lane;
     const bool have = s < n;
     uint2 it        = make_uint2(0u, 0u);
@@ -721,6 +742,8 @@ __device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, C
     unsigned long long key = NO_KEY;
     float lb2              = INFINITY;
     while (__any(cnt > 0)) {
+      CNL_STAT(8, 1);
+      CNL_STAT(9, __popcll(__ballot(cnt > 0)));
       test_group_glb<DIM>(pts, j, cnt, qx, qy, qz, key, lb2);
       j += 4;
       cnt -= 4;
@@ -744,22 +767,21 @@ __device__ __forceinline__ void cnl_drain_pool(const float4* __restrict__ pts, C
 // fixed point was examined (every point not examined is farther than min(L, extended gate)).
 // gl: the grid's list header -- the search-pass kernel gets it by value in its kernel arguments (scalar registers), the
 // converged-pass kernel, which searches rarely, reads it through GridDev::lists.
+// Phase 0 of cnl_search (below): the list of the query's cell and its first entry; e / eend = what is left of the list.
 template <int DIM, int TEAM>
-__device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl, CnlWave& w, int lane, bool need, float qx,
-                                           float qy, float qz, float r2box, float gfar, unsigned long long& bkey, float& b2,
-                                           float& L) {
+__device__ __forceinline__ void cnl_phase0(const GridDev& g, const GridLists& gl, int lane, bool need, float qx, float qy, float qz,
+                                           float r2box, float gfar, unsigned long long& bkey, float& b2, float& L, int& e,
+                                           int& eend, int stat_it = 3) {
   const int R  = gl.R;
   const int tl = lane & (TEAM - 1);   // lane within its team
-  const int owner_lane = lane - tl;   // the team's slot
-  // the query in cell units: cell c + fraction u along every axis
-  const float ux0 = (qx - g.ox) * g.inv_h, uy0 = (qy - g.oy) * g.inv_h, uz0 = DIM == 3 ? (qz - g.oz) * g.inv_h : 0.f;
   const int cx = cell_coord(qx, g.ox, g.inv_h);
   const int cy = cell_coord(qy, g.oy, g.inv_h);
   const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
   const int lx = cx + R, ly = cy + R, lz = DIM == 3 ? cz + R : 0;
   // (a query outside the extended grid is farther than the extended gate from every fixed point: no list, no match)
   const bool inl = need && lx >= 0 && lx < gl.lnx && ly >= 0 && ly < gl.lny && lz >= 0 && lz < gl.lnz;
-  int e = 0, eend = 0;
+  e = 0;
+  eend = 0;
   if (inl) {
     const int lc = (lz * gl.lny + ly) * gl.lnx + lx;
     e            = gl.start[lc];
@@ -774,7 +796,10 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
     uint4 h0      = make_uint4(0u, 0u, 0u, 0u);
     if (p0) h0 = gl.ent[e];
     int j = (int) h0.x + 4 * tl, cnt = p0 ? (int) (h0.y & 15u) + 1 - 4 * tl : 0;
+    CNL_STAT(10, __popcll(__ballot(need)));
     while (__any(cnt > 0)) {
+      CNL_STAT(1, 1);
+      CNL_STAT(2, __popcll(__ballot(cnt > 0)));
       test_group_glb<DIM>(g.pts, j, cnt, qx, qy, qz, bkey, b2);
       j += 4 * TEAM;
       cnt -= 4 * TEAM;
@@ -795,6 +820,23 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
       }
     }
   }
+}
+
+// Phases A and B of cnl_search: the headers of the rest of the list, the pooled survivors.  Takes what cnl_phase0 left --
+// (bkey, b2, L, e, eend) of the query (qx, qy, qz) -- whichever lane computed it (k_icp_step_cnl re-deals the queries of a
+// workgroup between the two).  Returns bkey / b2 in the first lane of every team.
+template <int DIM, int TEAM>
+__device__ __forceinline__ void cnl_phaseAB(const GridDev& g, const GridLists& gl, CnlWave& w, int lane, float qx, float qy,
+                                            float qz, unsigned long long& bkey, float& b2, float L, int e, int eend,
+                                            int stat_it = 3) {
+  const int R  = gl.R;
+  const int tl = lane & (TEAM - 1);   // lane within its team
+  const int owner_lane = lane - tl;   // the team's slot
+  // the query in cell units: cell c + fraction u along every axis
+  const float ux0 = (qx - g.ox) * g.inv_h, uy0 = (qy - g.oy) * g.inv_h, uz0 = DIM == 3 ? (qz - g.oz) * g.inv_h : 0.f;
+  const int cx = cell_coord(qx, g.ox, g.inv_h);
+  const int cy = cell_coord(qy, g.oy, g.inv_h);
+  const int cz = DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0;
   if (tl == 0) {
     w.key[lane]  = bkey;
     w.b2[lane]   = __float_as_uint(b2);
@@ -822,7 +864,11 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
   const float caz = ((fR + uz) + mz) * 16.f, cbz = ((fR + uz) - mz) * 16.f;
   int pool_n = 0;  // (wave-uniform)
   e += 4 * tl;     // the lanes of a team take the headers four at a time, in turn
+  CNL_STAT(0, 1);
+  CNL_STAT(11, __popcll(__ballot(e < eend)));
   while (__any(e < eend)) {
+    CNL_STAT(3, 1);
+    CNL_STAT(4, __popcll(__ballot(e < eend)));
     uint4 hd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -856,13 +902,22 @@ __device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl
     }
     e = stop ? eend : min(e + 4 * TEAM, eend);
     if (pool_n > CNL_POOL - 256) {  // (the next step may add 4 x 64)
-      cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);
+      cnl_drain_pool<DIM>(g.pts, w, lane, pool_n, stat_it);
       pool_n = 0;
     }
   }
-  cnl_drain_pool<DIM>(g.pts, w, lane, pool_n);  // (also the barrier before the slots are read back)
+  cnl_drain_pool<DIM>(g.pts, w, lane, pool_n, stat_it);  // (also the barrier before the slots are read back)
   bkey = w.key[owner_lane];
   b2   = __uint_as_float(w.b2[owner_lane]);
+}
+
+template <int DIM, int TEAM>
+__device__ __forceinline__ void cnl_search(const GridDev& g, const GridLists& gl, CnlWave& w, int lane, bool need, float qx,
+                                           float qy, float qz, float r2box, float gfar, unsigned long long& bkey, float& b2,
+                                           float& L, int stat_it = 3) {
+  int e, eend;
+  cnl_phase0<DIM, TEAM>(g, gl, lane, need, qx, qy, qz, r2box, gfar, bkey, b2, L, e, eend, stat_it);
+  cnl_phaseAB<DIM, TEAM>(g, gl, w, lane, qx, qy, qz, bkey, b2, L, e, eend, stat_it);
 }
 
 }  // namespace
@@ -3150,10 +3205,79 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     }
   }
   const bool need = active && !skipped && !KNOB(S.tune, 16);
-  if (__any(need)) {
+  if constexpr (TEAM == 1 && SRRG2_CNL_REDEAL != 0) {
+    // (experiment, see SRRG2_CNL_REDEAL) The queries of the workgroup are RE-DEALT between phase 0 and the header walk.  A
+    // wave walks the headers as long as its longest list lasts: 6.98 steps of four headers on the first pass of C4 with
+    // 39.8 of 64 lanes busy (tools/cnl_stats.py).  After phase 0 the length of a walk can be estimated (what is left of the
+    // list x the share of the gate ball the pruning ball covers): the 256 queries are sorted into four length classes, the
+    // short ones into the first waves, which then finish early and leave their issue slots to the other workgroups of
+    // the SIMD while the last wave(s) take the long walks with more lanes busy.  The adopting lane gets (q, e, eend, L) through LDS -- the tuple of slot s lies in the pool of the wave
+    // that adopts it, which is idle until its phase A -- and starts from an empty minimum; the owner merges what its
+    // phase 0 found with the slot of the adopting lane afterwards: a minimum and a runner-up over the same candidates
+    // whoever examined them, so the result is the same to the bit.
+    __shared__ unsigned long long wcnt[NW];
+    unsigned long long k0;
+    float b20, L;
+    int e, eend;
+    cnl_phase0<DIM, 1>(g, GL, lane, need, qx, qy, qz, r2box, gfar, k0, b20, L, e, eend, S.fc.epoch);
+    const float est = (float) (eend - e) * fminf(L * (1.f / gfar), 1.f);
+    const int cls   = (est > 4.f ? 1 : 0) + (est > 8.f ? 1 : 0) + (est > 16.f ? 1 : 0);
+    const unsigned long long m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+    const unsigned long long m0 = ~(m1 | m2 | m3);
+    if (lane == 0)
+      wcnt[wid] = (unsigned long long) __popcll(m0) | ((unsigned long long) __popcll(m1) << 16) |
+                  ((unsigned long long) __popcll(m2) << 32) | ((unsigned long long) __popcll(m3) << 48);
+    __syncthreads();
+    int slot;
+    {
+      unsigned long long tot = 0ull, before = 0ull;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const unsigned long long c = wcnt[k];
+        tot += c;
+        before += k < wid ? c : 0ull;
+      }
+      const unsigned long long mm = cls == 0 ? m0 : cls == 1 ? m1 : cls == 2 ? m2 : m3;
+      // classes before mine, waves before mine within my class, lanes before mine within my wave
+      const unsigned long long below = tot & ((1ull << (16 * cls)) - 1ull);  // (fields of the lower classes)
+      slot = (int) ((below & 0xffffull) + ((below >> 16) & 0xffffull) + ((below >> 32) & 0xffffull)) +
+             (int) ((before >> (16 * cls)) & 0xffffull) +
+             (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mm, 0u));
+    }
+    {
+      float* tw = reinterpret_cast<float*>(wlds[slot >> 6].pool);  // [6][64]
+      const int sl = slot & 63;
+      tw[sl]       = qx;
+      tw[64 + sl]  = qy;
+      tw[128 + sl] = qz;
+      tw[192 + sl] = L;
+      tw[256 + sl] = __int_as_float(e);
+      tw[320 + sl] = __int_as_float(eend);
+    }
+    __syncthreads();
+    {
+      const float* tr = reinterpret_cast<const float*>(wlds[wid].pool);
+      const float ax = tr[lane], ay = tr[64 + lane], az = tr[128 + lane], aL = tr[192 + lane];
+      const int ae = __float_as_int(tr[256 + lane]), aend = __float_as_int(tr[320 + lane]);
+      wave_lds_sync();  // (the pool is written next)
+      unsigned long long ka = NO_KEY;
+      float ba              = INFINITY;
+      cnl_phaseAB<DIM, 1>(g, GL, wlds[wid], lane, ax, ay, az, ka, ba, aL, ae, aend, S.fc.epoch);
+    }
+    __syncthreads();
+    if (need) {
+      const unsigned long long ka = wlds[slot >> 6].key[slot & 63];
+      const float ba              = __uint_as_float(wlds[slot >> 6].b2[slot & 63]);
+      const unsigned long long lo = ka < k0 ? ka : k0, hi = ka < k0 ? k0 : ka;
+      const float b2              = fminf(fminf(b20, ba), __uint_as_float((unsigned) (hi >> 32)));
+      best = key_best(lo);
+      bidx = key_idx(lo);
+      excl = sqrtf(fminf(b2, fminf(L, g.gate2_ext))) * 0.99999f;
+    }
+  } else if (__any(need)) {
     unsigned long long bkey;
     float b2, L;
-    cnl_search<DIM, TEAM>(g, GL, wlds[wid], lane, need, qx, qy, qz, r2box, gfar, bkey, b2, L);
+    cnl_search<DIM, TEAM>(g, GL, wlds[wid], lane, need, qx, qy, qz, r2box, gfar, bkey, b2, L, S.fc.epoch);
     if (need) {
       best = key_best(bkey);
       bidx = key_idx(bkey);
@@ -4669,6 +4793,17 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
   }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }
+
+#ifdef SRRG2_CNL_STATS
+extern "C" int srrg2_amd_debug_cnl_stats(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cnl_stats), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long zero[64];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cnl_stats), zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 #ifdef SRRG2_TILE_STATS
 extern "C" int srrg2_amd_debug_tile_stats(unsigned long long* out, int reset) {
