@@ -2093,6 +2093,26 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
 // of control_body / dm::solve / dm::box_plus / dm::se3_compose with the same operands in the same order, executed by the
 // lane that owns the result (operands fetched by v_readlane / ds_bpermute): the same bits.
 // ============================================================================================
+// -DSRRG2_PASS_TIMELINE: where the time of a fused pass launch goes (tools/pass_timeline.py): constant-rate clock readings
+// (100 MHz) of every workgroup of problem 0 at its start, after the control step (designated wave), after the record arrived, at
+// its end: one plain store each (atomics on shared words serialise and stretch a 12-us launch to 85 us).  Compiled out of the
+// product build.
+#ifdef SRRG2_PASS_TIMELINE
+__device__ unsigned long long g_pass_ts[16 * 512 * 8];  // [epoch][workgroup (tile)][stamp]: plain stores, reduced on the host
+#define PASS_TS_ANY(epoch, k) /* (by lane 0 of any wave: the last writer wins) */                      \
+  do {                                                                                                 \
+    if ((threadIdx.x & 63) == 0 && (epoch) >= 0 && (epoch) < 16 && blockIdx.y < 512 && blockIdx.x == 0) \
+      g_pass_ts[(((epoch) * 512) + blockIdx.y) * 8 + (k)] = wall_clock64();                            \
+  } while (0)
+#define PASS_TS(epoch, k)                                                                              \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && (epoch) >= 0 && (epoch) < 16 && blockIdx.y < 512 && blockIdx.x == 0)       \
+      g_pass_ts[(((epoch) * 512) + blockIdx.y) * 8 + (k)] = wall_clock64();                            \
+  } while (0)
+#else
+#define PASS_TS(epoch, k) do { } while (0)
+#define PASS_TS_ANY(epoch, k) do { } while (0)
+#endif
 namespace {
 
 __device__ __forceinline__ double rl_d(double v, int k) {  // lane k's value, k wave-uniform
@@ -2501,6 +2521,7 @@ __device__ __forceinline__ void fused_control_if_due(const SliceDev& S, ProblemS
   const unsigned long long g[1] = {
     pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
   if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<DIM == 3 ? 6 : 3, 1>(&S, 1, states, prob, g);
+  PASS_TS(S.fc.epoch, 1);
 }
 
 template <int DIM>
@@ -2534,6 +2555,7 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
     rec_lds[lane] = (unsigned) g;
   }
   __syncthreads();
+  PASS_TS(S.fc.epoch, 2);
 #pragma unroll
   for (int i = 0; i < 12; ++i) v.T[i] = __int_as_float(__builtin_amdgcn_readfirstlane((int) rec_lds[i]));
 #pragma unroll
@@ -2623,13 +2645,23 @@ namespace {
 // NW = waves that reduce together (through LDS); NW == 1: every wave on its own, no barrier (the rare second phase of
 // the converged pass).  Every lane contributed `per_lane` biased values to each of the entries [0, ACC_CHI_IN).
 template <int NW>
+__device__ __forceinline__ long long (&block_reduce_lds())[4][ACC_N] {
+  __shared__ long long red[4][ACC_N];  // (one array per NW: the stages of a split reduction meet in it)
+  return red;
+}
+// (STAGE: 0 = everything; 1 = only the wave's part -- its totals into LDS, after which the accumulators are dead --, 2 = only
+// the workgroup's part: barrier, sum over the waves, atomics.  The converged pass runs its second phase between the two.)
+template <int NW, int STAGE = 0>
 __device__ __forceinline__ void block_reduce_store_biased(long long (&acc)[ACC_N], long long* __restrict__ partials,
                                                           int prob, int block, int per_lane) {
-  __shared__ long long red[4][ACC_N];
+  long long (&red)[4][ACC_N] = block_reduce_lds<NW>();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  int my_index;
-  const long long total = wave_transpose_reduce(acc, lane, my_index);
-  if ((lane & 1) == 0) red[wid][my_index] = total;
+  if constexpr (STAGE != 2) {
+    int my_index;
+    const long long total = wave_transpose_reduce(acc, lane, my_index);
+    if ((lane & 1) == 0) red[wid][my_index] = total;
+  }
+  if constexpr (STAGE == 1) return;
   if (NW > 1)
     __syncthreads();
   else
@@ -2799,6 +2831,7 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     pass_view_legacy(S, st, pv);
     if (pv.stop) return;
   } else {
+    PASS_TS(S.fc.epoch, 0);
     fused_control_if_due<DIM>(S, states, prob);
   }
   const ProblemDev pd = probs[prob];
@@ -2927,6 +2960,22 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     const float r2box = hasp ? fminf(rr * rr, gfar) : gfar;
     open_ball2[k]     = (active && !have) ? r2box : -1.f;
     any_open |= active && !have;
+#ifdef SRRG2_PASS_TIMELINE
+    if constexpr (FUSED) {
+      if (active && !have && S.fc.epoch >= 0 && S.fc.epoch < 16 && blockIdx.x == 0) {
+        // census of the failed certificates: [epoch][499..511][5..7] of the stamp array are never stamped
+        unsigned long long* c = &g_pass_ts[((size_t) S.fc.epoch * 512 + 500) * 8];
+        const float gap = (pm[k] - d1) / g.h;  // margin left, in cells
+        atomicAdd(&c[0], 1ull);
+        if (!hasp) atomicAdd(&c[1], 1ull);
+        else if (gap < 1e-4f) atomicAdd(&c[2], 1ull);
+        else if (gap < 0.0202f) atomicAdd(&c[3], 1ull);
+        else atomicAdd(&c[4], 1ull);
+        if (dl > 1e-3f * g.h) atomicAdd(&c[5], 1ull);
+        if (pm[k] <= 0.f) atomicAdd(&c[6], 1ull);
+      }
+    }
+#endif
     if (k == 0)
       linearize(std::true_type{}, acc, have && ca, p[k], pf[k], pn[k], pnm[k], qx, qy, qz, best);
     else
@@ -2965,8 +3014,15 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
       }
     }
   }
-  block_reduce_store_biased<4>(acc, S.partials, prob, tile, PPT);
-  if (use_q || !__any(any_open)) return;
+  // (the wave's totals go to LDS now -- the accumulators are dead from here on --; the workgroup adds them up AFTER the second
+  // phase: a wave with failed certificates starts its searches without waiting for its siblings, which have nothing else
+  // to do but wait for it anyway)
+  block_reduce_store_biased<4, 1>(acc, S.partials, prob, tile, PPT);
+  if (use_q || !__any(any_open)) {
+    block_reduce_store_biased<4, 2>(acc, S.partials, prob, tile, PPT);
+    if constexpr (FUSED) PASS_TS(S.fc.epoch, 3);
+    return;
+  }
 
   // Phase 2 (waves with a failed certificate and no queue; rare once the estimate has settled): the whole wave searches
   // the ball of each such point, one at a time, then the points are linearised into a second set of sums which the wave
@@ -3051,7 +3107,16 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
   for (int k = 0; k < PPT; ++k) {
     const bool open = open_ball2[k] >= 0.f;
     float4 fk = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH)), nk = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (open && sidx[k] != NO_MATCH) {  // the new neighbour and its normal
+    // (a settled pass searches again for near-ties, and finds the neighbour it had: coordinates, normal and position are in
+    // the registers / in place -- two dependent round trips less at the tail of the launch)
+    // (one point per thread only: with two the kept neighbours of both would stay live through the searches -- 16 registers
+    // the batch kernels do not have)
+    bool same = false;
+    if constexpr (PPT == 1) same = open && sidx[k] != NO_MATCH && sidx[k] == __float_as_int(pf[k].w);
+    if (same) {
+      fk = pf[k];
+      nk = pn[k];
+    } else if (open && sidx[k] != NO_MATCH) {  // the new neighbour and its normal
       spos[k] = g.pos_of[sidx[k]];
       fk      = g.pts[spos[k]];
       if (PLANE || ngate) nk = g.nrm[spos[k]];
@@ -3063,15 +3128,20 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     else
       linearize(std::false_type{}, acc2, open, p[k], fk, nk, pnm[k], qx, qy, qz, sbest[k]);
     if (open) {
-      S.prev_m[gi_[k]]   = sexcl[k];
-      S.prev_pos[gi_[k]] = sidx[k] != NO_MATCH ? spos[k] : -1;
-      if (!GATHER) {
-        S.prev_f[gi_[k]] = fk;
-        if (PLANE || ngate) S.prev_n[gi_[k]] = nk;
+      S.prev_m[gi_[k]] = sexcl[k];
+      if (!same) {
+        S.prev_pos[gi_[k]] = sidx[k] != NO_MATCH ? spos[k] : -1;
+        if (!GATHER) {
+          S.prev_f[gi_[k]] = fk;
+          if (PLANE || ngate) S.prev_n[gi_[k]] = nk;
+        }
       }
     }
   }
   block_reduce_store_biased<1>(acc2, S.partials, prob, tile, PPT);
+  if constexpr (FUSED) PASS_TS_ANY(S.fc.epoch, 4);  // (a wave that ran the second phase)
+  block_reduce_store_biased<4, 2>(acc, S.partials, prob, tile, PPT);  // (phase 1's totals of the workgroup)
+  if constexpr (FUSED) PASS_TS(S.fc.epoch, 3);
 }
 
 template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
@@ -3101,6 +3171,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     pass_view_legacy(S, &states[prob], pv);
     if (pv.stop) return;
   } else {
+    PASS_TS(S.fc.epoch, 0);
     fused_control_if_due<DIM>(S, states, prob);
   }
   const ProblemDev pd = probs[prob];
@@ -3338,6 +3409,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     S.prev_m[gi] = excl;
   }
   block_reduce_store_biased<NW>(acc, S.partials, prob, tile, 1);
+  if constexpr (FUSED) PASS_TS(S.fc.epoch, 3);
 }
 
 // The correspondence records of the nearest-neighbour passes, on demand (get_correspondences, factor status, the scene
@@ -4793,6 +4865,18 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
   }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }
+
+#ifdef SRRG2_PASS_TIMELINE
+extern "C" int srrg2_amd_debug_pass_timeline(unsigned long long* out, int reset) {
+  const size_t bytes = sizeof(unsigned long long) * 16 * 512 * 8;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pass_ts), bytes) != hipSuccess) return -1;
+  if (reset) {
+    static unsigned long long zero[16 * 512 * 8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pass_ts), zero, bytes) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 #ifdef SRRG2_CNL_STATS
 extern "C" int srrg2_amd_debug_cnl_stats(unsigned long long* out, int reset) {
