@@ -2930,10 +2930,88 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     rk    = (pv.phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
   }
 
+  float open_ball2[PPT];  // squared radius of the ball to search; < 0: not open
+  bool any_open = false;
+  // the searches of the points whose certificate failed (wave-uniform control flow; results in the lanes that own the points)
+  auto search_open = [&](float (&sbest)[PPT], int (&sidx)[PPT], float (&sexcl)[PPT], int (&spos)[PPT]) {
+  #pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      sbest[k] = INFINITY; sexcl[k] = 0.f; sidx[k] = NO_MATCH; spos[k] = 0;
+      const bool open = open_ball2[k] >= 0.f;
+      if (!__ballot(open)) continue;
+      float qx = 0.f, qy = 0.f, qz = 0.f;
+      if (open) transform_point<DIM>(T, p[k], qx, qy, qz);
+      // The grid has cell neighbour lists and the wave has more than a few open points (a pass before convergence, a partial
+      // overlap: C2 at 60 % overlap 24.9 -> 43.0 k it/s): all of them in one pooled search.  A settled pass leaves a wave one
+      // or two: the 16-lane cooperative scans below finish those in fewer dependent round trips (C2 converged pass 8.6 us
+      // against 11 us with the pooled search for every open point).
+      if (g.list_R > 0 && __popcll(__ballot(open)) > 4) {
+        unsigned long long skey;
+        float sb2, sL;
+        cnl_search<DIM, 1>(g, *g.lists, fast_lds[wid].cnl, lane, open, qx, qy, qz, open_ball2[k], gfar, skey, sb2, sL);
+        if (open) {
+          sbest[k] = key_best(skey);
+          sidx[k]  = key_idx(skey);
+          sexcl[k] = sqrtf(fminf(sb2, fminf(sL, g.gate2_ext))) * 0.99999f;
+        }
+        continue;
+      }
+      const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
+      // small balls (the usual case: the ball of the previous neighbour): four searches per pass, 16 lanes each
+      unsigned long long near = __ballot(open && r2 == 2);
+      while (near) {
+        int src[4];
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          src[t] = near ? __ffsll((long long) near) - 1 : -1;
+          near &= near - 1;
+        }
+        const int team = lane >> 4;
+        const int mine = team == 0 ? src[0] : (team == 1 ? src[1] : (team == 2 ? src[2] : src[3]));
+        const int from = mine >= 0 ? mine : lane;
+        const float sqx = __shfl(qx, from), sqy = __shfl(qy, from), sqz = __shfl(qz, from), sball = __shfl(open_ball2[k], from);
+        const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
+        const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
+        float wbest, wexcl2;
+        int widx, wpos;
+        coop_scan<DIM, 16>(g, lane, coop_lds_w, sqx, sqy, sqz, scx, scy, scz, mine >= 0 ? 2 : -1, sball, wbest, widx, wpos, wexcl2);
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) {  // the result of team t goes to the lane that owns the point
+          const float rb = __shfl(wbest, 16 * t), re = __shfl(wexcl2, 16 * t);
+          const int ri = __shfl(widx, 16 * t), rp = __shfl(wpos, 16 * t);
+          if (lane == src[t]) {
+            sbest[k] = rb;
+            sidx[k]  = ri;
+            spos[k]  = rp;
+            sexcl[k] = sqrtf(re) * 0.99999f;
+          }
+        }
+      }
+      unsigned long long todo = __ballot(open && r2 != 2);
+      while (todo) {
+        const int src = __ffsll((long long) todo) - 1;
+        todo &= todo - 1;
+        const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
+        const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
+        const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
+        float wbest, wexcl2;
+        int widx, wpos;
+        coop_scan<DIM, 64>(g, lane, coop_lds_w, sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(open_ball2[k], src),
+                           wbest, widx, wpos, wexcl2);
+        if (lane == src) {
+          sbest[k] = wbest;
+          sidx[k]  = widx;
+          spos[k]  = wpos;
+          sexcl[k] = sqrtf(wexcl2) * 0.99999f;
+        }
+      }
+    }
+  };
+  constexpr bool defer = PPT == 1 && FUSED;  // (fused control steps: no deferred-search queue)
+  float d_qx = 0.f, d_qy = 0.f, d_qz = 0.f, d_best = INFINITY;
+  bool d_valid = false;
   // Phase 1: the certificates; points that keep their neighbour are linearised.  A failed certificate leaves the squared
   // radius of the ball to search (the ball contains the previous neighbour, hence the nearest one) behind.
-  float open_ball2[PPT];  // < 0: not open
-  bool any_open = false;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const bool active = inr[k] && finite3(p[k].x, p[k].y, p[k].z);
@@ -2976,11 +3054,53 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
       }
     }
 #endif
-    if (k == 0)
+    if constexpr (defer) {  // (linearised below, together with what the searches find)
+      d_qx = qx; d_qy = qy; d_qz = qz; d_best = best; d_valid = have && ca;
+    } else if (k == 0) {
       linearize(std::true_type{}, acc, have && ca, p[k], pf[k], pn[k], pnm[k], qx, qy, qz, best);
-    else
+    } else {
       linearize(std::false_type{}, acc, have && ca, p[k], pf[k], pn[k], pnm[k], qx, qy, qz, best);
+    }
     if (have) S.prev_m[gi_[k]] = excl;
+  }
+  if constexpr (defer) {
+    {
+      // One point per thread (single alignments, small batches: the launch waits for its last wave): the searches FIRST, then
+      // ONE linearisation of all 64 lanes -- kept and newly found neighbours alike -- and one reduction.  A settled pass
+      // still has a handful of near-ties to search for (C2: 8 - 15 of 100 000 points, profiles/r6e); as a second phase with
+      // its own linearisation, wave reduction and atomics they kept ten lone waves busy ~4 us after their siblings.
+      if (__any(any_open)) {
+        float sbest[PPT], sexcl[PPT];
+        int sidx[PPT], spos[PPT];
+        search_open(sbest, sidx, sexcl, spos);
+        const bool open = open_ball2[0] >= 0.f;
+        // (a near-tie searched again mostly finds the neighbour it had: coordinates, normal and position are in place)
+        const bool same = open && sidx[0] != NO_MATCH && sidx[0] == __float_as_int(pf[0].w);
+        if (open && !same) {
+          pf[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
+          pn[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (sidx[0] != NO_MATCH) {  // the new neighbour and its normal
+            spos[0] = g.pos_of[sidx[0]];
+            pf[0]   = g.pts[spos[0]];
+            if (PLANE || ngate) pn[0] = g.nrm[spos[0]];
+          }
+          S.prev_pos[gi_[0]] = sidx[0] != NO_MATCH ? spos[0] : -1;
+          if (!GATHER) {
+            S.prev_f[gi_[0]] = pf[0];
+            if (PLANE || ngate) S.prev_n[gi_[0]] = pn[0];
+          }
+        }
+        if (open) {
+          S.prev_m[gi_[0]] = sexcl[0];
+          d_best  = sbest[0];
+          d_valid = true;
+        }
+      }
+      linearize(std::true_type{}, acc, d_valid, p[0], pf[0], pn[0], pnm[0], d_qx, d_qy, d_qz, d_best);
+      block_reduce_store_biased<4>(acc, S.partials, prob, tile, PPT);
+      if constexpr (FUSED) PASS_TS(S.fc.epoch, 3);
+      return;
+    }
   }
   if (use_q) {
     // failed certificates go to the deferred-search kernel like the stragglers of k_icp_step
@@ -3030,78 +3150,7 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
   // of the scan, not on top of 64 accumulator registers.
   float sbest[PPT], sexcl[PPT];
   int sidx[PPT], spos[PPT];
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    sbest[k] = INFINITY; sexcl[k] = 0.f; sidx[k] = NO_MATCH; spos[k] = 0;
-    const bool open = open_ball2[k] >= 0.f;
-    if (!__ballot(open)) continue;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (open) transform_point<DIM>(T, p[k], qx, qy, qz);
-    // The grid has cell neighbour lists and the wave has more than a few open points (a pass before convergence, a partial
-    // overlap: C2 at 60 % overlap 24.9 -> 43.0 k it/s): all of them in one pooled search.  A settled pass leaves a wave one
-    // or two: the 16-lane cooperative scans below finish those in fewer dependent round trips (C2 converged pass 8.6 us
-    // against 11 us with the pooled search for every open point).
-    if (g.list_R > 0 && __popcll(__ballot(open)) > 4) {
-      unsigned long long skey;
-      float sb2, sL;
-      cnl_search<DIM, 1>(g, *g.lists, fast_lds[wid].cnl, lane, open, qx, qy, qz, open_ball2[k], gfar, skey, sb2, sL);
-      if (open) {
-        sbest[k] = key_best(skey);
-        sidx[k]  = key_idx(skey);
-        sexcl[k] = sqrtf(fminf(sb2, fminf(sL, g.gate2_ext))) * 0.99999f;
-      }
-      continue;
-    }
-    const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
-    // small balls (the usual case: the ball of the previous neighbour): four searches per pass, 16 lanes each
-    unsigned long long near = __ballot(open && r2 == 2);
-    while (near) {
-      int src[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        src[t] = near ? __ffsll((long long) near) - 1 : -1;
-        near &= near - 1;
-      }
-      const int team = lane >> 4;
-      const int mine = team == 0 ? src[0] : (team == 1 ? src[1] : (team == 2 ? src[2] : src[3]));
-      const int from = mine >= 0 ? mine : lane;
-      const float sqx = __shfl(qx, from), sqy = __shfl(qy, from), sqz = __shfl(qz, from), sball = __shfl(open_ball2[k], from);
-      const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
-      const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
-      float wbest, wexcl2;
-      int widx, wpos;
-      coop_scan<DIM, 16>(g, lane, coop_lds_w, sqx, sqy, sqz, scx, scy, scz, mine >= 0 ? 2 : -1, sball, wbest, widx, wpos, wexcl2);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {  // the result of team t goes to the lane that owns the point
-        const float rb = __shfl(wbest, 16 * t), re = __shfl(wexcl2, 16 * t);
-        const int ri = __shfl(widx, 16 * t), rp = __shfl(wpos, 16 * t);
-        if (lane == src[t]) {
-          sbest[k] = rb;
-          sidx[k]  = ri;
-          spos[k]  = rp;
-          sexcl[k] = sqrtf(re) * 0.99999f;
-        }
-      }
-    }
-    unsigned long long todo = __ballot(open && r2 != 2);
-    while (todo) {
-      const int src = __ffsll((long long) todo) - 1;
-      todo &= todo - 1;
-      const float sqx = __shfl(qx, src), sqy = __shfl(qy, src), sqz = __shfl(qz, src);
-      const int scx = cell_coord(sqx, g.ox, g.inv_h), scy = cell_coord(sqy, g.oy, g.inv_h);
-      const int scz = DIM == 3 ? cell_coord(sqz, g.oz, g.inv_h) : 0;
-      float wbest, wexcl2;
-      int widx, wpos;
-      coop_scan<DIM, 64>(g, lane, coop_lds_w, sqx, sqy, sqz, scx, scy, scz, __shfl(r2, src), __shfl(open_ball2[k], src),
-                         wbest, widx, wpos, wexcl2);
-      if (lane == src) {
-        sbest[k] = wbest;
-        sidx[k]  = widx;
-        spos[k]  = wpos;
-        sexcl[k] = sqrtf(wexcl2) * 0.99999f;
-      }
-    }
-  }
+  search_open(sbest, sidx, sexcl, spos);
   long long acc2[ACC_N];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
