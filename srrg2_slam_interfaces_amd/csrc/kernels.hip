@@ -3198,14 +3198,6 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
                                                        ProblemState* __restrict__ states) {
   icp_step_fast_body<DIM, PLANE, PPT, GATHER, FUSED>(S, probs, states);
 }
-// The two-points-per-thread pass held to 128 registers = four waves per SIMD (it needs 133: five spilled words); the default
-// for SE(3) point-to-plane batches with fused control steps, SRRG2_AMD_TUNE bit 24 switches back to the 133-register kernel.
-template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
-__global__ __launch_bounds__(256, 4) void k_icp_step_fast_occ4(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                                ProblemState* __restrict__ states) {
-  icp_step_fast_body<DIM, PLANE, PPT, GATHER, FUSED>(S, probs, states);
-}
-
 // ============================================================================================
 // The search pass over the cell neighbour lists (cnl_search above): TEAM lanes per moving point.
 // ============================================================================================
@@ -5008,12 +5000,6 @@ static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const Proble
                             int max_nm, hipStream_t s) {
   dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
   if (FUSED) grid = dim3(K, (max_nm + 256 * PPT - 1) / (256 * PPT));  // (x = problem, y = tile)
-  if constexpr (PPT == 2 && GATHER && FUSED) {
-    if (dim == 3 && plane && !(S.tune & (1 << 24))) {  // (C4-256 650 -> 658 k it/s, C4-64 +1 %, C4-32 neutral: profiles/r5z)
-      hipLaunchKernelGGL((k_icp_step_fast_occ4<3, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
-      return;
-    }
-  }
   if (dim == 3) {
     if (plane)
       hipLaunchKernelGGL((k_icp_step_fast<3, true, PPT, GATHER, FUSED>), grid, dim3(256), 0, s, S, probs, states);
