@@ -2104,6 +2104,14 @@ __device__ unsigned long long g_pass_ts[16 * 512 * 8];  // [epoch][workgroup (ti
     if ((threadIdx.x & 63) == 0 && (epoch) >= 0 && (epoch) < 16 && blockIdx.y < 512 && blockIdx.x == 0) \
       g_pass_ts[(((epoch) * 512) + blockIdx.y) * 8 + (k)] = wall_clock64();                            \
   } while (0)
+#define PASS_TS_W(epoch, k, dep) /* (inside wave_control: after `dep` has been computed) */             \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && (epoch) >= 0 && (epoch) < 16 && blockIdx.x == 0) {                         \
+      unsigned long long t_ = wall_clock64();                                                          \
+      if ((dep) != (dep)) t_ = 0; /* (a data dependence: the stamp cannot be scheduled ahead) */        \
+      g_pass_ts[(((epoch) * 512) + 0) * 8 + (k)] = t_;                                                  \
+    }                                                                                                  \
+  } while (0)
 #define PASS_TS(epoch, k)                                                                              \
   do {                                                                                                 \
     if (threadIdx.x == 0 && (epoch) >= 0 && (epoch) < 16 && blockIdx.y < 512 && blockIdx.x == 0)       \
@@ -2112,6 +2120,7 @@ __device__ unsigned long long g_pass_ts[16 * 512 * 8];  // [epoch][workgroup (ti
 #else
 #define PASS_TS(epoch, k) do { } while (0)
 #define PASS_TS_ANY(epoch, k) do { } while (0)
+#define PASS_TS_W(epoch, k, dep) do { } while (0)
 #endif
 namespace {
 
@@ -2287,18 +2296,19 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     pub_write_epoch(F.pub_epoch, prob, lane, epoch);
     return;
   }
+  PASS_TS_W(F.epoch, 5, Hl);
   // ---- dm::solve<D>: L D L^T, statement for statement; L(i, j) in lane i D + j (i > j), d(j) in lane j D + j of Dv,
   //      1 / d(j) in the same lane of Iv
+  //      RIGHT-LOOKING: every lane (i, j) carries its own running value H(i, j) - sum_{k done} (L(i, k) L(j, k)) d(k) and takes
+  //      the term of column k as soon as that column is final -- the same terms in the same (ascending k) order for every
+  //      entry, hence the same bits as dm::solve's loops, but one dependent step per pivot instead of 2 j: the critical
+  //      path of the step is this wave's chain of float64 operations (profiles/r6l).
   double Lv = 0.0, Dv = 0.0, Iv = 0.0;
-  bool bad = false;
+  double Tv = Hl;
+  bool bad  = false;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    double sj = rl_d(Hl, j * D + j);
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const double ljk = rl_d(Lv, j * D + k);
-      sj               = sj - (ljk * ljk) * rl_d(Dv, k * D + k);
-    }
+    const double sj = rl_d(Tv, j * D + j);
     if (!(sj > 0.0)) {
       bad = true;
       break;
@@ -2308,23 +2318,22 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
       Dv = sj;
       Iv = inv;
     }
-    double t = Hl;  // lane (i, j): H(i, j) - sum_k (L(i, k) L(j, k)) d(k)
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const double lik = __shfl(Lv, (hr * D + k) & 63);
-      const double ljk = rl_d(Lv, j * D + k);
-      t                = t - (lik * ljk) * rl_d(Dv, k * D + k);
+    if (hc == j && hr > j && lane < D * D) Lv = Tv * inv;
+    if (j + 1 < D) {  // entry (i, j'), j' > j: - (L(i, j) L(j', j)) d(j)   (the lanes left of / above are not read again)
+      const double lij = __shfl(Lv, (hr * D + j) & 63);
+      const double ljj = __shfl(Lv, (hc * D + j) & 63);
+      Tv               = Tv - (lij * ljj) * sj;
     }
-    if (hc == j && hr > j && lane < D * D) Lv = t * inv;
   }
   double yv = 0.0, dxv = 0.0;  // y(i), dx(i) in lane i
   if (!bad) {
+    // forward substitution by columns: lane i carries -b(i) - sum_{k done} L(i, k) y(k), final once k reaches i
+    double tv = -bl;
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      double t = -rl_d(bl, i);
-#pragma unroll
-      for (int k = 0; k < i; ++k) t = t - rl_d(Lv, i * D + k) * rl_d(yv, k);
-      if (lane == i) yv = t;
+    for (int k = 0; k < D; ++k) {
+      const double yk = rl_d(tv, k);
+      if (lane == k) yv = tv;
+      if (k + 1 < D) tv = tv - __shfl(Lv, (lane * D + k) & 63) * yk;
     }
 #pragma unroll
     for (int i = D - 1; i >= 0; --i) {
@@ -2336,6 +2345,7 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     const bool nf = lane < D && (!(dxv == dxv) || dxv > 1e300 || dxv < -1e300);
     bad           = __any(nf);
   }
+  PASS_TS_W(F.epoch, 6, dxv);
   // ---- what get_information / the batch records read: H, b, dx of this Gauss-Newton iteration
   if (lane < D * D) st->last_H[lane] = Hl;
   if (lane < D) {
@@ -2395,6 +2405,7 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     }
     if (lane < TS) st->X[lane] = Xl;
   }
+  PASS_TS_W(F.epoch, 7, (double) Xl);
   // ---- IterationStats of this iteration (multi_aligner_impl.cpp:113-115): one 4-byte word of the record per lane
   const float chi_in_f = (float) chi_in, chi_out_f = (float) chi_out;
   if (nstats0 < F.max_stats && lane < 8) {

@@ -49,6 +49,8 @@ for e in range(16):
     print("%5d | %10d | %s  %s | %s | %s  %s  %s | %s  %s  %s | %6.2f" % (
         e, used.sum(), f(st.min()), f(st.max()), f(ctl) if ctl else "     -", f(seen.min()), f(np.median(seen)), f(seen.max()),
         f(end.min()), f(np.median(end)), f(end.max()), (end.max() - st.min()) / 100.0))
+    if ts[e, 0, 5] and ctl:
+        print("      control step: sums and H / b in the lanes at %s, dx solved at %s, X and the transforms at %s, published at %s" % (f(ts[e, 0, 5]), f(ts[e, 0, 6]), f(ts[e, 0, 7]), f(ctl)))
     if census[0]:
         print("      failed certificates: %d points (no previous neighbour %d; margin < 1e-4 cells %d, < 0.0202 cells %d, larger %d; moved > 1e-3 cells %d; no radius %d)" % tuple(census))
     p2 = ts[e, used, 4]
