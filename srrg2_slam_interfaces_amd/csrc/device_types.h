@@ -59,7 +59,9 @@ struct GridLists {
   float cls_b2[14];    // classes 0 .. 12 (R <= 3) + sentinel
 };
 #define CNL_MAX_R 3
-#define CNL_ENTRY_MAX 16
+#ifndef CNL_ENTRY_MAX
+#define CNL_ENTRY_MAX 16  // (<= 16: the count travels in four bits)
+#endif
 #define CNL_MAX_CLASS 12
 
 // Fused control steps (round 5; tuning.fused_control).  The control step of iteration i -- sum the slot sets, one
