@@ -147,3 +147,29 @@ def test_projective_slices_sharing_one_association(oracle, product):
     assert ref.status() == abi.SUCCESS
     assert_same_run(ref, fused, slices=(0, 1))
     assert_same_run(ref, unfused, slices=(0, 1))
+
+
+@pytest.mark.parametrize("slice_kind", [abi.SLICE_P2PLANE, abi.SLICE_P2P])
+def test_partial_overlap_through_the_one_linearisation_flow(oracle, product, slice_kind):
+    """A single alignment on the lists with fused control steps runs its converged passes as certificates -> searches -> ONE
+    linearisation of all lanes (icp_step_fast_body, `defer`).  A cropped fixed cloud and a large initial error keep MANY
+    certificates failing per wave for several passes (the pooled list search inside that flow, not only the four-at-a-time
+    team scans), neighbours change and points drop out of the gate: every iteration must still be the from-scratch search's."""
+    kind = abi.SE3_QUAT_RIGHT
+    d = syn.cloud_pair_3d(n=30000, seed=2601, t=(0.08, -0.05, 0.03), rpy_deg=(1.5, -2.0, 2.5))
+    d = {k: v.copy() for k, v in d.items()}
+    keep = d["fixed"][:, 0] <= np.quantile(d["fixed"][:, 0], 0.6)
+    d["fixed"], d["fixed_normals"] = d["fixed"][keep], d["fixed_normals"][keep]
+    cfg = cue_config(kind, slice_kind, 0.25, abi.ROBUST_CAUCHY, 0.05)
+
+    def build(al):
+        al.set_params(max_iterations=12, min_num_inliers=10, enable_inlier_only_runs=True)
+        setup_pair(al, d, cfg)
+        al.compute()
+
+    early = dict(FUSED, fast_from_iteration=1)  # (the converged-pass kernel while the estimate still moves)
+    ref, fused, fused_early, unfused = _runs(oracle, product, kind, build, [FUSED, early, UNFUSED])
+    assert ref.status() == abi.SUCCESS
+    for run in (fused, fused_early, unfused):
+        assert_same_run(ref, run)
+    assert fused.information().tobytes() == unfused.information().tobytes() == fused_early.information().tobytes()
