@@ -438,8 +438,9 @@ def measure(args, init_dist=True):
         fresh = fresh[5:]
         out["c2_fresh_fixed"] = {"ms_per_step": float(np.median(fresh)) * 1e3, "value": units_per_step / float(np.median(fresh)),
                                  "unit": "iterations/s",
-                                 "note": "the first compute() after every set_fixed (a tracker's frame): no lists yet -> grid "
-                                         "kernels + deferred-search kernel + one control launch per iteration"}
+                                 "note": "the first compute() after every set_fixed (a tracker's frame): no lists yet -> the search "
+                                         "passes on the grid kernels + deferred-search kernel with a control launch each, fused "
+                                         "control steps from the first converged pass on"}
         al.set_fixed(0, data["fixed"], data["fixed_normals"])
         step(); step()  # (back to the steady state for what follows)
     if world == 1 and not args.no_cpu_baseline and args.workload == "c2":

@@ -549,8 +549,10 @@ typedef struct srrg2_aligner_tuning {
   int32_t fused_control;        /* SRRG2_AMD_FUSED_CONTROL: the control step of an ICP iteration (sums, Gauss-Newton step, update,
                                    statistics, termination) runs on one wave in the prologue of the next iteration's first
                                    pass kernel instead of as a launch of its own: 0 = never, 1 / -1 = whenever the aligner is ONE
-                                   nearest-neighbour cue slice searched over cell neighbour lists, or projective slices that
-                                   share one association, and has no prior slice (carved out of reserved_)                 */
+                                   nearest-neighbour cue slice (searched over cell neighbour lists: every iteration; on the
+                                   grid kernels -- a first compute() on a fixed cloud --: from the first converged pass on), or
+                                   projective slices that share one association, and has no prior slice (carved out of
+                                   reserved_)                                                                            */
   int32_t reserved_[6];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */

@@ -1000,11 +1000,27 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // the step finds everything in the slices' records)
   const bool fuse_proj = proj_fused && (int) proj_group.size() == nslices && K == 1;
   fuse = fuse && (nslices == 1 || fuse_proj);
+  // A nearest-neighbour slice WITHOUT lists (the first compute() on a fixed cloud: a tracker's frame) or with the deferred-search
+  // queue runs its search passes on the grid kernels, which read ProblemState and have no prologue: those iterations keep their
+  // control launch (it publishes the record too), and the control steps are fused from the first converged pass on --
+  // `fused_all` = every pass kernel of this compute() can carry a control step, else only k_icp_step_fast (fast_at below).
+  bool fused_all = true;
+  int nm_max_cue = 0;
+  if (first_cue >= 0)
+    for (int k = 0; k < K; ++k) nm_max_cue = std::max(nm_max_cue, all[(size_t) first_cue * K + k].nm);
+  auto fast_at = [&](int slot0, int it) {  // (the choice of run_phase below)
+    return (slot0 > 0 || (it >= fast_from && it >= 1)) && !(C.tune & 4) && nm_max_cue >= fast_min;
+  };
   for (int si = 0; si < nslices && fuse; ++si) {
     const Slice* s = a->slices[si];
     fuse = s->cfg.kind != SRRG2_SLICE_PRIOR &&
-           (fuse_proj ? s->cfg.finder == SRRG2_FINDER_PROJECTIVE
-                      : (s->cfg.finder == SRRG2_FINDER_NN_GATED && cnl[(size_t) si] && !sdev[si].queue));
+           (fuse_proj ? s->cfg.finder == SRRG2_FINDER_PROJECTIVE : s->cfg.finder == SRRG2_FINDER_NN_GATED);
+    if (fuse && !fuse_proj && !(cnl[(size_t) si] && !sdev[si].queue)) {
+      fused_all = false;
+      // (worth it when converged passes follow; SRRG2_AMD_TUNE bit 27: lists or nothing, as before)
+      fuse = !split && !(C.tune & (1 << 27)) &&
+             (fast_at(0, a->params.max_iterations - 1) || (a->params.enable_inlier_only_runs && fast_at(a->params.max_iterations, 0)));
+    }
   }
   if (fuse) {
     if ((rc = a->pub.reserve((size_t) K * SRRG2_MAX_SLICES * PUB_SLICE_GRANULES))) return rc;
@@ -1093,7 +1109,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       // first pass of the next iteration, or -- the last iteration of a run -- as a launch)
       Ch[h].parity = epoch & 1;
       Ch[h].epoch  = epoch + 1;
-      if (!last_it) return;
+      // (the next iteration's first kernel applies this step -- if it can: the grid kernels cannot, and the launch after the
+      // probe iteration also reports the queue counters to the host)
+      const int slot0_now = last_phase && a->params.enable_inlier_only_runs ? a->params.max_iterations : 0;
+      if (!last_it && (fused_all || (fast_at(slot0_now, it + 1) && it != probe_it))) return;
     }
     if (last_phase && last_it) {
       // (the last step on one wave too -- k_icp_final_wave -- measured SLOWER than the 256-thread kernel on C2, 0.191 against
