@@ -1094,6 +1094,36 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   std::vector<char> queue_on((size_t) std::max(nslices, 1), 1);
   bool probed = false;
   bool final_launched = false;  // the last control step of compute() carried the post / finalize steps
+  // (the probe: the queue counters of iteration `probe_it`, reported by that iteration's control launch)
+  auto read_probe = [&]() {
+    probed = true;
+    for (int si = 0; si < nslices; ++si) {
+      if (!sdev[si].queue) continue;
+      volatile int* mirror = a->slices[si]->qprobe_host;
+      bool small           = true;
+      for (int k = 0; k < K; ++k) {
+        int spins = 0;
+        while (mirror[2 * k] == 0x7f7f7f7f || mirror[2 * k + 1] == 0x7f7f7f7f) {  // not reported yet
+          // (a problem that stopped before the probe iteration never reports: once the stream has drained, give up
+          // and keep the queue)
+          if ((++spins & 1023) == 0 && hipStreamQuery(a->stream) != hipErrorNotReady) break;  // drained or failed
+        }
+        const int near = mirror[2 * k], far = mirror[2 * k + 1];
+        if (near == 0x7f7f7f7f || far > 32 || near > std::max(1024, all[(size_t) si * K + k].nm / 64)) small = false;
+      }
+      queue_on[(size_t) si] = small ? 0 : 1;
+    }
+  };
+  // Does the pass of iteration `it` carry the control step of the one before it (a FUSED kernel instantiation)?  Without lists
+  // only the converged-pass kernel can, and only while the deferred-search queue is not needed: with the queue on (a partial
+  // overlap: hundreds of far searches per pass, C2 at 60 % overlap) the in-wave searches of the fused kernel cost more than the
+  // control launches they save (0.39 -> 0.57 ms, profiles/r6r) -- those alignments stay on the launches.
+  auto fused_pass = [&](int slot0, int it) {
+    if (!fuse) return false;
+    if (fused_all) return true;
+    const bool queue_needed = sdev[first_cue].queue && queue_on[(size_t) first_cue];
+    return fast_at(slot0, it) && !queue_needed && (slot0 > 0 || probed || probe_it < 0 || !sdev[first_cue].queue);
+  };
   auto control = [&](int it, bool last_phase, int h) {
     if (a->reduce_fn) {  // the ranks' partial sums, added in place, before anybody looks at them
       // (after a failure the hook is still called for the remaining control steps: the collectives of the ranks stay
@@ -1112,7 +1142,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       // (the next iteration's first kernel applies this step -- if it can: the grid kernels cannot, and the launch after the
       // probe iteration also reports the queue counters to the host)
       const int slot0_now = last_phase && a->params.enable_inlier_only_runs ? a->params.max_iterations : 0;
-      if (!last_it && (fused_all || (fast_at(slot0_now, it + 1) && it != probe_it))) return;
+      // (the verdict on the queue is needed one control step earlier than the loop below asks for it)
+      if (!fused_all && !probed && slot0_now == 0 && probe_it >= 0 && it == probe_it + 1) read_probe();
+      if (!last_it && fused_pass(slot0_now, it + 1) && (fused_all || it != probe_it)) return;
     }
     if (last_phase && last_it) {
       // (the last step on one wave too -- k_icp_final_wave -- measured SLOWER than the 256-thread kernel on C2, 0.191 against
@@ -1137,25 +1169,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   };
   auto run_phase = [&](int slot0, bool last_phase) -> int {
     for (int it = 0; it < a->params.max_iterations; ++it) {
-      if (!probed && slot0 == 0 && probe_it >= 0 && it == probe_it + 2) {
-        probed = true;
-        for (int si = 0; si < nslices; ++si) {
-          if (!sdev[si].queue) continue;
-          volatile int* mirror = a->slices[si]->qprobe_host;
-          bool small           = true;
-          for (int k = 0; k < K; ++k) {
-            int spins = 0;
-            while (mirror[2 * k] == 0x7f7f7f7f || mirror[2 * k + 1] == 0x7f7f7f7f) {  // not reported yet
-              // (a problem that stopped before the probe iteration never reports: once the stream has drained, give up
-              // and keep the queue)
-              if ((++spins & 1023) == 0 && hipStreamQuery(a->stream) != hipErrorNotReady) break;  // drained or failed
-            }
-            const int near = mirror[2 * k], far = mirror[2 * k + 1];
-            if (near == 0x7f7f7f7f || far > 32 || near > std::max(1024, all[(size_t) si * K + k].nm / 64)) small = false;
-          }
-          queue_on[(size_t) si] = small ? 0 : 1;
-        }
-      }
+      if (!probed && slot0 == 0 && probe_it >= 0 && it == probe_it + 2) read_probe();
       if (!proj_group.empty()) {
         SliceDev pack[4];
         const ProblemDev* pp[4];
@@ -1241,6 +1255,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             // (a pipelined batch has one cue slice: each half's pass is followed by that half's control step on its stream)
             sd.prob0 = h0[h];
             if (fuse) {
+              if (!fused_pass(slot0, it)) sd.fc.pub = nullptr;  // (this pass on the kernels that read ProblemState)
               sd.fc.ctl   = a->ctl_dev.p + h;
               sd.fc.epoch = epoch;
               sd.partials = s->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
