@@ -531,7 +531,8 @@ typedef struct srrg2_aligner_tuning {
   int32_t queue_min_points;     /* SRRG2_AMD_QUEUE_MIN: smallest moving cloud that uses the deferred-search kernel (90000) */
   int32_t msort_segments;       /* SRRG2_AMD_MSORT_SEGMENTS: workgroups per cloud of the batch Morton sort; 0 = automatic */
   int32_t msort_key_bits;       /* SRRG2_AMD_MSORT_BITS: total bits of the (anisotropic) Morton key of the moving-cloud
-                                   sort; 0 = automatic (15 for batches sorted in LDS, 18 for single clouds); -1 = the
+                                   sort; 0 = automatic (15: one kernel, histogram in LDS; 16 .. 18 take the global-histogram
+                                   kernels); -1 = the
                                    round-2 isotropic keys (4 / 5 / 6 bits per axis by batch size)                      */
   int32_t lds_tile;             /* SRRG2_AMD_LDS_TILE: search passes of batches stage each wave's neighbourhood of the
                                    fixed cloud in LDS (1) or gather it per lane (0); -1 = automatic                     */

@@ -559,10 +559,12 @@ int upload_moving(srrg2_aligner* a, int si, const float* coords, int cs, const f
   const int mk    = a->tuning.msort_key_bits;
   const int aniso = mk >= 0 ? 1 : 0;
   const int bits  = K <= 4 ? 6 : (K <= 32 ? 5 : 4);
-  // (automatic: one cloud 18 bits -- its passes are ~1 % faster on the finer order, its sort 20 us slower: a tracker that binds a
-  // new moving cloud per frame may prefer msort_key_bits = 15 --; batches of 2 .. 4 alignments were on 18 bits as well, i.e. on
-  // the eight launches of the global-histogram sort: 0.32 -> 0.25 ms per 4-batch with the LDS sort, profiles/r6v)
-  int kbits       = aniso ? (mk > 0 ? mk : (K <= 1 ? 18 : 15)) : 3 * bits;
+  // (automatic: 15 bits = the one-kernel sort in LDS for every call.  Round 5 kept 18 bits -- the eight launches of the
+  // global-histogram sort -- for calls of up to four clouds: the passes of ONE 100 k-point cloud are ~1 % faster on the finer
+  // order, but its sort is 70-100 us slower, and a caller that binds a new moving cloud per alignment -- a tracker, a
+  // compute_batch of 1 .. 4 -- pays that every time: 0.28 -> 0.20 ms per single 50 k-point compute_batch, 0.32 -> 0.25 ms per
+  // 4-batch, set_moving of a tracker frame 0.105 -> 0.086 ms (profiles/r6v, r6y).  msort_key_bits = 18 brings it back.)
+  int kbits       = aniso ? (mk > 0 ? mk : 15) : 3 * bits;
   kbits           = std::min(kbits, 18);  // (more than 6 bits per axis would collide in the key's bit spreading)
   // (the global-histogram sort indexes K << kbits cells with an int: coarser keys when a huge batch asks for fine ones)
   while (kbits > 3 && ((long long) K << kbits) > 0x3fffffffLL) --kbits;
