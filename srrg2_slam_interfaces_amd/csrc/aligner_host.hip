@@ -765,6 +765,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     const int small_max = tn.small_max_points;
     small = ncue == 1 && a->slices[fc]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm <= small_max &&
             a->timeline_path.empty() && !a->reduce_fn;  // (the one-workgroup kernel has no place for the reduction)
+    // (round 5, late: ... and only where the launches cannot carry their control steps -- prior slices next to the cue slice, or
+    // fused_control = 0.  With fused control steps and lists the launch-per-pass path has overtaken it at every size: a
+    // 1000-beam scan 0.226 -> 0.134 ms, 1000 3-D points 0.42 -> 0.135 ms, 256 x 1000 points per call 0.56 -> 0.31 ms,
+    // first compute() on a new fixed cloud 0.42 -> 0.26 ms; 300 points: equal there, 0.24 -> 0.12 ms afterwards; profiles/r6z)
+    small = small && (nslices > ncue || tn.fused_control == 0 || a->params.max_iterations < 2);
   }
   // The converged pass kernel takes over from iteration `fast_from` of the first run (all of the inlier-only run): by
   // then nearly every point keeps its neighbour.  Batches give it `fast_ppt` points per thread and a queue.
