@@ -2967,9 +2967,31 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
         }
         continue;
       }
+      // No lists (the first compute() on a fixed cloud) and MANY open points -- the estimate still moves at iteration 3, or a
+      // 2-D point-to-point alignment that creeps towards its solution: 2 700 of 3 000 certificates fail in every pass of a
+      // 3000-beam scan pair, and four-at-a-time team scans took 42 us per pass where the search pass takes 16.  Every open lane
+      // scans the 3^DIM block around its own query first (scan_radius1, the first phase of k_icp_step, same acceptance rule:
+      // a candidate inside the radius the block is guaranteed to cover); what that does not settle goes to the teams.
+      bool open_k = open;
+      if constexpr (PPT == 1) {
+        if (!(g.list_R > 0) && __popcll(__ballot(open)) > 4) {
+          unsigned long long lkey = NO_KEY;
+          float lb2 = INFINITY, lc2 = INFINITY;
+          if (open)
+            scan_radius1<DIM>(g, qx, qy, qz, cell_coord(qx, g.ox, g.inv_h), cell_coord(qy, g.oy, g.inv_h),
+                              DIM == 3 ? cell_coord(qz, g.oz, g.inv_h) : 0, open_ball2[k], lkey, lb2, lc2);
+          const float b2_1 = bound2_of(1, g.h);
+          if (open && key_idx(lkey) != NO_MATCH && key_best(lkey) <= gfar && key_best(lkey) <= b2_1) {
+            sbest[k] = key_best(lkey);
+            sidx[k]  = key_idx(lkey);
+            sexcl[k] = sqrtf(fminf(fminf(lb2, lc2), b2_1)) * 0.99999f;
+            open_k   = false;
+          }
+        }
+      }
       const int r2 = open_ball2[k] <= bound2_of(2, g.h) ? 2 : max(rfar, 3);
       // small balls (the usual case: the ball of the previous neighbour): four searches per pass, 16 lanes each
-      unsigned long long near = __ballot(open && r2 == 2);
+      unsigned long long near = __ballot(open_k && r2 == 2);
       while (near) {
         int src[4];
   #pragma unroll
@@ -2998,7 +3020,7 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
           }
         }
       }
-      unsigned long long todo = __ballot(open && r2 != 2);
+      unsigned long long todo = __ballot(open_k && r2 != 2);
       while (todo) {
         const int src = __ffsll((long long) todo) - 1;
         todo &= todo - 1;

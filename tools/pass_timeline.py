@@ -14,20 +14,29 @@ import numpy as np
 import srrg2_slam_interfaces_amd as pkg
 from srrg2_slam_interfaces_amd import _abi as abi, _capi, synthetic as syn
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+scan2d = "--scan2d" in sys.argv  # a 2-D scan pair, SE(2) point-to-point, a NEW fixed scan before every compute() (no lists)
+args = [x for x in sys.argv[1:] if not x.startswith("--")]
+n = int(args[0]) if args else (3000 if scan2d else 100000)
 lib = _capi.lib()
-al = pkg.MultiAligner(abi.SE3_QUAT_RIGHT)
+kind = abi.SE2_RIGHT if scan2d else abi.SE3_QUAT_RIGHT
+al = pkg.MultiAligner(kind)
 al.set_params(max_iterations=10, min_num_inliers=10)
-c = abi.default_slice_config(abi.SE3_QUAT_RIGHT)
-c.kind, c.finder, c.finder_max_distance, c.finder_normal_cos = abi.SLICE_P2PLANE, abi.FINDER_NN_GATED, 0.25, 0.8
+c = abi.default_slice_config(kind)
+if scan2d:
+    c.kind, c.finder, c.finder_max_distance = abi.SLICE_P2P, abi.FINDER_NN_GATED, 0.5
+    pr = syn.scan_pair_2d(beams=n, sigma=0.01, seed=1234)
+else:
+    c.kind, c.finder, c.finder_max_distance, c.finder_normal_cos = abi.SLICE_P2PLANE, abi.FINDER_NN_GATED, 0.25, 0.8
+    pr = syn.batch_3d(K=1, n=n, seed=2000, shared_fixed_group=1)[0]
 c.robustifier, c.robustifier_chi_threshold = abi.ROBUST_CAUCHY, 0.05
 al.add_slice(c)
-pr = syn.batch_3d(K=1, n=n, seed=2000, shared_fixed_group=1)[0]
-al.set_fixed(0, pr["fixed"], pr["fixed_normals"])
-al.set_moving(0, pr["moving"], pr["moving_normals"])
+al.set_fixed(0, pr["fixed"], pr.get("fixed_normals"))
+al.set_moving(0, pr["moving"], pr.get("moving_normals"))
 buf = (C.c_uint64 * (16 * 512 * 8))()
 for rep in range(4):  # (the second compute() builds the lists; the later ones run on them)
-    al.set_moving_in_fixed(syn.identity(3))
+    if scan2d:
+        al.set_fixed(0, pr["fixed"], pr.get("fixed_normals"))
+    al.set_moving_in_fixed(syn.identity(2 if scan2d else 3))
     lib.srrg2_amd_debug_pass_timeline(buf, 1)
     al.compute()
 lib.srrg2_amd_debug_pass_timeline(buf, 0)
