@@ -770,14 +770,14 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // 1000-beam scan 0.226 -> 0.134 ms, 1000 3-D points 0.42 -> 0.135 ms, 256 x 1000 points per call 0.56 -> 0.31 ms,
     // first compute() on a new fixed cloud 0.42 -> 0.26 ms; 300 points: equal there, 0.24 -> 0.12 ms afterwards; profiles/r6z)
     // ... except on a NEW fixed cloud (no lists yet: a laser tracker's every frame), where the search passes of the
-    // launch-per-pass path run on the grid kernels with a control launch each: 2-D scans and the smallest 3-D clouds stay on
-    // the one-workgroup kernel there (1000 beams: 0.235 against 0.34 ms; 360 beams: 0.115 against 0.29 ms; 1000 3-D points:
-    // 0.42 against 0.26 ms -- those go with the launches), profiles/r7a.
+    // launch-per-pass path run on the grid kernels with a control launch each: the smallest clouds stay on the one-workgroup
+    // kernel there (360 beams: 0.113 against 0.124 ms, 384 3-D points 0.245 against 0.255 ms; from ~700 points on the launches
+    // win: 1000 beams 0.154 against 0.232 ms, 1000 3-D points 0.26 against 0.42 ms), profiles/r7a, r7e.
     if (small && !(nslices > ncue || tn.fused_control == 0 || a->params.max_iterations < 2)) {
       const Slice* sfc = a->slices[fc];
       const int sl     = tn.search_lists;
       const bool lists = sl >= 2 || (sl == 1 && K > 4) || (sl < 0 && (K > 4 || sfc->grid_computes >= 1 || sfc->lists_tried));
-      small            = !lists && (a->dim == 2 || max_nm <= 384);
+      small            = !lists && max_nm <= 384;
     }
   }
   // The converged pass kernel takes over from iteration `fast_from` of the first run (all of the inlier-only run): by
