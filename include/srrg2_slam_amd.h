@@ -521,7 +521,8 @@ typedef struct srrg2_aligner_tuning {
   int32_t strategy_mask;        /* SRRG2_AMD_TUNE bit mask (DESIGN.md "Strategy knobs"); 0 = defaults                 */
   int32_t queue_probe_iteration;/* SRRG2_AMD_QPROBE: iteration whose deferred-search counters decide whether the
                                    deferred-search launch is kept (default 1; -1 = never drop it)                      */
-  int32_t small_max_points;     /* SRRG2_AMD_SMALL_MAX: largest moving cloud run by the one-workgroup kernel (1024)    */
+  int32_t small_max_points;     /* SRRG2_AMD_SMALL_MAX: upper limit of the clouds the one-workgroup kernel may take
+                                   (1024; below it the faster of the two paths is chosen per configuration)            */
   int32_t fast_from_iteration;  /* SRRG2_AMD_FAST_FROM: first iteration the converged-pass kernel takes (3)           */
   int32_t fast_points_per_thread; /* SRRG2_AMD_FAST_PPT: 1, 2 or 4; 0 (default) = 2 for launches of 64 alignments or more, else 1 */
   int32_t fast_min_points;      /* SRRG2_AMD_FAST_MIN: smallest moving cloud using the converged-pass kernel (0)       */

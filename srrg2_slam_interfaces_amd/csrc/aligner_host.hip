@@ -773,6 +773,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // launch-per-pass path run on the grid kernels with a control launch each: the smallest clouds stay on the one-workgroup
     // kernel there (360 beams: 0.113 against 0.124 ms, 384 3-D points 0.245 against 0.255 ms; from ~700 points on the launches
     // win: 1000 beams 0.154 against 0.232 ms, 1000 3-D points 0.26 against 0.42 ms), profiles/r7a, r7e.
+    // (aligners whose control steps stay launches -- a prior slice next to the cue slice: a laser tracker with odometry --:
+    // the one-workgroup kernel up to ~640 points; 360 beams 0.126 against 0.165 ms, 1000 beams 0.246 against 0.19 ms, r7f)
+    if (small && (nslices > ncue || tn.fused_control == 0 || a->params.max_iterations < 2)) small = max_nm <= 640;
     if (small && !(nslices > ncue || tn.fused_control == 0 || a->params.max_iterations < 2)) {
       const Slice* sfc = a->slices[fc];
       const int sl     = tn.search_lists;
