@@ -255,7 +255,9 @@ float bound2_of_host(int r, float h) {
 }
 
 // (re)build the finder's search grid of one slice; called from set_fixed
-int build_grid(srrg2_aligner* a, Slice* s) {
+// force_h > 0: this cell size (grown until the grid fits) instead of the automatic one (ensure_lists: a grid coarse enough for
+// the neighbour lists)
+int build_grid(srrg2_aligner* a, Slice* s, float force_h = 0.f) {
   const int n = s->nf;
   int rc;
   if ((rc = s->scalars.reserve(16))) return rc;
@@ -309,8 +311,8 @@ int build_grid(srrg2_aligner* a, Slice* s) {
     g.ny = nvalid > 0 ? ccoord(mx[1], g.oy) + 1 : 1;
     g.nz = (nvalid > 0 && dim == 3) ? ccoord(mx[2], g.oz) + 1 : 1;
   };
-  float h = fit_cell(s->cfg.finder_cell_size > 0.f ? s->cfg.finder_cell_size : gate * 0.25f);
-  if (!(s->cfg.finder_cell_size > 0.f) && nvalid > 0) {
+  float h = fit_cell(force_h > 0.f ? force_h : (s->cfg.finder_cell_size > 0.f ? s->cfg.finder_cell_size : gate * 0.25f));
+  if (!(force_h > 0.f) && !(s->cfg.finder_cell_size > 0.f) && nvalid > 0) {
     // Automatic cell size: probe the density with a histogram at gate/4 and rescale so that an occupied cell holds
     // ~8 points on average (surface-like scaling: occupancy ~ h^2).  Too small a cell leaves many lanes unsettled
     // after the 3^DIM block (misaligned first iterations, sparser regions), too large a cell inflates the candidate
@@ -393,9 +395,39 @@ int build_grid(srrg2_aligner* a, Slice* s) {
 // Cell neighbour lists of a slice's grid (k_icp_step_cnl; GridDev::list_*): once per grid, on the first compute() that wants
 // them.  Leaves grid.list_R = 0 when the lists are not available: a cube radius above CNL_MAX_R (dense clouds: the lists
 // would hold thousands of cells each) or more entries than `max_entries`.
+int ensure_lists_of_grid(srrg2_aligner* a, Slice* s, long long max_entries);
 int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
   if (s->lists_tried) return 0;
   s->lists_tried = true;
+  GridDev& g     = s->grid;
+  g.list_R       = 0;
+  int rc;
+  // A dense cloud gets cells so small (~8 points each) that the extended gate spans more than CNL_MAX_R of them: no lists, every
+  // compute() on the grid kernels (200 k points: 0.34 ms where 100 k take 0.18).  The grid kernels do like the fine grid --
+  // but this is the SECOND compute() on the cloud (or a batch), and with lists the coarser grid wins by far: 200 k points
+  // 0.34 -> 0.23 ms, 400 k 0.63 -> 0.36 ms (profiles/r7h).  The grid is rebuilt once with the smallest cells that keep the
+  // radius at CNL_MAX_R; if the lists do not fit even then, the fine grid comes back.  (Any grid gives the same results.)
+  if (g.rmax > CNL_MAX_R && s->nf > 0 && s->nf <= 2000000 && !(s->cfg.finder_cell_size > 0.f) &&
+      !(a->tuning.strategy_mask & (1 << 28))) {
+    const float h_fine = g.h;
+    const int computes = s->grid_computes;
+    const float h_list = s->cfg.finder_max_distance * 1.25f / ((float) CNL_MAX_R - 0.011f);
+    if (h_list > h_fine) {
+      if ((rc = build_grid(a, s, h_list))) return rc;
+      s->lists_tried   = true;
+      s->grid_computes = computes;
+      if (g.rmax <= CNL_MAX_R && (rc = ensure_lists_of_grid(a, s, max_entries))) return rc;
+      if (g.list_R == 0) {  // (no lists after all: back to the grid the grid kernels prefer)
+        if ((rc = build_grid(a, s, h_fine))) return rc;
+        s->lists_tried   = true;
+        s->grid_computes = computes;
+      }
+      return 0;
+    }
+  }
+  return ensure_lists_of_grid(a, s, max_entries);
+}
+int ensure_lists_of_grid(srrg2_aligner* a, Slice* s, long long max_entries) {
   GridDev& g     = s->grid;
   g.list_R       = 0;
   const int R    = g.rmax;
@@ -864,8 +896,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
                             (search_lists < 0 && (K > 4 || s->grid_computes >= 1 || s->lists_tried));
     s->grid_computes++;
     if (s->cfg.finder == SRRG2_FINDER_NN_GATED && !small && want_lists) {
-      // (the lists are built once per grid; 16 Mi entries = 256 MB: far above C2 / C4, a guard for dense clouds)
-      if ((rc = ensure_lists(a, s, 16LL << 20))) return rc;
+      // (the lists are built once per grid; the guard: 96 Mi entries = 1.5 GB -- C2: 3 M entries, a 2 M-point cloud: ~60 M)
+      if ((rc = ensure_lists(a, s, 96LL << 20))) return rc;
       cnl[(size_t) si] = s->grid.list_R > 0 ? 1 : 0;
     }
     const bool use_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && !(C.tune & 512) && nm_max_s >= queue_min && K <= 4 && !small &&
