@@ -415,7 +415,10 @@ typedef struct srrg2_posegraph_tuning {
   float   lag_below;        /* SRRG2_AMD_PG_LAG: a Gauss-Newton iteration keeps the hierarchy's numerics of the previous one
                                when that one moved no variable by more than this (0.05; 0 = never: every iteration rebuilds
                                interpolation and coarse operators, 3 ms each on C5)                                   */
-  int32_t reserved_[8];
+  int32_t device_structure; /* SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of the hierarchy (interpolation, Q = H Ps, column
+                               lists, coarse edges) are built on the device by sort + unique (1) instead of on the host (0: 13 of
+                               the 25 ms a structure build takes on C5); the arrays are the same entry for entry          */
+  int32_t reserved_[7];
 } srrg2_posegraph_tuning;
 void srrg2_posegraph_default_tuning(srrg2_posegraph_tuning* t);
 int srrg2_posegraph_get_tuning(srrg2_posegraph_h h, srrg2_posegraph_tuning* t_out);

@@ -32,6 +32,8 @@
 #endif
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "det_math.h"
 #include "host_util.h"
 
@@ -1421,7 +1423,14 @@ struct srrg2_posegraph_s {
     bool use_graph = true;      // SRRG2_AMD_PG_GRAPH
     bool debug = false;         // SRRG2_AMD_PG_DEBUG
     bool keep_structure = true; // the hierarchy's structure survives a set() with the same topology
+    bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
   } sw;
+  // scratch of the device-side pattern build (pg_device_patterns)
+  DevBuf<unsigned long long> st_keys_a, st_keys_b;
+  DevBuf<int> st_cnt, st_off, st_slot, st_ia, st_ib, st_counts;
+  DevBuf<unsigned long long> st_total;
+  DevBuf<char> st_temp;
+  double st_ms[5] = {0, 0, 0, 0, 0};  // (debug) P sorted / Q counted / Q sorted / columns + coarse edges counted / coarse edges sorted
   srrg2_posegraph_tuning tuning{};
   bool mg_dirty      = true;
   // host mirrors for the incremental interface (incidence lists are rebuilt lazily from these)
@@ -1606,6 +1615,309 @@ void columns_of(HostPool& pool, int ncols, const std::vector<int>& col_of_entry,
   });
 }
 
+// ---- the sparsity patterns of one level, built on the device ------------------------------------------------------------
+// Every pattern of the hierarchy is a sorted set of (row, column) pairs: rows of Ps = the aggregates of a node and of its
+// neighbours, rows of Q = H Ps = the union of the rows of Ps over a node and its neighbours, the coarse edges = the pairs
+// (A, B > A) with B in the row of Q of some row of column A of Ps.  The host built them row by row with stamp arrays (13 ms of
+// the 25 ms a structure build cost on C5, on 16 threads); here every pattern is: count the candidates, scan, write them as
+// keys row * (nc + 1) + column, ONE radix sort, unique -- a canonical order, so the arrays are those of the host build entry for
+// entry (SRRG2_AMD_PG_DEVICE_STRUCTURE=0 keeps the host build; tests/test_gpu_posegraph.py compares the two).  The column
+// lists are stable sorts of the entries by column.  The host keeps what is sequential: the greedy matching.
+typedef unsigned long long st_key;
+
+__global__ __launch_bounds__(PG_THREADS) void k_st_p_candidates(int n, int nc, int smoothed, const int* __restrict__ agg,
+                                                                const int* __restrict__ inc_start, const int2* __restrict__ inc_adj,
+                                                                st_key* __restrict__ keys, int* __restrict__ slot_node) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const st_key none = (st_key) n * (st_key) (nc + 1);
+  const int q0 = inc_start[v], q1 = inc_start[v + 1];
+  const size_t base = (size_t) v + (size_t) q0;  // slot 0: the node itself, then its incidences
+  const int a = agg[v];
+  keys[base]      = a >= 0 ? (st_key) v * (st_key) (nc + 1) + (st_key) a : none;
+  slot_node[base] = v;
+  for (int q = q0; q < q1; ++q) {
+    const int b = (a >= 0 && smoothed) ? agg[inc_adj[q].x] : -1;
+    keys[base + 1 + (size_t) (q - q0)]      = b >= 0 ? (st_key) v * (st_key) (nc + 1) + (st_key) b : none;
+    slot_node[base + 1 + (size_t) (q - q0)] = v;
+  }
+}
+
+// counts[which] = number of keys below `none` among the nsel sorted unique keys (`none`, if present, is the last one)
+__global__ void k_st_valid(const st_key* __restrict__ keys, const int* __restrict__ nsel, st_key none, int* __restrict__ counts,
+                           int which) {
+  const int m   = *nsel;
+  counts[which] = (m > 0 && keys[m - 1] >= none) ? m - 1 : m;
+}
+
+// rows, columns and row starts of a sorted unique key list
+__global__ __launch_bounds__(PG_THREADS) void k_st_decode(int nrows, int nc, const int* __restrict__ counts, int which,
+                                                          const st_key* __restrict__ keys, int* __restrict__ start,
+                                                          int* __restrict__ col, int* __restrict__ row_of) {
+  const int m = counts[which];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) {
+    const st_key k = keys[t];
+    const int r    = (int) (k / (st_key) (nc + 1));
+    if (col) col[t] = (int) (k - (st_key) r * (st_key) (nc + 1));
+    if (row_of) row_of[t] = r;
+  }
+  if (t <= nrows) {  // start[t] = the first key of row t or beyond
+    const st_key want = (st_key) t * (st_key) (nc + 1);
+    int lo = 0, hi = m;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    start[t] = lo;
+  }
+}
+
+// slot t = (node v, itself or one of its neighbours j): the row of Ps of j goes into the row of Q of v
+__device__ __forceinline__ int st_slot_other(int t, int v, const int* __restrict__ inc_start, const int2* __restrict__ inc_adj) {
+  const int s = t - (v + inc_start[v]);
+  return s == 0 ? v : inc_adj[inc_start[v] + s - 1].x;
+}
+__global__ __launch_bounds__(PG_THREADS) void k_st_q_count(int slots, const int* __restrict__ slot_node, const int* __restrict__ agg,
+                                                           const int* __restrict__ inc_start, const int2* __restrict__ inc_adj,
+                                                           const int* __restrict__ prow_start, int* __restrict__ cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= slots) return;
+  const int v = slot_node[t];
+  const int j = st_slot_other(t, v, inc_start, inc_adj);
+  cnt[t]      = agg[v] >= 0 ? prow_start[j + 1] - prow_start[j] : 0;
+}
+__global__ __launch_bounds__(PG_THREADS) void k_st_q_candidates(int slots, int nc, const int* __restrict__ slot_node,
+                                                                const int* __restrict__ inc_start, const int2* __restrict__ inc_adj,
+                                                                const int* __restrict__ prow_start, const int* __restrict__ pcol,
+                                                                const int* __restrict__ cnt, const int* __restrict__ off,
+                                                                st_key* __restrict__ keys) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= slots || cnt[t] == 0) return;
+  const int v = slot_node[t];
+  const int j = st_slot_other(t, v, inc_start, inc_adj);
+  st_key* out = keys + off[t];
+  for (int e = prow_start[j], k = 0; e < prow_start[j + 1]; ++e, ++k) out[k] = (st_key) v * (st_key) (nc + 1) + (st_key) pcol[e];
+}
+// *total += sum of cnt[0, m) in 64 bits (the guards against fill and against 32-bit offsets look at this one)
+__global__ __launch_bounds__(PG_THREADS) void k_st_sum64(int m, const int* __restrict__ cnt, unsigned long long* __restrict__ total) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long c = t < m ? (unsigned long long) cnt[t] : 0ull;
+  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, c);
+}
+// counts[which] = off[m - 1] + cnt[m - 1] (the total behind an exclusive scan)
+__global__ void k_st_total(int m, const int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ counts, int which) {
+  counts[which] = m > 0 ? off[m - 1] + cnt[m - 1] : 0;
+}
+__global__ __launch_bounds__(PG_THREADS) void k_st_iota(int m, int* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) out[t] = t;
+}
+// column starts and the {entry, row} pairs of a pattern's entries sorted by column (rows ascending: the sort is stable)
+__global__ __launch_bounds__(PG_THREADS) void k_st_columns(int m, int ncols, const int* __restrict__ sorted_col,
+                                                           const int* __restrict__ ent, const int* __restrict__ row_of,
+                                                           int* __restrict__ csc_start, int2* __restrict__ csc2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) csc2[t] = make_int2(ent[t], row_of[ent[t]]);
+  if (t <= ncols) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sorted_col[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    csc_start[t] = lo;
+  }
+}
+// entry e = Ps[i, A] puts the columns B > A of row i of Q into row A of the coarse pattern
+__global__ __launch_bounds__(PG_THREADS) void k_st_ce_count(int np, const int* __restrict__ pcol, const int* __restrict__ prow_of,
+                                                            const int* __restrict__ qrow_start, const int* __restrict__ qcol,
+                                                            int* __restrict__ first, int* __restrict__ cnt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np) return;
+  const int A = pcol[e], i = prow_of[e];
+  int lo = qrow_start[i], hi = qrow_start[i + 1];
+  const int end = hi;
+  while (lo < hi) {  // first column behind A
+    const int mid = (lo + hi) >> 1;
+    if (qcol[mid] <= A) lo = mid + 1; else hi = mid;
+  }
+  first[e] = lo;
+  cnt[e]   = end - lo;
+}
+__global__ __launch_bounds__(PG_THREADS) void k_st_ce_candidates(int np, int nc, const int* __restrict__ pcol,
+                                                                 const int* __restrict__ qcol, const int* __restrict__ first,
+                                                                 const int* __restrict__ cnt, const int* __restrict__ off,
+                                                                 st_key* __restrict__ keys) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np) return;
+  const st_key A = (st_key) pcol[e];
+  st_key* out    = keys + off[e];
+  for (int k = 0; k < cnt[e]; ++k) out[k] = A * (st_key) (nc + 1) + (st_key) qcol[first[e] + k];
+}
+__global__ __launch_bounds__(PG_THREADS) void k_st_ce_decode(int nc, const int* __restrict__ counts, int which,
+                                                             const st_key* __restrict__ keys, int2* __restrict__ ceij) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= counts[which]) return;
+  const st_key k = keys[t];
+  const int A    = (int) (k / (st_key) (nc + 1));
+  ceij[t]        = make_int2(A, (int) (k - (st_key) A * (st_key) (nc + 1)));
+}
+
+inline int st_bits(unsigned long long x) {  // number of bits needed for the values 0 .. x
+  int b = 1;
+  while (b < 64 && (x >> b) != 0) ++b;
+  return b;
+}
+inline dim3 st_grid(size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); }
+
+// sorted unique keys of keys_a[0, m) -> keys_b[0, counts[which]) (`none` keys dropped from the count)
+int st_sort_unique(srrg2_posegraph_s* g, int m, st_key none, int which) {
+  int rc;
+  size_t t1 = 0, t2 = 0;
+  const int end_bit = std::min(64, st_bits(none));
+  if ((rc = g->st_keys_b.reserve((size_t) std::max(m, 1)))) return rc;
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, t1, g->st_keys_a.p, g->st_keys_b.p, m, 0, end_bit, g->stream));
+  HIP_TRY(hipcub::DeviceSelect::Unique(nullptr, t2, g->st_keys_b.p, g->st_keys_a.p, g->st_counts.p + 7, m, g->stream));
+  if ((rc = g->st_temp.reserve(std::max(t1, t2) + 256))) return rc;
+  t1 = t2 = g->st_temp.cap;
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(g->st_temp.p, t1, g->st_keys_a.p, g->st_keys_b.p, m, 0, end_bit, g->stream));
+  HIP_TRY(hipcub::DeviceSelect::Unique(g->st_temp.p, t2, g->st_keys_b.p, g->st_keys_a.p, g->st_counts.p + 7, m, g->stream));
+  hipLaunchKernelGGL(k_st_valid, dim3(1), dim3(1), 0, g->stream, g->st_keys_a.p, g->st_counts.p + 7, none, g->st_counts.p, which);
+  return 0;  // (the unique keys are in st_keys_a again)
+}
+int st_exclusive_sum(srrg2_posegraph_s* g, int m, int which) {
+  int rc;
+  size_t t = 0;
+  if ((rc = g->st_off.reserve((size_t) std::max(m, 1)))) return rc;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t, g->st_cnt.p, g->st_off.p, m, g->stream));
+  if ((rc = g->st_temp.reserve(t + 256))) return rc;
+  t = g->st_temp.cap;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(g->st_temp.p, t, g->st_cnt.p, g->st_off.p, m, g->stream));
+  hipLaunchKernelGGL(k_st_total, dim3(1), dim3(1), 0, g->stream, m, g->st_cnt.p, g->st_off.p, g->st_counts.p, which);
+  return 0;
+}
+// the 64-bit sum of st_cnt[0, m), on the host
+int st_total_of_counts(srrg2_posegraph_s* g, int m, unsigned long long* out) {
+  int rc;
+  if ((rc = g->st_total.reserve(1))) return rc;
+  HIP_TRY(hipMemsetAsync(g->st_total.p, 0, sizeof(unsigned long long), g->stream));
+  hipLaunchKernelGGL(k_st_sum64, st_grid((size_t) m), dim3(PG_THREADS), 0, g->stream, m, g->st_cnt.p, g->st_total.p);
+  HIP_TRY(hipMemcpyAsync(out, g->st_total.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  return 0;
+}
+int st_read_count(srrg2_posegraph_s* g, int which, int* out) {
+  HIP_TRY(hipMemcpyAsync(out, g->st_counts.p + which, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+  HIP_TRY(hipStreamSynchronize(g->stream));
+  return 0;
+}
+// entries of a pattern by column: csc_ent, csc_start, csc2
+int st_columns(srrg2_posegraph_s* g, int m, int ncols, const int* col, const int* row_of, DevBuf<int>& csc_start,
+               DevBuf<int>& csc_ent, DevBuf<int2>& csc2) {
+  int rc;
+  if ((rc = csc_start.reserve((size_t) ncols + 1)) || (rc = csc_ent.reserve((size_t) std::max(m, 1))) ||
+      (rc = csc2.reserve((size_t) std::max(m, 1))) || (rc = g->st_ia.reserve((size_t) std::max(m, 1))) ||
+      (rc = g->st_ib.reserve((size_t) std::max(m, 1))))
+    return rc;
+  hipLaunchKernelGGL(k_st_iota, st_grid((size_t) m), dim3(PG_THREADS), 0, g->stream, m, g->st_ia.p);
+  size_t t = 0;
+  const int end_bit = st_bits((unsigned long long) std::max(ncols, 1));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, t, col, g->st_ib.p, g->st_ia.p, csc_ent.p, m, 0, end_bit, g->stream));
+  if ((rc = g->st_temp.reserve(t + 256))) return rc;
+  t = g->st_temp.cap;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(g->st_temp.p, t, col, g->st_ib.p, g->st_ia.p, csc_ent.p, m, 0, end_bit, g->stream));
+  hipLaunchKernelGGL(k_st_columns, st_grid((size_t) std::max(m, ncols + 1)), dim3(PG_THREADS), 0, g->stream, m, ncols,
+                     g->st_ib.p, csc_ent.p, row_of, csc_start.p, csc2.p);
+  return 0;
+}
+
+// The patterns of level L (n nodes, ne blocks, nc aggregates; L->agg, inc_start, inc_adj already on the device) -> L's pattern
+// arrays, the counts, the coarse edges on the host.  `smoothed` in: wanted; out: what the fill guard allowed.  Returns 1 when the
+// exact size of Q is over the limit of a smoothed level (the caller repeats the level with the tentative interpolation), 2 when
+// a candidate list would need 64-bit offsets (the caller builds this hierarchy on the host).
+int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int nc, long long q_limit, bool* smoothed, int* np_out,
+                       int* nq_out, std::vector<int>* ceij) {
+  int rc;
+  const int slots  = n + 2 * ne;
+  const st_key row = (st_key) (nc + 1);
+  if ((rc = g->st_counts.reserve(8)) || (rc = g->st_keys_a.reserve((size_t) std::max(slots, 1))) ||
+      (rc = g->st_slot.reserve((size_t) std::max(slots, 1))) || (rc = g->st_cnt.reserve((size_t) std::max(slots, 1))) ||
+      (rc = L->prow_start.reserve((size_t) n + 1)) || (rc = L->qrow_start.reserve((size_t) n + 1)))
+    return rc;
+  int np = 0, nq = 0, bound = 0;
+  auto t_stage = std::chrono::steady_clock::now();
+  auto stage   = [&](int k) {
+    const auto now = std::chrono::steady_clock::now();
+    g->st_ms[k] += std::chrono::duration<double, std::milli>(now - t_stage).count();
+    t_stage = now;
+  };
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hipLaunchKernelGGL(k_st_p_candidates, st_grid((size_t) n), dim3(PG_THREADS), 0, g->stream, n, nc, *smoothed ? 1 : 0, L->agg.p,
+                       L->inc_start.p, L->inc_adj.p, g->st_keys_a.p, g->st_slot.p);
+    if ((rc = st_sort_unique(g, slots, (st_key) n * row, 0)) || (rc = st_read_count(g, 0, &np))) return rc;
+    stage(0);
+    if ((rc = L->pcol.reserve((size_t) std::max(np, 1))) || (rc = L->prow_of.reserve((size_t) std::max(np, 1)))) return rc;
+    hipLaunchKernelGGL(k_st_decode, st_grid((size_t) std::max(np, n + 1)), dim3(PG_THREADS), 0, g->stream, n, nc, g->st_counts.p, 0,
+                       g->st_keys_a.p, L->prow_start.p, L->pcol.p, L->prow_of.p);
+    // candidates of Q = the fill guard's bound
+    hipLaunchKernelGGL(k_st_q_count, st_grid((size_t) slots), dim3(PG_THREADS), 0, g->stream, slots, g->st_slot.p, L->agg.p,
+                       L->inc_start.p, L->inc_adj.p, L->prow_start.p, g->st_cnt.p);
+    unsigned long long bound64 = 0;
+    if ((rc = st_total_of_counts(g, slots, &bound64))) return rc;
+    stage(1);
+    if (*smoothed && bound64 > (unsigned long long) (16 * q_limit)) {
+      *smoothed = false;
+      continue;
+    }
+    if (bound64 > 0x7fff0000ull) return 2;
+    if ((rc = st_exclusive_sum(g, slots, 1))) return rc;
+    bound = (int) bound64;
+    break;
+  }
+  if ((rc = g->st_keys_a.reserve((size_t) std::max(bound, 1)))) return rc;
+  hipLaunchKernelGGL(k_st_q_candidates, st_grid((size_t) slots), dim3(PG_THREADS), 0, g->stream, slots, nc, g->st_slot.p,
+                     L->inc_start.p, L->inc_adj.p, L->prow_start.p, L->pcol.p, g->st_cnt.p, g->st_off.p, g->st_keys_a.p);
+  if ((rc = st_sort_unique(g, bound, (st_key) n * row, 2)) || (rc = st_read_count(g, 2, &nq))) return rc;
+  stage(2);
+  if (*smoothed && (long long) nq > q_limit) return 1;
+  if ((rc = L->qcol.reserve((size_t) std::max(nq, 1))) || (rc = L->qrow_of.reserve((size_t) std::max(nq, 1)))) return rc;
+  hipLaunchKernelGGL(k_st_decode, st_grid((size_t) std::max(nq, n + 1)), dim3(PG_THREADS), 0, g->stream, n, nc, g->st_counts.p, 2,
+                     g->st_keys_a.p, L->qrow_start.p, L->qcol.p, L->qrow_of.p);
+  if ((rc = st_columns(g, np, nc, L->pcol.p, L->prow_of.p, L->pcsc_start, L->pcsc_ent, L->pcsc2)) ||
+      (rc = st_columns(g, nq, nc, L->qcol.p, L->qrow_of.p, L->qcsc_start, L->qcsc_ent, L->qcsc2)))
+    return rc;
+  // coarse edges
+  int mce = 0, nce = 0;
+  if ((rc = g->st_cnt.reserve((size_t) std::max(np, 1))) || (rc = g->st_ia.reserve((size_t) std::max(np, 1)))) return rc;
+  hipLaunchKernelGGL(k_st_ce_count, st_grid((size_t) np), dim3(PG_THREADS), 0, g->stream, np, L->pcol.p, L->prow_of.p,
+                     L->qrow_start.p, L->qcol.p, g->st_ia.p, g->st_cnt.p);
+  {
+    unsigned long long mce64 = 0;
+    if ((rc = st_total_of_counts(g, np, &mce64))) return rc;
+    stage(3);
+    if (mce64 > 0x7fff0000ull) return 2;
+    mce = (int) mce64;
+  }
+  if ((rc = st_exclusive_sum(g, np, 3))) return rc;
+  if ((rc = g->st_keys_a.reserve((size_t) std::max(mce, 1)))) return rc;
+  hipLaunchKernelGGL(k_st_ce_candidates, st_grid((size_t) np), dim3(PG_THREADS), 0, g->stream, np, nc, L->pcol.p, L->qcol.p,
+                     g->st_ia.p, g->st_cnt.p, g->st_off.p, g->st_keys_a.p);
+  if ((rc = st_sort_unique(g, mce, (st_key) nc * row, 4)) || (rc = st_read_count(g, 4, &nce))) return rc;
+  ceij->assign(2 * (size_t) nce, 0);
+  if (nce > 0) {
+    // (decoded into the key scratch's other half, read back for the next level's matching)
+    int2* out = reinterpret_cast<int2*>(g->st_keys_b.p);
+    hipLaunchKernelGGL(k_st_ce_decode, st_grid((size_t) nce), dim3(PG_THREADS), 0, g->stream, nc, g->st_counts.p, 4, g->st_keys_a.p, out);
+    HIP_TRY(hipMemcpyAsync(ceij->data(), out, sizeof(int2) * (size_t) nce, hipMemcpyDeviceToHost, g->stream));
+    HIP_TRY(hipStreamSynchronize(g->stream));
+  }
+  stage(4);
+  *np_out = np;
+  *nq_out = nq;
+  return 0;
+}
+
 // Aggregation hierarchy from the graph's structure and the current poses (host; only when the structure changed).
 int build_hierarchy(srrg2_posegraph_s* g) {
   const int V = g->V, E = g->E, D = g->D, T = g->T;
@@ -1615,6 +1927,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
   HostPool pool(std::min(16, HostPool::usable_cpus()));
+  bool device_structure = g->sw.device_structure;
+  for (double& m : g->st_ms) m = 0.0;
   g->pg_force_tentative.clear();
   g->levels.clear();  // (the levels' device buffers stay in g->level_pool: a rebuild reuses them, they only ever grow)
   std::vector<float> poses((size_t) std::max(V, 1) * T);
@@ -1775,10 +2089,26 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     // pose with thousands of factors) puts its whole row into the rows of Q = H Ps of all its neighbours -- quadratic in
     // its degree.  When the pattern of Q would exceed 64 blocks per node (C5: 11 / 43 / 77 on its three levels) this
     // level falls back to the tentative interpolation (row = the node's own aggregate, no smoothing).
-    std::vector<int> prow_start, pcol, prow_of;
     bool smoothed = g->sw.omega_p != 0.0 &&
                     !g->pg_force_tentative.count(level);
     const long long q_limit = 64LL * std::max(n, 4096);
+    int np = 0, nq = 0;
+    std::vector<int> ceij;
+    if (device_structure) {
+      // the patterns on the device (pg_device_patterns): the arrays land in L's buffers, the coarse edges come back
+      if ((rc = upload(L->agg, agg))) return rc;
+      const int r = pg_device_patterns(g, L, n, ne, nc, q_limit, &smoothed, &np, &nq, &ceij);
+      if (r < 0) return r;
+      if (r == 1) g->pg_force_tentative.insert(level);
+      if (r == 2) device_structure = false;
+      if (r != 0) {  // this level again: without smoothing / on the host
+        --level;
+        g->levels.pop_back();
+        continue;
+      }
+      ms_pattern += ms_since(t_pattern);
+    } else {
+    std::vector<int> prow_start, pcol, prow_of;
     for (int attempt = 0; attempt < 2; ++attempt) {
       pattern_rows(pool, n, nc, (long long) n + 2LL * ne, prow_start, pcol, &prow_of, [&](int v, std::vector<int>& stamp, std::vector<int>& out) {
         if (agg[(size_t) v] < 0) return;
@@ -1818,7 +2148,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     }
     ms_p += ms_since(t_pattern);
     const auto t_q = std::chrono::steady_clock::now();
-    const int np = (int) pcol.size();
+    np = (int) pcol.size();
     std::vector<int> pcsc_start, pcsc_ent;
     std::vector<int2> pcsc2;
     columns_of(pool, nc, pcol, prow_of, pcsc_start, pcsc_ent, pcsc2);
@@ -1846,7 +2176,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       g->levels.pop_back();
       continue;
     }
-    const int nq = (int) qcol.size();
+    nq = (int) qcol.size();
     ms_q += ms_since(t_q);
     const auto t_csc = std::chrono::steady_clock::now();
     // Q by column (two-phase levels: r_c = Ps^T r - Q^T x1)
@@ -1856,7 +2186,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     ms_csc += ms_since(t_csc);
     const auto t_ce = std::chrono::steady_clock::now();
     // coarse edges (A < B): B in the row of Q of some row of column A of Ps
-    std::vector<int> ce_start, ce_col, ceij;
+    std::vector<int> ce_start, ce_col;
     pattern_rows(pool, nc, nc, (long long) nq * 4, ce_start, ce_col, nullptr, [&](int A, std::vector<int>& stamp, std::vector<int>& out) {
       for (int m = pcsc_start[(size_t) A]; m < pcsc_start[(size_t) A + 1]; ++m) {
         const int i = prow_of[(size_t) pcsc_ent[(size_t) m]];
@@ -1876,9 +2206,18 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         ceij[2 * (size_t) k]     = A;
         ceij[2 * (size_t) k + 1] = ce_col[(size_t) k];
       }
-    const int nce = (int) (ceij.size() / 2);
     ms_ce += ms_since(t_ce);
     ms_pattern += ms_since(t_pattern);
+    const auto t_up0 = std::chrono::steady_clock::now();
+    if ((rc = upload(L->agg, agg)) || (rc = upload(L->prow_start, prow_start)) || (rc = upload(L->pcol, pcol)) ||
+        (rc = upload(L->prow_of, prow_of)) || (rc = upload(L->pcsc_start, pcsc_start)) || (rc = upload(L->pcsc_ent, pcsc_ent)) ||
+        (rc = upload(L->qrow_start, qrow_start)) || (rc = upload(L->qcol, qcol)) || (rc = upload(L->qrow_of, qrow_of)) ||
+        (rc = upload(L->qcsc_start, qcsc_start)) || (rc = upload(L->qcsc_ent, qcsc_ent)) ||
+        (rc = upload(L->pcsc2, pcsc2)) || (rc = upload(L->qcsc2, qcsc2)))
+      return rc;
+    ms_up += ms_since(t_up0);
+    }  // (host patterns)
+    const int nce = (int) (ceij.size() / 2);
     const auto t_up = std::chrono::steady_clock::now();
     L->nc  = nc;
     L->nce = nce;
@@ -1895,12 +2234,7 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       while (parts < 8 && 4.0 * parts < avg_row) parts *= 2;
       L->prow_parts = parts;
     }
-    if ((rc = upload(L->agg, agg)) || (rc = upload(L->prow_start, prow_start)) || (rc = upload(L->pcol, pcol)) ||
-        (rc = upload(L->prow_of, prow_of)) || (rc = upload(L->pcsc_start, pcsc_start)) || (rc = upload(L->pcsc_ent, pcsc_ent)) ||
-        (rc = upload(L->qrow_start, qrow_start)) || (rc = upload(L->qcol, qcol)) || (rc = upload(L->qrow_of, qrow_of)) ||
-        (rc = L->Ps.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Q.reserve((size_t) std::max(nq, 1) * D * D)) ||
-        (rc = upload(L->qcsc_start, qcsc_start)) || (rc = upload(L->qcsc_ent, qcsc_ent)) ||
-        (rc = upload(L->pcsc2, pcsc2)) || (rc = upload(L->qcsc2, qcsc2)) ||
+    if ((rc = L->Ps.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Q.reserve((size_t) std::max(nq, 1) * D * D)) ||
         (rc = L->Psf.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Qf.reserve((size_t) std::max(nq, 1) * D * D)))
       return rc;
     ms_up += ms_since(t_up);
@@ -1913,8 +2247,11 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   if (g->sw.debug) {
     std::fprintf(stderr, "posegraph hierarchy:");
     for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative");
-    std::fprintf(stderr, " coarsest %s; built in %.1f ms on the host (matching %.1f, patterns %.1f)\n",
-                 g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, ms_pattern);
+    std::fprintf(stderr, " coarsest %s; built in %.1f ms (matching on the host %.1f, patterns on the %s %.1f)\n",
+                 g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, device_structure ? "device" : "host", ms_pattern);
+    if (device_structure)
+      std::fprintf(stderr, "  on the device: P sorted %.1f, Q counted %.1f, Q sorted %.1f, columns + coarse edges counted %.1f, coarse edges sorted %.1f ms\n",
+                   g->st_ms[0], g->st_ms[1], g->st_ms[2], g->st_ms[3], g->st_ms[4]);
     std::fprintf(stderr, "  incidences + uploads %.1f, P pattern %.1f, Q pattern %.1f, column lists %.1f, coarse edges %.1f, uploads %.1f ms\n",
                  ms_inc, ms_p, ms_q, ms_csc, ms_ce, ms_up);
   }
@@ -2273,13 +2610,15 @@ void srrg2_posegraph_default_tuning(srrg2_posegraph_tuning* t) {
   t->omega_p        = (float) MG_OMEGA_P;
   t->omega          = (float) MG_OMEGA;
   t->lag_below      = 0.05f;
+  t->device_structure = 1;
 }
 
 static void apply_tuning(srrg2_posegraph_s* g, const srrg2_posegraph_tuning& t) {
   // (the built-in dampings are doubles: a knob left at its float default keeps the exact built-in value)
   srrg2_posegraph_tuning d;
   srrg2_posegraph_default_tuning(&d);
-  const bool structure_changes = g->sw.match_passes != t.match_passes || (g->sw.omega_p != 0.0) != (t.omega_p != 0.f);
+  const bool structure_changes = g->sw.match_passes != t.match_passes || (g->sw.omega_p != 0.0) != (t.omega_p != 0.f) ||
+                                 g->sw.device_structure != (t.device_structure != 0);  // (the same arrays either way: an A/B switch)
   g->sw.match_passes   = t.match_passes;
   g->sw.omega_p        = t.omega_p == d.omega_p ? (double) MG_OMEGA_P : (double) t.omega_p;
   g->sw.omega          = t.omega == d.omega ? (double) MG_OMEGA : (double) t.omega;
@@ -2288,6 +2627,7 @@ static void apply_tuning(srrg2_posegraph_s* g, const srrg2_posegraph_tuning& t) 
   g->sw.use_graph      = t.use_graph != 0;
   g->sw.debug          = t.debug != 0;
   g->sw.keep_structure = t.keep_structure != 0;
+  g->sw.device_structure = t.device_structure != 0;
   if (structure_changes) g->mg_dirty = true;  // (aggregate sizes / smoothed patterns are part of the structure)
   g->tuning = t;
 }
@@ -2328,6 +2668,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     geti("SRRG2_AMD_PG_TWO_PHASE", t.two_phase);
     geti("SRRG2_AMD_PG_GRAPH", t.use_graph);
     geti("SRRG2_AMD_PG_KEEP_STRUCTURE", t.keep_structure);
+    geti("SRRG2_AMD_PG_DEVICE_STRUCTURE", t.device_structure);
     getf("SRRG2_AMD_PG_OMEGA_P", t.omega_p);
     getf("SRRG2_AMD_PG_OMEGA", t.omega);
     getf("SRRG2_AMD_PG_LAG", t.lag_below);

@@ -28,7 +28,7 @@ class PoseGraphTuning(C.Structure):
     """srrg2_posegraph_tuning: strategy knobs of the solver; every setting solves to the same tolerance"""
     _fields_ = [("match_passes", C.c_int32), ("two_phase", C.c_int32), ("use_graph", C.c_int32), ("debug", C.c_int32),
                 ("keep_structure", C.c_int32), ("omega_p", C.c_float), ("omega", C.c_float), ("lag_below", C.c_float),
-                ("reserved_", C.c_int32 * 8)]
+                ("device_structure", C.c_int32), ("reserved_", C.c_int32 * 7)]
 
 
 def default_params():

@@ -236,3 +236,53 @@ def test_tuning_struct_round_trip_and_kept_structure(product, monkeypatch):
     ref2.set_graph(g2["poses_init"], g2["ij"], g2["Z"])
     ref2.solve()
     assert keep.poses().tobytes() == ref2.poses().tobytes()
+
+
+def _hub_graph(V=3000, seed=29):
+    g = syn.pose_graph_3d(V=V, E=V + 500, seed=seed)
+    gt = g["poses_gt"].astype(np.float64)
+    hub_j = np.arange(2, V, dtype=np.int32)
+    Zh = np.stack([syn.se3_mul(syn.se3_inv(gt[0]), gt[j]) for j in hub_j]).astype(np.float32)
+    ij = np.concatenate([g["ij"], np.stack([np.zeros(V - 2, dtype=np.int32), hub_j], 1)]).astype(np.int32)
+    return g["poses_init"], ij, np.concatenate([g["Z"], Zh]).astype(np.float32), (np.arange(V) == 1).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", ["se3_four_levels", "se2", "hub_fill_guard", "plain_aggregation", "fixed_and_disabled"])
+def test_device_built_structure_equals_the_host_built_one(product, case):
+    """the hierarchy's sparsity patterns built on the device (sort + unique: `device_structure`, the default) are the arrays of
+    the host build entry for entry, so the two solves agree BIT FOR BIT -- poses, chi, CG iteration counts -- on graphs with
+    three coarse levels, in SE(2), with a hub that trips the fill guard, without smoothing, with Fixed variables and disabled
+    factors"""
+    kind, kw, tune = abi.SE3_QUAT_RIGHT, {}, {}
+    if case == "se3_four_levels":
+        g = syn.pose_graph_3d(V=6000, E=22000, seed=31)
+        poses, ij, Z = g["poses_init"], g["ij"], g["Z"]
+    elif case == "se2":
+        kind = abi.SE2_RIGHT
+        g = syn.pose_graph_2d(V=3000, E=8000, seed=32)
+        poses, ij, Z = g["poses_init"], g["ij"], g["Z"]
+    elif case == "hub_fill_guard":
+        poses, ij, Z, fixed = _hub_graph()
+        kw = {"fixed_mask": fixed}
+    elif case == "plain_aggregation":
+        g = syn.pose_graph_3d(V=2500, E=9000, seed=33)
+        poses, ij, Z = g["poses_init"], g["ij"], g["Z"]
+        tune = {"omega_p": 0.0}
+    else:
+        g = syn.pose_graph_3d(V=2500, E=9000, seed=34)
+        poses, ij, Z = g["poses_init"], g["ij"], g["Z"]
+        rng = np.random.default_rng(5)
+        kw = {"fixed_mask": (rng.random(2500) < 0.02).astype(np.uint8) | (np.arange(2500) == 0).astype(np.uint8),
+              "enabled": (rng.random(ij.shape[0]) < 0.9).astype(np.uint8)}
+    out = []
+    for device in (1, 0):
+        pg = product.PoseGraph(kind)
+        pg.set_tuning(device_structure=device, **tune)
+        assert pg.tuning().device_structure == device
+        pg.set_graph(poses, ij, Z, **kw)
+        st = pg.solve()
+        out.append((pg.poses().copy(), [s["pcg_iterations"] for s in st], [s["chi"] for s in st], [s["solver_status"] for s in st]))
+    assert out[0][3] == out[1][3] and (case == "fixed_and_disabled" or all(c == 0 for c in out[0][3]))
+    assert out[0][1] == out[1][1]
+    assert out[0][2] == out[1][2]
+    assert out[0][0].tobytes() == out[1][0].tobytes()
