@@ -1777,6 +1777,10 @@ int st_sort_unique(srrg2_posegraph_s* g, int m, st_key none, int which) {
   size_t t1 = 0, t2 = 0;
   const int end_bit = std::min(64, st_bits(none));
   if ((rc = g->st_keys_b.reserve((size_t) std::max(m, 1)))) return rc;
+  if (m == 0) {  // (nothing to sort: an empty pattern)
+    HIP_TRY(hipMemsetAsync(g->st_counts.p + which, 0, sizeof(int), g->stream));
+    return 0;
+  }
   HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, t1, g->st_keys_a.p, g->st_keys_b.p, m, 0, end_bit, g->stream));
   HIP_TRY(hipcub::DeviceSelect::Unique(nullptr, t2, g->st_keys_b.p, g->st_keys_a.p, g->st_counts.p + 7, m, g->stream));
   if ((rc = g->st_temp.reserve(std::max(t1, t2) + 256))) return rc;
@@ -1790,6 +1794,10 @@ int st_exclusive_sum(srrg2_posegraph_s* g, int m, int which) {
   int rc;
   size_t t = 0;
   if ((rc = g->st_off.reserve((size_t) std::max(m, 1)))) return rc;
+  if (m == 0) {
+    HIP_TRY(hipMemsetAsync(g->st_counts.p + which, 0, sizeof(int), g->stream));
+    return 0;
+  }
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t, g->st_cnt.p, g->st_off.p, m, g->stream));
   if ((rc = g->st_temp.reserve(t + 256))) return rc;
   t = g->st_temp.cap;
@@ -1820,6 +1828,10 @@ int st_columns(srrg2_posegraph_s* g, int m, int ncols, const int* col, const int
       (rc = csc2.reserve((size_t) std::max(m, 1))) || (rc = g->st_ia.reserve((size_t) std::max(m, 1))) ||
       (rc = g->st_ib.reserve((size_t) std::max(m, 1))))
     return rc;
+  if (m == 0) {  // (every column empty)
+    HIP_TRY(hipMemsetAsync(csc_start.p, 0, sizeof(int) * ((size_t) ncols + 1), g->stream));
+    return 0;
+  }
   hipLaunchKernelGGL(k_st_iota, st_grid((size_t) m), dim3(PG_THREADS), 0, g->stream, m, g->st_ia.p);
   size_t t = 0;
   const int end_bit = st_bits((unsigned long long) std::max(ncols, 1));
