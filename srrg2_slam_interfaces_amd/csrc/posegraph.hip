@@ -2706,6 +2706,8 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   g->part_pAp.release(); g->part_rr.release(); g->part_bb.release(); g->part_chi.release(); g->part_n.release();
   g->inc_start.release(); g->inc_edge.release(); g->sc.release(); g->act_edge.release(); g->levels_dev.release();
   g->coarse_A.release(); g->coarse_inv.release();
+  g->st_keys_a.release(); g->st_keys_b.release(); g->st_cnt.release(); g->st_off.release(); g->st_slot.release();
+  g->st_ia.release(); g->st_ib.release(); g->st_counts.release(); g->st_total.release(); g->st_temp.release();
   for (MgLevelBufs* L : g->level_pool) {
     L->release();
     delete L;
