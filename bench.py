@@ -565,7 +565,7 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
     g = syn.pose_graph_3d(V=V, E=E, seed=5000)
     E = int(g["ij"].shape[0])
     pg = pkg.PoseGraph(abi.SE3_QUAT_RIGHT)
-    pg.set_tuning(keep_structure=0)  # COLD solves: every one builds the structure of the multigrid hierarchy on the host
+    pg.set_tuning(keep_structure=0)  # COLD solves: every one builds the structure of the multigrid hierarchy (matching on the host, patterns on the device)
     times, st = [], None
     for _ in range(4):
         pg.set_graph(g["poses_init"], g["ij"], g["Z"])
@@ -620,7 +620,7 @@ def measure_c5(cpu_seconds=30.0, with_cpu=True):
         "warm": {"same_topology_ms": float(np.median(warm)) * 1e3,
                  "after_appending_one_variable_and_factor_ms": t_append * 1e3,
                  "pcg_iterations_after_append": [s_["pcg_iterations"] for s_ in st_app],
-                 "note": "ms_per_step is the COLD solve (hierarchy structure built on the host every time); same_topology = "
+                 "note": "ms_per_step is the COLD solve (hierarchy structure rebuilt every time: matching on the host, sparsity patterns on the device); same_topology = "
                          "set_graph with unchanged edges keeps the structure; an append rebuilds it"},
     }
     if with_cpu:

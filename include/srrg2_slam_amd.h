@@ -406,7 +406,7 @@ typedef struct srrg2_posegraph_tuning {
   int32_t use_graph;        /* SRRG2_AMD_PG_GRAPH: chunks of 10 CG iterations replayed from a HIP graph (1); 0 = launched one
                                by one (needed under rocprofv3 --kernel-trace)                                        */
   int32_t debug;            /* SRRG2_AMD_PG_DEBUG: print the hierarchy and the host's set-up time by phase to stderr (0) */
-  int32_t keep_structure;   /* the multigrid hierarchy's STRUCTURE (aggregates, sparsity patterns: host work, 24 ms on C5)
+  int32_t keep_structure;   /* the multigrid hierarchy's STRUCTURE (aggregates, sparsity patterns: 13 ms per build on C5)  
                                is kept while the graph's topology does not change -- srrg2_posegraph_set with the same
                                edges, fixed and enabled masks -- (1); 0 = rebuilt by the first solve after every set    */
   float   omega_p;          /* SRRG2_AMD_PG_OMEGA_P: damping of the Jacobi sweep that smooths the interpolation (0.66; 0 =
