@@ -1429,6 +1429,8 @@ struct srrg2_posegraph_s {
   DevBuf<unsigned long long> st_keys_a, st_keys_b;
   DevBuf<int> st_cnt, st_off, st_slot, st_ia, st_ib, st_counts;
   DevBuf<unsigned long long> st_total;
+  unsigned long long st_offset_limit = 0x7fff0000ull;  // candidate lists beyond this many entries: the host build (32-bit offsets);
+                                                       // SRRG2_AMD_PG_OFFSET_LIMIT lowers it (tests of that fallback)
   DevBuf<char> st_temp;
   double st_ms[5] = {0, 0, 0, 0, 0};  // (debug) P sorted / Q counted / Q sorted / columns + coarse edges counted / coarse edges sorted
   srrg2_posegraph_tuning tuning{};
@@ -1851,6 +1853,7 @@ int st_columns(srrg2_posegraph_s* g, int m, int ncols, const int* col, const int
 int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int nc, long long q_limit, bool* smoothed, int* np_out,
                        int* nq_out, std::vector<int>* ceij) {
   int rc;
+  if ((unsigned long long) n + 2ull * (unsigned long long) ne > g->st_offset_limit) return 2;
   const int slots  = n + 2 * ne;
   const st_key row = (st_key) (nc + 1);
   if ((rc = g->st_counts.reserve(8)) || (rc = g->st_keys_a.reserve((size_t) std::max(slots, 1))) ||
@@ -1882,7 +1885,7 @@ int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int 
       *smoothed = false;
       continue;
     }
-    if (bound64 > 0x7fff0000ull) return 2;
+    if (bound64 > g->st_offset_limit) return 2;
     if ((rc = st_exclusive_sum(g, slots, 1))) return rc;
     bound = (int) bound64;
     break;
@@ -1908,7 +1911,7 @@ int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int 
     unsigned long long mce64 = 0;
     if ((rc = st_total_of_counts(g, np, &mce64))) return rc;
     stage(3);
-    if (mce64 > 0x7fff0000ull) return 2;
+    if (mce64 > g->st_offset_limit) return 2;
     mce = (int) mce64;
   }
   if ((rc = st_exclusive_sum(g, np, 3))) return rc;
@@ -2685,6 +2688,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_OMEGA", t.omega);
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_OFFSET_LIMIT")) g->st_offset_limit = std::min<unsigned long long>(std::strtoull(e, nullptr, 10), 0x7fff0000ull);
     if (t.match_passes < 1) t.match_passes = 1;
     apply_tuning(g, t);
   }

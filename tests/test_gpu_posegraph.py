@@ -286,3 +286,25 @@ def test_device_built_structure_equals_the_host_built_one(product, case):
     assert out[0][1] == out[1][1]
     assert out[0][2] == out[1][2]
     assert out[0][0].tobytes() == out[1][0].tobytes()
+
+
+def test_device_structure_falls_back_to_the_host_build(product, monkeypatch, capfd):
+    """a candidate list that would not fit 32-bit offsets sends the structure build back to the host (posegraph.hip:
+    pg_device_patterns returns 2); forced here by lowering the limit (SRRG2_AMD_PG_OFFSET_LIMIT, read at create) below the
+    size of level 1's lists: level 0's patterns come from the device, the rest from the host -- same arrays, same bits"""
+    g = syn.pose_graph_3d(V=6000, E=22000, seed=31)
+    ref = product.PoseGraph(abi.SE3_QUAT_RIGHT)
+    ref.set_graph(g["poses_init"], g["ij"], g["Z"])
+    sr = ref.solve()
+    for limit in ("60000", "1000"):  # (level 0 has 50 000 slots: the first limit trips on its Q candidates, the second at once)
+        monkeypatch.setenv("SRRG2_AMD_PG_OFFSET_LIMIT", limit)
+        monkeypatch.setenv("SRRG2_AMD_PG_DEBUG", "1")
+        pg = product.PoseGraph(abi.SE3_QUAT_RIGHT)
+        monkeypatch.delenv("SRRG2_AMD_PG_OFFSET_LIMIT")
+        monkeypatch.delenv("SRRG2_AMD_PG_DEBUG")
+        assert pg.tuning().device_structure == 1
+        pg.set_graph(g["poses_init"], g["ij"], g["Z"])
+        st = pg.solve()
+        assert "patterns on the host" in capfd.readouterr().err
+        assert [s["pcg_iterations"] for s in st] == [s["pcg_iterations"] for s in sr]
+        assert pg.poses().tobytes() == ref.poses().tobytes()
