@@ -2444,9 +2444,22 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         MgLevelBufs* L = g->levels[(size_t) l];
         auto grid_of = [](size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); };
         hipLaunchKernelGGL(k_mg_interp<D>, dim3(blocks_for(L->n)), dim3(PG_THREADS), 0, g->stream, pair(l), T, g->poses.p);
-        hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * L->row_parts), dim3(PG_THREADS), 0, g->stream,
-                           pair(l), L->smoothed ? omega_p : 0.0);
-        hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * L->row_parts), dim3(PG_THREADS), 0, g->stream, pair(l));
+        // Lanes per row of H in the two set-up products that walk rows (k_mg_psmooth, k_mg_hp): a quarter of the cycle's
+        // `row_parts` where the launch stays above ~64 k lanes.  The cycle's kernels do a block-vector product per incidence and
+        // want ~8 incidences per lane; these do a look-up and a block-BLOCK product per incidence into 36 accumulators, and the
+        // butterfly that adds the lanes' blocks costs as much as several of them (C5's levels 1 / 2: Q 651 -> 557, 431 -> 381 us,
+        // Ps 121 -> 87, 68 -> 47 us; the 100-node level needs all its lanes; the Galerkin product by COLUMNS of Ps is 1.3-1.6 x
+        // slower with half the lanes: profiles/r8k_ab_setup_lanes.txt).
+        auto setup_pair = [&](size_t items) {
+          MgPair sp = pair(l);
+          for (int k = 0; k < 2; ++k)
+            if (sp.L.row_parts >= 2 && items * (size_t) (sp.L.row_parts / 2) >= 65536) sp.L.row_parts /= 2;
+          return sp;
+        };
+        const MgPair sp_p = setup_pair((size_t) L->np), sp_q = setup_pair((size_t) L->nq);
+        hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * sp_p.L.row_parts), dim3(PG_THREADS), 0, g->stream,
+                           sp_p, L->smoothed ? omega_p : 0.0);
+        hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * sp_q.L.row_parts), dim3(PG_THREADS), 0, g->stream, sp_q);
         hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
                            pair(l));
         hipLaunchKernelGGL(k_mg_dinv<D>, dim3((unsigned) ((L->nc + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
