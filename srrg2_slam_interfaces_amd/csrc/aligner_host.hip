@@ -119,6 +119,7 @@ struct srrg2_aligner_s {
   // other parts' pass kernels have the chip.  The parts share nothing but read-only data (fixed cloud, grid, lists).
   static constexpr int MAX_PARTS = 8;
   hipStream_t pstream[MAX_PARTS]{};  // pstream[0] == stream
+  int cu_count          = 256;       // compute units of the device (FusedCtl::first_round)
   hipEvent_t ev_staged  = nullptr;   // the staging copies of a batch upload (stream) before the other parts' sorts
   int parts_dirty       = 0;         // pstream[1 .. parts_dirty) may still be running the tail of the last pipelined batch
   int batch_parts       = 0;         // upload_moving -> run_compute: the batch at hand runs as this many parts (0: one)
@@ -421,6 +422,8 @@ int ensure_lists(srrg2_aligner* a, Slice* s, long long max_entries) {
         if ((rc = build_grid(a, s, h_fine))) return rc;
         s->lists_tried   = true;
         s->grid_computes = computes;
+        // (complete before anybody reads the grid: the other parts of a pipelined batch run on other streams)
+        HIP_TRY(hipStreamSynchronize(a->stream));
       }
       return 0;
     }
@@ -482,8 +485,14 @@ int ensure_lists_of_grid(srrg2_aligner* a, Slice* s, long long max_entries) {
   HIP_TRY(hipMemcpyAsync(&total, total_dev, sizeof(int), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
   if (total < 0 || (long long) total > max_entries) return 0;
-  if ((rc = s->list_ent.reserve((size_t) std::max(total, 1) + 8))) return rc;
-  if ((rc = s->list_box.reserve((size_t) std::max(s->nf, 1) + 8))) return rc;
+  // (the lists are an optional accelerator -- up to 1.5 GB of them, allocated implicitly by the second compute() on a cloud:
+  // a device that cannot hold them keeps the grid kernels instead of failing compute())
+  if (s->list_ent.reserve((size_t) std::max(total, 1) + 8) || s->list_box.reserve((size_t) std::max(s->nf, 1) + 8)) {
+    (void) hipGetLastError();
+    s->list_ent.release();
+    s->list_box.release();
+    return 0;
+  }
   L.start = s->list_start.p;
   L.ent   = s->list_ent.p;
   srrg2amd::launch_cnl_build(g, L, s->list_offs.p, (int) offs4.size(), s->list_start.p, s->list_box.p, s->list_ent.p, a->stream);
@@ -907,7 +916,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     const bool fast_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && K > 4 && !small && fast_batch_queue;
     s->fast_queue_only = fast_queue && !use_queue;
     const int nblocks    = PARTIAL_SLOTS;
-    if ((rc = s->partials.reserve((size_t) 2 * K * nblocks * ACC_N))) return rc;  // (two buffers: fused control steps)
+    if ((rc = s->partials.reserve((size_t) 3 * K * nblocks * ACC_N))) return rc;  // (three buffers: fused control steps, FusedCtl)
     if (use_queue || fast_queue) {
       if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 10))) return rc;  // QEntry = 10 x 4 bytes
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
@@ -1076,6 +1085,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
              (fast_at(0, a->params.max_iterations - 1) || (a->params.enable_inlier_only_runs && fast_at(a->params.max_iterations, 0)));
     }
   }
+  // (the fused launches carry the tile index in gridDim.y -- x = problem, so that the control steps run in the launch's first
+  // workgroups --, and y stops at 65 535: clouds beyond that many tiles of the four-lanes-per-point first pass, 4.19 M points,
+  // keep the control launches and the x = tile grids of the legacy kernels)
+  if (((long long) nm_max_cue * 4 + 255) / 256 > 65535) fuse = false;
   if (fuse) {
     if ((rc = a->pub.reserve((size_t) K * SRRG2_MAX_SLICES * PUB_SLICE_GRANULES))) return rc;
     if ((rc = a->pub_epoch.reserve((size_t) K * PUB_EPOCH_REPLICAS * PUB_EPOCH_STRIDE))) return rc;
@@ -1115,6 +1128,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     if (fuse) Ch[h].ctl_dev = a->ctl_dev.p + h;
   }
   int epoch = 0;  // control steps applied (or scheduled inside a pass) so far: what the next passes build on
+  int pround = 0; // rounds of passes launched so far: round k adds into slot-set buffer k % 3 (FusedCtl::prev_partials)
+  auto slot_buffer = [&](Slice* sl, int k) { return sl->partials.p + (size_t) (k % 3) * K * PARTIAL_SLOTS * ACC_N; };
   if (fuse)
     for (int si = 0; si < nslices; ++si) {
       sdev[si].fc.pub       = a->pub.p;
@@ -1123,7 +1138,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       sdev[si].fc.min_num_correspondences = a->slices[si]->cfg.min_num_correspondences;
       sdev[si].fc.max_stats = slots;
       sdev[si].fc.has_term  = a->has_term ? 1 : 0;
-      sdev[si].fc.first_round = 1536;  // (256 CUs x 6 workgroups: nothing beyond them is resident when a launch starts)
+      sdev[si].fc.first_round = a->cu_count * 6;  // (CUs x 6 workgroups: nothing beyond them is resident when a launch starts)
     }
   if (split && (small || a->reduce_fn || a->profile || !a->timeline_path.empty()))
     return fail(SRRG2_E_STATE, "internal: a pipelined batch on a path that cannot be split");
@@ -1189,10 +1204,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
     const bool last_it = it == a->params.max_iterations - 1;
     if (fuse) {
-      // (the passes of this iteration added into slot-set buffer epoch & 1; its control step produces epoch + 1: inside the
+      // (the passes of this iteration added into slot-set buffer pround % 3; its control step produces epoch + 1: inside the
       // first pass of the next iteration, or -- the last iteration of a run -- as a launch)
-      Ch[h].parity = epoch & 1;
-      Ch[h].epoch  = epoch + 1;
+      Ch[h].parity      = pround % 3;
+      Ch[h].zero_parity = (pround + 2) % 3;
+      Ch[h].epoch       = epoch + 1;
       // (the next iteration's first kernel applies this step -- if it can: the grid kernels cannot, and the launch after the
       // probe iteration also reports the queue counters to the host)
       const int slot0_now = last_phase && a->params.enable_inlier_only_runs ? a->params.max_iterations : 0;
@@ -1209,7 +1225,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         sd.prob0             = h0[h];
         sd.fc.ctl            = a->ctl_dev.p + h;
         sd.fc.epoch          = epoch + 1;
-        sd.fc.prev_partials  = a->slices[first_cue]->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
+        sd.fc.prev_partials  = slot_buffer(a->slices[first_cue], pround);
+        sd.fc.zero_partials  = slot_buffer(a->slices[first_cue], pround + 2);
         srrg2amd::launch_icp_final_wave(Ch[h], sd, a->states.p, a->stats.p, a->outs_host, a->stats_host,
                                         !a->params.enable_inlier_only_runs, hstream[h]);
       } else {
@@ -1252,8 +1269,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             Slice* sz              = a->slices[proj_group[z]];
             pack[z].fc.ctl         = a->ctl_dev.p;
             pack[z].fc.epoch       = epoch;
-            pack[z].partials       = sz->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
-            pack[z].fc.prev_partials = sz->partials.p + (size_t) ((epoch + 1) & 1) * K * PARTIAL_SLOTS * ACC_N;
+            pack[z].partials       = slot_buffer(sz, pround);
+            pack[z].fc.prev_partials = slot_buffer(sz, pround + 2);  // (round pround - 1; the step zeroes the one after this round's)
+            pack[z].fc.zero_partials = slot_buffer(sz, pround + 1);
             pack[z].fc.prior       = (slot0 > 0 || it > 0) ? 1 : 0;
           }
         if (proj_fused) {
@@ -1266,6 +1284,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
         if (a->profile) HIP_TRY(hipEventRecord(e1, a->stream));
         control(it, last_phase, 0);
         ++epoch;
+        ++pround;
         continue;
       }
       for (int si = 0; si < nslices; ++si) {
@@ -1312,8 +1331,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
               if (!fused_pass(slot0, it)) sd.fc.pub = nullptr;  // (this pass on the kernels that read ProblemState)
               sd.fc.ctl   = a->ctl_dev.p + h;
               sd.fc.epoch = epoch;
-              sd.partials = s->partials.p + (size_t) (epoch & 1) * K * PARTIAL_SLOTS * ACC_N;
-              sd.fc.prev_partials = s->partials.p + (size_t) ((epoch + 1) & 1) * K * PARTIAL_SLOTS * ACC_N;
+              sd.partials = slot_buffer(s, pround);
+              sd.fc.prev_partials = slot_buffer(s, pround + 2);  // (round pround - 1; the step zeroes the one after this round's)
+              sd.fc.zero_partials = slot_buffer(s, pround + 1);
               sd.fc.prior         = (slot0 > 0 || it > 0) ? 1 : 0;
             }
             const ProblemDev* pt = a->probs.p + (size_t) si * K;
@@ -1335,6 +1355,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       }
       if (!split) control(it, last_phase, 0);
       ++epoch;
+      ++pround;
     }
     return 0;
   };
@@ -1580,10 +1601,12 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
   if (const char* tl = std::getenv("SRRG2_AMD_TIMELINE")) a->timeline_path = tl;
   a->hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess;
-  a->pstream[0] = a->stream;
-  for (int p = 1; ok && p < srrg2_aligner::MAX_PARTS; ++p)
-    ok = hipStreamCreateWithFlags(&a->pstream[p], hipStreamNonBlocking) == hipSuccess;
+  a->pstream[0] = a->stream;  // (pstream[1 ..]: created by the first pipelined batch that wants them, compute_batch)
   ok = ok && hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming) == hipSuccess;
+  if (ok && (hipDeviceGetAttribute(&a->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || a->cu_count <= 0)) {
+    (void) hipGetLastError();
+    a->cu_count = 256;
+  }
   if (!ok) {
     for (int p = 0; p < srrg2_aligner::MAX_PARTS; ++p)
       if (a->pstream[p]) (void) hipStreamDestroy(a->pstream[p]);
@@ -2066,6 +2089,15 @@ int srrg2_aligner_compute_batch(srrg2_aligner_h a, int K, const float* coords, i
     if (want >= 2 && one_cue && a->slices[0]->cfg.finder == SRRG2_FINDER_NN_GATED && max_nm > tn.small_max_points &&
         !tn.fast_batch_queue && !a->reduce_fn && !a->profile && a->timeline_path.empty()) {
       nparts = want;
+      // (the parts' streams are created when a batch first wants them: an application with hundreds of aligners -- per-thread
+      // relocalisers -- that never runs pipelined batches owns one stream per aligner, not eight)
+      for (int p = 1; p < nparts; ++p)
+        if (!a->pstream[p] && hipStreamCreateWithFlags(&a->pstream[p], hipStreamNonBlocking) != hipSuccess) {
+          (void) hipGetLastError();
+          a->pstream[p] = nullptr;
+          nparts        = p >= 2 ? p : 0;  // (fewer parts, or none)
+          break;
+        }
       for (int p = 0; p <= nparts; ++p) pbegin[p] = (int) ((long long) K * p / nparts);  // (contiguous, sizes differ by <= 1)
     }
   }

@@ -90,7 +90,12 @@ struct FusedCtl {
   unsigned* pub_epoch;         // [K][PUB_EPOCH_REPLICAS][PUB_EPOCH_STRIDE]
   const CtlParams* ctl;        // device copy of this compute()'s control parameters (written by k_icp_init): termination criterion
   srrg2_iteration_stats* stats;
-  long long* prev_partials;    // the slot sets the control step of this launch's epoch consumes: buffer (epoch - 1) & 1, [K][32][32]
+  long long* prev_partials;    // the slot sets the control step of this launch's epoch consumes, [K][32][32]: one of THREE buffers --
+                               // the passes of round k add into buffer k % 3, the control step behind them reads it and zeroes
+                               // buffer (k + 2) % 3 (`zero_partials`: read by the step before, added to again by the round after
+                               // next), so the buffer a fused step reads is READ-ONLY for the whole launch that carries it: a
+                               // polling wave may apply the step itself from the same inputs (pass_view_fused)
+  long long* zero_partials;
   int epoch;                   // control steps the passes of this launch build on
   int min_num_correspondences; // of the (one) cue slice
   int max_stats;
@@ -208,7 +213,7 @@ struct SliceCtl {
   int* qprobe_host;         // pinned host copy of the counters of iteration probe_it ([problem][near, far]), or null
   const ProblemDev* probs;  // [problem] table of the slice (device): point counts for the decision threshold
   int nm_global;            // > 0: moving points of the alignment over ALL ranks (point-sharded alignment: sizes the exponent)
-  const long long* partials;  // [2][problem][PARTIAL_SLOTS][ACC_N] (null for priors; the second buffer is used by fused control steps)
+  const long long* partials;  // [3][problem][PARTIAL_SLOTS][ACC_N] (null for priors; buffers 1 and 2 are used by fused control steps)
   const unsigned* pinf_bits;      // [problem] max |coord| of the finite moving points (float bits)
   const unsigned* ninf_bits;      // [1] max |component| of the fixed normals
   const unsigned* finf_bits;      // [1] max |coordinate| of the fixed cloud (given-correspondences slices)
@@ -235,12 +240,14 @@ struct CtlParams {
   int probe_it;   // iteration after which the use of the deferred-search queue is decided (-1: never)
   int seq;        // sequence number of this compute() (completion flag in ProblemOut)
   int prob0, nprob;  // the problems [prob0, prob0 + nprob) of the batch are this launch's (nprob = 0: all K)
-  // fused control steps (FusedCtl): the records, the epoch THIS control step produces (0: k_icp_init) and which of the two
-  // slot-set buffers it consumes (pass e adds into buffer e & 1; SliceCtl::partials is the base of both: [2][K][32][32])
+  // fused control steps (FusedCtl): the records, the epoch THIS control step produces (0: k_icp_init), which of the three
+  // slot-set buffers it consumes (`parity`: the passes of round k add into buffer k % 3; SliceCtl::partials is the base of all:
+  // [3][K][32][32]) and which one it zeroes (`zero_parity` = (k + 2) % 3; legacy, pub == nullptr: one buffer, zeroed when read)
   unsigned long long* pub;  // null: legacy
   unsigned* pub_epoch;
   CtlParams* ctl_dev;       // k_icp_init stores this record there for the fused control steps
   int epoch;
   int parity;
+  int zero_parity;
   SliceCtl slices[SRRG2_MAX_SLICES];
 };

@@ -2194,9 +2194,15 @@ __device__ __forceinline__ void pub_publish_state(const CtlParams& C, const Prob
 // loaded by the caller) carry the state the step needs, the slot sets are addressed from the kernel arguments.  Nothing waits
 // for its plain stores (state, statistics, zeroed slot sets: read after the next kernel boundary); the new records and the
 // epoch words are self-contained 8-byte stores.  D = 3 | 6.
-template <int D, int MAXS>
+// PUBLISH = false: the step of a POLLING wave (pass_view_fused / records_fused: the designated wave has not published within
+// the poll limit).  Everything the step reads is read-only for the whole launch -- the records of the previous epoch, the
+// slot sets of the previous round (FusedCtl::prev_partials: zeroed two rounds later, not here), the termination windows but
+// for the entry of this iteration, which comes from the registers -- so any wave computes the same records from them; this
+// variant stores NOTHING (workgroup (problem, 0) stays the only writer of state, statistics, slot sets and records) and
+// returns this lane's granule of every slice's new record in `out`.
+template <int D, int MAXS, bool PUBLISH = true>
 __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, int ns, ProblemState* __restrict__ states, int prob,
-                                             const unsigned long long (&g)[MAXS]) {
+                                             const unsigned long long (&g)[MAXS], unsigned (*out)[MAXS] = nullptr) {
   const FusedCtl& F  = Sv[0].fc;
   const int lane     = threadIdx.x & 63;
   ProblemState* st   = &states[prob];
@@ -2229,10 +2235,14 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
   if (fl0 & PUB_FLAG_STOP) {  // (the passes return at their first instruction; the records only move to the new epoch)
 #pragma unroll
     for (int z = 0; z < MAXS; ++z)
-      if (z < ns)
-        pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane,
-                  ((unsigned long long) epoch << 32) | (unsigned) g[z]);
-    pub_write_epoch(F.pub_epoch, prob, lane, epoch);
+      if (z < ns) {
+        if constexpr (PUBLISH)
+          pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane,
+                    ((unsigned long long) epoch << 32) | (unsigned) g[z]);
+        else
+          (*out)[z] = (unsigned) g[z];
+      }
+    if constexpr (PUBLISH) pub_write_epoch(F.pub_epoch, prob, lane, epoch);
     return;
   }
   // (termination criterion: the windows, one entry per lane, in flight with the slot sets)
@@ -2256,10 +2266,14 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
   for (int z = 0; z < MAXS; ++z) {
     if (z >= ns) break;  // (uniform)
     v[z] += __shfl_xor(v[z], 32);  // the total of entry (lane & 31)
-    // the slot sets are accumulated with atomics by the passes: this buffer is added to again two passes from now
-    long long* p = Sv[z].fc.prev_partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
+    // the slot sets are accumulated with atomics by the passes: the buffer that the round AFTER this launch's adds into is
+    // zeroed here (it was read by the control step before this one); the buffer just read stays as it is until the launch
+    // has retired -- a polling wave may still have to read it (PUBLISH = false)
+    if constexpr (PUBLISH) {
+      long long* p = Sv[z].fc.zero_partials + (size_t) prob * PARTIAL_SLOTS * ACC_N;
 #pragma unroll
-    for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+      for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+    }
     const double scaled = (double) v[z] * dm::pow2(-kexp[z]);
     const int nc = (int) rl_ll(v[z], ACC_N_CORR), n_in = (int) rl_ll(v[z], ACC_N_IN), n_out = (int) rl_ll(v[z], ACC_N_OUT);
     good |= nc > Sv[z].fc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
@@ -2271,29 +2285,36 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     num_corr += nc >= 0 ? nc : 0;
     chi_in  = chi_in + rl_d(scaled, ACC_CHI_IN);
     chi_out = chi_out + rl_d(scaled, ACC_CHI_OUT);
-    const int s = Sv[z].slice_idx;
-    if (lane == 0) {
-      st->ncorr[s] = nc;
-      st->ninl[s]  = n_in;
+    if constexpr (PUBLISH) {
+      const int s = Sv[z].slice_idx;
+      if (lane == 0) {
+        st->ncorr[s] = nc;
+        st->ninl[s]  = n_in;
+      }
+      if (lane < 12) st->Tlast[s][lane] = told[z];  // the transforms the passes of this iteration ran with
     }
-    if (lane < 12) st->Tlast[s][lane] = told[z];  // the transforms the passes of this iteration ran with
   }
-  if (lane == 0) st->npasses = npasses0 + 1;
+  if constexpr (PUBLISH)
+    if (lane == 0) st->npasses = npasses0 + 1;
   if (!good) {  // multi_aligner_impl.cpp:107-111
-    if (lane == 0) {
-      st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;
-      st->done   = 1;
-    }
+    if constexpr (PUBLISH)
+      if (lane == 0) {
+        st->status = SRRG2_NOT_ENOUGH_CORRESPONDENCES;
+        st->done   = 1;
+      }
 #pragma unroll
     for (int z = 0; z < MAXS; ++z) {
       if (z >= ns) break;
       unsigned nv = (unsigned) g[z];
       if (lane == PUB_G_FLAGS) nv = fl0 | PUB_FLAG_STOP;
       if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
-      pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane,
-                ((unsigned long long) epoch << 32) | nv);
+      if constexpr (PUBLISH)
+        pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane,
+                  ((unsigned long long) epoch << 32) | nv);
+      else
+        (*out)[z] = nv;
     }
-    pub_write_epoch(F.pub_epoch, prob, lane, epoch);
+    if constexpr (PUBLISH) pub_write_epoch(F.pub_epoch, prob, lane, epoch);
     return;
   }
   PASS_TS_W(F.epoch, 5, Hl);
@@ -2347,12 +2368,14 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
   }
   PASS_TS_W(F.epoch, 6, dxv);
   // ---- what get_information / the batch records read: H, b, dx of this Gauss-Newton iteration
-  if (lane < D * D) st->last_H[lane] = Hl;
-  if (lane < D) {
-    st->last_b[lane]  = bl;
-    st->last_dx[lane] = bad ? 0.0 : dxv;
+  if constexpr (PUBLISH) {
+    if (lane < D * D) st->last_H[lane] = Hl;
+    if (lane < D) {
+      st->last_b[lane]  = bl;
+      st->last_dx[lane] = bad ? 0.0 : dxv;
+    }
+    if (lane < 12) st->Xprev[lane] = Xl;
   }
-  if (lane < 12) st->Xprev[lane] = Xl;
   // ---- X <- X * v2t(dx) (dm::box_plus), the element of lane l < TS
   if (!bad) {
     if constexpr (D == 3) {
@@ -2403,18 +2426,20 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
       if (j == 3) o = o + a3;
       if (lane < 12) Xl = (float) o;
     }
-    if (lane < TS) st->X[lane] = Xl;
+    if constexpr (PUBLISH)
+      if (lane < TS) st->X[lane] = Xl;
   }
   PASS_TS_W(F.epoch, 7, (double) Xl);
   // ---- IterationStats of this iteration (multi_aligner_impl.cpp:113-115): one 4-byte word of the record per lane
   const float chi_in_f = (float) chi_in, chi_out_f = (float) chi_out;
-  if (nstats0 < F.max_stats && lane < 8) {
+  if (PUBLISH && nstats0 < F.max_stats && lane < 8) {
     static_assert(sizeof(srrg2_iteration_stats) == 32, "eight words");
     const int sw = lane == 0 ? nstats0 : lane == 1 ? num_in : lane == 2 ? num_out : lane == 3 ? num_sup : lane == 4 ? num_corr
                  : lane == 5 ? (bad ? 1 : 0) : lane == 6 ? __float_as_int(chi_in_f) : __float_as_int(chi_out_f);
     reinterpret_cast<int*>(F.stats + (size_t) prob * F.max_stats + nstats0)[lane] = sw;
   }
-  if (lane == 0) st->nstats = nstats0 + 1;
+  if constexpr (PUBLISH)
+    if (lane == 0) st->nstats = nstats0 + 1;
   // ---- AlignerTerminationCriteriaStandard_::hasToStop (aligner_termination_criteria_impl.cpp:24-65, has_to_stop below)
   bool stop = false;
   int wc1   = wc;
@@ -2442,7 +2467,7 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
       if (chi_range > (float) tp.num_outliers_range) stop = false;  // :53
       if (chi_range / (float) xmax > tp.chi_epsilon) stop = false;
     }
-    if (lane == 0) {
+    if (PUBLISH && lane == 0) {
       st->w_corr[slot] = num_corr;
       st->w_inl[slot]  = num_in;
       st->w_out[slot]  = num_out;
@@ -2450,7 +2475,7 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
       st->w_count      = wc + 1;
     }
   }
-  if (stop && lane == 0) st->done = 1;  // :124-126
+  if (PUBLISH && stop && lane == 0) st->done = 1;  // :124-126
   // ---- finder transforms robot_in_sensor * X (finder_transform_of) of the slices, the previous ones kept; the records of
   //      the new epoch, then the epoch words
   const unsigned x_up = __float_as_uint(__shfl(Xl, (lane - PUB_G_X) & 63));
@@ -2483,9 +2508,9 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
         if (i == 2) f = j == 2 ? 1.f : 0.f;
         tnew = f;
       }
-      if (lane < 12) st->Tf[s][lane] = tnew;
+      if (PUBLISH && lane < 12) st->Tf[s][lane] = tnew;
     }
-    if (lane < 12) st->Tfprev[s][lane] = told[z];
+    if (PUBLISH && lane < 12) st->Tfprev[s][lane] = told[z];
     const unsigned told_up = __float_as_uint(__shfl(told[z], (lane - 12) & 63));  // (every lane takes part in the shuffle)
     unsigned nv = 0u;
     if (lane < 12) nv = __float_as_uint(tnew);
@@ -2496,9 +2521,12 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     if (lane == PUB_G_WCOUNT) nv = (unsigned) wc1;
     if (lane == PUB_G_NPASSES) nv = (unsigned) (npasses0 + 1);
     if (lane >= PUB_G_X && lane < PUB_G_X + 12) nv = x_up;
-    pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane, ((unsigned long long) epoch << 32) | nv);
+    if constexpr (PUBLISH)
+      pub_store(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane, ((unsigned long long) epoch << 32) | nv);
+    else
+      (*out)[z] = nv;
   }
-  pub_write_epoch(F.pub_epoch, prob, lane, epoch);
+  if constexpr (PUBLISH) pub_write_epoch(F.pub_epoch, prob, lane, epoch);
 }
 
 // What a pass kernel needs of the state.  Legacy (FUSED = false: its own kernel instantiations, the code of round 4): read from
@@ -2526,12 +2554,48 @@ __device__ __forceinline__ void pass_view_legacy(const SliceDev& S, const Proble
 // Top of a fused pass kernel: wave 0 of workgroup (0, problem) applies the control step of the previous iteration if the
 // record still stands at the previous epoch (this wave is the only writer of the record during the launch).  Before the
 // workgroup requests its points: the step's registers are free again when the pass needs its own.
+// How long a polling wave waits for the designated one before it applies the step itself (polls of ~1 us each: an
+// agent-scope load and a short sleep).  Nothing in HIP promises that workgroup (problem, 0) is dispatched before its siblings;
+// it is in practice, and when it is not -- or it is slow: a debugger, a profiler that serialises, a shared GPU -- the pollers
+// proceed on their own computation of the same record instead of spinning (round 5 trapped after 2^24 polls: process-fatal).
+#ifndef SRRG2_FUSED_POLL_LIMIT
+#define SRRG2_FUSED_POLL_LIMIT 64
+#endif
+// -DSRRG2_FUSED_STALL=<n>: the designated wave sleeps n x ~3.4 us before its control step, so that every polling wave runs into
+// the limit and takes the fallback (tests/test_gpu_fused_control.py builds such a library and compares bits); the counter says
+// how many waves did.
+#ifdef SRRG2_FUSED_STALL
+__device__ unsigned long long g_fused_fallbacks;
+extern "C" int srrg2_amd_debug_fused_fallbacks(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_fallbacks), sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned long long zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fused_fallbacks), &zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define FUSED_STALL()                                                              \
+  do {                                                                             \
+    for (int stall_i = 0; stall_i < (SRRG2_FUSED_STALL); ++stall_i) __builtin_amdgcn_s_sleep(127); \
+  } while (0)
+#define FUSED_FALLBACK_COUNT()                                                     \
+  do {                                                                             \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_fused_fallbacks, 1ull);              \
+  } while (0)
+#else
+#define FUSED_STALL() do { } while (0)
+#define FUSED_FALLBACK_COUNT() do { } while (0)
+#endif
+
 template <int DIM>
 __device__ __forceinline__ void fused_control_if_due(const SliceDev& S, ProblemState* __restrict__ states, int prob) {
   if (blockIdx.y != 0 || threadIdx.x >= 64) return;  // (fused launches: x = problem, y = tile)
   const unsigned long long g[1] = {
     pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
-  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<DIM == 3 ? 6 : 3, 1>(&S, 1, states, prob, g);
+  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) {
+    FUSED_STALL();
+    wave_control<DIM == 3 ? 6 : 3, 1>(&S, 1, states, prob, g);
+  }
   PASS_TS(S.fc.epoch, 1);
 }
 
@@ -2550,17 +2614,30 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
     if (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) {
       // (workgroup (0, problem) applied the control step at its very top -- fused_control_if_due -- before it came here)
       const unsigned* ep = S.fc.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.y & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
+      // Poll the epoch word, then the record (the epoch words are written after it).  Past the limit: if the record still
+      // stands WHOLE at the previous epoch, this wave computes the new one itself, into registers (wave_control<.., false>:
+      // same inputs, all read-only during this launch, same bits; nothing is stored); a record in the middle of being
+      // published is simply waited for -- its writer is running.
       int spins = 0;
-      while ((int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S.fc.epoch) {
+      for (;;) {
+        if ((int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= S.fc.epoch) {
+          g = pub_load(rec);
+          if (__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) break;
+        }
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 24)) __builtin_trap();  // (never: workgroup (0, problem) is dispatched before its siblings)
-      }
-      g     = pub_load(rec);
-      spins = 0;
-      while (!__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) {  // (the epoch words are written after the record)
-        __builtin_amdgcn_s_sleep(2);
-        g = pub_load(rec);
-        if (++spins > (1 << 24)) __builtin_trap();
+        if (++spins > SRRG2_FUSED_POLL_LIMIT) {
+          g = pub_load(rec);
+          if (__all((unsigned) (g >> 32) == (unsigned) S.fc.epoch)) break;
+          if (__all((unsigned) (g >> 32) == (unsigned) (S.fc.epoch - 1))) {
+            const unsigned long long gv[1] = {g};
+            unsigned nv[1];
+            wave_control<DIM == 3 ? 6 : 3, 1, false>(&S, 1, states, prob, gv, &nv);
+            g = (unsigned long long) nv[0];
+            FUSED_FALLBACK_COUNT();
+            break;
+          }
+          spins = 0;
+        }
       }
     }
     rec_lds[lane] = (unsigned) g;
@@ -2594,11 +2671,16 @@ __device__ __forceinline__ void fused_control_if_due_multi(const SliceDev* __res
       stale = stale || (unsigned) (g[z] >> 32) != (unsigned) Sv[0].fc.epoch;
     }
   }
-  if (__any(stale)) wave_control<6, MAXS>(Sv, ns, states, prob, g);  // (projective finders: SE(3))
+  if (__any(stale)) {
+    FUSED_STALL();
+    wave_control<6, MAXS>(Sv, ns, states, prob, g);  // (projective finders: SE(3))
+  }
 }
+// (ns_all: the slices of the aligner -- the control step is one step for all of them, whatever this kernel reads)
 template <int MAXS>
 __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, int ns, int prob,
-                                              unsigned (&rec)[MAXS][PUB_SLICE_GRANULES]) {
+                                              unsigned (&rec)[MAXS][PUB_SLICE_GRANULES], ProblemState* __restrict__ states,
+                                              int ns_all) {
   const int lane = threadIdx.x & 63;
   if (threadIdx.x < 64) {
     const FusedCtl& F = Sv[0].fc;
@@ -2614,22 +2696,46 @@ __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, i
     }
     if (__any(stale)) {
       const unsigned* ep = F.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.x & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
+      // (as pass_view_fused: poll, and past the limit apply the step in registers if every record stands whole at the
+      // previous epoch)
       int spins = 0;
-      while ((int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < F.epoch) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 24)) __builtin_trap();  // (never: workgroup (0, problem) is dispatched before its siblings)
-      }
-      spins = 0;
-      do {  // (the epoch words are written after the records)
-        stale = false;
+      for (;;) {
+        const bool published = (int) __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= F.epoch;
+        const bool limit     = ++spins > SRRG2_FUSED_POLL_LIMIT;
+        if (published || limit) {
+          stale = false;
 #pragma unroll
-        for (int z = 0; z < MAXS; ++z)
-          if (z < ns) {
-            g[z]  = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
-            stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
+          for (int z = 0; z < MAXS; ++z)
+            if (z < ns) {
+              g[z]  = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+              stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
+            }
+          if (!__any(stale)) break;
+        }
+        if (limit) {
+          unsigned long long ga[4];
+          bool old = true;
+#pragma unroll
+          for (int z = 0; z < 4; ++z) {
+            ga[z] = 0ull;
+            if (z < ns_all) {
+              ga[z] = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+              old   = old && (unsigned) (ga[z] >> 32) == (unsigned) (F.epoch - 1);
+            }
           }
-        if (++spins > (1 << 24)) __builtin_trap();
-      } while (__any(stale));
+          if (__all(old)) {
+            unsigned nv[4];
+            wave_control<6, 4, false>(Sv, ns_all, states, prob, ga, &nv);
+#pragma unroll
+            for (int z = 0; z < MAXS; ++z)
+              if (z < ns) g[z] = (unsigned long long) nv[z];
+            FUSED_FALLBACK_COUNT();
+            break;
+          }
+          spins = 0;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
     }
 #pragma unroll
     for (int z = 0; z < MAXS; ++z)
@@ -3882,7 +3988,7 @@ __global__ __launch_bounds__(256) void k_proj_zbuf_fz(SlicePack P, int nslices, 
   float4 p            = make_float4(NAN, 0.f, 0.f, 0.f);
   if (inr) p = S.mpts[pd.moff + i];  // (requested before the record: it does not depend on the state)
   __shared__ unsigned rec[1][PUB_SLICE_GRANULES];
-  records_fused<1>(P.s, 1, prob, rec);
+  records_fused<1>(P.s, 1, prob, rec, states, nslices);
   PassView pv;
   view_of_record(rec[0], pv);
   if (pv.stop || !inr) return;
@@ -4102,7 +4208,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int ns
   __shared__ unsigned rec[FUSED ? 4 : 1][PUB_SLICE_GRANULES];
   PassView pv0;
   if constexpr (FUSED) {
-    records_fused<4>(P.s, nslices, prob, rec);
+    records_fused<4>(P.s, nslices, prob, rec, states, nslices);
     view_of_record(rec[0], pv0);
   }
   {  // ping-pong reset of the (one) z-buffer, as in step_proj_body
@@ -4551,7 +4657,7 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
-    for (int buf = 0; buf < (C.pub ? 2 : 1); ++buf) {  // (the second buffer: fused control steps, pass e adds into buffer e & 1)
+    for (int buf = 0; buf < (C.pub ? 3 : 1); ++buf) {  // (buffers 1, 2: fused control steps, round k adds into buffer k % 3)
       long long* p = const_cast<long long*>(sc.partials) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
       for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += blockDim.x) p[k] = 0;
     }
@@ -4687,9 +4793,11 @@ __device__ void icp_control_block(const CtlParams& C, ProblemState* st, srrg2_it
     part[c][a] = v;
     __syncthreads();
     // the slot sets are accumulated with atomics by the step kernels: reset them for the next iteration
-    // (after the barrier: every thread of the block has finished reading)
+    // (after the barrier: every thread of the block has finished reading; fused control steps: not the buffer just read but
+    // the one the round after next adds into -- FusedCtl::prev_partials --, legacy: zero_parity == parity == 0)
+    long long* pz = const_cast<long long*>(sc.partials) + ((size_t) C.zero_parity * C.K + prob) * PARTIAL_SLOTS * ACC_N;
 #pragma unroll
-    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) p[(size_t) (c + 8 * q) * ACC_N + a] = 0;
+    for (int q = 0; q < PARTIAL_SLOTS / 8; ++q) pz[(size_t) (c + 8 * q) * ACC_N + a] = 0;
     if (threadIdx.x < ACC_N) {
       long long t = 0;
 #pragma unroll
@@ -4757,15 +4865,26 @@ __device__ void icp_post_one(const CtlParams& C, ProblemState* st, const srrg2_i
   }
 }
 
-__global__ void k_icp_post(CtlParams C, ProblemState* __restrict__ states, const srrg2_iteration_stats* __restrict__ stats) {
-  int prob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (prob >= (C.nprob > 0 ? C.nprob : C.K)) return;
-  prob += C.prob0;
-  icp_post_one(C, &states[prob], stats, prob);
-  if (C.pub) {  // (fused control steps: phase / done changed; one thread per problem)
-    for (int l = 0; l < PUB_SLICE_GRANULES; ++l) pub_publish_state(C, &states[prob], prob, l, (unsigned) C.epoch);
-    for (int l = 0; l < PUB_EPOCH_REPLICAS; ++l) pub_write_epoch(C.pub_epoch, prob, l, (unsigned) C.epoch);
+// (one wave per problem)
+__global__ __launch_bounds__(64) void k_icp_post(CtlParams C, ProblemState* __restrict__ states,
+                                                 const srrg2_iteration_stats* __restrict__ stats) {
+  const int prob = blockIdx.x + C.prob0;
+  if (threadIdx.x == 0) icp_post_one(C, &states[prob], stats, prob);
+  if (!C.pub) return;
+  // fused control steps.  The slot sets: a run that stopped early (termination criterion, too few correspondences) left the
+  // sums of its last round in the buffer that round added into -- the control steps zero the buffer of the round after next,
+  // not the one they read (FusedCtl::prev_partials) -- and the inlier-only run starts on zeroed buffers like the first one.
+  for (int s = 0; s < C.nslices; ++s) {
+    const SliceCtl& sc = C.slices[s];
+    if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
+    for (int buf = 0; buf < 3; ++buf) {
+      long long* p = const_cast<long long*>(sc.partials) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
+      for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += 64) p[k] = 0;
+    }
   }
+  __syncthreads();  // (phase / done changed: thread 0's stores to the state, read back by the wave)
+  pub_publish_state(C, &states[prob], prob, threadIdx.x, (unsigned) C.epoch);
+  pub_write_epoch(C.pub_epoch, prob, threadIdx.x, (unsigned) C.epoch);
 }
 
 // end of compute(): _pruneCorrespondences bookkeeping, fixTransform, Success (:88-94).  One block per problem; the
@@ -5234,7 +5353,7 @@ void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_it
                      with_post ? 1 : 0);
 }
 void launch_icp_post(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats, hipStream_t s) {
-  hipLaunchKernelGGL(k_icp_post, dim3(((C.nprob > 0 ? C.nprob : C.K) + 63) / 64), dim3(64), 0, s, C, states, stats);
+  hipLaunchKernelGGL(k_icp_post, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(64), 0, s, C, states, stats);
 }
 void launch_icp_finalize(const CtlParams& C, ProblemState* states, const srrg2_iteration_stats* stats,
                          ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {

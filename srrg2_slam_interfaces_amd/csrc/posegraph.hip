@@ -1347,6 +1347,134 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_converged(int nblocks, double
   }
 }
 
+// ---- fused steps of a CG iteration (round 6) ------------------------------------------------------------------------------
+// A CG iteration was 18 launches, of which four did node-local work between two grid-wide dependencies: level 0's first
+// smoothing step x1 = omega Dinv r (now in the kernel that produces r), level 1's (in level 0's restriction), the cycle's last
+// update x += omega Dinv res (in the r.z kernel), and the convergence test (block 0 of the cycle's first residual pass: the sum
+// of update_xr's partials is complete behind the kernel boundary).  14 launches; same operations on the same operands in the same
+// order per entry, so the same numbers as the unfused sequence (SRRG2_AMD_PG_FUSED_CG=0 keeps that one).
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_pg_update_xr_smooth(int n, int nblocks, const double* __restrict__ p,
+                                                                    const double* __restrict__ Ap, double* __restrict__ x,
+                                                                    double* __restrict__ r, const double* __restrict__ part_rz,
+                                                                    const double* __restrict__ part_pAp, double* __restrict__ part_rr,
+                                                                    MgPair LV, const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = LV.L;
+  const double rz  = sum_partials(part_rz, nblocks);
+  const double pap = sum_partials(part_pAp, nblocks);
+  const double alpha = pap > 0.0 ? rz / pap : 0.0;
+  __shared__ double sh_r[PG_ROWS];  // (PG_ROWS rows per tile, a multiple of D: a node never straddles tiles)
+  double rr = 0.0;
+  for (int base = blockIdx.x * PG_ROWS; base < n; base += gridDim.x * PG_ROWS) {
+    const int t   = base + (int) threadIdx.x;
+    const bool on = threadIdx.x < PG_ROWS && t < n;
+    if (on) {
+      x[t] = x[t] + alpha * p[t];
+      const double ri = r[t] - alpha * Ap[t];
+      r[t] = ri;
+      rr   = rr + ri * ri;
+      sh_r[threadIdx.x] = ri;
+    }
+    __syncthreads();
+    if (on) {  // x1 = omega Dinv r of this row's node (mg_smooth0)
+      const int v = t / D, row = t - v * D, l0 = (int) threadIdx.x - row;
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) s = s + (double) L.Dinvf[((size_t) v * D + row) * D + c] * sh_r[l0 + c];
+      L.x[t] = L.omega * s;
+    }
+    __syncthreads();
+  }
+  rr = block_sum(rr);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = rr;
+}
+
+// res = r - H x on level 0; `check`: block 0 first sums r.r of the update before it and publishes the iteration's scalars
+// (k_pg_converged's work; the blocks that have already read `done` finish a pass nobody reads)
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_residual0(MgPair LV, int check, int nblocks, double tol,
+                                                             const double* __restrict__ part_rr, const double* __restrict__ part_bb,
+                                                             PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  if (check && blockIdx.x == 0) {
+    const double rr = sum_partials(part_rr, nblocks);
+    const double bb = sum_partials(part_bb, nblocks);
+    if (threadIdx.x == 0) {
+      sc->rr = rr;
+      sc->bb = bb;
+      sc->pcg_iters += 1;
+      if (rr <= tol * tol * bb) sc->done = 1;
+    }
+  }
+  mg_residual<D>(LV.L, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// r_c = Ps^T res on level 0 and x1_c = omega_c D_c^-1 r_c for level 1: a coarse node owns NL = 8 * parts adjacent lanes, every
+// lane takes whole blocks of the column (as k_mg_down2), the lanes meet by shuffles
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_restrict_smooth(MgPair LV, int parts, const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = LV.L;
+  const MgLevel C = LV.C;
+  const int t  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NL = 8 * parts;
+  const int k = t & (NL - 1), I = t / NL;
+  const bool on = I < L.nc;
+  double s[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) s[a] = 0.0;
+  if (on) {
+    const int me = L.pcsc_start[I + 1];
+    for (int m0 = L.pcsc_start[I] + k; m0 < me; m0 += 2 * NL) {
+      const int2 e0  = L.pcsc2[m0];
+      const bool two = m0 + NL < me;
+      const int2 e1  = two ? L.pcsc2[m0 + NL] : e0;
+      double u[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) u[a] = 0.0;
+      mg_block_tmulsub<D>(L.Psf + (size_t) e0.x * D * D, L.res + (size_t) e0.y * D, 1.0, s);
+      mg_block_tmulsub<D>(L.Psf + (size_t) e1.x * D * D, L.res + (size_t) e1.y * D, two ? 1.0 : 0.0, u);
+#pragma unroll
+      for (int a = 0; a < D; ++a) s[a] = s[a] + u[a];
+    }
+  }
+  for (int off = NL >> 1; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) s[a] = s[a] + __shfl_xor(s[a], off);
+  }
+  if (on && k < D) {
+    double x1 = 0.0, sk = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      x1 = x1 + (double) C.Dinvf[((size_t) I * D + k) * D + c] * s[c];
+      sk = k == c ? s[c] : sk;
+    }
+    C.r[(size_t) I * D + k] = sk;
+    C.x[(size_t) I * D + k] = C.omega * x1;
+  }
+}
+
+// the cycle's last step z = x + omega Dinv res on level 0 and the partial r.z
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_pg_update_dot(int n, MgPair LV, const double* __restrict__ r,
+                                                              double* __restrict__ part_rz_new, const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = LV.L;
+  double s = 0.0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const int v = t / D, row = t - v * D;
+    double u = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) u = u + (double) L.Dinvf[((size_t) v * D + row) * D + c] * L.res[(size_t) v * D + c];
+    const double z = L.x[t] + L.omega * u;
+    L.x[t] = z;
+    s      = s + r[t] * z;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) part_rz_new[blockIdx.x] = s;
+}
+
 template <int D>
 __global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int T, int variable_kind, const uint8_t* __restrict__ fixed,
                                                          const double* __restrict__ x, float* __restrict__ poses,
@@ -1424,6 +1552,7 @@ struct srrg2_posegraph_s {
     bool debug = false;         // SRRG2_AMD_PG_DEBUG
     bool keep_structure = true; // the hierarchy's structure survives a set() with the same topology
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
+    bool fused_cg = true;          // SRRG2_AMD_PG_FUSED_CG: 14 launches per CG iteration instead of 18 (round 6; an A/B switch: same numbers)
   } sw;
   // scratch of the device-side pattern build (pg_device_patterns)
   DevBuf<unsigned long long> st_keys_a, st_keys_b;
@@ -2306,7 +2435,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   int rc;
   if (g->mg_dirty && (rc = build_hierarchy(g))) return rc;
   const int nl  = (int) g->levels.size() - 1;  // index of the coarsest level
-  const int nb  = std::max(std::min((n + PG_THREADS - 1) / PG_THREADS, 1024), 1);  // grid-stride element-wise kernels
+  const int nb  = std::max(std::min((n + PG_ROWS - 1) / PG_ROWS, 1024), 1);  // grid-stride element-wise kernels (tiles of PG_ROWS rows)
   const int nbv = std::max((V + PG_THREADS - 1) / PG_THREADS, 1);
   const int nbe = std::max((E + PG_THREADS - 1) / PG_THREADS, 1);
   const int nchi = std::min(nbe, 1024);
@@ -2346,15 +2475,29 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     int p2 = down ? Lb->col_parts : std::max(Lb->row_parts, Lb->prow_parts);
     return std::min(std::max(p2, 1), 8);
   };
-  auto vcycle2 = [&]() {
+  // (fused CG steps, k_pg_update_xr_smooth ...: `head` = level 0's x1 is already there, `check` = the first residual pass carries the
+  // convergence test, `tail` = the caller's k_pg_update_dot applies the last update; sw.fused_cg)
+  const bool fused_cg = g->sw.fused_cg && two_phase;
+  const double tol_d  = (double) p->pcg_tolerance;
+  auto vcycle2 = [&](bool head, bool check, bool tail) {
     const MgLevelBufs* L0b = g->levels[0];
     const int bl0 = blocks_for(L0b->n * D), bc0 = blocks_for(L0b->nc * D * L0b->col_parts), br0 = blocks_for(L0b->n * D * L0b->row_parts);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, pair(0), g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(0), g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(bc0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, pair(0), g->sc.p);
-    if (lf > 1)  // x1 of level 1 (the levels below get theirs from k_mg_down2)
-      hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(g->levels[1]->n * D)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0,
-                         pair(1), g->sc.p);
+    if (!head) hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0, pair(0), g->sc.p);
+    if (fused_cg)
+      hipLaunchKernelGGL(k_mg_residual0<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, pair(0), check ? 1 : 0, nb, tol_d, g->part_rr.p,
+                         g->part_bb.p, g->sc.p);
+    else
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(0), g->sc.p);
+    if (fused_cg && L0b->nc > 0) {  // restriction + x1 of level 1 in one launch
+      const int pp = std::min(std::max(L0b->col_parts / 2, 1), 8);
+      hipLaunchKernelGGL(k_mg_restrict_smooth<D>, dim3((unsigned) (((size_t) L0b->nc * 8 * pp + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS),
+                         0, g->stream, pair(0), pp, g->sc.p);
+    } else {
+      hipLaunchKernelGGL(k_mg_op<D>, dim3(bc0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESTRICT, pair(0), g->sc.p);
+      if (lf > 1)  // x1 of level 1 (the levels below get theirs from k_mg_down2)
+        hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(g->levels[1]->n * D)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_SMOOTH0,
+                           pair(1), g->sc.p);
+    }
     // (the last two-phase level's down phase and the dense coarsest solve share a launch when the coarsest level is tiny)
     const bool fuse_last = g->coarsest_dense && lf == nl && lf >= 2 && g->levels[(size_t) nl]->n <= MG_FUSE_LAST_NODES &&
                            g->levels[(size_t) nl]->n == g->levels[(size_t) nl - 1]->nc;
@@ -2380,11 +2523,12 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     else
       hipLaunchKernelGGL(k_mg_op<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, pair(0), g->sc.p);
     hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(0), g->sc.p);
-    hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, pair(0), g->sc.p);
+    if (!tail) hipLaunchKernelGGL(k_mg_op<D>, dim3(bl0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, pair(0), g->sc.p);
   };
+  const bool fused_path = fused_cg && lf >= 1 && nl >= 1;  // (the two-phase cycle runs, with the fused CG steps around it)
   auto vcycle = [&]() {
     if (two_phase && lf >= 1 && nl >= 1) {
-      vcycle2();
+      vcycle2(false, false, false);
       return;
     }
     for (int l = 0; l < lf; ++l) {
@@ -2490,8 +2634,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     double* z = L0->x.p;
     hipLaunchKernelGGL(k_pg_pcg_init, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, g->b.p, g->x.p, r, g->part_bb.p, g->sc.p,
                        g->part_chi.p, g->part_n.p, nchi);
-    vcycle();
-    hipLaunchKernelGGL(k_pg_dot_rz, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, r, z, g->part_rz.p, g->sc.p);
+    if (fused_path) {
+      vcycle2(false, false, true);
+      hipLaunchKernelGGL(k_pg_update_dot<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, pair(0), r, g->part_rz.p, g->sc.p);
+    } else {
+      vcycle();
+      hipLaunchKernelGGL(k_pg_dot_rz, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, r, z, g->part_rz.p, g->sc.p);
+    }
     hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, 1, z, g->p.p, g->part_rz.p, g->part_rz.p, g->sc.p);
     PgScalars h{};
     int launched = 0;
@@ -2500,12 +2649,19 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         double* rz_cur = ((first + k) & 1) ? g->part_rz_new.p : g->part_rz.p;
         double* rz_nxt = ((first + k) & 1) ? g->part_rz.p : g->part_rz_new.p;
         hipLaunchKernelGGL(k_pg_spmv<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, pair(0), g->p.p, g->Ap.p, g->part_pAp.p, g->sc.p);
+        if (fused_path) {
+          hipLaunchKernelGGL(k_pg_update_xr_smooth<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, g->p.p, g->Ap.p, g->x.p, r, rz_cur,
+                             g->part_pAp.p, g->part_rr.p, pair(0), g->sc.p);
+          vcycle2(true, true, true);
+          hipLaunchKernelGGL(k_pg_update_dot<D>, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, pair(0), r, rz_nxt, g->sc.p);
+        } else {
         hipLaunchKernelGGL(k_pg_update_xr, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, (double) p->pcg_tolerance, g->p.p,
                            g->Ap.p, g->x.p, r, rz_cur, g->part_pAp.p, g->part_rr.p, g->part_bb.p, g->sc.p);
         hipLaunchKernelGGL(k_pg_converged, dim3(1), dim3(PG_THREADS), 0, g->stream, nb, (double) p->pcg_tolerance, g->part_rr.p,
                            g->part_bb.p, g->sc.p);
         vcycle();
         hipLaunchKernelGGL(k_pg_dot_rz, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, r, z, rz_nxt, g->sc.p);
+        }
         hipLaunchKernelGGL(k_pg_update_p, dim3(nb), dim3(PG_THREADS), 0, g->stream, n, nb, 0, z, g->p.p, rz_cur, rz_nxt, g->sc.p);
       }
     };
@@ -2701,6 +2857,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_OMEGA", t.omega);
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_OFFSET_LIMIT")) g->st_offset_limit = std::min<unsigned long long>(std::strtoull(e, nullptr, 10), 0x7fff0000ull);
     if (t.match_passes < 1) t.match_passes = 1;
     apply_tuning(g, t);

@@ -173,3 +173,24 @@ def test_partial_overlap_through_the_one_linearisation_flow(oracle, product, sli
     for run in (fused, fused_early, unfused):
         assert_same_run(ref, run)
     assert fused.information().tobytes() == unfused.information().tobytes() == fused_early.information().tobytes()
+
+
+def test_polling_waves_apply_the_control_step_themselves():
+    """a fused pass whose record is stale polls workgroup (problem, 0) of the SAME launch -- dispatch
+    order is not a HIP guarantee.  Past SRRG2_FUSED_POLL_LIMIT polls the polling wave applies the control step itself, in
+    registers, from inputs that are read-only for the whole launch (the previous epoch's records, the previous round's slot
+    sets: three buffers, zeroed two rounds later), and proceeds: no trap, no dependence on scheduling.  Proven on a library
+    built with -DSRRG2_FUSED_STALL (the designated wave sleeps ~0.3 ms first): a single alignment with the termination criterion
+    and an inlier-only run, SE(2), a batch with an empty cloud, two projective slices on one association -- the oracle's bits in
+    every scenario, and the fallback counter moves in each."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stall = os.path.join(root, "srrg2_slam_interfaces_amd", "lib", "libsrrg2_slam_amd_stall.so")
+    assert os.path.exists(stall), "build it with `make -C srrg2_slam_interfaces_amd/csrc stall` (__graft_entry__.build() does)"
+    env = dict(os.environ, SRRG2_AMD_LIB=stall)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers_scripts", "fused_stall_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "STALL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
