@@ -2676,8 +2676,11 @@ __device__ __forceinline__ void fused_control_if_due_multi(const SliceDev* __res
     wave_control<6, MAXS>(Sv, ns, states, prob, g);  // (projective finders: SE(3))
   }
 }
-// (ns_all: the slices of the aligner -- the control step is one step for all of them, whatever this kernel reads)
-template <int MAXS>
+// (ns_all: the slices of the aligner -- the control step is one step for all of them, whatever this kernel reads.
+// FIRST = the iteration's first kernel, the one that carries the control step: only there can a record be stale -- the
+// step kernel behind it starts behind a kernel boundary that the designated wave's stores have crossed, reads current
+// records and carries no fallback: wave_control for four slices inside it took it from 98 to 203 registers)
+template <int MAXS, bool FIRST>
 __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, int ns, int prob,
                                               unsigned (&rec)[MAXS][PUB_SLICE_GRANULES], ProblemState* __restrict__ states,
                                               int ns_all) {
@@ -2685,7 +2688,7 @@ __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, i
   if (threadIdx.x < 64) {
     const FusedCtl& F = Sv[0].fc;
     unsigned long long g[MAXS];
-    bool stale = false;
+    bool stale = false, fallback = false;
 #pragma unroll
     for (int z = 0; z < MAXS; ++z) {
       g[z] = 0ull;
@@ -2694,6 +2697,7 @@ __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, i
         stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
       }
     }
+    (void) fallback;
     if (__any(stale)) {
       const unsigned* ep = F.pub_epoch + ((size_t) prob * PUB_EPOCH_REPLICAS + (blockIdx.x & (PUB_EPOCH_REPLICAS - 1))) * PUB_EPOCH_STRIDE;
       // (as pass_view_fused: poll, and past the limit apply the step in registers if every record stands whole at the
@@ -2712,29 +2716,55 @@ __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, i
             }
           if (!__any(stale)) break;
         }
-        if (limit) {
-          unsigned long long ga[4];
+        if (limit && !FIRST) break;  // (unreachable: see above)
+        if constexpr (FIRST) if (limit) {
+          // (the step itself BEHIND the loop: inside it, the loop-invariant scalar loads of four slices' records are hoisted
+          // in front of the loop and spill the kernel's scalar registers into vector ones -- 60 -> 197 of them)
           bool old = true;
 #pragma unroll
-          for (int z = 0; z < 4; ++z) {
-            ga[z] = 0ull;
-            if (z < ns_all) {
-              ga[z] = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
-              old   = old && (unsigned) (ga[z] >> 32) == (unsigned) (F.epoch - 1);
-            }
-          }
+          for (int z = 0; z < 4; ++z)
+            if (z < ns_all)
+              old = old && (unsigned) (pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane) >> 32) ==
+                             (unsigned) (F.epoch - 1);
           if (__all(old)) {
-            unsigned nv[4];
-            wave_control<6, 4, false>(Sv, ns_all, states, prob, ga, &nv);
-#pragma unroll
-            for (int z = 0; z < MAXS; ++z)
-              if (z < ns) g[z] = (unsigned long long) nv[z];
-            FUSED_FALLBACK_COUNT();
+            fallback = true;
             break;
           }
           spins = 0;
         }
         __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    if constexpr (FIRST) {
+      if (fallback) {
+        unsigned long long ga[4];
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+          ga[z] = 0ull;
+          if (z < ns_all) ga[z] = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+        }
+        bool old = true;
+#pragma unroll
+        for (int z = 0; z < 4; ++z)
+          if (z < ns_all) old = old && (unsigned) (ga[z] >> 32) == (unsigned) (F.epoch - 1);
+        if (__all(old)) {  // (still whole at the previous epoch: computed here)
+          unsigned nv[4];
+          wave_control<6, 4, false>(Sv, ns_all, states, prob, ga, &nv);
+#pragma unroll
+          for (int z = 0; z < MAXS; ++z)
+            if (z < ns) g[z] = (unsigned long long) nv[z];
+          FUSED_FALLBACK_COUNT();
+        } else {  // (its writer has started in the meantime: it finishes within microseconds)
+          do {
+            stale = false;
+#pragma unroll
+            for (int z = 0; z < MAXS; ++z)
+              if (z < ns) {
+                g[z]  = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+                stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
+              }
+          } while (__any(stale));
+        }
       }
     }
 #pragma unroll
@@ -3988,7 +4018,7 @@ __global__ __launch_bounds__(256) void k_proj_zbuf_fz(SlicePack P, int nslices, 
   float4 p            = make_float4(NAN, 0.f, 0.f, 0.f);
   if (inr) p = S.mpts[pd.moff + i];  // (requested before the record: it does not depend on the state)
   __shared__ unsigned rec[1][PUB_SLICE_GRANULES];
-  records_fused<1>(P.s, 1, prob, rec, states, nslices);
+  records_fused<1, true>(P.s, 1, prob, rec, states, nslices);
   PassView pv;
   view_of_record(rec[0], pv);
   if (pv.stop || !inr) return;
@@ -4208,7 +4238,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_fused(SlicePack P, int ns
   __shared__ unsigned rec[FUSED ? 4 : 1][PUB_SLICE_GRANULES];
   PassView pv0;
   if constexpr (FUSED) {
-    records_fused<4>(P.s, nslices, prob, rec, states, nslices);
+    records_fused<4, false>(P.s, nslices, prob, rec, states, nslices);
     view_of_record(rec[0], pv0);
   }
   {  // ping-pong reset of the (one) z-buffer, as in step_proj_body

@@ -32,7 +32,7 @@
 #endif
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include "det_math.h"
 #include "host_util.h"
@@ -311,6 +311,16 @@ struct MgLevel {  // device view of one level (level 0 = the pose graph without 
   const int* qcsc_ent;          // [nq]
   const int2* pcsc2;            // [np] / [nq]: the columns again as {entry, its row} (one load instead of a dependent pair)
   const int2* qcsc2;
+  // product lists of the set-up (round 6): entry q of Q = H Ps is the sum over qp_list[qp_start[q] .. qp_start[q + 1]) of
+  // H(y) * Ps[x] with y = -1: the row's diagonal block, else the incidence code (edge << 1) | side; coarse edge k of the Galerkin
+  // product is the sum over gp_list[gp_start[k] ..) of Ps[x]^T * Q[y]; qdiag[e] = the entry of Q in the row and column of entry e
+  // of Ps (the coarse diagonal blocks).  They are the sorted candidate lists of the pattern build with their origins as payload:
+  // k_mg_hp / k_mg_galerkin found every product by a binary search per (entry, incidence), five in six of them in vain.
+  const int* qp_start;
+  const int2* qp_list;
+  const int* gp_start;
+  const int2* gp_list;
+  const int* qdiag;
   double *x, *r, *res;          // [n][D] work vectors of the cycle
 };
 
@@ -340,6 +350,8 @@ __device__ __forceinline__ MgLevel mg_level(const MgLevel* __restrict__ levels, 
   L.Hd = mg_glob(L.Hd); L.Ho = mg_glob(L.Ho); L.P = mg_glob(L.P); L.Ps = mg_glob(L.Ps); L.Q = mg_glob(L.Q); L.Dinv = mg_glob(L.Dinv);
   L.Hdf = mg_glob(L.Hdf); L.Hof = mg_glob(L.Hof); L.Dinvf = mg_glob(L.Dinvf); L.Psf = mg_glob(L.Psf); L.Qf = mg_glob(L.Qf);
   L.qcsc_start = mg_glob(L.qcsc_start); L.qcsc_ent = mg_glob(L.qcsc_ent); L.pcsc2 = mg_glob(L.pcsc2); L.qcsc2 = mg_glob(L.qcsc2);
+  L.qp_start = mg_glob(L.qp_start); L.qp_list = mg_glob(L.qp_list); L.gp_start = mg_glob(L.gp_start); L.gp_list = mg_glob(L.gp_list);
+  L.qdiag = mg_glob(L.qdiag);
   L.x = mg_glob(L.x); L.r = mg_glob(L.r); L.res = mg_glob(L.res);
   return L;
 }
@@ -1052,6 +1064,72 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(MgPair LV) {
   for (int k = 0; k < D * D; ++k) out[k] = acc[k];
 }
 
+// Q = H Ps and the Galerkin product over the product lists (MgLevel::qp_list / gp_list): `parts` adjacent lanes share an
+// output block, lane `part` takes every parts-th product of its list (a fixed order) and the lanes add their blocks with the
+// fixed butterfly -- deterministic, and the same list order on the host-built and the device-built structure.
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_hp_list(MgPair LV, int parts) {
+  const MgLevel L = LV.L;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.nq * parts) return;  // (whole groups: the bound is a multiple of `parts`)
+  const int part = t & (parts - 1), q = t / parts;
+  const int i = L.qrow_of[q];
+  double w[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) w[k] = 0.0;
+  const int k1 = L.qp_start[q + 1];
+  for (int k = L.qp_start[q] + part; k < k1; k += parts) {
+    const int2 pr    = L.qp_list[k];
+    const double* Pe = L.Ps + (size_t) pr.x * D * D;
+    if (pr.y < 0) {
+      mg_block_mac<D, false>(w, L.Hd + (size_t) i * D * D, Pe);
+    } else {
+      const double* B = L.Ho + (size_t) (pr.y >> 1) * D * D;
+      if (pr.y & 1)
+        mg_block_mac<D, true>(w, B, Pe);
+      else
+        mg_block_mac<D, false>(w, B, Pe);
+    }
+  }
+  mg_group_sum<D * D>(w, parts);
+  if (part != 0) return;
+  double* out = L.Q + (size_t) q * D * D;
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) out[k] = w[k];
+}
+
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin_list(MgPair LV, int parts) {
+  const MgLevel L = LV.L;
+  const MgLevel C = LV.C;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (L.nc + L.nce) * parts) return;
+  const int part = t & (parts - 1), blk = t / parts;
+  double acc[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) acc[k] = 0.0;
+  double* out;
+  if (blk < L.nc) {  // diagonal block A: the entries of column A of Ps against the entries of Q in their rows, column A
+    out = C.Hd + (size_t) blk * D * D;
+    for (int m = L.pcsc_start[blk] + part; m < L.pcsc_start[blk + 1]; m += parts) {
+      const int e = L.pcsc_ent[m];
+      mg_block_mac<D, true>(acc, L.Ps + (size_t) e * D * D, L.Q + (size_t) L.qdiag[e] * D * D);
+    }
+  } else {
+    const int ke = blk - L.nc;
+    out = C.Ho + (size_t) ke * D * D;
+    const int k1 = L.gp_start[ke + 1];
+    for (int k = L.gp_start[ke] + part; k < k1; k += parts) {
+      const int2 pr = L.gp_list[k];
+      mg_block_mac<D, true>(acc, L.Ps + (size_t) pr.x * D * D, L.Q + (size_t) pr.y * D * D);
+    }
+  }
+  mg_group_sum<D * D>(acc, parts);
+  if (part != 0) return;
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) out[k] = acc[k];
+}
+
 // inverse diagonal blocks of level l (the smoother)
 template <int D>
 __global__ __launch_bounds__(PG_THREADS) void k_mg_dinv(MgPair LV, PgScalars* __restrict__ sc) {
@@ -1512,7 +1590,11 @@ struct MgLevelBufs {
   DevBuf<int> qcsc_start, qcsc_ent;
   DevBuf<int2> pcsc2, qcsc2;
   DevBuf<double> Hd, Ho, Ps, Q, Dinv, x, r, res;
+  DevBuf<unsigned long long> qp_list, gp_list;  // (int2 {x, y} = the low and the high word)
+  DevBuf<int> qp_start, gp_start, qdiag;
+  long long nqp = 0, ngp = 0;                   // products of Q = H Ps / of the coarse edges
   void release() {
+    qp_list.release(); gp_list.release(); qp_start.release(); gp_start.release(); qdiag.release();
     eij.release(); inc_start.release(); inc_adj.release(); agg.release(); rep0.release(); prow_start.release();
     pcol.release(); prow_of.release(); pcsc_start.release(); pcsc_ent.release(); qrow_start.release(); qcol.release();
     qrow_of.release(); Hd.release(); Ho.release(); P.release(); Ps.release(); Q.release(); Dinv.release(); x.release();
@@ -1552,11 +1634,15 @@ struct srrg2_posegraph_s {
     bool debug = false;         // SRRG2_AMD_PG_DEBUG
     bool keep_structure = true; // the hierarchy's structure survives a set() with the same topology
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
+    bool product_lists = true;     // SRRG2_AMD_PG_PRODUCT_LISTS: the set-up products over the lists the pattern build leaves (round 6; 0: the searching kernels)
+    int list_lane_products = 4;    // SRRG2_AMD_PG_LIST_LANES: products per lane the list kernels aim at
     bool fused_cg = true;          // SRRG2_AMD_PG_FUSED_CG: 14 launches per CG iteration instead of 18 (round 6; an A/B switch: same numbers)
   } sw;
   // scratch of the device-side pattern build (pg_device_patterns)
   DevBuf<unsigned long long> st_keys_a, st_keys_b;
   DevBuf<int> st_cnt, st_off, st_slot, st_ia, st_ib, st_counts;
+  DevBuf<unsigned long long> st_vals;  // payload of the candidate keys (the product lists)
+  DevBuf<unsigned> st_rle;             // run lengths of the sorted keys
   DevBuf<unsigned long long> st_total;
   unsigned long long st_offset_limit = 0x7fff0000ull;  // candidate lists beyond this many entries: the host build (32-bit offsets);
                                                        // SRRG2_AMD_PG_OFFSET_LIMIT lowers it (tests of that fallback)
@@ -1822,13 +1908,19 @@ __global__ __launch_bounds__(PG_THREADS) void k_st_q_candidates(int slots, int n
                                                                 const int* __restrict__ inc_start, const int2* __restrict__ inc_adj,
                                                                 const int* __restrict__ prow_start, const int* __restrict__ pcol,
                                                                 const int* __restrict__ cnt, const int* __restrict__ off,
-                                                                st_key* __restrict__ keys) {
+                                                                st_key* __restrict__ keys, unsigned long long* __restrict__ vals) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= slots || cnt[t] == 0) return;
   const int v = slot_node[t];
-  const int j = st_slot_other(t, v, inc_start, inc_adj);
+  const int s = t - (v + inc_start[v]);
+  const int2 adj = s == 0 ? make_int2(v, -1) : inc_adj[inc_start[v] + s - 1];  // (.y: the block of H this slot multiplies by; -1 = the diagonal one)
+  const int j = adj.x;
   st_key* out = keys + off[t];
-  for (int e = prow_start[j], k = 0; e < prow_start[j + 1]; ++e, ++k) out[k] = (st_key) v * (st_key) (nc + 1) + (st_key) pcol[e];
+  unsigned long long* vo = vals + off[t];
+  for (int e = prow_start[j], k = 0; e < prow_start[j + 1]; ++e, ++k) {
+    out[k] = (st_key) v * (st_key) (nc + 1) + (st_key) pcol[e];
+    vo[k]  = ((unsigned long long) (unsigned) adj.y << 32) | (unsigned) e;  // int2 {entry of Ps, block of H}
+  }
 }
 // *total += sum of cnt[0, m) in 64 bits (the guards against fill and against 32-bit offsets look at this one)
 __global__ __launch_bounds__(PG_THREADS) void k_st_sum64(int m, const int* __restrict__ cnt, unsigned long long* __restrict__ total) {
@@ -1863,7 +1955,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_st_columns(int m, int ncols, con
 // entry e = Ps[i, A] puts the columns B > A of row i of Q into row A of the coarse pattern
 __global__ __launch_bounds__(PG_THREADS) void k_st_ce_count(int np, const int* __restrict__ pcol, const int* __restrict__ prow_of,
                                                             const int* __restrict__ qrow_start, const int* __restrict__ qcol,
-                                                            int* __restrict__ first, int* __restrict__ cnt) {
+                                                            int* __restrict__ first, int* __restrict__ cnt, int* __restrict__ qdiag) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= np) return;
   const int A = pcol[e], i = prow_of[e];
@@ -1875,16 +1967,21 @@ __global__ __launch_bounds__(PG_THREADS) void k_st_ce_count(int np, const int* _
   }
   first[e] = lo;
   cnt[e]   = end - lo;
+  qdiag[e] = lo - 1;  // (column A itself: the row of Q holds every column of the row of Ps)
 }
 __global__ __launch_bounds__(PG_THREADS) void k_st_ce_candidates(int np, int nc, const int* __restrict__ pcol,
                                                                  const int* __restrict__ qcol, const int* __restrict__ first,
                                                                  const int* __restrict__ cnt, const int* __restrict__ off,
-                                                                 st_key* __restrict__ keys) {
+                                                                 st_key* __restrict__ keys, unsigned long long* __restrict__ vals) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= np) return;
   const st_key A = (st_key) pcol[e];
   st_key* out    = keys + off[e];
-  for (int k = 0; k < cnt[e]; ++k) out[k] = A * (st_key) (nc + 1) + (st_key) qcol[first[e] + k];
+  unsigned long long* vo = vals + off[e];
+  for (int k = 0; k < cnt[e]; ++k) {
+    out[k] = A * (st_key) (nc + 1) + (st_key) qcol[first[e] + k];
+    vo[k]  = ((unsigned long long) (unsigned) (first[e] + k) << 32) | (unsigned) e;  // int2 {entry of Ps, entry of Q}
+  }
 }
 __global__ __launch_bounds__(PG_THREADS) void k_st_ce_decode(int nc, const int* __restrict__ counts, int which,
                                                              const st_key* __restrict__ keys, int2* __restrict__ ceij) {
@@ -1902,24 +1999,49 @@ inline int st_bits(unsigned long long x) {  // number of bits needed for the val
 }
 inline dim3 st_grid(size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); }
 
-// sorted unique keys of keys_a[0, m) -> keys_b[0, counts[which]) (`none` keys dropped from the count)
-int st_sort_unique(srrg2_posegraph_s* g, int m, st_key none, int which) {
+// sorted unique keys of keys_a[0, m) -> keys_a[0, counts[which]) (`none` keys dropped from the count); their run lengths stay in
+// st_rle.  vals_out: the keys carry st_vals as payload -- a radix sort is stable, so the payloads of equal keys keep the order in
+// which the candidates were written -- sorted into vals_out: with st_run_starts, the product lists of the pattern's entries.
+// (rocPRIM directly: sort, run-length encode, scan; round 5 went through the hipCUB layer)
+__global__ void k_st_set(int* __restrict__ p, int v) { *p = v; }
+int st_sort_unique(srrg2_posegraph_s* g, int m, st_key none, int which, unsigned long long* vals_out = nullptr) {
   int rc;
   size_t t1 = 0, t2 = 0;
-  const int end_bit = std::min(64, st_bits(none));
-  if ((rc = g->st_keys_b.reserve((size_t) std::max(m, 1)))) return rc;
+  const unsigned end_bit = (unsigned) std::min(64, st_bits(none));
+  if ((rc = g->st_keys_b.reserve((size_t) std::max(m, 1))) || (rc = g->st_rle.reserve((size_t) std::max(m, 1)))) return rc;
   if (m == 0) {  // (nothing to sort: an empty pattern)
     HIP_TRY(hipMemsetAsync(g->st_counts.p + which, 0, sizeof(int), g->stream));
     return 0;
   }
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, t1, g->st_keys_a.p, g->st_keys_b.p, m, 0, end_bit, g->stream));
-  HIP_TRY(hipcub::DeviceSelect::Unique(nullptr, t2, g->st_keys_b.p, g->st_keys_a.p, g->st_counts.p + 7, m, g->stream));
+  unsigned* nruns = reinterpret_cast<unsigned*>(g->st_counts.p + 7);
+  if (vals_out)
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, g->st_keys_a.p, g->st_keys_b.p, g->st_vals.p, vals_out, (unsigned) m, 0u, end_bit, g->stream));
+  else
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, t1, g->st_keys_a.p, g->st_keys_b.p, (unsigned) m, 0u, end_bit, g->stream));
+  HIP_TRY(rocprim::run_length_encode(nullptr, t2, g->st_keys_b.p, (unsigned) m, g->st_keys_a.p, g->st_rle.p, nruns, g->stream));
   if ((rc = g->st_temp.reserve(std::max(t1, t2) + 256))) return rc;
   t1 = t2 = g->st_temp.cap;
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(g->st_temp.p, t1, g->st_keys_a.p, g->st_keys_b.p, m, 0, end_bit, g->stream));
-  HIP_TRY(hipcub::DeviceSelect::Unique(g->st_temp.p, t2, g->st_keys_b.p, g->st_keys_a.p, g->st_counts.p + 7, m, g->stream));
+  if (vals_out)
+    HIP_TRY(rocprim::radix_sort_pairs(g->st_temp.p, t1, g->st_keys_a.p, g->st_keys_b.p, g->st_vals.p, vals_out, (unsigned) m, 0u, end_bit, g->stream));
+  else
+    HIP_TRY(rocprim::radix_sort_keys(g->st_temp.p, t1, g->st_keys_a.p, g->st_keys_b.p, (unsigned) m, 0u, end_bit, g->stream));
+  HIP_TRY(rocprim::run_length_encode(g->st_temp.p, t2, g->st_keys_b.p, (unsigned) m, g->st_keys_a.p, g->st_rle.p, nruns, g->stream));
   hipLaunchKernelGGL(k_st_valid, dim3(1), dim3(1), 0, g->stream, g->st_keys_a.p, g->st_counts.p + 7, none, g->st_counts.p, which);
   return 0;  // (the unique keys are in st_keys_a again)
+}
+// starts[0 .. nruns] = the offsets of the runs of the last st_sort_unique (no `none` key among them), starts[nruns] = total
+int st_run_starts(srrg2_posegraph_s* g, int nruns, int total, DevBuf<int>& starts) {
+  int rc;
+  if ((rc = starts.reserve((size_t) nruns + 1))) return rc;
+  if (nruns > 0) {
+    size_t t = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, t, g->st_rle.p, starts.p, 0, (size_t) nruns, rocprim::plus<int>(), g->stream));
+    if ((rc = g->st_temp.reserve(t + 256))) return rc;
+    t = g->st_temp.cap;
+    HIP_TRY(rocprim::exclusive_scan(g->st_temp.p, t, g->st_rle.p, starts.p, 0, (size_t) nruns, rocprim::plus<int>(), g->stream));
+  }
+  hipLaunchKernelGGL(k_st_set, dim3(1), dim3(1), 0, g->stream, starts.p + nruns, total);
+  return 0;
 }
 int st_exclusive_sum(srrg2_posegraph_s* g, int m, int which) {
   int rc;
@@ -1929,10 +2051,10 @@ int st_exclusive_sum(srrg2_posegraph_s* g, int m, int which) {
     HIP_TRY(hipMemsetAsync(g->st_counts.p + which, 0, sizeof(int), g->stream));
     return 0;
   }
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t, g->st_cnt.p, g->st_off.p, m, g->stream));
+  HIP_TRY(rocprim::exclusive_scan(nullptr, t, g->st_cnt.p, g->st_off.p, 0, (size_t) m, rocprim::plus<int>(), g->stream));
   if ((rc = g->st_temp.reserve(t + 256))) return rc;
   t = g->st_temp.cap;
-  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(g->st_temp.p, t, g->st_cnt.p, g->st_off.p, m, g->stream));
+  HIP_TRY(rocprim::exclusive_scan(g->st_temp.p, t, g->st_cnt.p, g->st_off.p, 0, (size_t) m, rocprim::plus<int>(), g->stream));
   hipLaunchKernelGGL(k_st_total, dim3(1), dim3(1), 0, g->stream, m, g->st_cnt.p, g->st_off.p, g->st_counts.p, which);
   return 0;
 }
@@ -1965,11 +2087,11 @@ int st_columns(srrg2_posegraph_s* g, int m, int ncols, const int* col, const int
   }
   hipLaunchKernelGGL(k_st_iota, st_grid((size_t) m), dim3(PG_THREADS), 0, g->stream, m, g->st_ia.p);
   size_t t = 0;
-  const int end_bit = st_bits((unsigned long long) std::max(ncols, 1));
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, t, col, g->st_ib.p, g->st_ia.p, csc_ent.p, m, 0, end_bit, g->stream));
+  const unsigned end_bit = (unsigned) st_bits((unsigned long long) std::max(ncols, 1));
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, t, col, g->st_ib.p, g->st_ia.p, csc_ent.p, (unsigned) m, 0u, end_bit, g->stream));
   if ((rc = g->st_temp.reserve(t + 256))) return rc;
   t = g->st_temp.cap;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(g->st_temp.p, t, col, g->st_ib.p, g->st_ia.p, csc_ent.p, m, 0, end_bit, g->stream));
+  HIP_TRY(rocprim::radix_sort_pairs(g->st_temp.p, t, col, g->st_ib.p, g->st_ia.p, csc_ent.p, (unsigned) m, 0u, end_bit, g->stream));
   hipLaunchKernelGGL(k_st_columns, st_grid((size_t) std::max(m, ncols + 1)), dim3(PG_THREADS), 0, g->stream, m, ncols,
                      g->st_ib.p, csc_ent.p, row_of, csc_start.p, csc2.p);
   return 0;
@@ -2019,12 +2141,16 @@ int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int 
     bound = (int) bound64;
     break;
   }
-  if ((rc = g->st_keys_a.reserve((size_t) std::max(bound, 1)))) return rc;
+  if ((rc = g->st_keys_a.reserve((size_t) std::max(bound, 1))) || (rc = g->st_vals.reserve((size_t) std::max(bound, 1))) ||
+      (rc = L->qp_list.reserve((size_t) std::max(bound, 1))))
+    return rc;
   hipLaunchKernelGGL(k_st_q_candidates, st_grid((size_t) slots), dim3(PG_THREADS), 0, g->stream, slots, nc, g->st_slot.p,
-                     L->inc_start.p, L->inc_adj.p, L->prow_start.p, L->pcol.p, g->st_cnt.p, g->st_off.p, g->st_keys_a.p);
-  if ((rc = st_sort_unique(g, bound, (st_key) n * row, 2)) || (rc = st_read_count(g, 2, &nq))) return rc;
+                     L->inc_start.p, L->inc_adj.p, L->prow_start.p, L->pcol.p, g->st_cnt.p, g->st_off.p, g->st_keys_a.p, g->st_vals.p);
+  if ((rc = st_sort_unique(g, bound, (st_key) n * row, 2, L->qp_list.p)) || (rc = st_read_count(g, 2, &nq))) return rc;
   stage(2);
   if (*smoothed && (long long) nq > q_limit) return 1;
+  if ((rc = st_run_starts(g, nq, bound, L->qp_start))) return rc;  // (the candidates of an entry of Q = its products)
+  L->nqp = bound;
   if ((rc = L->qcol.reserve((size_t) std::max(nq, 1))) || (rc = L->qrow_of.reserve((size_t) std::max(nq, 1)))) return rc;
   hipLaunchKernelGGL(k_st_decode, st_grid((size_t) std::max(nq, n + 1)), dim3(PG_THREADS), 0, g->stream, n, nc, g->st_counts.p, 2,
                      g->st_keys_a.p, L->qrow_start.p, L->qcol.p, L->qrow_of.p);
@@ -2033,9 +2159,11 @@ int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int 
     return rc;
   // coarse edges
   int mce = 0, nce = 0;
-  if ((rc = g->st_cnt.reserve((size_t) std::max(np, 1))) || (rc = g->st_ia.reserve((size_t) std::max(np, 1)))) return rc;
+  if ((rc = g->st_cnt.reserve((size_t) std::max(np, 1))) || (rc = g->st_ia.reserve((size_t) std::max(np, 1))) ||
+      (rc = L->qdiag.reserve((size_t) std::max(np, 1))))
+    return rc;
   hipLaunchKernelGGL(k_st_ce_count, st_grid((size_t) np), dim3(PG_THREADS), 0, g->stream, np, L->pcol.p, L->prow_of.p,
-                     L->qrow_start.p, L->qcol.p, g->st_ia.p, g->st_cnt.p);
+                     L->qrow_start.p, L->qcol.p, g->st_ia.p, g->st_cnt.p, L->qdiag.p);
   {
     unsigned long long mce64 = 0;
     if ((rc = st_total_of_counts(g, np, &mce64))) return rc;
@@ -2044,10 +2172,14 @@ int pg_device_patterns(srrg2_posegraph_s* g, MgLevelBufs* L, int n, int ne, int 
     mce = (int) mce64;
   }
   if ((rc = st_exclusive_sum(g, np, 3))) return rc;
-  if ((rc = g->st_keys_a.reserve((size_t) std::max(mce, 1)))) return rc;
+  if ((rc = g->st_keys_a.reserve((size_t) std::max(mce, 1))) || (rc = g->st_vals.reserve((size_t) std::max(mce, 1))) ||
+      (rc = L->gp_list.reserve((size_t) std::max(mce, 1))))
+    return rc;
   hipLaunchKernelGGL(k_st_ce_candidates, st_grid((size_t) np), dim3(PG_THREADS), 0, g->stream, np, nc, L->pcol.p, L->qcol.p,
-                     g->st_ia.p, g->st_cnt.p, g->st_off.p, g->st_keys_a.p);
-  if ((rc = st_sort_unique(g, mce, (st_key) nc * row, 4)) || (rc = st_read_count(g, 4, &nce))) return rc;
+                     g->st_ia.p, g->st_cnt.p, g->st_off.p, g->st_keys_a.p, g->st_vals.p);
+  if ((rc = st_sort_unique(g, mce, (st_key) nc * row, 4, L->gp_list.p)) || (rc = st_read_count(g, 4, &nce))) return rc;
+  if ((rc = st_run_starts(g, nce, mce, L->gp_start))) return rc;  // (the candidates of a coarse edge = its products)
+  L->ngp = mce;
   ceij->assign(2 * (size_t) nce, 0);
   if (nce > 0) {
     // (decoded into the key scratch's other half, read back for the next level's matching)
@@ -2350,6 +2482,72 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         ceij[2 * (size_t) k]     = A;
         ceij[2 * (size_t) k + 1] = ce_col[(size_t) k];
       }
+    // The product lists (MgLevel::qp_list / gp_list / qdiag), in the order the device build's stable sort leaves them: an entry
+    // of Q takes the slots of its row in order -- the node itself, then its incidences -- and every slot's row of Ps ascending;
+    // a coarse edge (A, B) takes the entries of column A of Ps in row order.  Two passes each (count, fill), rows / columns
+    // dealt to the pool's threads: every output list belongs to one row resp. one column.
+    std::vector<int> qp_start((size_t) nq + 1, 0), gp_start(ce_col.size() + 1, 0), qdiag((size_t) std::max(np, 1), 0);
+    std::vector<unsigned long long> qp_list, gp_list;
+    {
+      const int nt = (int) std::max(1LL, std::min((long long) pool.size(), ((long long) nq + np) / 16384 + 1));
+      auto rows_of = [&](int t, int total) { return std::make_pair((int) ((long long) total * t / nt), (int) ((long long) total * (t + 1) / nt)); };
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+          for (size_t q = 0; q < (size_t) nq; ++q) qp_start[q + 1] += qp_start[q];
+          qp_list.resize((size_t) std::max(qp_start[(size_t) nq], 1));
+        }
+        pool.run(nt, [&](int t) {
+          std::vector<int> colpos((size_t) std::max(nc, 1), -1), cur;
+          const auto rr = rows_of(t, n);
+          for (int v = rr.first; v < rr.second; ++v) {
+            if (agg[(size_t) v] < 0) continue;
+            const int q0 = qrow_start[(size_t) v], q1 = qrow_start[(size_t) v + 1];
+            for (int q = q0; q < q1; ++q) colpos[(size_t) qcol[(size_t) q]] = q;
+            if (pass == 1) cur.assign(qp_start.begin() + q0, qp_start.begin() + q1);
+            auto slot = [&](int j, int hcode) {
+              for (int e = prow_start[(size_t) j]; e < prow_start[(size_t) j + 1]; ++e) {
+                const int q = colpos[(size_t) pcol[(size_t) e]];
+                if (pass == 0)
+                  qp_start[(size_t) q + 1]++;
+                else
+                  qp_list[(size_t) cur[(size_t) (q - q0)]++] = ((unsigned long long) (unsigned) hcode << 32) | (unsigned) e;
+              }
+            };
+            slot(v, -1);
+            for (int k = inc_start[(size_t) v]; k < inc_start[(size_t) v + 1]; ++k) slot(inc_adj[(size_t) k].x, inc_adj[(size_t) k].y);
+          }
+        });
+      }
+      const int nce_h = (int) ce_col.size();
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+          for (size_t k = 0; k < (size_t) nce_h; ++k) gp_start[k + 1] += gp_start[k];
+          gp_list.resize((size_t) std::max(gp_start[(size_t) nce_h], 1));
+        }
+        pool.run(nt, [&](int t) {
+          std::vector<int> cur;
+          const auto cr = rows_of(t, nc);
+          for (int A = cr.first; A < cr.second; ++A) {
+            const int k0 = ce_start[(size_t) A], k1 = ce_start[(size_t) A + 1];
+            if (pass == 1) cur.assign(gp_start.begin() + k0, gp_start.begin() + k1);
+            for (int m = pcsc_start[(size_t) A]; m < pcsc_start[(size_t) A + 1]; ++m) {
+              const int e = pcsc_ent[(size_t) m], i = prow_of[(size_t) e];
+              const int* first = qcol.data() + qrow_start[(size_t) i];
+              const int* end   = qcol.data() + qrow_start[(size_t) i + 1];
+              const int* q     = std::upper_bound(first, end, A);
+              if (pass == 0) qdiag[(size_t) e] = (int) (q - qcol.data()) - 1;
+              for (; q < end; ++q) {
+                const int k = (int) (std::lower_bound(ce_col.begin() + k0, ce_col.begin() + k1, *q) - ce_col.begin());
+                if (pass == 0)
+                  gp_start[(size_t) k + 1]++;
+                else
+                  gp_list[(size_t) cur[(size_t) (k - k0)]++] = ((unsigned long long) (unsigned) (q - qcol.data()) << 32) | (unsigned) e;
+              }
+            }
+          }
+        });
+      }
+    }
     ms_ce += ms_since(t_ce);
     ms_pattern += ms_since(t_pattern);
     const auto t_up0 = std::chrono::steady_clock::now();
@@ -2357,8 +2555,12 @@ int build_hierarchy(srrg2_posegraph_s* g) {
         (rc = upload(L->prow_of, prow_of)) || (rc = upload(L->pcsc_start, pcsc_start)) || (rc = upload(L->pcsc_ent, pcsc_ent)) ||
         (rc = upload(L->qrow_start, qrow_start)) || (rc = upload(L->qcol, qcol)) || (rc = upload(L->qrow_of, qrow_of)) ||
         (rc = upload(L->qcsc_start, qcsc_start)) || (rc = upload(L->qcsc_ent, qcsc_ent)) ||
-        (rc = upload(L->pcsc2, pcsc2)) || (rc = upload(L->qcsc2, qcsc2)))
+        (rc = upload(L->pcsc2, pcsc2)) || (rc = upload(L->qcsc2, qcsc2)) || (rc = upload(L->qp_start, qp_start)) ||
+        (rc = upload(L->qp_list, qp_list)) || (rc = upload(L->gp_start, gp_start)) || (rc = upload(L->gp_list, gp_list)) ||
+        (rc = upload(L->qdiag, qdiag)))
       return rc;
+    L->nqp = qp_start[(size_t) nq];
+    L->ngp = gp_start[ce_col.size()];
     ms_up += ms_since(t_up0);
     }  // (host patterns)
     const int nce = (int) (ceij.size() / 2);
@@ -2390,7 +2592,9 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   }
   if (g->sw.debug) {
     std::fprintf(stderr, "posegraph hierarchy:");
-    for (MgLevelBufs* L : g->levels) std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative");
+    for (MgLevelBufs* L : g->levels)
+      std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s; products %lld + %lld) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative",
+                   L->nc > 0 ? L->nqp : 0LL, L->nc > 0 ? L->ngp : 0LL);
     std::fprintf(stderr, " coarsest %s; built in %.1f ms (matching on the host %.1f, patterns on the %s %.1f)\n",
                  g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, device_structure ? "device" : "host", ms_pattern);
     if (device_structure)
@@ -2414,6 +2618,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     v.Hdf = L->Hdf.p; v.Hof = L->Hof.p; v.Dinvf = L->Dinvf.p;
     v.Psf = l + 1 < nl ? L->Psf.p : nullptr; v.Qf = l + 1 < nl ? L->Qf.p : nullptr;
     v.qcsc_start = L->qcsc_start.p; v.qcsc_ent = L->qcsc_ent.p; v.pcsc2 = L->pcsc2.p; v.qcsc2 = L->qcsc2.p;
+    v.qp_start = L->qp_start.p; v.qp_list = reinterpret_cast<const int2*>(L->qp_list.p); v.gp_start = L->gp_start.p;
+    v.gp_list = reinterpret_cast<const int2*>(L->gp_list.p); v.qdiag = L->qdiag.p;
     v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Ps = L->Ps.p; v.Q = L->Q.p; v.Dinv = L->Dinv.p; v.x = L->x.p;
     v.r = L->r.p; v.res = L->res.p;
   }
@@ -2603,9 +2809,22 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         const MgPair sp_p = setup_pair((size_t) L->np), sp_q = setup_pair((size_t) L->nq);
         hipLaunchKernelGGL(k_mg_psmooth<D>, grid_of((size_t) L->np * sp_p.L.row_parts), dim3(PG_THREADS), 0, g->stream,
                            sp_p, L->smoothed ? omega_p : 0.0);
+        if (g->sw.product_lists) {
+          // lanes per output block: ~list_lane_products products each (C5: 3.3 / 14 / 60 products per entry of Q on levels 0 - 2)
+          auto lanes_for = [&](double per_block, int cap) {
+            int lanes = 1;
+            while (lanes < cap && per_block > (double) g->sw.list_lane_products * lanes) lanes *= 2;
+            return lanes;
+          };
+          const int lq = lanes_for(L->nq > 0 ? (double) L->nqp / L->nq : 0.0, 16);
+          const int lg = lanes_for(L->nc + L->nce > 0 ? (double) (L->ngp + L->np) / (L->nc + L->nce) : 0.0, 32);
+          hipLaunchKernelGGL(k_mg_hp_list<D>, grid_of((size_t) L->nq * lq), dim3(PG_THREADS), 0, g->stream, pair(l), lq);
+          hipLaunchKernelGGL(k_mg_galerkin_list<D>, grid_of((size_t) (L->nc + L->nce) * lg), dim3(PG_THREADS), 0, g->stream, pair(l), lg);
+        } else {
         hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * sp_q.L.row_parts), dim3(PG_THREADS), 0, g->stream, sp_q);
         hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
                            pair(l));
+        }
         hipLaunchKernelGGL(k_mg_dinv<D>, dim3((unsigned) ((L->nc + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
                            pair(l + 1), g->sc.p);
       }
@@ -2858,6 +3077,8 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_PRODUCT_LISTS")) g->sw.product_lists = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_LIST_LANES")) g->sw.list_lane_products = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("SRRG2_AMD_PG_OFFSET_LIMIT")) g->st_offset_limit = std::min<unsigned long long>(std::strtoull(e, nullptr, 10), 0x7fff0000ull);
     if (t.match_passes < 1) t.match_passes = 1;
     apply_tuning(g, t);
@@ -2882,6 +3103,7 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   g->coarse_A.release(); g->coarse_inv.release();
   g->st_keys_a.release(); g->st_keys_b.release(); g->st_cnt.release(); g->st_off.release(); g->st_slot.release();
   g->st_ia.release(); g->st_ib.release(); g->st_counts.release(); g->st_total.release(); g->st_temp.release();
+  g->st_vals.release(); g->st_rle.release();
   for (MgLevelBufs* L : g->level_pool) {
     L->release();
     delete L;
