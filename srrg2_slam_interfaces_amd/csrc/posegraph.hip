@@ -757,16 +757,9 @@ __device__ __forceinline__ void mg_block_mul(const float* __restrict__ B, const 
 // xc: the coarse correction (levels[l + 1].res when that level is a two-phase level too, else its x)
 // A node owns NL = 8 * parts adjacent lanes; every lane takes WHOLE blocks of the node's rows of H, Q and Ps (all D rows
 // of the result from one 144-byte load, two blocks in flight), the lanes of a node meet by shuffles.
+// (lane k of the NL lanes of node v; `on`: the node exists)
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_up2(MgPair LV, int parts, int xc_in_res,
-                                                       const PgScalars* __restrict__ sc) {
-  if (sc->done || sc->bad) return;
-  const MgLevel L = LV.L;
-  const double* __restrict__ xc = xc_in_res ? LV.C.res : LV.C.x;
-  const int t  = blockIdx.x * blockDim.x + threadIdx.x;
-  const int NL = 8 * parts;
-  const int k = t & (NL - 1), v = t / NL;
-  const bool on = v < L.n;
+__device__ __forceinline__ void mg_up2_node(const MgLevel& L, const double* __restrict__ xc, int v, int k, int NL, bool on) {
   double y[D], p[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) y[a] = p[a] = 0.0;
@@ -810,6 +803,123 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_up2(MgPair LV, int parts, int
     }
     L.res[(size_t) v * D + k] = L.x[(size_t) v * D + k] + pk + L.omega * u;
   }
+}
+
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_up2(MgPair LV, int parts, int xc_in_res,
+                                                       const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = LV.L;
+  const double* __restrict__ xc = xc_in_res ? LV.C.res : LV.C.x;
+  const int t  = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NL = 8 * parts;
+  const int k = t & (NL - 1), v = t / NL;
+  mg_up2_node<D>(L, xc, v, k, NL, v < L.n);
+}
+
+// The bottom of the cycle as ONE dense operator (round 6).  The last two-phase level L (C5: 100 nodes) and the dense coarsest
+// level behind it (13 nodes) were two launches of dependent round trips -- k_mg_down2_coarsest 19.7 us (column starts -> {entry,
+// row} pairs -> blocks and vectors -> LDS -> dense solve) and k_mg_up2 10.1 us -- for < 1 MB of operands.  What they compute is
+// linear in the level's r:   x1 = S r (S = omega D^-1),  x_c = Cinv (Ps^T r - Q^T x1) = Cinv G^T r with G = Ps - S Q,
+//   res = x1 + Ps x_c + S (r - H x1 - Q x_c) = (2 S - S H S) r + G Cinv G^T r = B r,
+// an N x N matrix (N = 600) that the set-up forms once per hierarchy (k_bd_*: four small launches after the coarsest inverse) and the
+// cycle applies in one launch with no index and no dependent load (k_mg_bottom_dense: ~5 us).  The same operator up to rounding
+// (formed from the float64 blocks, stored as float32 like the cycle's other copies, upper triangle mirrored: exactly symmetric).
+// A first attempt fused the two launches as they were, every workgroup of the up phase redoing the down phase for itself: 33.7 us
+// against 29.8 (profiles/r9d).
+template <int D, bool TRANSPOSE_A, typename TB>
+__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* __restrict__ A, const TB* __restrict__ B);  // (below)
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_bd_g(MgPair LV, double* __restrict__ G) {
+  // G[i, A] = Ps[i, A] - S_i Q[i, A]   (dense N x M, zero where neither has an entry)
+  const MgLevel L = LV.L;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.n * L.nc) return;
+  const int i = t / L.nc, A = t - i * L.nc;
+  const int M = L.nc * D;
+  double g[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) g[k] = 0.0;
+  const int q = mg_find(L.qcol, L.qrow_start[i], L.qrow_start[i + 1], A);
+  if (q >= 0) mg_block_mac<D, false>(g, L.Dinv + (size_t) i * D * D, L.Q + (size_t) q * D * D);
+  const int e = mg_find(L.pcol, L.prow_start[i], L.prow_start[i + 1], A);
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      G[(size_t) (i * D + r) * M + A * D + c] = (e >= 0 ? L.Ps[(size_t) e * D * D + r * D + c] : 0.0) - L.omega * g[r * D + c];
+}
+// W = G Cinv   (N x M)
+__global__ __launch_bounds__(PG_THREADS) void k_bd_w(int N, int M, const double* __restrict__ G, const double* __restrict__ Cinv,
+                                                      double* __restrict__ W) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * M) return;
+  const int row = t / M, c = t - row * M;
+  double s = 0.0;
+  for (int k = 0; k < M; ++k) s = s + G[(size_t) row * M + k] * Cinv[(size_t) k * M + c];
+  W[t] = s;
+}
+// A = 2 S - S H S into the dense accumulator (zeroed before): one thread per diagonal block / per off-diagonal block of H (written
+// to both sides; the blocks of a level below level 0 are unique per node pair)
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_bd_a(MgPair LV, double* __restrict__ Bacc) {
+  const MgLevel L = LV.L;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.n + L.ne) return;
+  const int N = L.n * D;
+  const double w = L.omega;
+  int i, j;
+  const double* H;
+  if (t < L.n) {
+    i = j = t;
+    H = L.Hd + (size_t) t * D * D;
+  } else {
+    const int2 ij = L.eij[t - L.n];
+    i = ij.x;
+    j = ij.y;
+    H = L.Ho + (size_t) (t - L.n) * D * D;
+  }
+  double T[D * D], U[D * D];
+#pragma unroll
+  for (int k = 0; k < D * D; ++k) T[k] = U[k] = 0.0;
+  mg_block_mac<D, false>(T, H, L.Dinv + (size_t) j * D * D);  // H_ij Dinv_j
+  mg_block_mac<D, false>(U, L.Dinv + (size_t) i * D * D, T);  // Dinv_i H_ij Dinv_j
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double v = -(w * w) * U[r * D + c];
+      if (i == j) v = v + 2.0 * w * L.Dinv[(size_t) i * D * D + r * D + c];
+      Bacc[(size_t) (i * D + r) * N + j * D + c] = v;
+      if (i != j) Bacc[(size_t) (j * D + c) * N + i * D + r] = v;
+    }
+}
+// B = A + W G^T, upper triangle computed and mirrored, stored as float32
+__global__ __launch_bounds__(PG_THREADS) void k_bd_b(int N, int M, const double* __restrict__ W, const double* __restrict__ G,
+                                                      const double* __restrict__ Bacc, float* __restrict__ Bf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * N) return;
+  const int row = t / N, c = t - row * N;
+  if (row > c) return;
+  double s = Bacc[(size_t) row * N + c];
+  for (int k = 0; k < M; ++k) s = s + W[(size_t) row * M + k] * G[(size_t) c * M + k];
+  Bf[(size_t) row * N + c] = (float) s;
+  Bf[(size_t) c * N + row] = (float) s;
+}
+// res = B r on the last two-phase level: 32 lanes per row
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_bottom_dense(MgPair LV, const float* __restrict__ Bf, const PgScalars* __restrict__ sc) {
+  if (sc->done || sc->bad) return;
+  const MgLevel L = LV.L;
+  const int N = L.n * D;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t >> 5, part = t & 31;
+  double s = 0.0;
+  if (row < N)
+    for (int c = part; c < N; c += 32) s = s + (double) Bf[(size_t) row * N + c] * L.r[c];
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) s = s + __shfl_xor(s, off);
+  if (row < N && part == 0) L.res[row] = s;
 }
 
 // x += Ps x_coarse with the coarse correction taken from the coarse level's `res` (a two-phase level below a six-phase one)
@@ -1621,6 +1731,8 @@ struct srrg2_posegraph_s {
   DevBuf<MgLevel> levels_dev;
   std::vector<MgLevel> level_views;      // host copies of the records in levels_dev (kernel arguments: MgPair)
   DevBuf<double> coarse_A, coarse_inv;
+  DevBuf<double> bottom_acc, bottom_G, bottom_W;  // the dense bottom operator of the cycle (k_bd_*): A = 2S - SHS, G = Ps - SQ, W = G Cinv
+  DevBuf<float> bottom_B;                         // ... and B = A + W G^T, what k_mg_bottom_dense applies
   int coarsest_dense = 1;
   // strategy knobs (srrg2_posegraph_tuning): defaults overridden by the SRRG2_AMD_PG_* environment ONCE, in
   // srrg2_posegraph_create; srrg2_posegraph_set_tuning replaces them
@@ -1636,6 +1748,7 @@ struct srrg2_posegraph_s {
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
     bool product_lists = true;     // SRRG2_AMD_PG_PRODUCT_LISTS: the set-up products over the lists the pattern build leaves (round 6; 0: the searching kernels)
     int list_lane_products = 4;    // SRRG2_AMD_PG_LIST_LANES: products per lane the list kernels aim at
+    bool fused_bottom = true;      // SRRG2_AMD_PG_FUSED_BOTTOM: the bottom of the cycle as one dense operator (k_mg_bottom_dense, round 6)
     bool fused_cg = true;          // SRRG2_AMD_PG_FUSED_CG: 14 launches per CG iteration instead of 18 (round 6; an A/B switch: same numbers)
   } sw;
   // scratch of the device-side pattern build (pg_device_patterns)
@@ -2290,51 +2403,44 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     for (int v = 0; v < n; ++v) agg[(size_t) v] = excluded[(size_t) v] ? -1 : v;  // singletons first
     int nagg = n;
     {
-      // pass structure: cur_id[v] = aggregate after the previous pass; adjacency between aggregates through the edges
-      std::vector<int> cur(agg);
+      // pass structure: cur[v] = aggregate of v after the previous pass, named by its first member (an aggregate a that takes a
+      // partner b keeps the name a, and a < b: every node below a has been matched by the time a is visited), so `cur[a] == a`
+      // says "a names an aggregate" and the representative position of aggregate a is node a's.  The candidates of an
+      // aggregate are the aggregates of its members' graph neighbours, enumerated through the members' incidence lists: the
+      // same candidate set as a neighbour list between aggregates (round 5 built one per pass from the edges: count, scan,
+      // fill -- three passes over 2 ne entries where this needs one over n), and the minimum with its tie-break does not care
+      // how often or in which order a candidate shows up: the same matching, 6.7 -> ~4 ms on C5.
+      std::vector<float> pos(3 * (size_t) n);
+      for (int v = 0; v < n; ++v) position(rep0[(size_t) v], pos.data() + 3 * (size_t) v);
+      std::vector<int> cur(agg), mstart, mlist, match((size_t) n);
       for (int pass = 0; pass < match_passes; ++pass) {
-        // representative position of each current aggregate = position of its first member
-        std::vector<int> first((size_t) n, -1);
-        for (int v = 0; v < n; ++v)
-          if (cur[(size_t) v] >= 0 && first[(size_t) cur[(size_t) v]] < 0) first[(size_t) cur[(size_t) v]] = v;
-        // neighbours of every current aggregate
-        // (the first pass needs no lists: every aggregate is one node, its incidence list IS its neighbour list)
-        const bool direct = pass == 0;
-        std::vector<int> nb_start((size_t) n + 1, 0), nb_list;  // (CSR, in edge order; serial: shared atomic counters
-        // across the host's two sockets were 2.6 x slower than one thread)
-        for (int e = 0; e < ne && !direct; ++e) {
-          const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
-          if (a < 0 || b < 0 || a == b) continue;
-          nb_start[(size_t) a + 1]++;
-          nb_start[(size_t) b + 1]++;
+        const bool direct = pass == 0;  // (every aggregate is one node)
+        if (!direct) {  // members of every aggregate (CSR by aggregate name, members ascending)
+          mstart.assign((size_t) n + 1, 0);
+          mlist.resize((size_t) n);
+          for (int v = 0; v < n; ++v)
+            if (cur[(size_t) v] >= 0) mstart[(size_t) cur[(size_t) v] + 1]++;
+          for (int a = 0; a < n; ++a) mstart[(size_t) a + 1] += mstart[(size_t) a];
+          std::vector<int> fill(mstart.begin(), mstart.end() - 1);
+          for (int v = 0; v < n; ++v)
+            if (cur[(size_t) v] >= 0) mlist[(size_t) fill[(size_t) cur[(size_t) v]]++] = v;
         }
-        for (int a = 0; a < n && !direct; ++a) nb_start[(size_t) a + 1] += nb_start[(size_t) a];
-        nb_list.resize((size_t) std::max(nb_start[(size_t) n], 1));
-        if (!direct) {
-          std::vector<int> fill(nb_start.begin(), nb_start.end() - 1);
-          for (int e = 0; e < ne; ++e) {
-            const int a = cur[(size_t) eij[2 * (size_t) e]], b = cur[(size_t) eij[2 * (size_t) e + 1]];
-            if (a < 0 || b < 0 || a == b) continue;
-            nb_list[(size_t) fill[(size_t) a]++] = b;
-            nb_list[(size_t) fill[(size_t) b]++] = a;
-          }
-        }
-        std::vector<int> match((size_t) n, -1);
+        std::fill(match.begin(), match.end(), -1);
         for (int a = 0; a < n; ++a) {
-          if (first[(size_t) a] < 0 || match[(size_t) a] >= 0) continue;
-          float pa[3];
-          position(rep0[(size_t) first[(size_t) a]], pa);
+          if (cur[(size_t) a] != a || match[(size_t) a] >= 0) continue;
+          const float* pa = pos.data() + 3 * (size_t) a;
           int best = -1;
           float bd = 3.0e38f;
-          const int k0 = direct ? inc_start[(size_t) a] : nb_start[(size_t) a];
-          const int k1 = direct ? inc_start[(size_t) a + 1] : nb_start[(size_t) a + 1];
-          for (int k = k0; k < k1; ++k) {
-            const int b = direct ? inc_adj[(size_t) k].x : nb_list[(size_t) k];
-            if (b < 0 || cur[(size_t) b] < 0 || match[(size_t) b] >= 0 || b == a) continue;
-            float pb[3];
-            position(rep0[(size_t) first[(size_t) b]], pb);
-            const float d = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]);
-            if (d < bd || (d == bd && b < best)) { bd = d; best = b; }
+          const int m0 = direct ? 0 : mstart[(size_t) a], m1 = direct ? 1 : mstart[(size_t) a + 1];
+          for (int m = m0; m < m1; ++m) {
+            const int v = direct ? a : mlist[(size_t) m];
+            for (int k = inc_start[(size_t) v]; k < inc_start[(size_t) v + 1]; ++k) {
+              const int b = cur[(size_t) inc_adj[(size_t) k].x];
+              if (b < 0 || b == a || match[(size_t) b] >= 0) continue;
+              const float* pb = pos.data() + 3 * (size_t) b;
+              const float d = (pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) + (pa[2] - pb[2]) * (pa[2] - pb[2]);
+              if (d < bd || (d == bd && b < best)) { bd = d; best = b; }
+            }
           }
           match[(size_t) a] = a;
           if (best >= 0) match[(size_t) best] = a;
@@ -2685,6 +2791,16 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   // convergence test, `tail` = the caller's k_pg_update_dot applies the last update; sw.fused_cg)
   const bool fused_cg = g->sw.fused_cg && two_phase;
   const double tol_d  = (double) p->pcg_tolerance;
+  // the bottom of the cycle as one dense operator (k_bd_*, k_mg_bottom_dense): the conditions of k_mg_down2_coarsest and a level small
+  // enough for an N x N matrix
+  const bool dense_bottom = g->sw.fused_bottom && two_phase && g->coarsest_dense && lf == nl && lf >= 2 && g->levels[(size_t) nl]->n <= MG_FUSE_LAST_NODES &&
+                            g->levels[(size_t) nl]->n == g->levels[(size_t) nl - 1]->nc && g->levels[(size_t) nl - 1]->n * D <= 1024;
+  if (dense_bottom) {
+    const size_t Nb = (size_t) g->levels[(size_t) nl - 1]->n * D, Mb = (size_t) g->levels[(size_t) nl]->n * D;
+    if ((rc = g->bottom_B.reserve(Nb * Nb)) || (rc = g->bottom_acc.reserve(Nb * Nb)) || (rc = g->bottom_G.reserve(Nb * Mb)) ||
+        (rc = g->bottom_W.reserve(Nb * Mb)))
+      return rc;
+  }
   auto vcycle2 = [&](bool head, bool check, bool tail) {
     const MgLevelBufs* L0b = g->levels[0];
     const int bl0 = blocks_for(L0b->n * D), bc0 = blocks_for(L0b->nc * D * L0b->col_parts), br0 = blocks_for(L0b->n * D * L0b->row_parts);
@@ -2707,9 +2823,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     // (the last two-phase level's down phase and the dense coarsest solve share a launch when the coarsest level is tiny)
     const bool fuse_last = g->coarsest_dense && lf == nl && lf >= 2 && g->levels[(size_t) nl]->n <= MG_FUSE_LAST_NODES &&
                            g->levels[(size_t) nl]->n == g->levels[(size_t) nl - 1]->nc;
+    const bool bottom = dense_bottom;  // (k_mg_bottom_dense: that launch and the up phase of level lf - 1 as one dense operator)
     for (int l = 1; l < lf; ++l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
-      if (l == lf - 1 && fuse_last)
+      if (l == lf - 1 && bottom)
+        hipLaunchKernelGGL(k_mg_bottom_dense<D>, dim3((unsigned) (((size_t) Lb->n * D * 32 + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0,
+                           g->stream, pair(l), g->bottom_B.p, g->sc.p);
+      else if (l == lf - 1 && fuse_last)
         hipLaunchKernelGGL(k_mg_down2_coarsest<D>, dim3(1), dim3(1024), 0, g->stream, pair(l), g->coarse_inv.p, g->sc.p);
       else if (Lb->nc > 0)
         hipLaunchKernelGGL(k_mg_down2<D>, dim3((unsigned) Lb->nc), dim3(MG_DOWN2_THREADS), 0, g->stream, pair(l), g->sc.p);
@@ -2717,7 +2837,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     if (!fuse_last)
       hipLaunchKernelGGL(k_mg_coarse_cycle<D>, dim3(1), dim3(1024), 0, g->stream, g->levels_dev.p, lf, nl, g->coarse_inv.p,
                          g->coarsest_dense, g->sc.p);
-    for (int l = lf - 1; l >= 1; --l) {
+    for (int l = lf - 1 - (bottom ? 1 : 0); l >= 1; --l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
       const int pp = parts2(Lb, false);
       hipLaunchKernelGGL(k_mg_up2<D>, dim3((unsigned) (((size_t) Lb->n * 8 * pp + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream, pair(l), pp,
@@ -2838,6 +2958,17 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         if (!lds_ok) (void) hipGetLastError();
         hipLaunchKernelGGL(k_mg_coarsest_inverse<D>, dim3(1), dim3(1024), (size_t) in_lds * lds_need, g->stream, pair(nl),
                            g->coarse_A.p, g->coarse_inv.p, g->sc.p, in_lds);
+      }
+      if (dense_bottom && !reuse) {  // B of the last two-phase level (behind its D^-1, Q, Ps and the coarsest inverse)
+        const MgLevelBufs* Lb = g->levels[(size_t) nl - 1];
+        const int Nb = Lb->n * D, Mb = g->levels[(size_t) nl]->n * D;
+        auto grid_of = [](size_t items) { return dim3((unsigned) std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1)); };
+        HIP_TRY(hipMemsetAsync(g->bottom_acc.p, 0, sizeof(double) * (size_t) Nb * Nb, g->stream));
+        hipLaunchKernelGGL(k_bd_g<D>, grid_of((size_t) Lb->n * Lb->nc), dim3(PG_THREADS), 0, g->stream, pair(nl - 1), g->bottom_G.p);
+        hipLaunchKernelGGL(k_bd_w, grid_of((size_t) Nb * Mb), dim3(PG_THREADS), 0, g->stream, Nb, Mb, g->bottom_G.p, g->coarse_inv.p, g->bottom_W.p);
+        hipLaunchKernelGGL(k_bd_a<D>, grid_of((size_t) Lb->n + Lb->ne), dim3(PG_THREADS), 0, g->stream, pair(nl - 1), g->bottom_acc.p);
+        hipLaunchKernelGGL(k_bd_b, grid_of((size_t) Nb * Nb), dim3(PG_THREADS), 0, g->stream, Nb, Mb, g->bottom_W.p, g->bottom_G.p, g->bottom_acc.p,
+                           g->bottom_B.p);
       }
       hierarchy_fresh = true;
       // the V-cycle's float32 copies of every level's blocks (the coarsest level is inverted, not cycled through)
@@ -3077,6 +3208,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_BOTTOM")) g->sw.fused_bottom = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_PRODUCT_LISTS")) g->sw.product_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_LIST_LANES")) g->sw.list_lane_products = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("SRRG2_AMD_PG_OFFSET_LIMIT")) g->st_offset_limit = std::min<unsigned long long>(std::strtoull(e, nullptr, 10), 0x7fff0000ull);
@@ -3101,6 +3233,7 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   g->part_pAp.release(); g->part_rr.release(); g->part_bb.release(); g->part_chi.release(); g->part_n.release();
   g->inc_start.release(); g->inc_edge.release(); g->sc.release(); g->act_edge.release(); g->levels_dev.release();
   g->coarse_A.release(); g->coarse_inv.release();
+  g->bottom_acc.release(); g->bottom_G.release(); g->bottom_W.release(); g->bottom_B.release();
   g->st_keys_a.release(); g->st_keys_b.release(); g->st_cnt.release(); g->st_off.release(); g->st_slot.release();
   g->st_ia.release(); g->st_ib.release(); g->st_counts.release(); g->st_total.release(); g->st_temp.release();
   g->st_vals.release(); g->st_rle.release();
