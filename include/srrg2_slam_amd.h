@@ -409,9 +409,9 @@ typedef struct srrg2_posegraph_tuning {
   int32_t keep_structure;   /* the multigrid hierarchy's STRUCTURE (aggregates, sparsity patterns: 13 ms per build on C5)  
                                is kept while the graph's topology does not change -- srrg2_posegraph_set with the same
                                edges, fixed and enabled masks -- (1); 0 = rebuilt by the first solve after every set    */
-  float   omega_p;          /* SRRG2_AMD_PG_OMEGA_P: damping of the Jacobi sweep that smooths the interpolation (0.66; 0 =
+  float   omega_p;          /* SRRG2_AMD_PG_OMEGA_P: damping of the Jacobi sweep that smooths the interpolation (0.75; 0 =
                                plain aggregation)                                                                    */
-  float   omega;            /* SRRG2_AMD_PG_OMEGA: damping of the block-Jacobi smoother (0.7)                           */
+  float   omega;            /* SRRG2_AMD_PG_OMEGA: damping of the block-Jacobi smoother (0.8)                           */
   float   lag_below;        /* SRRG2_AMD_PG_LAG: a Gauss-Newton iteration keeps the hierarchy's numerics of the previous one
                                when that one moved no variable by more than this (0.05; 0 = never: every iteration rebuilds
                                interpolation and coarse operators, 3 ms each on C5)                                   */
@@ -439,6 +439,12 @@ int srrg2_posegraph_add_factor(srrg2_posegraph_h h, int i, int j, const float* Z
 int srrg2_posegraph_set_factor_enabled(srrg2_posegraph_h h, int factor_id, int enabled);
 int srrg2_posegraph_remove_factor(srrg2_posegraph_h h, int factor_id);
 int srrg2_posegraph_size(srrg2_posegraph_h h, int* num_variables, int* num_factors, int* num_enabled_factors);
+/* How the last solve treated what was appended since the multigrid hierarchy's structure was built: `hierarchy_builds` =
+ * structure builds of this handle so far; `eliminated_leaves` = variables the last solve eliminated exactly instead of rebuilding
+ * (makeNewMap's pattern, multi_graph_slam_impl.cpp:52-90: one new variable with one factor to an older one -- a leaf of the graph,
+ * whose Schur complement leaves the older graph's system and with it the hierarchy untouched; up to 32 of them, then a rebuild; a
+ * factor between two older variables, a changed flag or keep_structure = 0 rebuild as before). */
+int srrg2_posegraph_structure_info(srrg2_posegraph_h h, int* hierarchy_builds, int* eliminated_leaves);
 
 /* ---- scene slices kept in HBM between frames: clipping and correspondence-based merging ------
  * the tracker-side steps either side of align()

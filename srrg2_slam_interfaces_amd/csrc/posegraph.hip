@@ -262,8 +262,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
 // float32 blocks PCG needed 151 / 175 / 200 iterations on C5 and the coarsest Cholesky failed in the fourth
 // Gauss-Newton iteration (profiles/r2k_bench_c5_float32_blocks.json).
 // =====================================================================================================================
-#define MG_OMEGA 0.7
-#define MG_OMEGA_P 0.66  // damping of the interpolation smoother
+#define MG_OMEGA 0.8     // (0.7 until round 6: swept again on the spanning-tree aggregates, profiles/r9/r9h_*)
+#define MG_OMEGA_P 0.75  // damping of the interpolation smoother (0.66 = (4/3) / lambda_max until round 6; same sweep)
 #define MG_MAX_LEVELS 16
 #define MG_FUSE_NODES 170   // levels of at most this many nodes run inside the single-workgroup launch (one row per thread)
 #define MG_COARSEST_NODES 32
@@ -1535,6 +1535,85 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_converged(int nblocks, double
   }
 }
 
+// ---- appended leaves eliminated exactly (round 6) -----------------------------------------------------------------------
+// MultiGraphSLAM_::makeNewMap appends ONE variable and ONE factor per new local map (multi_graph_slam_impl.cpp:52-90).  Such a
+// variable is a LEAF of the graph: eliminating it from H dx = -b (its Schur complement) leaves the system of the graph without
+// it -- so the multigrid hierarchy built before the append, structure AND coarse space, stays exactly what that system needs
+// (round 4 patched the new pose into / beside the aggregates: 1.5 - 3 x the CG iterations; round 5 rebuilt the structure:
+// 12 - 15 ms per append).  The variables appended since the hierarchy was built (the `tail`: indices >= V0, each with exactly
+// one factor to a variable of lower index, its parent) are eliminated children first,
+//   K_v = S_v^-1 H_vp,  c_v = S_v^-1 b_v,  H_pp -= H_pv K_v,  b_p -= H_pv c_v     (S_v = H_vv with its own children's terms)
+// CG runs on the first V0 variables, then dx_v = -(c_v + K_v dx_p) parents first.  A handful of sequential 6 x 6 operations:
+// one thread.  Anything else that changed (a factor between two old variables, a flag, a long tail) rebuilds as before.
+template <int D>
+__global__ void k_pg_tail_down(int ntail, int V0, const int* __restrict__ parent, const int* __restrict__ ecode,
+                               const uint8_t* __restrict__ fixed, double* __restrict__ Hd, double* __restrict__ b,
+                               double* __restrict__ Minv, const double* __restrict__ Ho, double* __restrict__ K,
+                               double* __restrict__ cv, PgScalars* __restrict__ sc) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int t = ntail - 1; t >= 0; --t) {
+    const int v = V0 + t, p = parent[t], code = ecode[t];
+    const double* Hb = Ho + (size_t) (code >> 1) * D * D;  // block (i, j) of the factor; the child is its j end when code & 1
+    double S[D * D], Hvp[D * D];
+    for (int k = 0; k < D * D; ++k) S[k] = Hd[(size_t) v * D * D + k];
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) Hvp[r * D + c] = (code & 1) ? Hb[c * D + r] : Hb[r * D + c];
+    double Kv[D * D], cvv[D];
+    bool bad = false;
+    for (int col = 0; col <= D; ++col) {  // S X = [H_vp | b_v]  (dm::solve solves A x = -rhs)
+      double rhs[D], x[D];
+      for (int r = 0; r < D; ++r) rhs[r] = col < D ? -Hvp[r * D + col] : -b[(size_t) v * D + r];
+      if (dm::solve<D>(S, rhs, x)) bad = true;
+      for (int r = 0; r < D; ++r) {
+        if (col < D) Kv[r * D + col] = bad ? 0.0 : x[r];
+        else cvv[r] = bad ? 0.0 : x[r];
+      }
+    }
+    if (bad) sc->bad = 1;
+    const bool pfixed = fixed[p] != 0;
+    for (int k = 0; k < D * D; ++k) K[(size_t) t * D * D + k] = pfixed ? 0.0 : Kv[k];
+    for (int r = 0; r < D; ++r) cv[(size_t) t * D + r] = cvv[r];
+    if (pfixed) continue;  // (an identity row: dx_p = 0, nothing to update)
+    for (int r = 0; r < D; ++r) {  // H_pv = H_vp^T
+      double sb = 0.0;
+      for (int k = 0; k < D; ++k) sb = sb + Hvp[k * D + r] * cvv[k];
+      b[(size_t) p * D + r] = b[(size_t) p * D + r] - sb;
+      for (int c = 0; c < D; ++c) {
+        double sh = 0.0;
+        for (int k = 0; k < D; ++k) sh = sh + Hvp[k * D + r] * Kv[k * D + c];
+        Hd[(size_t) p * D * D + r * D + c] = Hd[(size_t) p * D * D + r * D + c] - sh;
+      }
+    }
+    if (p < V0) {  // the level-0 smoother's block of a parent inside the hierarchy (k_pg_vertices inverted the block before the update)
+      double Hp[D * D];
+      for (int k = 0; k < D * D; ++k) Hp[k] = Hd[(size_t) p * D * D + k];
+      bool badp = false;
+      for (int c = 0; c < D; ++c) {
+        double rhs[D], x[D];
+        for (int r = 0; r < D; ++r) rhs[r] = r == c ? -1.0 : 0.0;
+        if (dm::solve<D>(Hp, rhs, x)) badp = true;
+        for (int r = 0; r < D; ++r) Minv[(size_t) p * D * D + r * D + c] = badp ? 0.0 : x[r];
+      }
+      if (badp) sc->bad = 1;
+    }
+  }
+}
+template <int D>
+__global__ void k_pg_tail_up(int ntail, int V0, const int* __restrict__ parent, const uint8_t* __restrict__ fixed,
+                             const double* __restrict__ K, const double* __restrict__ cv, double* __restrict__ x,
+                             const PgScalars* __restrict__ sc) {
+  if (blockIdx.x != 0 || threadIdx.x != 0 || sc->bad) return;
+  for (int t = 0; t < ntail; ++t) {
+    const int v = V0 + t, p = parent[t];
+    for (int r = 0; r < D; ++r) {
+      double s = cv[(size_t) t * D + r];
+      if (!fixed[p])
+        for (int c = 0; c < D; ++c) s = s + K[(size_t) t * D * D + r * D + c] * x[(size_t) p * D + c];
+      x[(size_t) v * D + r] = -s;
+    }
+  }
+}
+
 // ---- fused steps of a CG iteration (round 6) ------------------------------------------------------------------------------
 // A CG iteration was 18 launches, of which four did node-local work between two grid-wide dependencies: level 0's first
 // smoothing step x1 = omega Dinv r (now in the kernel that produces r), level 1's (in level 0's restriction), the cycle's last
@@ -1664,7 +1743,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_update_dot(int n, MgPair LV, 
 }
 
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int T, int variable_kind, const uint8_t* __restrict__ fixed,
+__global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int V0, int T, int variable_kind, const uint8_t* __restrict__ fixed,
                                                          const double* __restrict__ x, float* __restrict__ poses,
                                                          PgScalars* __restrict__ sc) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1675,7 +1754,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_apply(int V, int T, int varia
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     dx[k] = on ? x[(size_t) v * D + k] : 0.0;
-    m     = fmax(m, fabs(dx[k]));
+    if (v < V0) m = fmax(m, fabs(dx[k]));  // (an appended leaf's own step says nothing about the hierarchy's poses)
   }
   // the size of the step, for the host: a hierarchy built at nearly the same poses can be kept (pg_solve_t)
 #pragma unroll
@@ -1748,6 +1827,7 @@ struct srrg2_posegraph_s {
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
     bool product_lists = true;     // SRRG2_AMD_PG_PRODUCT_LISTS: the set-up products over the lists the pattern build leaves (round 6; 0: the searching kernels)
     int list_lane_products = 4;    // SRRG2_AMD_PG_LIST_LANES: products per lane the list kernels aim at
+    bool tree_positions = true;    // SRRG2_AMD_PG_TREE_POSITIONS: the matching's geometry from a spanning tree of the measurements (round 6)
     bool fused_bottom = true;      // SRRG2_AMD_PG_FUSED_BOTTOM: the bottom of the cycle as one dense operator (k_mg_bottom_dense, round 6)
     bool fused_cg = true;          // SRRG2_AMD_PG_FUSED_CG: 14 launches per CG iteration instead of 18 (round 6; an A/B switch: same numbers)
   } sw;
@@ -1763,8 +1843,16 @@ struct srrg2_posegraph_s {
   double st_ms[5] = {0, 0, 0, 0, 0};  // (debug) P sorted / Q counted / Q sorted / columns + coarse edges counted / coarse edges sorted
   srrg2_posegraph_tuning tuning{};
   bool mg_dirty      = true;
+  // the graph the hierarchy was built for, and what has been appended since (k_pg_tail_down / k_pg_tail_up)
+  int hier_V = 0, hier_E = 0;
+  int hier_builds = 0;                  // structure builds of this handle (srrg2_posegraph_structure_info)
+  bool tail_pending = false;            // variables / factors appended since: classified at the next solve
+  int ntail = 0;                        // > 0: the last hier_V .. V variables are eliminated leaves
+  DevBuf<int> tail_parent, tail_ecode;
+  DevBuf<double> tail_K, tail_c;
   // host mirrors for the incremental interface (incidence lists are rebuilt lazily from these)
   std::vector<int> h_ij;
+  std::vector<float> h_Z;  // the measurements (the spanning-tree geometry of the matching, build_hierarchy)
   std::vector<uint8_t> h_enabled, h_removed, h_fixed;
   bool inc_dirty = false;
 };
@@ -2322,6 +2410,15 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   g->levels.clear();  // (the levels' device buffers stay in g->level_pool: a rebuild reuses them, they only ever grow)
   std::vector<float> poses((size_t) std::max(V, 1) * T);
   HIP_TRY(hipMemcpy(poses.data(), g->poses.p, sizeof(float) * (size_t) V * T, hipMemcpyDeviceToHost));
+  // The geometry the matching measures distances in.  The CURRENT poses are a poor one when the hierarchy is built from an initial
+  // guess: C5's odometry integration has drifted by up to 62 m, two poses half a metre apart through a loop closure look metres
+  // apart, the "nearest free neighbour" is then the odometry neighbour, the aggregates come out as pieces of the trajectory instead
+  // of compact blobs -- and the cycle built on them needs 42 - 51 CG iterations per solve once the poses have converged, where
+  // aggregates matched at the converged poses need 28 (the same graph after an append, round 5: [19, 26, 28, 29, ...]).  Round 6:
+  // positions from a BREADTH-FIRST spanning tree of the measurements, rooted at the Fixed variables -- every pose is its tree
+  // parent's composed with the factor's Z, a path of ~100 factors instead of up to 50 000, so neighbours agree to centimetres
+  // whatever the initial guess is; it depends on the topology and the measurements only, like the structure it is used for.
+  // (sw.tree_positions = false / SRRG2_AMD_PG_TREE_POSITIONS=0: the current poses, as before)
   auto position = [&](int v, float* out) {
     const float* X = poses.data() + (size_t) v * T;
     if (D == 6) { out[0] = X[3]; out[1] = X[7]; out[2] = X[11]; } else { out[0] = X[2]; out[1] = X[5]; out[2] = 0.f; }
@@ -2344,6 +2441,107 @@ int build_hierarchy(srrg2_posegraph_s* g) {
   int rc;
   if ((rc = upload(g->act_edge, act))) return rc;
   g->coarsest_dense = 1;
+  const auto t_tree = std::chrono::steady_clock::now();
+  if (g->sw.tree_positions && E > 0) {
+    const std::vector<float>& hZ = g->h_Z;  // (the measurements' host mirror: set() / add_factor keep it)
+    // adjacency of the free variables over level 0's edges (eij / act, above); the factors that touch a Fixed variable seed the tree
+    const int ne0 = (int) (eij.size() / 2);
+    // ({neighbour, factor code} side by side: the walk below is bound by its dependent look-ups -- 5.9 ms with the neighbour
+    // fetched from the factor's endpoints, per visit)
+    std::vector<int> a_start((size_t) V + 1, 0);
+    std::vector<int2> a_adj((size_t) std::max(2 * ne0, 1));
+    for (int k = 0; k < 2 * ne0; ++k) a_start[(size_t) eij[(size_t) k] + 1]++;
+    for (int v = 0; v < V; ++v) a_start[(size_t) v + 1] += a_start[(size_t) v];
+    {
+      std::vector<int> cur(a_start.begin(), a_start.end() - 1);
+      for (int k = 0; k < ne0; ++k) {
+        const int i = eij[2 * (size_t) k], j = eij[2 * (size_t) k + 1];
+        a_adj[(size_t) cur[(size_t) i]++] = make_int2(j, 2 * act[(size_t) k]);      // this end is the factor's first endpoint
+        a_adj[(size_t) cur[(size_t) j]++] = make_int2(i, 2 * act[(size_t) k] + 1);  // ... its second
+      }
+    }
+    if (g->sw.debug) std::fprintf(stderr, "  tree: adjacency %.2f ms\n", ms_since(t_tree));
+    std::vector<char> seen((size_t) V, 0);
+    std::vector<int> queue;
+    queue.reserve((size_t) V);
+    auto place = [&](int u, int w, int e, bool w_is_first) {  // X_w from X_u through factor e
+      // (plain float products: this geometry ranks neighbours, centimetres matter and not the last bit -- dm::se3_compose's
+      // float64 products with their conversions were 4 of the walk's 4.7 ms)
+      float* Xw = poses.data() + (size_t) w * T;
+      const float* A = poses.data() + (size_t) u * T;
+      const float* Ze = hZ.data() + (size_t) e * T;
+      const int R = D == 6 ? 3 : 2, W = R + 1;  // rotation size, row stride
+      float B[12];
+      if (w_is_first) {  // Z^-1 = [R^T, -R^T t]
+        for (int r = 0; r < R; ++r) {
+          float t = 0.f;
+          for (int c = 0; c < R; ++c) {
+            B[r * W + c] = Ze[c * W + r];
+            t -= Ze[c * W + r] * Ze[c * W + R];
+          }
+          B[r * W + R] = t;
+        }
+      } else {
+        for (int k = 0; k < R * W; ++k) B[k] = Ze[k];
+      }
+      float out[12];
+      for (int r = 0; r < R; ++r) {
+        for (int c = 0; c < W; ++c) {
+          float v = c == R ? A[r * W + R] : 0.f;
+          for (int k = 0; k < R; ++k) v += A[r * W + k] * B[k * W + c];
+          out[r * W + c] = v;
+        }
+      }
+      for (int k = 0; k < R * W; ++k) Xw[k] = out[k];
+      if (D != 6) { Xw[6] = 0.f; Xw[7] = 0.f; Xw[8] = 1.f; }
+    };
+    // (the walk only records who is placed from whom through which factor; the poses follow in discovery order -- parents before
+    // children -- with the factor's Z and the parent's pose prefetched a few steps ahead: every placement reads a random 48 bytes
+    // of 9.6 MB of measurements, 50 000 dependent cache misses were 5 of the tree's 6 ms)
+    struct Placed { int w, u, code; };
+    std::vector<Placed> placed;
+    placed.reserve((size_t) V);
+    auto grow = [&]() {
+      for (size_t head = 0; head < queue.size(); ++head) {
+        const int u = queue[head];
+        for (int k = a_start[(size_t) u]; k < a_start[(size_t) u + 1]; ++k) {
+          const int w = a_adj[(size_t) k].x;
+          if (seen[(size_t) w]) continue;
+          seen[(size_t) w] = 1;
+          placed.push_back({w, u, a_adj[(size_t) k].y});
+          queue.push_back(w);
+        }
+      }
+      queue.clear();
+    };
+    auto place_all = [&]() {
+      const size_t np_ = placed.size();
+      for (size_t k = 0; k < np_; ++k) {
+        if (k + 12 < np_) {
+          __builtin_prefetch(hZ.data() + (size_t) (placed[k + 12].code >> 1) * T);
+          __builtin_prefetch(poses.data() + (size_t) placed[k + 12].u * T);
+        }
+        place(placed[k].u, placed[k].w, placed[k].code >> 1, (placed[k].code & 1) != 0);
+      }
+      placed.clear();
+    };
+    for (int v = 0; v < V; ++v) seen[(size_t) v] = g->h_fixed[(size_t) v] ? 1 : 0;  // (the Fixed variables keep their poses)
+    for (int e = 0; e < E; ++e) {  // the free neighbours of the Fixed variables are the tree's first generation, in factor order
+      if (!g->h_enabled[(size_t) e]) continue;
+      const int i = g->h_ij[2 * (size_t) e], j = g->h_ij[2 * (size_t) e + 1];
+      if (g->h_fixed[(size_t) i] && !seen[(size_t) j]) { seen[(size_t) j] = 1; place(i, j, e, false); queue.push_back(j); }
+      else if (g->h_fixed[(size_t) j] && !seen[(size_t) i]) { seen[(size_t) i] = 1; place(j, i, e, true); queue.push_back(i); }
+    }
+    if (g->sw.debug) std::fprintf(stderr, "  tree: + seeds %.2f ms\n", ms_since(t_tree));
+    grow();
+    if (g->sw.debug) std::fprintf(stderr, "  tree: + walk %.2f ms\n", ms_since(t_tree));
+    place_all();
+    if (g->sw.debug) std::fprintf(stderr, "  tree: + poses %.2f ms\n", ms_since(t_tree));
+    for (int v = 0; v < V; ++v)  // a component without a Fixed variable: its first variable keeps its pose
+      if (!seen[(size_t) v]) { seen[(size_t) v] = 1; queue.push_back(v); grow(); place_all(); }
+  }
+  const double ms_tree = ms_since(t_tree);
+
   // matching passes per level: 2 -> aggregates of <= 4 poses, 3 -> <= 8 (fewer levels, slower convergence; measured in
   // DESIGN.md section 6)
   const int match_passes = g->sw.match_passes;
@@ -2701,8 +2899,8 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     for (MgLevelBufs* L : g->levels)
       std::fprintf(stderr, " %d nodes / %d blocks (P %d, Q %d%s; products %lld + %lld) ->", L->n, L->ne, L->np, L->nq, L->smoothed ? "" : ", tentative",
                    L->nc > 0 ? L->nqp : 0LL, L->nc > 0 ? L->ngp : 0LL);
-    std::fprintf(stderr, " coarsest %s; built in %.1f ms (matching on the host %.1f, patterns on the %s %.1f)\n",
-                 g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_match, device_structure ? "device" : "host", ms_pattern);
+    std::fprintf(stderr, " coarsest %s; built in %.1f ms (spanning-tree positions %.1f, matching on the host %.1f, patterns on the %s %.1f)\n",
+                 g->coarsest_dense ? "dense" : "smoothed", ms_since(t_begin), ms_tree, ms_match, device_structure ? "device" : "host", ms_pattern);
     if (device_structure)
       std::fprintf(stderr, "  on the device: P sorted %.1f, Q counted %.1f, Q sorted %.1f, columns + coarse edges counted %.1f, coarse edges sorted %.1f ms\n",
                    g->st_ms[0], g->st_ms[1], g->st_ms[2], g->st_ms[3], g->st_ms[4]);
@@ -2737,15 +2935,53 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     if ((rc = g->coarse_A.reserve(std::max<size_t>(N * N, 1))) || (rc = g->coarse_inv.reserve(std::max<size_t>(N * N, 1)))) return rc;
   }
   g->mg_dirty = false;
+  g->hier_V = V;
+  g->hier_E = E;
+  g->hier_builds++;
+  g->ntail = 0;
+  g->tail_pending = false;
   return 0;
+}
+
+// The variables / factors appended since the hierarchy was built: a forest of leaves (every new variable free, with exactly one
+// factor to a variable of lower index, every new factor such a factor, enabled), at most 32 of them -> their parents and factor
+// codes on the device, g->ntail set.  Anything else -> false: the caller rebuilds the hierarchy.
+bool pg_classify_tail(srrg2_posegraph_s* g) {
+  const int V0 = g->hier_V, E0 = g->hier_E, nt = g->V - V0;
+  g->ntail = 0;
+  if (!g->sw.keep_structure) return false;  // (the knob's meaning: every change rebuilds)
+  if (nt <= 0 || nt > 32 || g->E - E0 != nt) return false;
+  std::vector<int> parent((size_t) nt, -1), code((size_t) nt, 0);
+  for (int e = E0; e < g->E; ++e) {
+    if (!g->h_enabled[(size_t) e] || g->h_removed[(size_t) e]) return false;
+    const int i = g->h_ij[2 * (size_t) e], j = g->h_ij[2 * (size_t) e + 1];
+    const int c = std::max(i, j), p = std::min(i, j);
+    if (c < V0 || parent[(size_t) (c - V0)] >= 0) return false;
+    parent[(size_t) (c - V0)] = p;
+    code[(size_t) (c - V0)]   = (e << 1) | (c == j ? 1 : 0);
+  }
+  for (int t = 0; t < nt; ++t)
+    if (parent[(size_t) t] < 0 || g->h_fixed[(size_t) (V0 + t)]) return false;
+  const int D = g->D;
+  if (upload(g->tail_parent, parent) || upload(g->tail_ecode, code) || g->tail_K.reserve((size_t) nt * D * D) ||
+      g->tail_c.reserve((size_t) nt * D))
+    return false;
+  g->ntail = nt;
+  return true;
 }
 
 template <int D>
 int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_posegraph_stats* stats, int* n_inout) {
   const int V = g->V, E = g->E, T = g->T;
-  const int n = V * D;
   int rc;
+  if (!g->mg_dirty && g->tail_pending) {  // appended since the hierarchy was built: leaves to eliminate, or a rebuild
+    g->tail_pending = false;
+    if (!pg_classify_tail(g)) g->mg_dirty = true;
+  }
   if (g->mg_dirty && (rc = build_hierarchy(g))) return rc;
+  // CG and the hierarchy cover the first Vc variables; the tail behind them is eliminated (k_pg_tail_down / k_pg_tail_up)
+  const int ntail = g->ntail, Vc = V - ntail;
+  const int n = Vc * D;  // CG's unknowns
   const int nl  = (int) g->levels.size() - 1;  // index of the coarsest level
   const int nb  = std::max(std::min((n + PG_ROWS - 1) / PG_ROWS, 1024), 1);  // grid-stride element-wise kernels (tiles of PG_ROWS rows)
   const int nbv = std::max((V + PG_THREADS - 1) / PG_THREADS, 1);
@@ -2756,7 +2992,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
   if ((rc = g->Ho.reserve((size_t) std::max(E, 1) * D * D))) return rc;
   if ((rc = g->contrib.reserve((size_t) std::max(E, 1) * (sizeof(EdgeContrib<D>) / sizeof(double))))) return rc;
   for (DevBuf<double>* v : {&g->b, &g->x, &g->r, &g->p, &g->Ap})
-    if ((rc = v->reserve((size_t) std::max(n, 1)))) return rc;
+    if ((rc = v->reserve((size_t) std::max(V * D, 1)))) return rc;
   for (DevBuf<double>* v : {&g->part_rz, &g->part_rz_new, &g->part_pAp, &g->part_rr, &g->part_bb})
     if ((rc = v->reserve((size_t) nb))) return rc;
   if ((rc = g->part_chi.reserve((size_t) nchi))) return rc;
@@ -2898,10 +3134,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
                        g->inc_edge.p, g->enabled.p, contrib, (double) p->damping, g->Hd.p, g->b.p, g->Minv.p, g->sc.p);
     // hierarchy numerics: level 0 = float32 copies; then interpolation, Galerkin product, smoother of every level
     {
-      const size_t nel = std::max((size_t) V, (size_t) L0->ne) * D * D;
+      if (ntail > 0)  // the appended leaves folded into their parents' blocks and right-hand sides
+        hipLaunchKernelGGL(k_pg_tail_down<D>, dim3(1), dim3(64), 0, g->stream, ntail, Vc, g->tail_parent.p, g->tail_ecode.p, g->fixed.p,
+                           g->Hd.p, g->b.p, g->Minv.p, g->Ho.p, g->tail_K.p, g->tail_c.p, g->sc.p);
+      const size_t nel = std::max((size_t) Vc, (size_t) L0->ne) * D * D;
       hipLaunchKernelGGL(k_mg_pack0<D>, dim3((unsigned) ((nel + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream,
-                         V, L0->ne, g->act_edge.p, g->Hd.p, g->Ho.p, L0->Hd.p, L0->Ho.p);
-      HIP_TRY(hipMemcpyAsync(L0->Dinv.p, g->Minv.p, sizeof(double) * (size_t) V * D * D, hipMemcpyDeviceToDevice, g->stream));
+                         Vc, L0->ne, g->act_edge.p, g->Hd.p, g->Ho.p, L0->Hd.p, L0->Ho.p);
+      HIP_TRY(hipMemcpyAsync(L0->Dinv.p, g->Minv.p, sizeof(double) * (size_t) Vc * D * D, hipMemcpyDeviceToDevice, g->stream));
       // The interpolation is the aggregates' rigid motion at the CURRENT poses and the coarse operators are Galerkin
       // products of the CURRENT H: 3.7 ms per Gauss-Newton iteration on C5.  Once the last step moved no variable by more
       // than `lag_below` the poses -- hence P, Ps and, to first order, H -- are what they were: the hierarchy of the
@@ -3052,7 +3291,10 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
       HIP_TRY(hipMemcpyAsync(&h, g->sc.p, sizeof(h), hipMemcpyDeviceToHost, g->stream));
       HIP_TRY(hipStreamSynchronize(g->stream));
     }
-    hipLaunchKernelGGL(k_pg_apply<D>, dim3(nbv), dim3(PG_THREADS), 0, g->stream, V, T, g->kind, g->fixed.p, g->x.p,
+    if (ntail > 0)
+      hipLaunchKernelGGL(k_pg_tail_up<D>, dim3(1), dim3(64), 0, g->stream, ntail, Vc, g->tail_parent.p, g->fixed.p, g->tail_K.p, g->tail_c.p,
+                         g->x.p, g->sc.p);
+    hipLaunchKernelGGL(k_pg_apply<D>, dim3(nbv), dim3(PG_THREADS), 0, g->stream, V, Vc, T, g->kind, g->fixed.p, g->x.p,
                        g->poses.p, g->sc.p);
     HIP_TRY(hipGetLastError());
     if (lag_below > 0.0 && it + 1 < p->max_iterations) {  // the size of this step decides about the next iteration's hierarchy
@@ -3208,6 +3450,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_TREE_POSITIONS")) g->sw.tree_positions = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_BOTTOM")) g->sw.fused_bottom = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_PRODUCT_LISTS")) g->sw.product_lists = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_LIST_LANES")) g->sw.list_lane_products = std::max(1, std::atoi(e));
@@ -3234,6 +3477,7 @@ int srrg2_posegraph_destroy(srrg2_posegraph_h g) {
   g->inc_start.release(); g->inc_edge.release(); g->sc.release(); g->act_edge.release(); g->levels_dev.release();
   g->coarse_A.release(); g->coarse_inv.release();
   g->bottom_acc.release(); g->bottom_G.release(); g->bottom_W.release(); g->bottom_B.release();
+  g->tail_parent.release(); g->tail_ecode.release(); g->tail_K.release(); g->tail_c.release();
   g->st_keys_a.release(); g->st_keys_b.release(); g->st_cnt.release(); g->st_off.release(); g->st_slot.release();
   g->st_ia.release(); g->st_ib.release(); g->st_counts.release(); g->st_total.release(); g->st_temp.release();
   g->st_vals.release(); g->st_rle.release();
@@ -3296,6 +3540,7 @@ int srrg2_posegraph_set(srrg2_posegraph_h g, int V, const float* poses, const ui
                              std::find(g->h_removed.begin(), g->h_removed.end(), (uint8_t) 1) == g->h_removed.end();
   g->V = V;
   g->E = E;
+  g->h_Z.assign(Z, Z + (size_t) E * T);
   if (same_topology) return 0;  // (incidence lists and hierarchy structure are still those of this topology)
   g->h_ij.assign(ij, ij + 2 * (size_t) E);
   g->h_enabled.assign(en.begin(), en.begin() + E);
@@ -3323,7 +3568,7 @@ int srrg2_posegraph_add_variable(srrg2_posegraph_h g, const float* pose, int fix
   g->V         = V + 1;
   g->h_fixed.push_back(fx);
   g->inc_dirty = true;
-  g->mg_dirty  = true;
+  g->tail_pending = true;  // (the next solve eliminates it as a leaf or rebuilds the hierarchy: pg_classify_tail)
   return 0;
 }
 
@@ -3350,12 +3595,13 @@ int srrg2_posegraph_add_factor(srrg2_posegraph_h g, int i, int j, const float* Z
   HIP_TRY(hipMemcpy(g->enabled.p + E, &en, 1, hipMemcpyHostToDevice));
   g->h_ij.push_back(i);
   g->h_ij.push_back(j);
+  g->h_Z.insert(g->h_Z.end(), Z, Z + T);
   g->h_enabled.push_back(en);
   g->h_removed.push_back(0);
   if (id_out) *id_out = E;
   g->E         = E + 1;
   g->inc_dirty = true;
-  g->mg_dirty  = true;
+  g->tail_pending = true;
   return 0;
 }
 
@@ -3382,6 +3628,13 @@ int srrg2_posegraph_remove_factor(srrg2_posegraph_h g, int factor_id) {
   g->h_enabled[(size_t) factor_id] = 0;
   g->h_removed[(size_t) factor_id] = 1;
   HIP_TRY(hipMemcpy(g->enabled.p + factor_id, &en, 1, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int srrg2_posegraph_structure_info(srrg2_posegraph_h g, int* hierarchy_builds, int* eliminated_leaves) {
+  if (!g) return fail(SRRG2_E_INVALID, "posegraph_structure_info: null handle");
+  if (hierarchy_builds) *hierarchy_builds = g->hier_builds;
+  if (eliminated_leaves) *eliminated_leaves = g->ntail;
   return 0;
 }
 

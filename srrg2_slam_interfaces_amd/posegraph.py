@@ -145,6 +145,12 @@ class PoseGraph:
         self._check(self._fn("size")(self._h, C.byref(v), C.byref(f), C.byref(e)))
         return v.value, f.value, e.value
 
+    def structure_info(self):
+        """(structure builds of the multigrid hierarchy so far, appended leaves the last solve eliminated instead of rebuilding)"""
+        b, t = C.c_int(0), C.c_int(0)
+        self._check(self._fn("structure_info")(self._h, C.byref(b), C.byref(t)))
+        return b.value, t.value
+
     def solve(self, params=None):
         params = params or default_params()
         n = C.c_int(max(params.max_iterations, 1))

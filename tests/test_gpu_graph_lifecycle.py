@@ -79,3 +79,64 @@ def test_lifecycle_matches_one_shot_graph_and_oracle(oracle, product):
     # no valid closure -> optimize() is a no-op (multi_graph_slam_impl.cpp:302-304)
     life.loop_validate([])
     assert life.optimize(params) == []
+
+
+def test_appended_leaves_are_eliminated_not_rebuilt(oracle, product):
+    """makeNewMap appends one variable and one factor per local map (multi_graph_slam_impl.cpp:52-90).  Such variables are leaves:
+    the solve eliminates them exactly (Schur complement; the multigrid hierarchy of the graph before them stays valid as it is) and
+    back-substitutes -- a chain of three new maps and one more hanging off an old pose, each starting metres away from where its
+    factor wants it.  Same poses as the same graph solved in one shot from the same start and as the oracle's; no structure build.
+    A closure between two old poses rebuilds, as before."""
+    kind = abi.SE3_QUAT_RIGHT
+    g = syn.pose_graph_3d(V=3000, E=10000, seed=91)
+    poses0, ij, Z = g["poses_init"], g["ij"], g["Z"]
+    V, E = poses0.shape[0], ij.shape[0]
+    params = pgm.PoseGraphParams(6, 300, 1e-8, 0.0)
+    inc = product.PoseGraph(kind, 0)
+    inc.set_graph(poses0, ij, Z)
+    inc.solve(params)
+    assert inc.structure_info() == (1, 0)
+    start = inc.poses().copy()
+    rng = np.random.RandomState(5)
+    new_pose, new_ij, new_Z = [], [], []
+    for parent in (V - 1, V, V + 1, 1234):  # a chain V-1 -> V -> V+1 -> V+2, and a leaf on pose 1234
+        t = rng.uniform(-0.5, 0.5, 3)
+        Zk = syn.se3(t, rng.uniform(-0.2, 0.2, 3)).astype(np.float32)
+        # (metres and a third of a radian away from parent * Z, where the factor wants it)
+        where = list(start) + new_pose
+        far = syn.se3_mul(syn.se3_mul(where[parent], Zk), syn.se3(rng.uniform(-3, 3, 3), rng.uniform(-0.3, 0.3, 3))).astype(np.float32)
+        vid = inc.add_variable(far)
+        # (both orientations of the new factor: the new pose as its second and as its first endpoint)
+        if len(new_pose) % 2 == 0:
+            inc.add_factor(parent, vid, Zk)
+            new_ij.append((parent, vid)); new_Z.append(Zk)
+        else:
+            Zinv = np.linalg.inv(np.vstack([Zk, [0, 0, 0, 1]]).astype(np.float64))[:3].astype(np.float32)
+            inc.add_factor(vid, parent, Zinv)
+            new_ij.append((vid, parent)); new_Z.append(Zinv)
+        new_pose.append(far)
+    st = inc.solve(params)
+    assert inc.structure_info() == (1, 4), inc.structure_info()
+    assert all(s_["solver_status"] == 0 and s_["pcg_iterations"] < 300 for s_ in st)
+    # the same graph in one shot from the same start
+    P1 = np.concatenate([start, np.array(new_pose, np.float32)], axis=0)
+    ij1 = np.concatenate([ij, np.array(new_ij, np.int32)], axis=0)
+    Z1 = np.concatenate([Z, np.array(new_Z, np.float32)], axis=0)
+    one = product.PoseGraph(kind, 0)
+    one.set_graph(P1, ij1, Z1)
+    st1 = one.solve(params)
+    assert one.structure_info() == (1, 0)
+    assert np.max(np.abs(one.poses() - inc.poses())) < 2e-4
+    assert abs(st1[-1]["chi"] - st[-1]["chi"]) <= 1e-3 * max(1.0, st1[-1]["chi"])
+    # every new pose sits where its factor puts it (a leaf's factor ends with zero residual)
+    Xf = inc.poses()
+    for (i, j), Zk in zip(new_ij, new_Z):
+        assert np.max(np.abs(_rel(Xf[i], Xf[j]) - Zk)) < 1e-4
+    ref = oracle.OraclePoseGraph(kind)
+    ref.set_graph(P1, ij1, Z1)
+    ref.solve(pgm.PoseGraphParams(6, 8000, 1e-8, 0.0))
+    assert np.max(np.abs(ref.poses() - inc.poses())) < 5e-4
+    # a closure between two old poses: the structure is rebuilt, nothing is eliminated any more
+    inc.add_factor(10, 2000, _rel(Xf[10], Xf[2000]))
+    inc.solve(params)
+    assert inc.structure_info() == (2, 0)

@@ -198,7 +198,7 @@ def test_tuning_struct_round_trip_and_kept_structure(product, monkeypatch):
     pg = product.PoseGraph(kind)
     t = pg.tuning()
     assert (t.match_passes, t.two_phase, t.use_graph, t.debug, t.keep_structure) == (3, 1, 1, 0, 1)
-    assert t.omega_p == pytest.approx(0.66) and t.omega == pytest.approx(0.7) and t.lag_below == pytest.approx(0.05)
+    assert t.omega_p == pytest.approx(0.75) and t.omega == pytest.approx(0.8) and t.lag_below == pytest.approx(0.05)
     pg.set_tuning(match_passes=2, use_graph=0)
     t = pg.tuning()
     assert (t.match_passes, t.use_graph, t.two_phase) == (2, 0, 1)
