@@ -351,6 +351,10 @@ int srrg2_aligner_set_point_shard(srrg2_aligner_h h, srrg2_reduce_fn fn, void* u
 int srrg2_amd_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream);
 /* wait for everything queued on `stream` (the hipStream_t a reduction hook was handed) to finish */
 int srrg2_amd_stream_synchronize(void* stream);
+/* device memory on the calling thread's current device, for bindings that stage a collective's buffer themselves (the record
+ * table of a sharded batch on RCCL: include/srrg2_slam_amd_multi_device.hpp, RcclRecordExchange) */
+int srrg2_amd_device_malloc(size_t bytes, void** out);
+int srrg2_amd_device_free(void* p);
 
 /* ---- pose graph: the global Solver of MultiGraphSLAM_ ---------------------- */
 /* MultiGraphSLAM_::optimize() (S/system/multi_graph_slam_impl.cpp:300-317): graph->bindFactors();

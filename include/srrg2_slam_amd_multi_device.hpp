@@ -15,6 +15,10 @@
 //                             for G handles of one process: sums / maxima through host memory, one barrier pair per call
 //   RcclPointShardReducer     the same hook on RCCL (librccl.so opened at run time, ncclCommInitAll over the devices of the
 //                             handles, ncclAllReduce on each aligner's stream: nothing but launches on the hook's path)
+//   RcclRecordExchange        ONE PROCESS PER GPU (the layout of bench.py --gpus N and of distributed.py): the K x
+//                             SRRG2_RECORD_FLOATS record table of a sharded batch by ONE ncclAllReduce(sum) over the int64 bit
+//                             patterns of its rows -- north_star's "RCCL all-reduce of the final Hessian", native: no
+//                             torch.distributed in a C++ host
 #pragma once
 #include <dlfcn.h>
 
@@ -264,6 +268,102 @@ private:
   Destroy _destroy      = nullptr;
   std::vector<void*> _comms;
   std::vector<Participant> _parts;
+};
+
+// ---- the record table between PROCESSES (one per GPU) -------------------------------------------------------------------
+// Every rank runs its share of the K alignments (k mod world: srrg2_multi_gpu_shard_indices), packs ITS records into a zero
+// table (srrg2_multi_gpu_pack_record) and calls allReduce: afterwards every rank holds every record -- X, statistics, H -- and
+// applies the accept gates of multi_loop_detector_brute_force_impl.cpp:94-112 to all K of them.  The sum runs over the rows'
+// int64 bit patterns (x + 0 = x for every pattern, -0.0 included): the table of distributed.py's all_reduce_records, bit for bit.
+// The communicator: rank 0 creates an id (createId) and hands its 128 bytes to the other ranks by whatever the application
+// launches its processes with (a file, an environment variable, MPI, a socket); every rank constructs with it -- a collective.
+class RcclRecordExchange {
+public:
+  struct UniqueId {
+    char bytes[128];  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+  };
+  static UniqueId createId() {
+    Api api = load();
+    UniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    const int rc = api.get_id(&id);
+    if (rc != 0) throw std::runtime_error("RcclRecordExchange| ncclGetUniqueId failed, code " + std::to_string(rc));
+    return id;
+  }
+  // local_rank: this process's GPU (srrg2_multi_gpu_init: device = local_rank mod device count, bound to the calling thread)
+  RcclRecordExchange(const UniqueId& id, int world, int rank, int local_rank) : _api(load()), _world(world), _rank(rank) {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("RcclRecordExchange| bad world / rank");
+    check(srrg2_multi_gpu_init(local_rank, &_device));
+    const int rc = _api.init_rank(&_comm, world, id, rank);
+    if (rc != 0) throw std::runtime_error("RcclRecordExchange| ncclCommInitRank failed, code " + std::to_string(rc));
+  }
+  ~RcclRecordExchange() {
+    if (_buf) (void) srrg2_amd_device_free(_buf);
+    if (_comm) (void) _api.destroy(_comm);
+  }
+  RcclRecordExchange(const RcclRecordExchange&)            = delete;
+  RcclRecordExchange& operator=(const RcclRecordExchange&) = delete;
+  int world() const { return _world; }
+  int rank() const { return _rank; }
+  int device() const { return _device; }
+
+  // this rank's rows of the K x SRRG2_RECORD_FLOATS table from its results (alignment k of this rank = results[j], k = rank + j world)
+  std::vector<double> localTable(const std::vector<srrg2_batch_result>& mine, int K, int variable_kind) const {
+    std::vector<double> table((size_t) K * SRRG2_RECORD_FLOATS, 0.0);
+    for (size_t j = 0; j < mine.size(); ++j) {
+      const int k = _rank + (int) j * _world;
+      if (k >= K) throw std::runtime_error("RcclRecordExchange::localTable| more results than this rank's share");
+      check(srrg2_multi_gpu_pack_record(k, variable_kind, &mine[j], table.data() + (size_t) k * SRRG2_RECORD_FLOATS));
+    }
+    return table;
+  }
+  // in place: every rank's rows summed over the ranks (a collective: every rank calls it with a table of the same size)
+  void allReduce(std::vector<double>& table) {
+    const size_t bytes = table.size() * sizeof(double);
+    if (bytes == 0) return;
+    if (bytes > _cap) {
+      if (_buf) check(srrg2_amd_device_free(_buf));
+      _buf = nullptr;
+      _cap = 0;
+      check(srrg2_amd_device_malloc(bytes, &_buf));
+      _cap = bytes;
+    }
+    check(srrg2_amd_memcpy(_buf, table.data(), bytes, 1, nullptr));
+    // ncclInt64 = 4, ncclSum = 0; the null stream: this exchange happens once per batch, after the results are on the host
+    const int rc = _api.all_reduce(_buf, _buf, table.size(), 4, 0, _comm, nullptr);
+    if (rc != 0) throw std::runtime_error("RcclRecordExchange| ncclAllReduce failed, code " + std::to_string(rc));
+    check(srrg2_amd_stream_synchronize(nullptr));
+    check(srrg2_amd_memcpy(table.data(), _buf, bytes, 0, nullptr));
+  }
+
+private:
+  struct Api {
+    int (*get_id)(UniqueId*);
+    int (*init_rank)(void**, int, UniqueId, int);
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, void*);
+    int (*destroy)(void*);
+  };
+  static Api load() {
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) throw std::runtime_error(std::string("RcclRecordExchange| cannot open librccl.so: ") + dlerror());
+    Api api;
+    api.get_id     = reinterpret_cast<int (*)(UniqueId*)>(dlsym(lib, "ncclGetUniqueId"));
+    api.init_rank  = reinterpret_cast<int (*)(void**, int, UniqueId, int)>(dlsym(lib, "ncclCommInitRank"));
+    api.all_reduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, void*)>(dlsym(lib, "ncclAllReduce"));
+    api.destroy    = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclCommDestroy"));
+    if (!api.get_id || !api.init_rank || !api.all_reduce || !api.destroy)
+      throw std::runtime_error("RcclRecordExchange| librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce");
+    return api;  // (the library stays loaded: RCCL keeps threads that outlive its communicators)
+  }
+  Api _api;
+  int _world, _rank, _device = 0;
+  void* _comm = nullptr;
+  void* _buf  = nullptr;
+  size_t _cap = 0;
 };
 
 }  // namespace srrg2_slam_amd

@@ -1816,6 +1816,18 @@ int srrg2_amd_stream_synchronize(void* stream) {
   return 0;
 }
 
+int srrg2_amd_device_malloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(SRRG2_E_INVALID, "srrg2_amd_device_malloc: bad arguments");
+  *out = nullptr;
+  HIP_TRY(hipMalloc(out, bytes));
+  return 0;
+}
+
+int srrg2_amd_device_free(void* p) {
+  if (p) HIP_TRY(hipFree(p));
+  return 0;
+}
+
 int srrg2_aligner_set_sensor_in_robot(srrg2_aligner_h a, int si, const float* T) {
   int rc = check_slice(a, si, "set_sensor_in_robot");
   if (rc) return rc;

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <thread>
@@ -233,6 +234,28 @@ int main() {
       for (int g = 0; g < 8; ++g) {  // handle g took k = g, g + 8, ...: 8 candidates each
         int n = 0;
         ASSERT_TRUE((n = srrg2_multi_gpu_shard_count(64, 8, g)) == 8);
+      }
+      // ... and the same table between PROCESSES, natively on RCCL (RcclRecordExchange: ncclCommInitRank from a unique id,
+      // ONE ncclAllReduce(sum) over the int64 patterns of the rows).  A one-GPU box can form a one-rank communicator: the
+      // rank owns every row, the collective runs for real (RCCL's kernel on the device) and must hand the table back bit for
+      // bit -- the table of the one-process path above and, through srrg2_multi_gpu_pack_record, of distributed.py
+      // (tests/test_multi_gpu_gloo.py compares the two packers).  A rank of a larger world contributes zeros elsewhere:
+      // x + 0 = x in int64 whatever the pattern, which the second call below checks on a table with -0.0, NaN and inf rows.
+      try {
+        const RcclRecordExchange::UniqueId id = RcclRecordExchange::createId();
+        RcclRecordExchange ex(id, 1, 0, 0);
+        std::vector<double> t = ex.localTable(one8, 64, SRRG2_SE3_QUAT_RIGHT);
+        ASSERT_TRUE(t.size() == table8.size() && std::memcmp(t.data(), table8.data(), t.size() * sizeof(double)) == 0);
+        ex.allReduce(t);
+        ASSERT_TRUE(std::memcmp(t.data(), table8.data(), t.size() * sizeof(double)) == 0);
+        std::vector<double> odd = {-0.0, std::numeric_limits<double>::quiet_NaN(), std::numeric_limits<double>::infinity(), 1e-310, -1.5};
+        const std::vector<double> odd0 = odd;
+        ex.allReduce(odd);
+        ASSERT_TRUE(std::memcmp(odd.data(), odd0.data(), odd.size() * sizeof(double)) == 0);
+        std::printf("RCCL record exchange: one-rank communicator, 64 x %d table ok\n", SRRG2_RECORD_FLOATS);
+      } catch (const std::runtime_error& e) {
+        std::fprintf(stderr, "RCCL record exchange: %s\n", e.what());
+        ++g_failures;
       }
     }
     detector.param_relocalize_aligners.clear();
