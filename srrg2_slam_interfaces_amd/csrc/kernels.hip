@@ -2960,6 +2960,25 @@ __device__ __forceinline__ void point_rows(const float* T, float kk, const float
 
 }  // namespace
 
+// (experiment, -DSRRG2_NT_LOADS: the per-point arrays of the converged pass -- read once per pass, 512 MB per pass of a
+// 256-batch -- loaded non-temporally so that they do not evict the shared fixed clouds from L2 / MALL)
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#ifdef SRRG2_NT_LOADS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#ifdef SRRG2_NT_LOADS
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
 // GATHER: the previous neighbour and its normal are gathered from the fixed cloud through prev_pos (batches: the cloud
 // is shared by all alignments and stays in L2; 8 instead of 36 streamed bytes per point) instead of read from prev_f / prev_n
 // (single alignments: no dependent load on the chain).
@@ -3051,18 +3070,18 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     inr[k]      = i < pd.nm;
     gi_[k]      = pd.moff + (inr[k] ? i : 0);  // (out of range: the loads below read point 0 of the problem, masked out later)
     int ppos    = -1;
-    p[k]        = S.mpts[gi_[k]];
-    pm[k]       = S.prev_m[gi_[k]];
+    p[k]        = ld_stream(S.mpts + gi_[k]);
+    pm[k]       = ld_stream(S.prev_m + gi_[k]);
     pf[k]       = make_float4(0.f, 0.f, 0.f, __int_as_float(NO_MATCH));
     pn[k]       = make_float4(0.f, 0.f, 0.f, 0.f);
     pnm[k]      = make_float4(0.f, 0.f, 0.f, 0.f);
     if (GATHER) {
-      ppos = S.prev_pos[gi_[k]];
+      ppos = ld_stream(S.prev_pos + gi_[k]);
     } else {
       pf[k] = S.prev_f[gi_[k]];
       if (PLANE || ngate) pn[k] = S.prev_n[gi_[k]];
     }
-    if (ngate) pnm[k] = S.mnrm[gi_[k]];
+    if (ngate) pnm[k] = ld_stream(S.mnrm + gi_[k]);
     if (GATHER && ppos >= 0 && ppos < g.n) {
       pf[k] = g.pts[ppos];
       if (PLANE || ngate) pn[k] = g.nrm[ppos];
