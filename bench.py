@@ -700,6 +700,19 @@ def main():
             out["c4_8"] = nested("c4", batch=8, steps=20, warmup=3)
             out["c4_distinct_8"] = measure_c4_distinct(iterations=args.iterations)
             out["c5"] = measure_c5(with_cpu=not args.no_cpu_baseline)
+            # the primary caller's frame (MultiTrackerBase_::align binds a NEW fixed cloud every frame, multi_tracker_impl.cpp:97-98):
+            # clip the local map, set_moving / set_fixed, compute, merge -- everything resident in HBM
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_tracker
+
+                tr = bench_tracker.run(points=100_000, frames=30)
+                out["tracker_frame"] = {"tracker_frame_ms": tr["ms_per_frame_on_device"], "ms": tr["ms"], "frames_per_s": tr["frames_per_s_on_device"],
+                                        "points_per_frame": tr["points_per_frame"], "status": tr["status"],
+                                        "note": "host wall clock around the blocking C-ABI calls of one frame, 100 000-point measurement against the "
+                                                "clipped local map; `upload` (the measurement's host-to-device copy) is not in tracker_frame_ms"}
+            except Exception as e:
+                out["tracker_frame"] = {"error": repr(e)}
             # BASELINE's second half asks for >= 6x at 8 GPUs on the 256-alignment job: at 8 GPUs every rank runs 32 per
             # launch, so the one-GPU figures bound the strong-scaling ratio from above (no collective on the data path)
             out["projected_8gpu_speedup"] = 8.0 * out["c4_32"]["value"] / out["c4_256"]["value"]

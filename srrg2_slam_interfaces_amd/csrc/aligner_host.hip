@@ -258,17 +258,20 @@ float bound2_of_host(int r, float h) {
 // (re)build the finder's search grid of one slice; called from set_fixed
 // force_h > 0: this cell size (grown until the grid fits) instead of the automatic one (ensure_lists: a grid coarse enough for
 // the neighbour lists)
-int build_grid(srrg2_aligner* a, Slice* s, float force_h = 0.f) {
+// (have_bbox: set_fixed's ingest has left the bounding box and the count of valid points in the scalars already -- k_ingest_bbox)
+int build_grid(srrg2_aligner* a, Slice* s, float force_h = 0.f, bool have_bbox = false) {
   const int n = s->nf;
   int rc;
   if ((rc = s->scalars.reserve(16))) return rc;
-  unsigned init[16];
-  for (int i = 0; i < 3; ++i) { init[i] = 0xffffffffu; init[3 + i] = 0u; }
-  init[6] = 0; init[7] = 0; init[8] = 0;
-  for (int i = 9; i < 16; ++i) init[i] = 0;
-  // ninf (init[7]) is accumulated by the normal ingest which already ran: keep it
-  HIP_TRY(hipMemcpyAsync(s->scalars.p, init, 7 * sizeof(unsigned), hipMemcpyHostToDevice, a->stream));
-  srrg2amd::launch_bbox(s->fixed_raw.p, n, s->scalars.p, s->scalars.p + 3, (int*) (s->scalars.p + 6), a->stream);
+  if (!have_bbox) {
+    unsigned init[16];
+    for (int i = 0; i < 3; ++i) { init[i] = 0xffffffffu; init[3 + i] = 0u; }
+    init[6] = 0; init[7] = 0; init[8] = 0;
+    for (int i = 9; i < 16; ++i) init[i] = 0;
+    // ninf (init[7]) is accumulated by the normal ingest which already ran: keep it
+    HIP_TRY(hipMemcpyAsync(s->scalars.p, init, 7 * sizeof(unsigned), hipMemcpyHostToDevice, a->stream));
+    srrg2amd::launch_bbox(s->fixed_raw.p, n, s->scalars.p, s->scalars.p + 3, (int*) (s->scalars.p + 6), a->stream);
+  }
   unsigned back[8];
   HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, a->stream));
   HIP_TRY(hipStreamSynchronize(a->stream));
@@ -381,8 +384,8 @@ int build_grid(srrg2_aligner* a, Slice* s, float force_h = 0.f) {
   if ((rc = s->pos_of.reserve((size_t) std::max(n, 1)))) return rc;
   HIP_TRY(hipMemsetAsync(s->cell_start.p, 0, ((size_t) ncell + 1) * sizeof(int), a->stream));
   srrg2amd::launch_grid_count(g, s->fixed_raw.p, n, s->cell_start.p, a->stream);
-  srrg2amd::launch_exclusive_scan(s->cell_start.p, ncell, s->scan_sums.p, (int*) (s->scalars.p + 8), a->stream);
-  HIP_TRY(hipMemcpyAsync(s->cursor.p, s->cell_start.p, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, a->stream));
+  // (the scan's last phase leaves the scatter's cursors beside the cell starts)
+  srrg2amd::launch_exclusive_scan(s->cell_start.p, ncell, s->scan_sums.p, (int*) (s->scalars.p + 8), a->stream, s->cursor.p);
   srrg2amd::launch_grid_scatter(g, s->fixed_raw.p, s->fixed_has_normals ? s->fixed_nrm_raw.p : nullptr, n, s->cursor.p,
                                 s->fixed_sorted.p, s->fixed_has_normals ? s->fixed_nrm_sorted.p : nullptr, s->pos_of.p, a->stream);
   g.cell_start = s->cell_start.p;
@@ -1724,11 +1727,21 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   if ((rc = s->scalars.reserve(16))) return rc;
   const size_t bytes_c = (size_t) n * a->dim * 4;
   if (mem == SRRG2_MEM_HOST && (rc = a->staging.reserve(2 * bytes_c + 64))) return rc;
-  HIP_TRY(hipMemsetAsync(s->scalars.p, 0, 16 * sizeof(unsigned), a->stream));
+  // (the scalars: bounding box minima start at all ones, everything else at zero; a nearest-neighbour slice's ingest leaves the box
+  // and the count of valid points there on its way -- one pass over the cloud and one launch instead of two, round 6)
+  const bool nn = s->cfg.finder == SRRG2_FINDER_NN_GATED;
+  {
+    unsigned init[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(s->scalars.p, init, sizeof(init), hipMemcpyHostToDevice, a->stream));
+  }
   const float* dsrc;
   int sf;
   if ((rc = stage_input(a, coords, cs, n, a->dim, mem, &dsrc, &sf, 0))) return rc;
-  srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, 1, a->stream);  // [10] = |fixed|inf
+  if (nn)
+    srrg2amd::launch_ingest_bbox(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, s->scalars.p, s->scalars.p + 3,
+                                 (int*) (s->scalars.p + 6), a->stream);
+  else
+    srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, 1, a->stream);  // [10] = |fixed|inf
   if (normals) {
     const float* nsrc;
     int nsf;
@@ -1737,7 +1750,7 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   }
   s->nf                = n;
   s->fixed_has_normals = normals != nullptr;
-  if (s->cfg.finder == SRRG2_FINDER_NN_GATED && (rc = build_grid(a, s))) return rc;  // projective: organised cloud as is
+  if (nn && (rc = build_grid(a, s, 0.f, /*have_bbox=*/n > 0))) return rc;  // projective: organised cloud as is
   HIP_TRY(hipStreamSynchronize(a->stream));
   s->has_fixed = true;
   return 0;

@@ -9,10 +9,12 @@ void launch_ingest(const float* src, int stride_floats, int n, int dim, float4* 
 void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* probs, int K, int max_nm, int dim,
                          float4* dst, unsigned* maxabs_bits, int finite_per_point, hipStream_t s);
 void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s);
+void launch_ingest_bbox(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits, unsigned* mn,
+                        unsigned* mx, int* nvalid, hipStream_t s);
 void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s);
 void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s);
 int scan_num_blocks(int n);
-void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s);
+void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s, int* copy = nullptr);
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
                          float4* out_nrm, int* pos_of, hipStream_t s);
 // cell neighbour lists of the grid (GridDev::list_*): ent == null counts the entries per cell into list_start, else fills

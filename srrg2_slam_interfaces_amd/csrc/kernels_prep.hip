@@ -66,12 +66,26 @@ __global__ void k_ingest_batch(const float* __restrict__ src, int stride_floats,
 // ============================================================================================
 // grid build
 // ============================================================================================
-__global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
-                       int* __restrict__ nvalid) {
+// SRC != nullptr (k_ingest_bbox): the points are ingested on the way -- caller layout in, float4 out, max |coordinate| of the
+// finite points -- a fixed cloud's set_fixed in one pass over the cloud instead of two launches (round 6: a tracker sets a new
+// fixed cloud every frame, multi_tracker_impl.cpp:97-98)
+template <bool INGEST>
+__device__ __forceinline__ void bbox_body(const float* __restrict__ src, int stride_floats, int dim, float4* __restrict__ dst,
+                                          unsigned* __restrict__ maxabs_bits, const float4* __restrict__ pts, int n,
+                                          unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out, int* __restrict__ nvalid) {
   unsigned mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
   int valid = 0;
+  float amax = 0.f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 p = pts[i];
+    float4 p;
+    if constexpr (INGEST) {
+      const float* q = src + (size_t) i * stride_floats;
+      p      = make_float4(q[0], q[1], dim == 3 ? q[2] : 0.f, 0.f);
+      dst[i] = p;
+      if (finite3(p.x, p.y, p.z)) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)));
+    } else {
+      p = pts[i];
+    }
     if (finite3(p.x, p.y, p.z)) {
       valid += 1;
       const unsigned k[3] = {fkey(p.x), fkey(p.y), fkey(p.z)};
@@ -92,7 +106,11 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
     valid += __shfl_xor(valid, off);
   }
   // one atomic per block and value (a few grid-striding blocks): same-address atomics serialise at tens of ns each
-  __shared__ unsigned red[4][7];
+  __shared__ unsigned red[4][8];
+  if constexpr (INGEST) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  }
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -100,8 +118,13 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
       red[threadIdx.x >> 6][3 + d] = mx[d];
     }
     red[threadIdx.x >> 6][6] = (unsigned) valid;
+    red[threadIdx.x >> 6][7] = __float_as_uint(amax);  // (non-negative floats order like their bit patterns)
   }
   __syncthreads();
+  if (INGEST && threadIdx.x == 7 && maxabs_bits) {
+    const unsigned v = max(max(red[0][7], red[1][7]), max(red[2][7], red[3][7]));
+    if (v != 0u) atomicMax(maxabs_bits, v);
+  }
   if (threadIdx.x < 7) {
     const int d = threadIdx.x;
     if (d < 3) {
@@ -115,6 +138,15 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
       if (v) atomicAdd(nvalid, v);
     }
   }
+}
+__global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
+                       int* __restrict__ nvalid) {
+  bbox_body<false>(nullptr, 0, 3, nullptr, nullptr, pts, n, mn_out, mx_out, nvalid);
+}
+__global__ void k_ingest_bbox(const float* __restrict__ src, int stride_floats, int n, int dim, float4* __restrict__ dst,
+                              unsigned* __restrict__ maxabs_bits, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
+                              int* __restrict__ nvalid) {
+  bbox_body<true>(src, stride_floats, dim, dst, maxabs_bits, nullptr, n, mn_out, mx_out, nvalid);
 }
 
 __device__ __forceinline__ int grid_cell_of(const GridDev& g, float4 p) {
@@ -223,13 +255,18 @@ __global__ void k_scan_sums(int* __restrict__ block_sums, int nblocks, int* __re
   if (threadIdx.x == 0) *grand_total = carry;
 }
 
+// (copy != nullptr: a second copy of the scanned values -- the scatter's cursors -- instead of a device-to-device copy behind the scan)
 __global__ void k_scan_add(int* __restrict__ data, int n, const int* __restrict__ block_sums,
-                           const int* __restrict__ grand_total) {
+                           const int* __restrict__ grand_total, int* __restrict__ copy) {
   int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   int add  = block_sums[blockIdx.x];
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k)
-    if (base + k < n) data[base + k] += add;
+    if (base + k < n) {
+      const int v    = data[base + k] + add;
+      data[base + k] = v;
+      if (copy) copy[base + k] = v;
+    }
   if (blockIdx.x == 0 && threadIdx.x == 0) data[n] = *grand_total;  // cell_start[ncell]
 }
 
@@ -719,6 +756,12 @@ void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* 
                      finite_per_point);
 }
 
+void launch_ingest_bbox(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits, unsigned* mn,
+                        unsigned* mx, int* nvalid, hipStream_t s) {
+  if (n <= 0) return;
+  const int bx = (n + 255) / 256;
+  hipLaunchKernelGGL(k_ingest_bbox, dim3(bx < 256 ? bx : 256), dim3(256), 0, s, src, stride_floats, n, dim, dst, maxabs_bits, mn, mx, nvalid);
+}
 void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s) {
   if (n <= 0) return;
   const int bx = (n + 255) / 256;
@@ -741,11 +784,11 @@ int scan_num_blocks(int n) {
   return (n + SCAN_TILE - 1) / SCAN_TILE;
 }
 
-void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s) {
+void launch_exclusive_scan(int* data, int n, int* block_sums, int* grand_total, hipStream_t s, int* copy) {
   int nb = scan_num_blocks(n);
   hipLaunchKernelGGL(k_scan_tiles, dim3(nb), dim3(SCAN_THREADS), 0, s, data, n, block_sums);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, s, block_sums, nb, grand_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, s, data, n, block_sums, grand_total);
+  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_THREADS), 0, s, data, n, block_sums, grand_total, copy);
 }
 
 void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm, int n, int* cursor, float4* out_pts,
@@ -766,8 +809,7 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
   // (few, grid-striding blocks per problem for the bounding box: its cost is the atomics, not the reads)
   hipLaunchKernelGGL(k_msort_bbox, dim3(bx < 32 ? bx : 32, K), dim3(256), 0, s, pts, probs, bb);
   hipLaunchKernelGGL(k_msort_count, grid, dim3(256), 0, s, pts, probs, bb, kbits, aniso, counts);
-  launch_exclusive_scan(counts, ncell, scan_sums, scan_total, s);
-  (void) hipMemcpyAsync(cursor, counts, (size_t) ncell * sizeof(int), hipMemcpyDeviceToDevice, s);
+  launch_exclusive_scan(counts, ncell, scan_sums, scan_total, s, cursor);  // (the cursors beside the starts: no copy behind the scan)
   hipLaunchKernelGGL(k_msort_scatter, grid, dim3(256), 0, s, pts, nrm, probs, bb, kbits, aniso, cursor, out_pts, out_nrm);
 }
 

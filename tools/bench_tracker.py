@@ -17,11 +17,11 @@ from srrg2_slam_interfaces_amd import mapping  # noqa: E402
 from srrg2_slam_interfaces_amd import synthetic as syn  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--points", type=int, default=100_000)
-    ap.add_argument("--frames", type=int, default=30)
-    args = ap.parse_args()
+def run(points=100_000, frames=30):
+    """the tracker cycle of multi_tracker_impl.cpp:83-123 with everything resident in HBM; returns the JSON object"""
+    import types
+
+    args = types.SimpleNamespace(points=points, frames=frames)
     b = pkg.scene_binding(0)
     scene, clipped, meas = mapping.Scene(b, 3), mapping.Scene(b, 3), mapping.Scene(b, 3)
     mg = mapping.MergerCorrespondenceHomo(b, mapping.MergerParams(50.0, 0.0025, 0))  # merge close points, never append
@@ -63,9 +63,16 @@ def main():
     ms = {k: 1e3 * v / nf for k, v in t.items()}
     on_device = sum(v for k, v in ms.items() if k != "upload")
     err = float(np.max(np.abs(est - poses[args.frames][:3].astype(np.float32))))
-    print(json.dumps({"points_per_frame": args.points, "scene_points": scene.size(), "ms": ms, "ms_per_frame_on_device": on_device,
-                      "frames_per_s_on_device": 1e3 / on_device, "pose_error_after_%d_frames" % args.frames: err,
-                      "status": al.status()}))
+    return {"points_per_frame": args.points, "scene_points": scene.size(), "ms": ms, "ms_per_frame_on_device": on_device,
+            "frames_per_s_on_device": 1e3 / on_device, "pose_error_after_%d_frames" % args.frames: err, "status": al.status()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=100_000)
+    ap.add_argument("--frames", type=int, default=30)
+    args = ap.parse_args()
+    print(json.dumps(run(args.points, args.frames)))
 
 
 if __name__ == "__main__":
