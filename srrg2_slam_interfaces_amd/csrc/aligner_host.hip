@@ -830,7 +830,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // The converged pass kernel takes over from iteration `fast_from` of the first run (all of the inlier-only run): by
   // then nearly every point keeps its neighbour.  Batches give it `fast_ppt` points per thread and a queue.
   const int fast_from = tn.fast_from_iteration;
-  // (measured on C4, 32 x 50k, profiles/r2c: one point per thread with the failed certificates searched by their own wave
+  // (measured on C4, 32 x 50k, profiles/archive/r2c: one point per thread with the failed certificates searched by their own wave
   // 37.7 us per pass / 268.8 k it/s; two points per thread 45 us -- the accumulators stay live across the search, 181
   // registers -- ; with a queue the nearly idle deferred-search launch costs 15 us per iteration: 31 + 15 us, 254 k it/s)
   // (0 = automatic: two points per thread share one reduction once a launch holds 64 alignments or more -- C4-256 575 -> 595 k it/s;
@@ -847,7 +847,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // (smallest moving cloud that uses the converged-pass kernel.  Sparse clouds of a few thousand points leave a larger
   // share of their certificates behind; since those searches run four at a time with 16 lanes each the kernel is ahead
   // at every size -- 2 000 points: 0.26 ms per compute() either way, 0.42 ms with one search per wave at a time,
-  // profiles/r2m_bench_small.json / r2n_bench_small*.json -- so the threshold is 0; kept as a switch)
+  // profiles/archive/r2m_bench_small.json / r2n_bench_small*.json -- so the threshold is 0; kept as a switch)
   const int fast_min = tn.fast_min_points;
   const bool fast_gather = tn.fast_gather >= 0 ? tn.fast_gather != 0 : K > 4;
   const bool fast_batch_queue = tn.fast_batch_queue != 0;
@@ -855,7 +855,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // 416 candidates, four workgroups per CU; 2: 504 candidates, three workgroups per CU)
   // (automatic: batches of more than four alignments -- C4-256 374 -> 406 k it/s, C4-32 305 -> 322 k, C4-8 167 -> 171 k;
   // single alignments are launch / latency bound and neutral to 1.5 % slower with it: 30 k points 41.7 -> 41.1 k it/s,
-  // profiles/r3i_ab_tile_default.txt)
+  // profiles/archive/r3i_ab_tile_default.txt)
   const int lds_tile = tn.lds_tile >= 0 ? tn.lds_tile : (K > 4 ? 1 : 0);
   // Search passes over the cell neighbour lists of the grid (k_icp_step_cnl, round 4): 0 = never, 1 = batches of more than
   // four alignments, 2 = every alignment (no deferred-search queue then).  -1 = automatic: batches always (the build --

@@ -105,7 +105,7 @@ __device__ __forceinline__ void test_candidate2(const float4 f, float qx, float 
 // no cap 27.4k / 196k, 0.25: 28.1k / 199k, 0.1: 28.7k / 202k it/s (round 2, grid scans).  Round 4, searches over the cell
 // neighbour lists (a search is cheaper, a candidate is not): C4-256 0.4 / 0.2 / 0.1 / 0.05 / 0.025 / 0: 539 / 575 / 596 / 611 /
 // 612 / 615 k it/s, C4-32 423 / 444 / 458 / 457 / 464 / 470 k, C2 43.2 / 44.8 / 45.4 / 45.9 / 45.7 / 45.5 k; tracker cycle, small
-// clouds and the 60 % overlap unchanged (profiles/r4w_ab_scan_margin.txt): the margin is the 2 % of a cell alone.
+// clouds and the 60 % overlap unchanged (profiles/archive/r4w_ab_scan_margin.txt): the margin is the 2 % of a cell alone.
 #ifndef PAD_CAP
 #define PAD_CAP 0.0f
 #endif
@@ -436,7 +436,7 @@ __device__ __forceinline__ uint8_t factor_accumulate(const float (&J)[ROWS][D], 
 // adds cannot change a bit; spreading the blocks over 32 slot sets keeps same-address contention (~10 ns per atomic)
 // at <= ceil(blocks/32) per address, and the control kernel has 32 x 32 values to sum instead of blocks x 32.
 // (History: one atomic target per entry serialised 391 blocks -> ~90 us; plain per-block partials made the control
-// kernel read 100 KB -> ~10 us.  profiles/r1a, r1b.)
+// kernel read 100 KB -> ~10 us.  profiles/archive/r1a, r1b.)
 // NW = waves per workgroup.  local != null: the workgroup owns the whole problem (k_icp_small) and adds into its LDS sums.
 template <int NW>
 __device__ __forceinline__ void block_reduce_store(long long (&acc)[ACC_N], long long* __restrict__ partials, int prob,
@@ -642,7 +642,7 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
 // The grid kernels enumerate CELLS -- the rows of the 3^DIM block, then the shell of the 5^DIM cube, then cubes of growing
 // radius -- and most of what they enumerate is empty: a cloud is a surface, one cell in six of a block holds points.  On the
 // tiles the bookkeeping of (mostly empty) rows, the second staging for the shell and the cooperative scans behind it were
-// 46 % of the first pass' vector instructions (profiles/r3n_tile_kernel_knob_attribution.txt), the candidates themselves a
+// 46 % of the first pass' vector instructions (profiles/archive/r3n_tile_kernel_knob_attribution.txt), the candidates themselves a
 // fifth.  The fixed cloud is set once and searched by every iteration of every alignment, so the enumeration is done ONCE
 // per fixed cloud: every cell of the (extended) grid gets the list of OCCUPIED cells that can hold a point within the
 // extended gate of a query in it (GridDev::list_*, ~20 entries of 8 bytes per cell on C4, at most 16 points per entry),
@@ -654,7 +654,7 @@ __device__ __forceinline__ void coop_scan(const GridDev& g, int lane, int* lds_w
 //      are appended to ONE pool of the wave in LDS (ballot + mbcnt: compact, in order);
 //   B. the wave works the pool off together, item s by lane s mod 64 -- a wave is as slow as its busiest lane, and with one
 //      list per lane a single point without a neighbour inside the gate (all ~20 entries survive) kept the other 63 lanes
-//      waiting: 28 group iterations per wave on the first pass for ~8 per lane on average (profiles/r4c_*).  The worker
+//      waiting: 28 group iterations per wave on the first pass for ~8 per lane on average (profiles/archive/r4c_*).  The worker
 //      merges its item's (key, runner-up) into the owner's slot with two LDS atomics: min of the 64-bit key, and the loser
 //      of that min -- the larger of the old and the new key -- is a candidate for the runner-up.
 // TEAM lanes share one query (TEAM = 1: throughput, one query per lane; TEAM = 4: a single alignment is a chain of
@@ -1495,9 +1495,9 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
 // ============================================================================================
 // Search passes of batches with the neighbourhood of every WAVE staged in LDS (k_icp_step_tile).
 //
-// What bounds k_icp_step in the throughput regime (profiles/r2u_*, r3a_*): the texture path is busy ~70 % of a search
+// What bounds k_icp_step in the throughput regime (profiles/archive/r2u_*, r3a_*): the texture path is busy ~70 % of a search
 // pass -- it moves 64 bytes per clock of REQUESTED lane data, so a 16-byte candidate gather costs a wave 16 of its cycles
-// however well its lanes coalesce (a finer Morton order of the moving cloud changes nothing: profiles/r3a_ab_msort.txt) --
+// however well its lanes coalesce (a finer Morton order of the moving cloud changes nothing: profiles/archive/r3a_ab_msort.txt) --
 // the vector ALUs ~65 %, at four waves per SIMD.  Here every wave fetches the candidates it needs ONCE, coalesced, into
 // LDS: the lanes of a wave are neighbours in space (Morton order), their 3^DIM blocks overlap, the union is a box of a
 // few dozen rows of cells.  The lanes then scan their own rows with ds_read_b128 (LDS: 128 bytes per clock, its own
@@ -1533,7 +1533,7 @@ struct WaveTile {             // per wave, in LDS
 // One group of four candidates from LDS, the first `cnt` of them valid (cnt >= 4: all).  (Measured without the masks --
 // a group that runs past its range then tests a few more real fixed points, which cannot change the minimum: 2 % fewer
 // vector instructions, but the candidates seen early shrink the ball the rest of the scan is pruned to, and with it the
-// exclusion radius left behind: the first converged pass went from 34 to 52 us.  profiles/r3h_*)
+// exclusion radius left behind: the first converged pass went from 34 to 52 us.  profiles/archive/r3h_*)
 template <int DIM>
 __device__ __forceinline__ void test_group_lds(const f4v* pts, int j, int cnt, float qx, float qy, float qz,
                                                unsigned long long& bkey, float& b2) {
@@ -2074,7 +2074,7 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
 // neighbour (exclusion-radius certificate, see icp_step_body): such a pass is a streaming kernel -- load the point, its
 // previous neighbour and the neighbour's normal, prove that the neighbour is unchanged, linearise, reduce -- and in
 // k_icp_step it pays for the generality of the search code around it (941 vector instructions per wave and point
-// on converged C4 passes, the pass is VALU-issue bound; profiles/r2a).  k_icp_step_fast is that pass alone:
+// on converged C4 passes, the pass is VALU-issue bound; profiles/archive/r2a).  k_icp_step_fast is that pass alone:
 //   * PPT moving points per thread share ONE 32-value transposing reduction (the reduction is ~230 of the ~500
 //     vector instructions of a point; the accumulators are plain int64 registers, no search state is live);
 //   * the fixed-point terms stay in their fma-biased form (bit pattern of FX_MAGIC + integer) and are summed as

@@ -836,9 +836,9 @@ bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, co
   // segments per problem: fill about half the chip's CUs (one 1024-thread workgroup each); segments get the coarser key
   // space of the big batches (16^3 cells for ~6-12 k points)
   const int seg_env = segments;
-  // (measured on C4, profiles/r2zk_ab_msort_segments.txt: 32 alignments 287 -> 305 k it/s with 4 segments, 8 alignments
+  // (measured on C4, profiles/archive/r2zk_ab_msort_segments.txt: 32 alignments 287 -> 305 k it/s with 4 segments, 8 alignments
   // 146 -> 161 k, 64 alignments 331 -> 345 k with 2; the passes lose 1.4 % of coherence, the sort goes from 118 to ~35 us;
-  // 128 alignments 362 -> 372 k with 2 (profiles/r2zs_env_tests.txt); 256: within noise, one workgroup per cloud)
+  // 128 alignments 362 -> 372 k with 2 (profiles/archive/r2zs_env_tests.txt); 256: within noise, one workgroup per cloud)
   int G = seg_env > 0 ? seg_env : (K >= 256 ? 1 : (K >= 64 ? 2 : (128 / K < 8 ? 128 / K : 8)));
   if (G < 1) G = 1;
   if (G > 1) {

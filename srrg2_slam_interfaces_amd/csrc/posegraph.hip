@@ -247,7 +247,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
 //     rigid motions) is represented exactly on every level;
 //   * the interpolation is smoothed by one damped block-Jacobi sweep, Ps = (I - 0.66 Dinv H) T.  With T alone the
 //     cycle's convergence degrades with the number of levels (C5, plain aggregation: 151-415 CG iterations per
-//     Gauss-Newton iteration, profiles/r2k); with Ps: 30-79.  The price is fill: a row of Ps holds the aggregates of a
+//     Gauss-Newton iteration, profiles/archive/r2k); with Ps: 30-79.  The price is fill: a row of Ps holds the aggregates of a
 //     pose and of its neighbours (C5: 4 blocks per row), the coarse operators have 40-120 blocks per row, so rows and
 //     columns of the coarse levels are shared by 2-32 adjacent lanes (MgLevel::row_parts / col_parts / prow_parts);
 //   * coarse operators by the Galerkin product Ps^T (H Ps) in two sparse products over patterns fixed on the host; every
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_pg_vertices(int V, const uint8_t
 // the smallest eigenvalue of a 50 000-pose graph with one gauge vertex is ~1e-9 of the largest, float32 blocks
 // (relative error 6e-8) make the operator indefinite in exactly the drift modes the solve is about -- measured: with
 // float32 blocks PCG needed 151 / 175 / 200 iterations on C5 and the coarsest Cholesky failed in the fourth
-// Gauss-Newton iteration (profiles/r2k_bench_c5_float32_blocks.json).
+// Gauss-Newton iteration (profiles/archive/r2k_bench_c5_float32_blocks.json).
 // =====================================================================================================================
 #define MG_OMEGA 0.8     // (0.7 until round 6: swept again on the spanning-tree aggregates, profiles/r9/r9h_*)
 #define MG_OMEGA_P 0.75  // damping of the interpolation smoother (0.66 = (4/3) / lambda_max until round 6; same sweep)
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_op(int op, MgPair LV,
 
 // ---- two-phase levels -------------------------------------------------------------------------------------------------
 // A V(1,1) cycle visits a level with six dependent phases (smooth, residual, restrict | prolong, residual, update): six
-// launches of which, below level 0, each is mostly launch floor (profiles/r3k_pg_trace.txt: 4.3 us for a launch with
+// launches of which, below level 0, each is mostly launch floor (profiles/archive/r3k_pg_trace.txt: 4.3 us for a launch with
 // nothing to do, 31 launches per CG iteration).  With Q = H Ps -- which the Galerkin product needs anyway -- the same cycle
 // takes ONE phase down and ONE up per level:
 //   down:  r_c = Ps^T (r - H x1) = Ps^T r - Q^T x1           x1 = omega D^-1 r is local to a node and written by whoever
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_op(int op, MgPair LV,
 // (every lane takes WHOLE blocks of the column -- all D rows of the result from one 144-byte block load and one load of
 // the vector's node, two blocks in flight -- instead of 32 lanes per row that each pick six strided words out of every
 // block: a dense 788-row column was 25 chains of three dependent loads in a row, 34 us for 11 MB on C5's level 2;
-// profiles/r3p_*.  The columns are stored a second time as {entry, row} pairs: one load less on the chain.)
+// profiles/archive/r3p_*.  The columns are stored a second time as {entry, row} pairs: one load less on the chain.)
 template <int D>
 __device__ __forceinline__ void mg_block_tmulsub(const float* __restrict__ B, const double* __restrict__ xv, double sign,
                                                  double (&s)[D]) {
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(MG_DOWN2_THREADS) void k_mg_down2(MgPair LV,
 
 // The down phase of the LAST two-phase level and the dense solve of the coarsest level behind it in one launch of one
 // workgroup: with a dozen coarsest nodes the two launches (13 workgroups, then one) were 11 + 18 us of mostly launch floor
-// and load latency per cycle (profiles/r3p_*).  A wave per coarsest node, the waves meet in LDS, 8 lanes share a row of
+// and load latency per cycle (profiles/archive/r3p_*).  A wave per coarsest node, the waves meet in LDS, 8 lanes share a row of
 // the dense inverse.
 template <int D>
 __global__ __launch_bounds__(1024) void k_mg_down2_coarsest(MgPair LV, const double* __restrict__ Cinv,

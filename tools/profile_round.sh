@@ -47,7 +47,8 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES"; do
   SRRG2_AMD_PG_GRAPH=0 timeout 900 rocprofv3 --pmc $c -d /tmp/pmc_c5_$n -o p -- python $R/tools/bench_posegraph.py > /dev/null 2>&1
   python $R/tools/rocpd_summary.py $O/pmc_c5_$n.txt $n=$(find /tmp/pmc_c5_$n -name '*.db' | head -1)
 done
-python $R/tools/traffic_c5_from_pmc.py $O/traffic_c5.json $O/pmc_c5_FETCH_SIZE.txt $O/pmc_c5_WRITE_SIZE.txt $O/pmc_c5_SQ_INSTS_VALU_SQ_WAVES.txt $O/rocprofv3_c5_summary.txt 3 10 384 > /dev/null 2>&1
+PCG=$(python -c "import json; print(sum(json.load(open('$O/bench_c5.json'))['config']['pcg_iterations']))" 2>/dev/null || echo 282)
+python $R/tools/traffic_c5_from_pmc.py $O/traffic_c5.json $O/pmc_c5_FETCH_SIZE.txt $O/pmc_c5_WRITE_SIZE.txt $O/pmc_c5_SQ_INSTS_VALU_SQ_WAVES.txt $O/rocprofv3_c5_summary.txt 3 10 $PCG > $O/traffic_c5.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d /tmp/pmc_valu -o p -- python $R/bench.py --workload c4 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/rocpd_summary.py $O/rocprofv3_c4_valu_pmc_summary.txt valu=$(find /tmp/pmc_valu -name '*.db' | head -1)
 # the search passes of the 256-alignment batch, pass by pass: durations, instructions, texture-path and LDS activity
