@@ -413,6 +413,9 @@ def measure(args, init_dist=True):
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "avg_launch_ms": kern_ms,
             "launches_timed": launches.value,
+            # the HIP-event brackets above hold a launch AND the gap to the next one (a launch-bound chain: C2 is ~12 dependent
+            # launches of 10-25 us); rocprofv3's kernel durations of the same command, per pass kernel, from the committed summary
+            **({"rocprofv3": rocprof_pass_split(args.workload)} if args.workload in ("c2", "c3") else {}),
         },
     }
 
@@ -509,6 +512,34 @@ def measure(args, init_dist=True):
                 out["cpu_baseline"]["all_cores"] = {"error": repr(e)}
     if world > 1:
         dist.destroy_process_group()
+    return out
+
+
+def rocprof_pass_split(workload):
+    """mean kernel duration of the pass kernels from the committed rocprofv3 --kernel-trace --stats summary of `bench.py --workload
+    <w>` (profiles/r9/r9final_rocprofv3_<w>_summary.txt; tools/profile_round.sh) and the roofline fraction that goes with it; the
+    passes from the second on carry the control step of the previous iteration (~3.2 us on one wave, profiles/r6e_pass_timeline_c2.txt)"""
+    path = os.path.join(ROOT, "profiles", "r9", "r9final_rocprofv3_%s_summary.txt" % workload)
+    if not os.path.exists(path):
+        return None
+    rows = []
+    for line in open(path):
+        f = [x.strip() for x in line.split("|")]
+        if len(f) == 5 and f[1].isdigit() and any(k in f[0] for k in ("k_icp_step_fast<", "k_icp_step_cnl<", "k_icp_step_proj_fused<", "k_proj_zbuf_fz")):
+            rows.append((f[0].replace("void ", "").split("(")[0], int(f[1]), float(f[3])))
+    if not rows:
+        return None
+    if workload == "c2":
+        calls = sum(r[1] for r in rows)
+        mean_us = sum(r[1] * r[2] for r in rows) / calls  # one launch per pass
+        alg = 4.8e6
+    else:  # c3: a pass = z-buffer launch + step launch
+        mean_us = sum(r[2] for r in rows)
+        alg = None
+    out = {"source": "profiles/r9/" + os.path.basename(path), "kernels_avg_us": {r[0]: r[2] for r in rows}, "mean_pass_us": mean_us,
+           "note": "kernel time only (no launch gaps); passes from the second on include the previous iteration's control step"}
+    if alg:
+        out["frac_of_8TBs_on_kernel_time"] = alg / (mean_us * 1e-6) / 8e12
     return out
 
 
