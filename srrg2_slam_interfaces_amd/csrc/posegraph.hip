@@ -923,12 +923,13 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_bottom_dense(MgPair LV, const
 }
 
 // x += Ps x_coarse with the coarse correction taken from the coarse level's `res` (a two-phase level below a six-phase one)
+// (xc_in_x: the coarse level ran its six phases -- its result is in its x)
 template <int D>
-__global__ __launch_bounds__(PG_THREADS) void k_mg_prolong_res(MgPair LV,
+__global__ __launch_bounds__(PG_THREADS) void k_mg_prolong_res(MgPair LV, int xc_in_x,
                                                                const PgScalars* __restrict__ sc) {
   if (sc->done || sc->bad) return;
   const MgLevel L = LV.L;
-  mg_prolong<D>(L, LV.C.res, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+  mg_prolong<D>(L, xc_in_x ? LV.C.x : LV.C.res, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // levels lf .. nl-1 (small) + the coarsest level nl in ONE workgroup: down, coarsest solve, up
@@ -1827,6 +1828,7 @@ struct srrg2_posegraph_s {
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
     bool product_lists = true;     // SRRG2_AMD_PG_PRODUCT_LISTS: the set-up products over the lists the pattern build leaves (round 6; 0: the searching kernels)
     int list_lane_products = 4;    // SRRG2_AMD_PG_LIST_LANES: products per lane the list kernels aim at
+    bool l1_six = false;           // SRRG2_AMD_PG_L1_SIX (experiment): level 1 on six phases through H instead of two through Q
     bool tree_positions = true;    // SRRG2_AMD_PG_TREE_POSITIONS: the matching's geometry from a spanning tree of the measurements (round 6)
     bool fused_bottom = true;      // SRRG2_AMD_PG_FUSED_BOTTOM: the bottom of the cycle as one dense operator (k_mg_bottom_dense, round 6)
     bool fused_cg = true;          // SRRG2_AMD_PG_FUSED_CG: 14 launches per CG iteration instead of 18 (round 6; an A/B switch: same numbers)
@@ -3037,6 +3039,9 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         (rc = g->bottom_W.reserve(Nb * Mb)))
       return rc;
   }
+  // level 1 on its six phases (through H: C5 18 MB per residual pass) instead of the two phases through Q (31 MB each way), with the
+  // fused restriction: five launches for two, fewer bytes (experiment switch SRRG2_AMD_PG_L1_SIX; needs a two-phase level 2 below)
+  const bool l1_six = g->sw.l1_six && fused_cg && lf >= 3;
   auto vcycle2 = [&](bool head, bool check, bool tail) {
     const MgLevelBufs* L0b = g->levels[0];
     const int bl0 = blocks_for(L0b->n * D), bc0 = blocks_for(L0b->nc * D * L0b->col_parts), br0 = blocks_for(L0b->n * D * L0b->row_parts);
@@ -3062,6 +3067,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
     const bool bottom = dense_bottom;  // (k_mg_bottom_dense: that launch and the up phase of level lf - 1 as one dense operator)
     for (int l = 1; l < lf; ++l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
+      if (l == 1 && l1_six) {  // level 1 through H instead of Q: residual, then restriction + x1 of level 2
+        hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(Lb->n * D * Lb->row_parts)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(1), g->sc.p);
+        const int pp = std::min(std::max(Lb->col_parts / 2, 1), 8);
+        hipLaunchKernelGGL(k_mg_restrict_smooth<D>, dim3((unsigned) (((size_t) Lb->nc * 8 * pp + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS),
+                           0, g->stream, pair(1), pp, g->sc.p);
+        continue;
+      }
       if (l == lf - 1 && bottom)
         hipLaunchKernelGGL(k_mg_bottom_dense<D>, dim3((unsigned) (((size_t) Lb->n * D * 32 + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0,
                            g->stream, pair(l), g->bottom_B.p, g->sc.p);
@@ -3075,13 +3087,19 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
                          g->coarsest_dense, g->sc.p);
     for (int l = lf - 1 - (bottom ? 1 : 0); l >= 1; --l) {
       const MgLevelBufs* Lb = g->levels[(size_t) l];
+      if (l == 1 && l1_six) {  // x = x1 + Ps x_c (level 2's result is in its res), residual, update: the result in level 1's x
+        hipLaunchKernelGGL(k_mg_prolong_res<D>, dim3(blocks_for(Lb->n * D * Lb->prow_parts)), dim3(PG_THREADS), 0, g->stream, pair(1), 0, g->sc.p);
+        hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(Lb->n * D * Lb->row_parts)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(1), g->sc.p);
+        hipLaunchKernelGGL(k_mg_op<D>, dim3(blocks_for(Lb->n * D)), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_UPDATE, pair(1), g->sc.p);
+        continue;
+      }
       const int pp = parts2(Lb, false);
       hipLaunchKernelGGL(k_mg_up2<D>, dim3((unsigned) (((size_t) Lb->n * 8 * pp + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream, pair(l), pp,
                          l + 1 < lf ? 1 : 0, g->sc.p);
     }
     const int bp0 = blocks_for(L0b->n * D * L0b->prow_parts);
     if (lf > 1)
-      hipLaunchKernelGGL(k_mg_prolong_res<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, pair(0), g->sc.p);
+      hipLaunchKernelGGL(k_mg_prolong_res<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, pair(0), l1_six ? 1 : 0, g->sc.p);
     else
       hipLaunchKernelGGL(k_mg_op<D>, dim3(bp0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_PROLONG, pair(0), g->sc.p);
     hipLaunchKernelGGL(k_mg_op<D>, dim3(br0), dim3(PG_THREADS), 0, g->stream, (int) MG_OP_RESIDUAL, pair(0), g->sc.p);
@@ -3215,7 +3233,7 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         const MgLevelBufs* L = g->levels[(size_t) l];
         const size_t items   = std::max((size_t) L->n, (size_t) L->ne) * D * D;
         hipLaunchKernelGGL(k_mg_to_float<D>, dim3((unsigned) std::min<size_t>(std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1), 4096)),
-                           dim3(PG_THREADS), 0, g->stream, pair(l), 1, (two_phase && l >= 1 && l < lf) ? 1 : 0);
+                           dim3(PG_THREADS), 0, g->stream, pair(l), 1, (two_phase && l >= 1 && l < lf && !(l == 1 && g->sw.l1_six && g->sw.fused_cg && lf >= 3)) ? 1 : 0);
       }
     }
     // PCG: r lives in level 0's r (the cycle's input), z = level 0's x (its output)
@@ -3450,6 +3468,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_L1_SIX")) g->sw.l1_six = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_TREE_POSITIONS")) g->sw.tree_positions = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_BOTTOM")) g->sw.fused_bottom = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_PRODUCT_LISTS")) g->sw.product_lists = std::atoi(e) != 0;
