@@ -140,3 +140,65 @@ def test_appended_leaves_are_eliminated_not_rebuilt(oracle, product):
     inc.add_factor(10, 2000, _rel(Xf[10], Xf[2000]))
     inc.solve(params)
     assert inc.structure_info() == (2, 0)
+
+
+def test_appended_leaves_se2_and_a_leaf_on_the_fixed_pose(oracle, product):
+    """the same through SE(2), with one leaf hanging off the FIXED pose 0 (an identity row: nothing is folded into it, the leaf's
+    step is its own) and one off a free pose; the spanning-tree geometry of the matching starts at that fixed pose"""
+    kind = abi.SE2_RIGHT
+    g = syn.pose_graph_2d(V=1500, E=4000, seed=5301)
+    poses0, ij, Z = g["poses_init"], g["ij"], g["Z"]
+    V = poses0.shape[0]
+    params = pgm.PoseGraphParams(6, 300, 1e-8, 0.0)
+    inc = product.PoseGraph(kind, 0)
+    inc.set_graph(poses0, ij, Z)
+    inc.solve(params)
+    assert inc.structure_info() == (1, 0)
+    start = inc.poses().copy()
+    new_pose, new_ij, new_Z = [], [], []
+    for n, parent in enumerate((0, 700)):
+        Zk = syn.se2(0.4 - 0.1 * n, -0.2, 0.3 + 0.2 * n).astype(np.float32)
+        far = (start[parent].astype(np.float64) @ Zk @ syn.se2(1.5, -2.0, 0.25)).astype(np.float32)
+        vid = inc.add_variable(far)
+        inc.add_factor(parent, vid, Zk)
+        new_pose.append(far); new_ij.append((parent, vid)); new_Z.append(Zk)
+    st = inc.solve(params)
+    assert inc.structure_info() == (1, 2)
+    assert all(s_["solver_status"] == 0 for s_ in st)
+    P1 = np.concatenate([start, np.array(new_pose, np.float32)], axis=0)
+    ij1 = np.concatenate([ij, np.array(new_ij, np.int32)], axis=0)
+    Z1 = np.concatenate([Z, np.array(new_Z, np.float32)], axis=0)
+    one = product.PoseGraph(kind, 0)
+    one.set_graph(P1, ij1, Z1)
+    one.solve(params)
+    assert np.max(np.abs(one.poses() - inc.poses())) < 2e-4
+    Xf = inc.poses().astype(np.float64)
+    for (i, j), Zk in zip(new_ij, new_Z):
+        assert np.max(np.abs(np.linalg.inv(Xf[i]) @ Xf[j] - Zk)) < 1e-4
+    ref = oracle.OraclePoseGraph(kind)
+    ref.set_graph(P1, ij1, Z1)
+    ref.solve(pgm.PoseGraphParams(6, 8000, 1e-8, 0.0))
+    assert np.max(np.abs(ref.poses() - inc.poses())) < 5e-4
+
+
+def test_structure_geometry_without_a_fixed_variable_and_with_two_components(oracle, product):
+    """the matching's spanning tree (build_hierarchy): a graph of two components, only one of which holds the Fixed pose -- the other
+    one's tree starts at its first pose with the pose it has; the free component is a null space of H that the coarsest solve leaves
+    alone (its vanished pivots), the anchored component converges like the graph on its own"""
+    kind = abi.SE3_QUAT_RIGHT
+    a = syn.pose_graph_3d(V=1200, E=4000, seed=611)
+    b = syn.pose_graph_3d(V=800, E=2600, seed=612)
+    Va = a["poses_init"].shape[0]
+    poses = np.concatenate([a["poses_init"], b["poses_init"]], axis=0)
+    ij = np.concatenate([a["ij"], b["ij"] + Va], axis=0).astype(np.int32)
+    Z = np.concatenate([a["Z"], b["Z"]], axis=0)
+    params = pgm.PoseGraphParams(6, 400, 1e-7, 1e-6)  # (a little damping: the unanchored component is singular without it)
+    both = product.PoseGraph(kind, 0)
+    both.set_graph(poses, ij, Z)
+    st = both.solve(params)
+    assert all(s_["solver_status"] == 0 for s_ in st)
+    alone = product.PoseGraph(kind, 0)
+    alone.set_graph(a["poses_init"], a["ij"], a["Z"])
+    alone.solve(params)
+    assert np.max(np.abs(both.poses()[:Va] - alone.poses())) < 5e-4
+    assert st[-1]["chi"] < 0.05 * st[0]["chi"]
