@@ -120,6 +120,8 @@ struct srrg2_aligner_s {
   static constexpr int MAX_PARTS = 8;
   hipStream_t pstream[MAX_PARTS]{};  // pstream[0] == stream
   int cu_count          = 256;       // compute units of the device (FusedCtl::first_round)
+  int fused_grid_max    = 130000;    // SRRG2_AMD_FUSED_GRID_MAX (read at create): largest cloud whose grid search passes drop the
+                                     // deferred-search queue for the fused kernel (run_compute)
   hipEvent_t ev_staged  = nullptr;   // the staging copies of a batch upload (stream) before the other parts' sorts
   int parts_dirty       = 0;         // pstream[1 .. parts_dirty) may still be running the tail of the last pipelined batch
   int batch_parts       = 0;         // upload_moving -> run_compute: the batch at hand runs as this many parts (0: one)
@@ -1081,6 +1083,25 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     const Slice* s = a->slices[si];
     fuse = s->cfg.kind != SRRG2_SLICE_PRIOR &&
            (fuse_proj ? s->cfg.finder == SRRG2_FINDER_PROJECTIVE : s->cfg.finder == SRRG2_FINDER_NN_GATED);
+    // Round 6: the grid kernel has a fused instantiation too (k_icp_step_fused) -- without the deferred-search queue, whose kernel and
+    // counters belong to the control LAUNCH.  Whether the queue is worth its launches depends on the frame: a tracker's 100 k-point
+    // frame against its clipped local map (everything overlaps, small motion) leaves it nearly empty -- compute() 0.225 -> 0.199 ms
+    // on the fused kernels --, a 60 % overlap fills it with hundreds of far searches per pass (0.405 ms with the queue, 0.498 without:
+    // profiles/r9/r9q_*).  The fused kernels have no counters to probe, so the evidence is the handle's PREVIOUS compute(): it matched
+    // at least 90 % of its moving points (a tracker aligns similar frames one after the other); a handle's first compute(), a frame
+    // after a partial overlap, clouds beyond `fused_grid_max` points and the LDS-tile kernels stay on the launches.
+    const int fused_grid_max = a->fused_grid_max;
+    const bool last_overlapped = a->computed && K == 1 && (size_t) si < a->last_nm_max.size() && a->last_nm_max[(size_t) si] > 0 &&
+                                 a->last_ncorr[si] >= (int) (0.9 * a->last_nm_max[(size_t) si]);
+    if (fuse && !fuse_proj && !cnl[(size_t) si] && !(lds_tile > 0) && !split && !(C.tune & (1 << 27)) &&
+        (!sdev[si].queue || (nm_max_cue <= fused_grid_max && last_overlapped) || fused_grid_max < 0 /* forced: tests */)) {
+      sdev[si].queue  = nullptr;  // (finished inside the step kernel)
+      sdev[si].qcount = nullptr;
+      C.slices[si].qcount = nullptr;
+      C.slices[si].qprobe_host = nullptr;
+      C.slices[si].probs = nullptr;
+      continue;
+    }
     if (fuse && !fuse_proj && !(cnl[(size_t) si] && !sdev[si].queue)) {
       fused_all = false;
       // (worth it when converged passes follow; SRRG2_AMD_TUNE bit 27: lists or nothing, as before)
@@ -1603,6 +1624,7 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
   tuning_from_environment(&a->tuning);
   if (const char* tl = std::getenv("SRRG2_AMD_TIMELINE")) a->timeline_path = tl;
   a->hosttime = std::getenv("SRRG2_AMD_HOSTTIME") != nullptr;
+  if (const char* fg = std::getenv("SRRG2_AMD_FUSED_GRID_MAX")) a->fused_grid_max = std::atoi(fg);
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess;
   a->pstream[0] = a->stream;  // (pstream[1 ..]: created by the first pipelined batch that wants them, compute_batch)
   ok = ok && hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming) == hipSuccess;

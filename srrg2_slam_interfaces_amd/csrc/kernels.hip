@@ -1043,36 +1043,55 @@ __device__ __forceinline__ void finish_point(const SliceDev& S, const float* T, 
 // the work) or, without a queue, handled here: radius-2 scan per lane, then wave-cooperative scans.
 // (body shared by k_icp_step -- 4 waves, tile = blockIdx.x, sums to the global slot sets -- and k_icp_small -- NW waves
 // looping over the tiles of its problem, state and sums in LDS)
+// What the body needs of the state: from ProblemState (k_icp_step, k_icp_small), or -- fused control steps, round 6: the grid
+// kernel of a first compute() on a new fixed cloud carries the control step of the previous iteration like the list kernels do --
+// from the published record (step_view_of_record below the fused prologue's definitions).
+struct StepView {
+  float T[12], Tprev[12];
+  int kexp, nstats;
+  bool phase1, prior, qmode;
+};
+__device__ __forceinline__ void step_view_of_state(const SliceDev& S, const ProblemState* st, StepView& v) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.T[i] = st->Tf[S.slice_idx][i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.Tprev[i] = st->Tfprev[S.slice_idx][i];
+  v.kexp   = st->kexp[S.slice_idx];
+  v.nstats = st->nstats;
+  v.phase1 = st->phase == 1;
+  v.prior  = st->nstats > 0 || st->phase == 1;
+  v.qmode  = st->qmode[S.slice_idx] != 0;
+}
 template <int DIM, bool PLANE, int NW>
-__device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDev pd, const ProblemState* st, int prob,
+__device__ __forceinline__ void icp_step_body(const SliceDev& S, const ProblemDev pd, const StepView& sv, int prob,
                                               int tile, int ntiles, int nprob, long long* local_sums) {
   float T[12];
-  load_T(st->Tf[S.slice_idx], T);
-  const int kexp     = st->kexp[S.slice_idx];
+  load_T(sv.T, T);
+  const int kexp     = sv.kexp;
   const double scale = dm::pow2(kexp);
-  const int rk       = (st->phase == 1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
+  const int rk       = (sv.phase1 && S.robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : S.robust_kind;
   const float thr    = S.robust_thr;
   const float kk     = S.variable_kind == SRRG2_SE3_QUAT_RIGHT ? 2.f : 1.f;
   const GridDev& g   = S.grid;
   const float b2_1   = bound2_of(1, g.h);
-  const bool use_prior = (st->nstats > 0 || st->phase == 1) && !(S.tune & 4);
+  const bool use_prior = sv.prior && !(S.tune & 4);
   // open points go to the deferred-search queue, or are finished here (no queue; or the control kernel saw that the
   // queue stays nearly empty: st->qmode, mirrored by the host which then drops the deferred-search launch)
-  const bool use_q = S.queue != nullptr && st->qmode[S.slice_idx] != 0;
+  const bool use_q = S.queue != nullptr && sv.qmode;
   // Scans of points without a neighbour inside the gate reach 25% beyond it once a prior exists: what they find (a
   // point just outside the gate, or nothing) then certifies "no match" for the following iterations without a search.
   const float gfar = (use_prior && !(S.tune & 65536)) ? g.gate2_ext : g.gate2;
   // cube radius that covers the ball of radius sqrt(gfar) (both computed by the host with the same bound)
   const int rfar = (use_prior && !(S.tune & 65536)) ? g.rmax : g.rfar_gate;
   float Tprev[12];  // the finder transform of the previous iteration (its queries: q' = Tprev * p)
-  load_T(st->Tfprev[S.slice_idx], Tprev);
+  load_T(sv.Tprev, Tprev);
 
   long long acc[ACC_N];
 #pragma unroll
   for (int a = 0; a < ACC_N; ++a) acc[a] = 0;
 #ifdef SRRG2_TIMELINE
-  unsigned long long* tl = (S.dbg && st->nstats < 32 && st->phase == 0)
-                             ? S.dbg + (((size_t) st->nstats * nprob + prob) * ntiles * NW + tile * NW + (threadIdx.x >> 6)) * 16
+  unsigned long long* tl = (S.dbg && sv.nstats < 32 && !sv.phase1)
+                             ? S.dbg + (((size_t) sv.nstats * nprob + prob) * ntiles * NW + tile * NW + (threadIdx.x >> 6)) * 16
                              : nullptr;
 #else
   unsigned long long* tl = nullptr;
@@ -1489,7 +1508,9 @@ __global__ __launch_bounds__(256) void k_icp_step(SliceDev S, const ProblemDev* 
   const int prob   = blockIdx.y + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
   ProblemState* st = &states[prob];
   if (st->done || st->finished) return;
-  icp_step_body<DIM, PLANE, 4>(S, probs[prob], st, prob, blockIdx.x, gridDim.x, gridDim.y, nullptr);
+  StepView sv;
+  step_view_of_state(S, st, sv);
+  icp_step_body<DIM, PLANE, 4>(S, probs[prob], sv, prob, blockIdx.x, gridDim.x, gridDim.y, nullptr);
 }
 
 // ============================================================================================
@@ -2653,6 +2674,35 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
   v.stop   = (fl & PUB_FLAG_STOP) != 0;
   v.phase1 = (fl & PUB_FLAG_PHASE1) != 0;
   v.prior  = (fl & PUB_FLAG_PRIOR) != 0;
+}
+
+// The search pass on the GRID (no cell neighbour lists yet: the first compute() on a new fixed cloud, a tracker's every frame)
+// with the control step of the previous iteration in its prologue (round 6).  Without the deferred-search queue: the open points
+// are finished inside the kernel (the queue's kernel and its counters belong to the control LAUNCH: run_compute keeps both for
+// clouds large enough for the queue to pay).  x = problem, y = tile, like the other fused launches.
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                        ProblemState* __restrict__ states) {
+  const int prob = blockIdx.x + S.prob0;
+  const int tile = (int) blockIdx.y;
+  fused_control_if_due<DIM>(S, states, prob);
+  const ProblemDev pd = probs[prob];
+  if (tile * 256 >= pd.nm && tile != 0) return;
+  PassView pv;
+  pass_view_fused<DIM>(S, states, prob, pv);
+  if (pv.stop || tile * 256 >= pd.nm) return;
+  StepView sv;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    sv.T[i]     = pv.T[i];
+    sv.Tprev[i] = pv.Tprev[i];
+  }
+  sv.kexp   = pv.kexp;
+  sv.nstats = 0;  // (the -DSRRG2_TIMELINE stamps only)
+  sv.phase1 = pv.phase1;
+  sv.prior  = pv.prior;
+  sv.qmode  = false;
+  icp_step_body<DIM, PLANE, 4>(S, pd, sv, prob, tile, (int) gridDim.y, (int) gridDim.x, nullptr);
 }
 
 // Several slices (the projective kernels: a pack of up to four slices that share one association): the control step of all
@@ -5033,7 +5083,9 @@ __global__ __launch_bounds__(512) void k_icp_small(SliceDev S, CtlParams C, cons
       if (threadIdx.x < ACC_N) sums[S.slice_idx][threadIdx.x] = 0;
       __syncthreads();
       for (int tile = 0; tile < ntiles; ++tile) {
-        icp_step_body<DIM, PLANE, NW>(S, pd, &sst, prob, tile, ntiles, C.K, sums[S.slice_idx]);
+        StepView sv;
+        step_view_of_state(S, &sst, sv);
+        icp_step_body<DIM, PLANE, NW>(S, pd, sv, prob, tile, ntiles, C.K, sums[S.slice_idx]);
         __syncthreads();  // (the body's shared scratch is reused by the next tile)
       }
       if (threadIdx.x < ACC_N)
@@ -5090,6 +5142,21 @@ static void launch_icp_queue(int dim, bool plane, const SliceDev& S, const Probl
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                      int max_nm, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
+  if (S.fc.pub) {  // fused control steps: the record instead of ProblemState, no deferred-search queue
+    dim3 fgrid(K, (max_nm + 255) / 256);
+    if (dim == 3) {
+      if (plane)
+        hipLaunchKernelGGL((k_icp_step_fused<3, true>), fgrid, dim3(256), 0, s, S, probs, states);
+      else
+        hipLaunchKernelGGL((k_icp_step_fused<3, false>), fgrid, dim3(256), 0, s, S, probs, states);
+    } else {
+      if (plane)
+        hipLaunchKernelGGL((k_icp_step_fused<2, true>), fgrid, dim3(256), 0, s, S, probs, states);
+      else
+        hipLaunchKernelGGL((k_icp_step_fused<2, false>), fgrid, dim3(256), 0, s, S, probs, states);
+    }
+    return;
+  }
   int bx = (max_nm + 255) / 256;  // one moving point per thread
   dim3 grid(bx, K);
   // (experiment: SRRG2_AMD_STEP_LDS = bytes of unused dynamic LDS per workgroup, to lower the occupancy on purpose)

@@ -194,3 +194,39 @@ def test_polling_waves_apply_the_control_step_themselves():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers_scripts", "fused_stall_check.py")], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "STALL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("kind,slice_kind", [(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE), (abi.SE2_RIGHT, abi.SLICE_P2P)])
+def test_grid_search_passes_with_fused_control_steps(oracle, product, kind, slice_kind, monkeypatch):
+    """Round 6: the search pass on the GRID (no cell neighbour lists: a tracker's first compute() on every new fixed cloud) has a
+    fused instantiation too (k_icp_step_fused: the control step of the previous iteration in its prologue, open points finished
+    inside the kernel instead of the deferred-search queue).  run_compute takes it on the evidence of the handle's previous
+    compute(); SRRG2_AMD_FUSED_GRID_MAX=-1 (read at create) forces it.  Termination criterion, inlier-only run and pruning, a
+    cropped fixed cloud (many far searches: what the queue exists for), a second compute() on a new fixed cloud: the oracle's bits."""
+    monkeypatch.setenv("SRRG2_AMD_FUSED_GRID_MAX", "-1")
+    if kind == abi.SE2_RIGHT:
+        d = syn.scan_pair_2d(beams=3000, sigma=0.01, seed=1234)
+        gate, thr = 0.5, 0.002
+    else:
+        d = syn.cloud_pair_3d(n=110000, seed=2200, noise_sigma=0.01, t=(0.08, -0.05, 0.03), rpy_deg=(1.5, -2.0, 2.5))
+        d = {k: v.copy() for k, v in d.items()}
+        keep = d["fixed"][:, 0] <= np.quantile(d["fixed"][:, 0], 0.7)
+        d["fixed"], d["fixed_normals"] = d["fixed"][keep], d["fixed_normals"][keep]
+        gate, thr = 0.25, 0.0005
+    cfg = cue_config(kind, slice_kind, gate, abi.ROBUST_CAUCHY, thr)
+
+    def build(al):
+        al.set_params(max_iterations=12, min_num_inliers=10, enable_inlier_only_runs=True, keep_only_inlier_correspondences=True)
+        al.set_termination_criteria(abi.default_termination_params())
+        setup_pair(al, d, cfg)
+        al.compute()
+        al.set_fixed(0, d["fixed"], d.get("fixed_normals"))  # (a new fixed cloud: no lists again)
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+
+    grid = {"search_lists": 0, "fused_control": 1}  # (never lists: every search pass on the grid kernel)
+    ref, fused, unfused = _runs(oracle, product, kind, build, [grid, dict(grid, fused_control=0)])
+    assert ref.status() == abi.SUCCESS
+    assert_same_run(ref, fused)
+    assert_same_run(ref, unfused)
+    assert fused.information().tobytes() == unfused.information().tobytes()
