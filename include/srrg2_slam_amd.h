@@ -25,7 +25,12 @@
  *    `mem` says where the caller's pointer lives.  SRRG2_MEM_DEVICE buffers are read
  *    on the handle's own (non-blocking) stream, which is NOT ordered after the
  *    stream that produced them: the producer must have completed (stream/event/
- *    device synchronised) before the call.
+ *    device synchronised) before the call.  SRRG2_MEM_DEVICE_KEPT (set_fixed / set_moving):
+ *    a device buffer that the caller leaves valid and unchanged until the next compute()
+ *    on the handle has returned -- the reference's own contract (its aligner keeps raw
+ *    pointers to the caller's clouds: aligner.h:130-131) -- so the call returns as soon as
+ *    the ingest is queued; a tracker's frame (scene arrays in HBM: srrg2_scene_device_arrays)
+ *    saves two host waits that way.
  *  - all arithmetic is float32 / int32 at the interface.
  */
 #ifndef SRRG2_SLAM_AMD_H
@@ -94,7 +99,7 @@ enum srrg2_factor_status {
   SRRG2_FACTOR_SUPPRESSED = 2  /* residual could not be evaluated            */
 };
 
-enum srrg2_mem { SRRG2_MEM_HOST = 0, SRRG2_MEM_DEVICE = 1 };
+enum srrg2_mem { SRRG2_MEM_HOST = 0, SRRG2_MEM_DEVICE = 1, SRRG2_MEM_DEVICE_KEPT = 2 };
 
 /* error codes (<0) */
 enum srrg2_error {

@@ -21,7 +21,7 @@ ROBUST_NONE, ROBUST_CLAMP, ROBUST_SATURATED, ROBUST_CAUCHY = 0, 1, 2, 3
 # enum srrg2_factor_status
 FACTOR_INLIER, FACTOR_KERNELIZED, FACTOR_SUPPRESSED = 0, 1, 2
 # enum srrg2_mem
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_DEVICE_KEPT = 0, 1, 2
 
 
 class Correspondence(C.Structure):

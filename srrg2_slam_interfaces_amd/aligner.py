@@ -213,12 +213,13 @@ class MultiAligner:
     def set_moving(self, slice_idx, coords, normals=None):
         self._set_cloud("set_moving", slice_idx, coords, normals)
 
-    def set_cloud_device(self, which, slice_idx, coords_ptr, coord_stride, normals_ptr, normal_stride, n):
-        """Device-resident input (``which`` = 'set_fixed' | 'set_moving'); pointers are raw ints."""
+    def set_cloud_device(self, which, slice_idx, coords_ptr, coord_stride, normals_ptr, normal_stride, n, kept=False):
+        """Device-resident input (``which`` = 'set_fixed' | 'set_moving'); pointers are raw ints.  ``kept``: the buffer stays
+        valid and unchanged until the next compute() has returned (SRRG2_MEM_DEVICE_KEPT: the call does not wait for the ingest)."""
         self._check(self._b.fn(which)(self._h, C.c_int(slice_idx), C.cast(coords_ptr, C.POINTER(C.c_float)),
                                       C.c_int(coord_stride),
                                       C.cast(normals_ptr, C.POINTER(C.c_float)) if normals_ptr else None,
-                                      C.c_int(normal_stride), C.c_int(n), C.c_int(abi.MEM_DEVICE)))
+                                      C.c_int(normal_stride), C.c_int(n), C.c_int(abi.MEM_DEVICE_KEPT if kept else abi.MEM_DEVICE)))
 
     def set_sensor_in_robot(self, slice_idx, T):
         """slice->setSensorInRobot with the transform looked up on every setMovingInFixed

@@ -227,7 +227,7 @@ int stage_input(srrg2_aligner* a, const float* src, int stride_bytes, int n, int
     return 0;
   }
   if (stride_bytes % 4 != 0 || stride_bytes < dim * 4) return fail(SRRG2_E_INVALID, "stride must be a multiple of 4 and >= dim*4");
-  if (mem == SRRG2_MEM_DEVICE) {
+  if (mem == SRRG2_MEM_DEVICE || mem == SRRG2_MEM_DEVICE_KEPT) {
     *dev_ptr       = src;
     *stride_floats = stride_bytes / 4;
     return 0;
@@ -1773,7 +1773,10 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   s->nf                = n;
   s->fixed_has_normals = normals != nullptr;
   if (nn && (rc = build_grid(a, s, 0.f, /*have_bbox=*/n > 0))) return rc;  // projective: organised cloud as is
-  HIP_TRY(hipStreamSynchronize(a->stream));
+  // (SRRG2_MEM_DEVICE_KEPT: the caller keeps the buffer as it is until the next compute() has returned -- the reference's own
+  // contract, its aligner holds raw pointers to the clouds -- so nothing waits here: the ingest is ordered in front of everything
+  // compute() launches)
+  if (mem != SRRG2_MEM_DEVICE_KEPT) HIP_TRY(hipStreamSynchronize(a->stream));
   s->has_fixed = true;
   return 0;
 }
@@ -1789,7 +1792,7 @@ int srrg2_aligner_set_moving(srrg2_aligner_h a, int si, const float* coords, int
     return fail(SRRG2_E_STATE, "set_moving: this slice shares the clouds of another slice (share_clouds): set them there");
   if ((rc = set_device(a))) return rc;
   const int32_t offsets[2] = {0, n};
-  return upload_moving(a, si, coords, cs, normals, ns, offsets, 1, mem);
+  return upload_moving(a, si, coords, cs, normals, ns, offsets, 1, mem, /*wait=*/mem != SRRG2_MEM_DEVICE_KEPT);
 }
 
 int srrg2_aligner_share_clouds(srrg2_aligner_h a, int si, int source) {

@@ -85,7 +85,8 @@ def test_merge_parity_with_duplicates(oracle, product, target, with_corr):
         mg.compute()
 
 
-def test_tracker_cycle_stays_on_device(oracle, product):
+@pytest.mark.parametrize("kept", [False, True])
+def test_tracker_cycle_stays_on_device(oracle, product, kept):
     """clip -> align (clipped scene = moving, measurement = fixed) -> merge, three frames; the product side feeds the
     aligner with the scene's device arrays and merges from the aligner's device-side correspondences."""
     kind = abi.SE3_QUAT_RIGHT
@@ -116,9 +117,9 @@ def test_tracker_cycle_stays_on_device(oracle, product):
             cl.compute()
             if side == "gpu":
                 cp, cn, n = clipped.device_arrays()
-                al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n)
+                al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n, kept=kept)  # (kept: SRRG2_MEM_DEVICE_KEPT, no wait for the ingest)
                 mp_, mn_, m = meas.device_arrays()
-                al.set_cloud_device("set_fixed", si, mp_, 16, mn_, 16, m)
+                al.set_cloud_device("set_fixed", si, mp_, 16, mn_, 16, m, kept=kept)
             else:
                 al.set_moving(si, *clipped.get())
                 al.set_fixed(si, *meas.get())

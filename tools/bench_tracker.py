@@ -17,6 +17,11 @@ from srrg2_slam_interfaces_amd import mapping  # noqa: E402
 from srrg2_slam_interfaces_amd import synthetic as syn  # noqa: E402
 
 
+# the scene arrays stay as they are until compute() has returned (the clip of the next frame and the next measurement come after
+# it): SRRG2_MEM_DEVICE_KEPT -- set_moving / set_fixed do not wait for their ingest (SRRG2_TRACKER_KEPT=0: they do)
+KEPT = os.environ.get("SRRG2_TRACKER_KEPT", "1") != "0"
+
+
 def run(points=100_000, frames=30):
     """the tracker cycle of multi_tracker_impl.cpp:83-123 with everything resident in HBM; returns the JSON object"""
     import types
@@ -47,9 +52,9 @@ def run(points=100_000, frames=30):
         cl.set_full_scene(scene); cl.set_clipped_scene_in_robot(clipped); cl.set_robot_in_local_map(est)
         cl.compute(); t2 = time.perf_counter()
         cp, cn, n = clipped.device_arrays()
-        al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n); t3 = time.perf_counter()
+        al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n, kept=KEPT); t3 = time.perf_counter()
         mp, mn, m = meas.device_arrays()
-        al.set_cloud_device("set_fixed", si, mp, 16, mn, 16, m); t4 = time.perf_counter()
+        al.set_cloud_device("set_fixed", si, mp, 16, mn, 16, m, kept=KEPT); t4 = time.perf_counter()
         al.set_moving_in_fixed(syn.identity(3))
         al.compute(); t5 = time.perf_counter()
         X = np.vstack([al.moving_in_fixed(), [0, 0, 0, 1]]).astype(np.float64)
