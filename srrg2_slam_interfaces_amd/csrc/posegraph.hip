@@ -827,8 +827,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_up2(MgPair LV, int parts, int
 // (formed from the float64 blocks, stored as float32 like the cycle's other copies, upper triangle mirrored: exactly symmetric).
 // A first attempt fused the two launches as they were, every workgroup of the up phase redoing the down phase for itself: 33.7 us
 // against 29.8 (profiles/r9d).
-template <int D, bool TRANSPOSE_A, typename TB>
-__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* __restrict__ A, const TB* __restrict__ B);  // (below)
+template <int D, bool TRANSPOSE_A, typename TA, typename TB>
+__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const TA* __restrict__ A, const TB* __restrict__ B);  // (below)
 template <int D>
 __global__ __launch_bounds__(PG_THREADS) void k_bd_g(MgPair LV, double* __restrict__ G) {
   // G[i, A] = Ps[i, A] - S_i Q[i, A]   (dense N x M, zero where neither has an entry)
@@ -847,7 +847,8 @@ __global__ __launch_bounds__(PG_THREADS) void k_bd_g(MgPair LV, double* __restri
   for (int r = 0; r < D; ++r)
 #pragma unroll
     for (int c = 0; c < D; ++c)
-      G[(size_t) (i * D + r) * M + A * D + c] = (e >= 0 ? L.Ps[(size_t) e * D * D + r * D + c] : 0.0) - L.omega * g[r * D + c];
+      G[(size_t) (i * D + r) * M + A * D + c] =
+        (e >= 0 ? (L.Psf ? (double) L.Psf[(size_t) e * D * D + r * D + c] : L.Ps[(size_t) e * D * D + r * D + c]) : 0.0) - L.omega * g[r * D + c];
 }
 // W = G Cinv   (N x M)
 __global__ __launch_bounds__(PG_THREADS) void k_bd_w(int N, int M, const double* __restrict__ G, const double* __restrict__ Cinv,
@@ -1029,13 +1030,13 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_interp(MgPair LV, int T,
 }
 
 // w (D x D, row-major) += A B  or  A^T B, as D rank-1 updates (12 operand values live at a time)
-template <int D, bool TRANSPOSE_A, typename TB>
-__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const double* __restrict__ A, const TB* __restrict__ B) {
+template <int D, bool TRANSPOSE_A, typename TA, typename TB>
+__device__ __forceinline__ void mg_block_mac(double (&w)[D * D], const TA* __restrict__ A, const TB* __restrict__ B) {
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double col[D], row[D];
 #pragma unroll
-    for (int r = 0; r < D; ++r) col[r] = TRANSPOSE_A ? A[a * D + r] : A[r * D + a];
+    for (int r = 0; r < D; ++r) col[r] = (double) (TRANSPOSE_A ? A[a * D + r] : A[r * D + a]);
 #pragma unroll
     for (int c = 0; c < D; ++c) row[c] = (double) B[a * D + c];
 #pragma unroll
@@ -1100,7 +1101,23 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(MgPair LV, double ome
   mg_block_mac<D, false>(o, L.Dinv + (size_t) i * D * D, w);
   double* out = L.Ps + (size_t) e * D * D;
 #pragma unroll
-  for (int k = 0; k < D * D; ++k) out[k] = (own ? (double) L.P[(size_t) i * D * D + k] : 0.0) - omega_p * o[k];
+  for (int k = 0; k < D * D; ++k) {
+    o[k]   = (own ? (double) L.P[(size_t) i * D * D + k] : 0.0) - omega_p * o[k];
+    out[k] = o[k];
+  }
+  // (the float32 copy the cycle restricts and prolongs with -- and, round 6, the set-up products multiply with: the coarse operators
+  // are then the Galerkin products of exactly the interpolation the cycle uses, and the products fetch 144 instead of 288 bytes of it;
+  // 16-byte stores: 36 scalar ones took this kernel from 132 to 223 us on level 0)
+  if (L.Psf) {
+    if constexpr (D == 6) {
+      float4* of = reinterpret_cast<float4*>(L.Psf + (size_t) e * D * D);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) of[k] = make_float4((float) o[4 * k], (float) o[4 * k + 1], (float) o[4 * k + 2], (float) o[4 * k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D * D; ++k) L.Psf[(size_t) e * D * D + k] = (float) o[k];
+    }
+  }
 }
 
 // Q = H Ps.  One thread per (entry of Q, part): the look-ups of Ps[j, B] over the incidences j of row i are the
@@ -1178,7 +1195,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin(MgPair LV) {
 // Q = H Ps and the Galerkin product over the product lists (MgLevel::qp_list / gp_list): `parts` adjacent lanes share an
 // output block, lane `part` takes every parts-th product of its list (a fixed order) and the lanes add their blocks with the
 // fixed butterfly -- deterministic, and the same list order on the host-built and the device-built structure.
-template <int D>
+template <int D, bool F32PS>
 __global__ __launch_bounds__(PG_THREADS) void k_mg_hp_list(MgPair LV, int parts) {
   const MgLevel L = LV.L;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1191,15 +1208,13 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_hp_list(MgPair LV, int parts)
   const int k1 = L.qp_start[q + 1];
   for (int k = L.qp_start[q] + part; k < k1; k += parts) {
     const int2 pr    = L.qp_list[k];
-    const double* Pe = L.Ps + (size_t) pr.x * D * D;
-    if (pr.y < 0) {
-      mg_block_mac<D, false>(w, L.Hd + (size_t) i * D * D, Pe);
+    const double* Pd = L.Ps + (size_t) pr.x * D * D;
+    const float* Pf  = L.Psf + (size_t) pr.x * D * D;
+    const double* B  = pr.y < 0 ? L.Hd + (size_t) i * D * D : L.Ho + (size_t) (pr.y >> 1) * D * D;
+    if (pr.y >= 0 && (pr.y & 1)) {
+      if constexpr (F32PS) mg_block_mac<D, true>(w, B, Pf); else mg_block_mac<D, true>(w, B, Pd);
     } else {
-      const double* B = L.Ho + (size_t) (pr.y >> 1) * D * D;
-      if (pr.y & 1)
-        mg_block_mac<D, true>(w, B, Pe);
-      else
-        mg_block_mac<D, false>(w, B, Pe);
+      if constexpr (F32PS) mg_block_mac<D, false>(w, B, Pf); else mg_block_mac<D, false>(w, B, Pd);
     }
   }
   mg_group_sum<D * D>(w, parts);
@@ -1209,7 +1224,7 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_hp_list(MgPair LV, int parts)
   for (int k = 0; k < D * D; ++k) out[k] = w[k];
 }
 
-template <int D>
+template <int D, bool F32PS>
 __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin_list(MgPair LV, int parts) {
   const MgLevel L = LV.L;
   const MgLevel C = LV.C;
@@ -1224,7 +1239,10 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin_list(MgPair LV, int 
     out = C.Hd + (size_t) blk * D * D;
     for (int m = L.pcsc_start[blk] + part; m < L.pcsc_start[blk + 1]; m += parts) {
       const int e = L.pcsc_ent[m];
-      mg_block_mac<D, true>(acc, L.Ps + (size_t) e * D * D, L.Q + (size_t) L.qdiag[e] * D * D);
+      if constexpr (F32PS)
+        mg_block_mac<D, true>(acc, L.Psf + (size_t) e * D * D, L.Q + (size_t) L.qdiag[e] * D * D);
+      else
+        mg_block_mac<D, true>(acc, L.Ps + (size_t) e * D * D, L.Q + (size_t) L.qdiag[e] * D * D);
     }
   } else {
     const int ke = blk - L.nc;
@@ -1232,7 +1250,10 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_galerkin_list(MgPair LV, int 
     const int k1 = L.gp_start[ke + 1];
     for (int k = L.gp_start[ke] + part; k < k1; k += parts) {
       const int2 pr = L.gp_list[k];
-      mg_block_mac<D, true>(acc, L.Ps + (size_t) pr.x * D * D, L.Q + (size_t) pr.y * D * D);
+      if constexpr (F32PS)
+        mg_block_mac<D, true>(acc, L.Psf + (size_t) pr.x * D * D, L.Q + (size_t) pr.y * D * D);
+      else
+        mg_block_mac<D, true>(acc, L.Ps + (size_t) pr.x * D * D, L.Q + (size_t) pr.y * D * D);
     }
   }
   mg_group_sum<D * D>(acc, parts);
@@ -1828,6 +1849,7 @@ struct srrg2_posegraph_s {
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
     bool product_lists = true;     // SRRG2_AMD_PG_PRODUCT_LISTS: the set-up products over the lists the pattern build leaves (round 6; 0: the searching kernels)
     int list_lane_products = 4;    // SRRG2_AMD_PG_LIST_LANES: products per lane the list kernels aim at
+    bool setup_f32_ps = true;      // SRRG2_AMD_PG_SETUP_F32_PS: the set-up products read the float32 copy of the interpolation (round 6)
     bool l1_six = false;           // SRRG2_AMD_PG_L1_SIX (experiment): level 1 on six phases through H instead of two through Q
     bool tree_positions = true;    // SRRG2_AMD_PG_TREE_POSITIONS: the matching's geometry from a spanning tree of the measurements (round 6)
     bool fused_bottom = true;      // SRRG2_AMD_PG_FUSED_BOTTOM: the bottom of the cycle as one dense operator (k_mg_bottom_dense, round 6)
@@ -3195,8 +3217,13 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
           };
           const int lq = lanes_for(L->nq > 0 ? (double) L->nqp / L->nq : 0.0, 16);
           const int lg = lanes_for(L->nc + L->nce > 0 ? (double) (L->ngp + L->np) / (L->nc + L->nce) : 0.0, 32);
-          hipLaunchKernelGGL(k_mg_hp_list<D>, grid_of((size_t) L->nq * lq), dim3(PG_THREADS), 0, g->stream, pair(l), lq);
-          hipLaunchKernelGGL(k_mg_galerkin_list<D>, grid_of((size_t) (L->nc + L->nce) * lg), dim3(PG_THREADS), 0, g->stream, pair(l), lg);
+          if (g->sw.setup_f32_ps && pair(l).L.Psf) {  // (the interpolation as float32 operand: MgLevel::Psf, written by k_mg_psmooth)
+            hipLaunchKernelGGL((k_mg_hp_list<D, true>), grid_of((size_t) L->nq * lq), dim3(PG_THREADS), 0, g->stream, pair(l), lq);
+            hipLaunchKernelGGL((k_mg_galerkin_list<D, true>), grid_of((size_t) (L->nc + L->nce) * lg), dim3(PG_THREADS), 0, g->stream, pair(l), lg);
+          } else {
+            hipLaunchKernelGGL((k_mg_hp_list<D, false>), grid_of((size_t) L->nq * lq), dim3(PG_THREADS), 0, g->stream, pair(l), lq);
+            hipLaunchKernelGGL((k_mg_galerkin_list<D, false>), grid_of((size_t) (L->nc + L->nce) * lg), dim3(PG_THREADS), 0, g->stream, pair(l), lg);
+          }
         } else {
         hipLaunchKernelGGL(k_mg_hp<D>, grid_of((size_t) L->nq * sp_q.L.row_parts), dim3(PG_THREADS), 0, g->stream, sp_q);
         hipLaunchKernelGGL(k_mg_galerkin<D>, grid_of((size_t) (L->nc + L->nce) * L->col_parts), dim3(PG_THREADS), 0, g->stream,
@@ -3468,6 +3495,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_SETUP_F32_PS")) g->sw.setup_f32_ps = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_L1_SIX")) g->sw.l1_six = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_TREE_POSITIONS")) g->sw.tree_positions = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_BOTTOM")) g->sw.fused_bottom = std::atoi(e) != 0;
