@@ -316,6 +316,14 @@ struct MgLevel {  // device view of one level (level 0 = the pose graph without 
   // product is the sum over gp_list[gp_start[k] ..) of Ps[x]^T * Q[y]; qdiag[e] = the entry of Q in the row and column of entry e
   // of Ps (the coarse diagonal blocks).  They are the sorted candidate lists of the pattern build with their origins as payload:
   // k_mg_hp / k_mg_galerkin found every product by a binary search per (entry, incidence), five in six of them in vain.
+  // Column-ordered float32 copies of Ps and Q (round 6): block m of Psfc / Qfc is the block of entry pcsc2[m].x / qcsc2[m].x, so a
+  // column is ONE contiguous run -- the restriction (level 0) and the down phases read their columns as a stream instead of 144-byte
+  // blocks scattered over the row-ordered arrays (55.7 MB per restriction for 29 MB of blocks); pcsc_pos / qcsc_pos = where an entry's
+  // block goes (the inverse of the column lists).
+  float* Psfc;
+  float* Qfc;
+  const int* pcsc_pos;
+  const int* qcsc_pos;
   const int* qp_start;
   const int2* qp_list;
   const int* gp_start;
@@ -352,6 +360,7 @@ __device__ __forceinline__ MgLevel mg_level(const MgLevel* __restrict__ levels, 
   L.qcsc_start = mg_glob(L.qcsc_start); L.qcsc_ent = mg_glob(L.qcsc_ent); L.pcsc2 = mg_glob(L.pcsc2); L.qcsc2 = mg_glob(L.qcsc2);
   L.qp_start = mg_glob(L.qp_start); L.qp_list = mg_glob(L.qp_list); L.gp_start = mg_glob(L.gp_start); L.gp_list = mg_glob(L.gp_list);
   L.qdiag = mg_glob(L.qdiag);
+  L.Psfc = mg_glob(L.Psfc); L.Qfc = mg_glob(L.Qfc); L.pcsc_pos = mg_glob(L.pcsc_pos); L.qcsc_pos = mg_glob(L.qcsc_pos);
   L.x = mg_glob(L.x); L.r = mg_glob(L.r); L.res = mg_glob(L.res);
   return L;
 }
@@ -619,7 +628,7 @@ __device__ __forceinline__ void mg_down2_column(const MgLevel& L, int I, int tid
   for (int a = 0; a < D; ++a) s[a] = 0.0;
   for (int m = L.pcsc_start[I] + tid; m < L.pcsc_start[I + 1]; m += nth) {
     const int2 er = L.pcsc2[m];
-    mg_block_tmulsub<D>(L.Psf + (size_t) er.x * D * D, L.r + (size_t) er.y * D, 1.0, s);
+    mg_block_tmulsub<D>(L.Psfc ? L.Psfc + (size_t) m * D * D : L.Psf + (size_t) er.x * D * D, L.r + (size_t) er.y * D, 1.0, s);
   }
   const int qe = L.qcsc_start[I + 1];
   for (int m0 = L.qcsc_start[I] + tid; m0 < qe; m0 += 2 * nth) {
@@ -629,8 +638,9 @@ __device__ __forceinline__ void mg_down2_column(const MgLevel& L, int I, int tid
     double t[D];
 #pragma unroll
     for (int a = 0; a < D; ++a) t[a] = 0.0;
-    mg_block_tmulsub<D>(L.Qf + (size_t) e0.x * D * D, L.x + (size_t) e0.y * D, -1.0, s);
-    mg_block_tmulsub<D>(L.Qf + (size_t) e1.x * D * D, L.x + (size_t) e1.y * D, two ? -1.0 : 0.0, t);
+    mg_block_tmulsub<D>(L.Qfc ? L.Qfc + (size_t) m0 * D * D : L.Qf + (size_t) e0.x * D * D, L.x + (size_t) e0.y * D, -1.0, s);
+    mg_block_tmulsub<D>(L.Qfc ? L.Qfc + (size_t) (two ? m0 + nth : m0) * D * D : L.Qf + (size_t) e1.x * D * D, L.x + (size_t) e1.y * D,
+                        two ? -1.0 : 0.0, t);
 #pragma unroll
     for (int a = 0; a < D; ++a) s[a] = s[a] + t[a];
   }
@@ -1109,13 +1119,22 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_psmooth(MgPair LV, double ome
   // are then the Galerkin products of exactly the interpolation the cycle uses, and the products fetch 144 instead of 288 bytes of it;
   // 16-byte stores: 36 scalar ones took this kernel from 132 to 223 us on level 0)
   if (L.Psf) {
+    const size_t ec = L.Psfc ? (size_t) L.pcsc_pos[e] : 0;  // (and the column-ordered copy)
     if constexpr (D == 6) {
       float4* of = reinterpret_cast<float4*>(L.Psf + (size_t) e * D * D);
+      float4* oc = reinterpret_cast<float4*>(L.Psfc + ec * D * D);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) of[k] = make_float4((float) o[4 * k], (float) o[4 * k + 1], (float) o[4 * k + 2], (float) o[4 * k + 3]);
+      for (int k = 0; k < 9; ++k) {
+        const float4 v = make_float4((float) o[4 * k], (float) o[4 * k + 1], (float) o[4 * k + 2], (float) o[4 * k + 3]);
+        of[k] = v;
+        if (L.Psfc) oc[k] = v;
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < D * D; ++k) L.Psf[(size_t) e * D * D + k] = (float) o[k];
+      for (int k = 0; k < D * D; ++k) {
+        L.Psf[(size_t) e * D * D + k]  = (float) o[k];
+        if (L.Psfc) L.Psfc[ec * D * D + k] = (float) o[k];
+      }
     }
   }
 }
@@ -1303,13 +1322,38 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_to_float(MgPair LV, int with_
     }
     if (k < no) L.Hof[k] = (float) L.Ho[k];
   }
-  if (L.Psf && with_p) {  // (Qf is read by the two-phase levels only: level 0's Q is 2.7 x its Ps)
-    const size_t np = (size_t) L.np * D * D, nq = with_q ? (size_t) L.nq * D * D : 0;
-    for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < np || k < nq; k += (size_t) gridDim.x * blockDim.x) {
-      if (k < np) L.Psf[k] = (float) L.Ps[k];
-      if (k < nq) L.Qf[k] = (float) L.Q[k];
+  // (Psf / Psfc: written by k_mg_psmooth; Qf / Qfc: k_mg_q_to_float below)
+  (void) with_p;
+  (void) with_q;
+}
+// the float32 copies of Q = H Ps of a two-phase level: row-ordered (the up phase) and column-ordered (the down phase); one entry per thread
+template <int D>
+__global__ __launch_bounds__(PG_THREADS) void k_mg_q_to_float(MgPair LV) {
+  const MgLevel L = LV.L;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= L.nq) return;
+  const double* src = L.Q + (size_t) q * D * D;
+  const size_t qc   = L.Qfc ? (size_t) L.qcsc_pos[q] : 0;
+  if constexpr (D == 6) {
+    float4* of = reinterpret_cast<float4*>(L.Qf + (size_t) q * D * D);
+    float4* oc = reinterpret_cast<float4*>(L.Qfc + qc * D * D);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 v = make_float4((float) src[4 * k], (float) src[4 * k + 1], (float) src[4 * k + 2], (float) src[4 * k + 3]);
+      of[k] = v;
+      if (L.Qfc) oc[k] = v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) {
+      L.Qf[(size_t) q * D * D + k] = (float) src[k];
+      if (L.Qfc) L.Qfc[qc * D * D + k] = (float) src[k];
     }
   }
+}
+__global__ __launch_bounds__(PG_THREADS) void k_st_invert(int m, const int* __restrict__ ent, int* __restrict__ pos) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) pos[ent[t]] = t;
 }
 
 // dense inverse of the coarsest operator: assemble, Cholesky in place, then one thread per column solves for the inverse
@@ -1722,8 +1766,9 @@ __global__ __launch_bounds__(PG_THREADS) void k_mg_restrict_smooth(MgPair LV, in
       double u[D];
 #pragma unroll
       for (int a = 0; a < D; ++a) u[a] = 0.0;
-      mg_block_tmulsub<D>(L.Psf + (size_t) e0.x * D * D, L.res + (size_t) e0.y * D, 1.0, s);
-      mg_block_tmulsub<D>(L.Psf + (size_t) e1.x * D * D, L.res + (size_t) e1.y * D, two ? 1.0 : 0.0, u);
+      mg_block_tmulsub<D>(L.Psfc ? L.Psfc + (size_t) m0 * D * D : L.Psf + (size_t) e0.x * D * D, L.res + (size_t) e0.y * D, 1.0, s);
+      mg_block_tmulsub<D>(L.Psfc ? L.Psfc + (size_t) (two ? m0 + NL : m0) * D * D : L.Psf + (size_t) e1.x * D * D, L.res + (size_t) e1.y * D,
+                          two ? 1.0 : 0.0, u);
 #pragma unroll
       for (int a = 0; a < D; ++a) s[a] = s[a] + u[a];
     }
@@ -1801,11 +1846,14 @@ struct MgLevelBufs {
   DevBuf<int> qcsc_start, qcsc_ent;
   DevBuf<int2> pcsc2, qcsc2;
   DevBuf<double> Hd, Ho, Ps, Q, Dinv, x, r, res;
+  DevBuf<float> Psfc, Qfc;                      // column-ordered copies (MgLevel::Psfc)
+  DevBuf<int> pcsc_pos, qcsc_pos;
   DevBuf<unsigned long long> qp_list, gp_list;  // (int2 {x, y} = the low and the high word)
   DevBuf<int> qp_start, gp_start, qdiag;
   long long nqp = 0, ngp = 0;                   // products of Q = H Ps / of the coarse edges
   void release() {
     qp_list.release(); gp_list.release(); qp_start.release(); gp_start.release(); qdiag.release();
+    Psfc.release(); Qfc.release(); pcsc_pos.release(); qcsc_pos.release();
     eij.release(); inc_start.release(); inc_adj.release(); agg.release(); rep0.release(); prow_start.release();
     pcol.release(); prow_of.release(); pcsc_start.release(); pcsc_ent.release(); qrow_start.release(); qcol.release();
     qrow_of.release(); Hd.release(); Ho.release(); P.release(); Ps.release(); Q.release(); Dinv.release(); x.release();
@@ -1849,6 +1897,9 @@ struct srrg2_posegraph_s {
     bool device_structure = true;  // SRRG2_AMD_PG_DEVICE_STRUCTURE: the sparsity patterns of a level are built on the device
     bool product_lists = true;     // SRRG2_AMD_PG_PRODUCT_LISTS: the set-up products over the lists the pattern build leaves (round 6; 0: the searching kernels)
     int list_lane_products = 4;    // SRRG2_AMD_PG_LIST_LANES: products per lane the list kernels aim at
+    bool column_copies = false;    // SRRG2_AMD_PG_COLUMN_COPIES (experiment, off): column-ordered float32 copies of Ps and Q for the down phases --
+                                   // k_mg_down2 20.0 -> 17.4 / 10.7 -> 9.9 us, the restriction unchanged, the solve 85.3-87.5 -> 90.0 ms: the second
+                                   // copy of Ps is 29 MB more per cycle and two more arrays to write per set-up (profiles/r9/r9s_*)
     bool setup_f32_ps = true;      // SRRG2_AMD_PG_SETUP_F32_PS: the set-up products read the float32 copy of the interpolation (round 6)
     bool l1_six = false;           // SRRG2_AMD_PG_L1_SIX (experiment): level 1 on six phases through H instead of two through Q
     bool tree_positions = true;    // SRRG2_AMD_PG_TREE_POSITIONS: the matching's geometry from a spanning tree of the measurements (round 6)
@@ -2909,8 +2960,13 @@ int build_hierarchy(srrg2_posegraph_s* g) {
       L->prow_parts = parts;
     }
     if ((rc = L->Ps.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Q.reserve((size_t) std::max(nq, 1) * D * D)) ||
-        (rc = L->Psf.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Qf.reserve((size_t) std::max(nq, 1) * D * D)))
+        (rc = L->Psf.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Qf.reserve((size_t) std::max(nq, 1) * D * D)) ||
+        (rc = L->Psfc.reserve((size_t) std::max(np, 1) * D * D)) || (rc = L->Qfc.reserve((size_t) std::max(nq, 1) * D * D)) ||
+        (rc = L->pcsc_pos.reserve((size_t) std::max(np, 1))) || (rc = L->qcsc_pos.reserve((size_t) std::max(nq, 1))))
       return rc;
+    // (where an entry's block goes in the column-ordered copies: the inverse of the column lists, which are on the device either way)
+    if (np > 0) hipLaunchKernelGGL(k_st_invert, st_grid((size_t) np), dim3(PG_THREADS), 0, g->stream, np, L->pcsc_ent.p, L->pcsc_pos.p);
+    if (nq > 0) hipLaunchKernelGGL(k_st_invert, st_grid((size_t) nq), dim3(PG_THREADS), 0, g->stream, nq, L->qcsc_ent.p, L->qcsc_pos.p);
     ms_up += ms_since(t_up);
     // next level
     n = nc;
@@ -2946,6 +3002,9 @@ int build_hierarchy(srrg2_posegraph_s* g) {
     v.Hdf = L->Hdf.p; v.Hof = L->Hof.p; v.Dinvf = L->Dinvf.p;
     v.Psf = l + 1 < nl ? L->Psf.p : nullptr; v.Qf = l + 1 < nl ? L->Qf.p : nullptr;
     v.qcsc_start = L->qcsc_start.p; v.qcsc_ent = L->qcsc_ent.p; v.pcsc2 = L->pcsc2.p; v.qcsc2 = L->qcsc2.p;
+    v.Psfc = (l + 1 < nl && g->sw.column_copies) ? L->Psfc.p : nullptr;
+    v.Qfc  = (l + 1 < nl && g->sw.column_copies) ? L->Qfc.p : nullptr;
+    v.pcsc_pos = L->pcsc_pos.p; v.qcsc_pos = L->qcsc_pos.p;
     v.qp_start = L->qp_start.p; v.qp_list = reinterpret_cast<const int2*>(L->qp_list.p); v.gp_start = L->gp_start.p;
     v.gp_list = reinterpret_cast<const int2*>(L->gp_list.p); v.qdiag = L->qdiag.p;
     v.Hd = L->Hd.p; v.Ho = L->Ho.p; v.P = L->P.p; v.Ps = L->Ps.p; v.Q = L->Q.p; v.Dinv = L->Dinv.p; v.x = L->x.p;
@@ -3260,7 +3319,11 @@ int pg_solve_t(srrg2_posegraph_s* g, const srrg2_posegraph_params* p, srrg2_pose
         const MgLevelBufs* L = g->levels[(size_t) l];
         const size_t items   = std::max((size_t) L->n, (size_t) L->ne) * D * D;
         hipLaunchKernelGGL(k_mg_to_float<D>, dim3((unsigned) std::min<size_t>(std::max<size_t>((items + PG_THREADS - 1) / PG_THREADS, 1), 4096)),
-                           dim3(PG_THREADS), 0, g->stream, pair(l), 1, (two_phase && l >= 1 && l < lf && !(l == 1 && g->sw.l1_six && g->sw.fused_cg && lf >= 3)) ? 1 : 0);
+                           dim3(PG_THREADS), 0, g->stream, pair(l), 1, 0);
+        // (Q in float32, row- and column-ordered: read by the two-phase levels only -- level 0's Q is 2.7 x its Ps)
+        const bool with_q = two_phase && l >= 1 && l < lf && !(l == 1 && g->sw.l1_six && g->sw.fused_cg && lf >= 3);
+        if (with_q && L->nq > 0 && pair(l).L.Qf)
+          hipLaunchKernelGGL(k_mg_q_to_float<D>, dim3((unsigned) ((L->nq + PG_THREADS - 1) / PG_THREADS)), dim3(PG_THREADS), 0, g->stream, pair(l));
       }
     }
     // PCG: r lives in level 0's r (the cycle's input), z = level 0's x (its output)
@@ -3495,6 +3558,7 @@ int srrg2_posegraph_create(int variable_kind, int device, srrg2_posegraph_h* out
     getf("SRRG2_AMD_PG_LAG", t.lag_below);
     if (std::getenv("SRRG2_AMD_PG_DEBUG")) t.debug = 1;
     if (const char* e = std::getenv("SRRG2_AMD_PG_FUSED_CG")) g->sw.fused_cg = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SRRG2_AMD_PG_COLUMN_COPIES")) g->sw.column_copies = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_SETUP_F32_PS")) g->sw.setup_f32_ps = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_L1_SIX")) g->sw.l1_six = std::atoi(e) != 0;
     if (const char* e = std::getenv("SRRG2_AMD_PG_TREE_POSITIONS")) g->sw.tree_positions = std::atoi(e) != 0;
