@@ -571,8 +571,10 @@ typedef struct srrg2_aligner_tuning {
                                    pass kernel instead of as a launch of its own: 0 = never, 1 / -1 = whenever the aligner is ONE
                                    nearest-neighbour cue slice (searched over cell neighbour lists: every iteration; on the
                                    grid kernels -- a first compute() on a fixed cloud --: from the first converged pass on), or
-                                   projective slices that share one association, and has no prior slice (carved out of
-                                   reserved_)                                                                            */
+                                   projective slices that share one association -- with up to two prior slices before or
+                                   behind them (an odometry prior, a motion model: the control wave linearises their
+                                   factors itself); 2 = as 1, but aligners WITH prior slices keep their control launches
+                                   (carved out of reserved_)                                                             */
   int32_t reserved_[6];
 } srrg2_aligner_tuning;
 /* built-in defaults (the environment is NOT consulted) */

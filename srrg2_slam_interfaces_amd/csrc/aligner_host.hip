@@ -821,8 +821,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     // win: 1000 beams 0.154 against 0.232 ms, 1000 3-D points 0.26 against 0.42 ms), profiles/r7a, r7e.
     // (aligners whose control steps stay launches -- a prior slice next to the cue slice: a laser tracker with odometry --:
     // the one-workgroup kernel up to ~640 points; 360 beams 0.126 against 0.165 ms, 1000 beams 0.246 against 0.19 ms, r7f)
-    if (small && (nslices > ncue || tn.fused_control == 0 || a->params.max_iterations < 2)) small = max_nm <= 640;
-    if (small && !(nslices > ncue || tn.fused_control == 0 || a->params.max_iterations < 2)) {
+    // (round 6, late: the control wave linearises prior slices too -- wave_prior --, such aligners follow the rule of the cue-only
+    // ones; fused_control = 2 / SRRG2_AMD_TUNE bit 24: prior + cue aligners on control launches, as before)
+    const bool priors_launch = nslices > ncue && (tn.fused_control == 2 || (tn.strategy_mask & (1 << 24)) || nslices - ncue > 2);
+    if (small && (priors_launch || tn.fused_control == 0 || a->params.max_iterations < 2)) small = max_nm <= 640;
+    if (small && !(priors_launch || tn.fused_control == 0 || a->params.max_iterations < 2)) {
       const Slice* sfc = a->slices[fc];
       const int sl     = tn.search_lists;
       const bool lists = sl >= 2 || (sl == 1 && K > 4) || (sl < 0 && (K > 4 || sfc->grid_computes >= 1 || sfc->lists_tried));
@@ -1066,8 +1069,22 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
          a->params.max_iterations >= 2;
   // (one nearest-neighbour cue slice, or projective slices that share one association -- k_proj_zbuf_fz --; no prior slices:
   // the step finds everything in the slices' records)
-  const bool fuse_proj = proj_fused && (int) proj_group.size() == nslices && K == 1;
-  fuse = fuse && (nslices == 1 || fuse_proj);
+  // (round 6, late: prior slices next to them -- an odometry prior or a motion model: what a tracker configures, S/instances.cpp:35-38
+  // -- are linearised by the control wave itself, wave_prior; they may stand before or behind the cue slices, not between two)
+  int ncue_all = 0, last_cue = -1, prior_mask = 0;
+  for (int si = 0; si < nslices; ++si) {
+    if (a->slices[si]->cfg.kind == SRRG2_SLICE_PRIOR) {
+      prior_mask |= 1 << si;
+    } else {
+      ++ncue_all;
+      last_cue = si;
+    }
+  }
+  const bool cues_consecutive = first_cue >= 0 && last_cue - first_cue + 1 == ncue_all;
+  // (at most two prior slices: the control wave keeps their linearisations in registers until the sums are in)
+  if (prior_mask && (tn.fused_control == 2 /* cue slices only, as before: A/B */ || (C.tune & (1 << 24)) || nslices - ncue_all > 2)) fuse = false;
+  const bool fuse_proj = proj_fused && (int) proj_group.size() == ncue_all && K == 1;
+  fuse = fuse && cues_consecutive && (ncue_all == 1 || fuse_proj);
   // A nearest-neighbour slice WITHOUT lists (the first compute() on a fixed cloud: a tracker's frame) or with the deferred-search
   // queue runs its search passes on the grid kernels, which read ProblemState and have no prologue: those iterations keep their
   // control launch (it publishes the record too), and the control steps are fused from the first converged pass on --
@@ -1081,8 +1098,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   };
   for (int si = 0; si < nslices && fuse; ++si) {
     const Slice* s = a->slices[si];
-    fuse = s->cfg.kind != SRRG2_SLICE_PRIOR &&
-           (fuse_proj ? s->cfg.finder == SRRG2_FINDER_PROJECTIVE : s->cfg.finder == SRRG2_FINDER_NN_GATED);
+    if (s->cfg.kind == SRRG2_SLICE_PRIOR) continue;
+    fuse = fuse_proj ? s->cfg.finder == SRRG2_FINDER_PROJECTIVE : s->cfg.finder == SRRG2_FINDER_NN_GATED;
     // Round 6: the grid kernel has a fused instantiation too (k_icp_step_fused) -- without the deferred-search queue, whose kernel and
     // counters belong to the control LAUNCH.  Whether the queue is worth its launches depends on the frame: a tracker's 100 k-point
     // frame against its clipped local map (everything overlaps, small motion) leaves it nearly empty -- compute() 0.225 -> 0.199 ms
@@ -1163,6 +1180,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       sdev[si].fc.max_stats = slots;
       sdev[si].fc.has_term  = a->has_term ? 1 : 0;
       sdev[si].fc.first_round = a->cu_count * 6;  // (CUs x 6 workgroups: nothing beyond them is resident when a launch starts)
+      sdev[si].fc.prior_mask  = prior_mask;
+      sdev[si].fc.nslices     = nslices;
     }
   if (split && (small || a->reduce_fn || a->profile || !a->timeline_path.empty()))
     return fail(SRRG2_E_STATE, "internal: a pipelined batch on a path that cannot be split");
@@ -1297,6 +1316,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             pack[z].fc.prev_partials = slot_buffer(sz, pround + 2);  // (round pround - 1; the step zeroes the one after this round's)
             pack[z].fc.zero_partials = slot_buffer(sz, pround + 1);
             pack[z].fc.prior       = (slot0 > 0 || it > 0) ? 1 : 0;
+            if (it == 0) pack[z].fc.prior_mask = 0;  // (as for the nearest-neighbour passes below)
           }
         if (proj_fused) {
           srrg2amd::launch_proj_step_fused(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
@@ -1359,6 +1379,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
               sd.fc.prev_partials = slot_buffer(s, pround + 2);  // (round pround - 1; the step zeroes the one after this round's)
               sd.fc.zero_partials = slot_buffer(s, pround + 1);
               sd.fc.prior         = (slot0 > 0 || it > 0) ? 1 : 0;
+              // (the first pass of a run starts behind the init / post LAUNCH: its record is current, no control step is due, and it
+              // runs on the instantiation without the prior factors' code -- the four-lanes-per-point search pass of a 100 k-point
+              // cloud took 40.6 us at the 128 registers of that code against 26.7 at its own 74)
+              if (it == 0) sd.fc.prior_mask = 0;
             }
             const ProblemDev* pt = a->probs.p + (size_t) si * K;
             hipStream_t hs = hstream[h];

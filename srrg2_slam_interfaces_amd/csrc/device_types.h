@@ -102,6 +102,9 @@ struct FusedCtl {
   int has_term;
   int first_round;             // workgroups (linear index, problem fastest) that may start before the control steps have published
   int prior;                   // neighbours of a previous pass of this compute() exist (every pass but the first of the first run)
+  int prior_mask;              // bit s: slice s is a PRIOR slice (its factor is linearised by the control wave from ctl->slices[s]:
+                               // wave_prior); 0: cue slices only
+  int nslices;                 // slices of the aligner (cue + prior)
 };
 
 // One cue slice (AlignerSliceProcessor_) as the step kernel sees it.

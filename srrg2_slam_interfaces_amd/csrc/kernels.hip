@@ -2145,6 +2145,8 @@ __device__ unsigned long long g_pass_ts[16 * 512 * 8];  // [epoch][workgroup (ti
 #endif
 namespace {
 
+__device__ float robust_weight(int kind, float thr, float chi, bool& kernelized);  // (defined with the control kernels below)
+
 __device__ __forceinline__ double rl_d(double v, int k) {  // lane k's value, k wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
@@ -2221,7 +2223,66 @@ __device__ __forceinline__ void pub_publish_state(const CtlParams& C, const Prob
 // for the entry of this iteration, which comes from the registers -- so any wave computes the same records from them; this
 // variant stores NOTHING (workgroup (problem, 0) stays the only writer of state, statistics, slot sets and records) and
 // returns this lane's granule of every slice's new record in `out`.
-template <int D, int MAXS, bool PUBLISH = true>
+// A prior slice's factor (SE2PriorErrorFactor / SE3PriorErrorFactorAD: prior_linearize below, statement for statement) on the
+// lanes of the control wave: every lane computes the error vector e and E = Z^-1 X itself (the same scalar code: the same bits
+// in every lane), lane r D + c then forms ITS entry w sum_k (J(k, r) info(k)) J(k, c) of the factor's H, lane a its entry of b --
+// the loops of prior_linearize over k, in the same order, with the entries of J picked per lane instead of stored (36 doubles).
+// Returns the factor's status; pH / pb = 0 for a suppressed factor (prior_linearize returns zeros there).
+// (prior_Z / prior_info / robust_thr: the slice's SliceCtl fields, fetched by the caller)
+template <int D>
+__device__ __forceinline__ int wave_prior(const float (&prior_Z)[12], const float (&prior_info)[6], float robust_thr, int rk,
+                                          const float (&X)[12], int lane, double& pH, double& pb, double& chi_out) {
+  const int hr = lane / D, hc = lane - hr * D;
+  double e[D];
+  float Zinv[12], E[12];
+  double qw = 0.0;
+  if constexpr (D == 6) {
+    dm::se3_inverse(prior_Z, Zinv);
+    dm::se3_compose(Zinv, X, E);
+    dm::se3_t2v_quat(E, e);
+    const double n2 = (e[3] * e[3] + e[4] * e[4]) + e[5] * e[5];
+    qw              = n2 < 1.0 ? sqrt(1.0 - n2) : 0.0;
+  } else {
+    dm::se2_inverse(prior_Z, Zinv);
+    dm::se2_compose(Zinv, X, E);
+    dm::se2_t2v(E, e);
+  }
+  // J(k, col), k uniform, col this lane's
+  auto Jat = [&](int k, int col) -> double {
+    if constexpr (D == 6) {
+      if (k < 3) return col == 0 ? (double) E[k * 4 + 0] : (col == 1 ? (double) E[k * 4 + 1] : (col == 2 ? (double) E[k * 4 + 2] : 0.0));
+      const double m0 = k == 3 ? qw : (k == 4 ? e[5] : -e[4]);
+      const double m1 = k == 3 ? -e[5] : (k == 4 ? qw : e[3]);
+      const double m2 = k == 3 ? e[4] : (k == 4 ? -e[3] : qw);
+      return col == 3 ? m0 : (col == 4 ? m1 : (col == 5 ? m2 : 0.0));
+    } else {
+      if (k < 2) return col == 0 ? (double) E[k * 3 + 0] : (col == 1 ? (double) E[k * 3 + 1] : 0.0);
+      return col == 2 ? 1.0 : 0.0;
+    }
+  };
+  double chi = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) chi = chi + (e[i] * (double) prior_info[i]) * e[i];
+  bool kernelized;
+  const float w = robust_weight(rk, robust_thr, (float) chi, kernelized);
+  chi_out       = chi;
+  const int status = !isfinite(chi) ? (int) SRRG2_FACTOR_SUPPRESSED
+                                    : (kernelized ? (int) SRRG2_FACTOR_KERNELIZED : (int) SRRG2_FACTOR_INLIER);
+  pH = 0.0;
+  pb = 0.0;
+  if (status == SRRG2_FACTOR_SUPPRESSED) return status;
+  double th = 0.0, tb = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    th = th + (Jat(k, hr) * (double) prior_info[k]) * Jat(k, hc);
+    tb = tb + (Jat(k, lane) * (double) prior_info[k]) * e[k];
+  }
+  pH = (double) w * th;
+  pb = (double) w * tb;
+  return status;
+}
+
+template <int D, int MAXS, bool PUBLISH = true, bool PRIORS = false>
 __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, int ns, ProblemState* __restrict__ states, int prob,
                                              const unsigned long long (&g)[MAXS], unsigned (*out)[MAXS] = nullptr) {
   const FusedCtl& F  = Sv[0].fc;
@@ -2229,6 +2290,15 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
   ProblemState* st   = &states[prob];
   const unsigned epoch = (unsigned) F.epoch;
   constexpr int TS   = D == 3 ? 9 : 12;  // words of X
+  // (prior slices: the head of their SliceCtl records -- kind .. prior_info, 25 words -- one word per lane, requested BEFORE the
+  // slot sets: loads return in order, and the priors are linearised while the slot sets are still on their way)
+  int pw[SRRG2_MAX_SLICES];
+#pragma unroll
+  for (int q = 0; q < SRRG2_MAX_SLICES; ++q) {
+    pw[q] = 0;
+    if constexpr (PRIORS)
+      if (((unsigned) F.prior_mask >> q) & 1u) pw[q] = reinterpret_cast<const int*>(&F.ctl->slices[q])[lane & 31];
+  }
   // ---- the slot sets of the passes of the previous epoch (buffer (epoch - 1) & 1) of every slice: requested first
   long long v[MAXS];
 #pragma unroll
@@ -2277,12 +2347,80 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
       wx = st->w_chi[lane];
     }
   }
+  // Prior factors (at most two: run_compute), linearised AHEAD of the sums: they depend on X only, which the record carries -- their
+  // float64 chain (a 4 x 4 inverse and product, the quaternion of the error, a division and a square root or two) runs while the
+  // slot sets are still on their way; the slice loop below adds the results in slice order.
+  int ps0 = -1, ps1 = -1, pt0 = 0, pt1 = 0;
+  double pH0 = 0.0, pb0 = 0.0, pc0 = 0.0, pH1 = 0.0, pb1 = 0.0, pc1 = 0.0;
+  if constexpr (PRIORS) {
+    const unsigned pm0 = (unsigned) F.prior_mask, pm1 = pm0 & (pm0 - 1u);
+    ps0 = pm0 ? __builtin_ctz(pm0) : -1;
+    ps1 = pm1 ? __builtin_ctz(pm1) : -1;
+    float Xa[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Xa[i] = i < TS ? rl_f(Xl, i) : 0.f;
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      const int sl = j == 0 ? ps0 : ps1;
+      if (sl < 0) break;
+      int pword = pw[0];
+#pragma unroll
+      for (int q = 1; q < SRRG2_MAX_SLICES; ++q) pword = sl == q ? pw[q] : pword;
+      constexpr int W_RK = (int) (offsetof(SliceCtl, robust_kind) / 4), W_THR = (int) (offsetof(SliceCtl, robust_thr) / 4),
+                    W_Z = (int) (offsetof(SliceCtl, prior_Z) / 4), W_INFO = (int) (offsetof(SliceCtl, prior_info) / 4);
+      static_assert(W_INFO + 6 <= 32, "the prefetched head of SliceCtl covers the prior's fields");
+      const int robust_kind  = __builtin_amdgcn_readlane(pword, W_RK);
+      const float robust_thr = __int_as_float(__builtin_amdgcn_readlane(pword, W_THR));
+      float pZ[12], pinfo[6];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pZ[i] = __int_as_float(__builtin_amdgcn_readlane(pword, W_Z + i));
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pinfo[i] = __int_as_float(__builtin_amdgcn_readlane(pword, W_INFO + i));
+      const int rk = ((fl0 & PUB_FLAG_PHASE1) && robust_kind != SRRG2_ROBUST_NONE) ? (int) SRRG2_ROBUST_CLAMP : robust_kind;
+      double pH, pb, pchi;
+      const int pstat = wave_prior<D>(pZ, pinfo, robust_thr, rk, Xa, lane, pH, pb, pchi);
+      if (j == 0) {
+        pH0 = pH; pb0 = pb; pc0 = pchi; pt0 = pstat;
+      } else {
+        pH1 = pH; pb1 = pb; pc1 = pchi; pt1 = pstat;
+      }
+    }
+  }
   const int hr = lane / D, hc = lane - hr * D;
   const int hsrc = hidx(hr < hc ? hr : hc, hr < hc ? hc : hr) & 31;
   double Hl = 0.0, bl = 0.0;  // H(r, c) in lane r D + c; b(a) in lane a
   int num_in = 0, num_out = 0, num_sup = 0, num_corr = 0;
   double chi_in = 0.0, chi_out = 0.0;
   bool good = false;
+  // The slices in slice order (the order of control_body's sums): the cue slices of the launch are consecutive (run_compute checks),
+  // prior slices may stand before and behind them (FusedCtl::prior_mask; none: the loop runs its cue part once).
+  const unsigned pmask = PRIORS ? (unsigned) F.prior_mask : 0u;  // (PRIORS: the kernel instantiations of aligners with prior slices)
+  const int first_cue  = Sv[0].slice_idx;
+  const int s_end      = pmask ? F.nslices : first_cue + 1;
+#pragma unroll 1
+  for (int sl = pmask ? 0 : first_cue; sl < s_end; ++sl) {
+  if ((pmask >> sl) & 1u) {
+    const bool pfirst = sl == ps0;
+    const double pH = pfirst ? pH0 : pH1, pb = pfirst ? pb0 : pb1, pchi = pfirst ? pc0 : pc1;
+    const int pstat = pfirst ? pt0 : pt1;
+    good = true;  // aligner_slice_processor_prior.h:66-68
+    Hl   = Hl + pH;
+    bl   = bl + pb;
+    if (pstat == SRRG2_FACTOR_INLIER) {
+      num_in += 1;
+      chi_in = chi_in + pchi;
+    } else if (pstat == SRRG2_FACTOR_KERNELIZED) {
+      num_out += 1;
+      chi_out = chi_out + pchi;
+    } else {
+      num_sup += 1;
+    }
+    num_corr += 1;  // (num_correspondences(): a prior slice counts one)
+    if constexpr (PUBLISH)
+      if (lane == 0) st->ninl[sl] = pstat == SRRG2_FACTOR_INLIER ? 1 : 0;
+    continue;
+  }
+  if (sl != first_cue) continue;  // (the cue slices: all of them at the first one's place)
 #pragma unroll
   for (int z = 0; z < MAXS; ++z) {
     if (z >= ns) break;  // (uniform)
@@ -2315,6 +2453,7 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
       if (lane < 12) st->Tlast[s][lane] = told[z];  // the transforms the passes of this iteration ran with
     }
   }
+  }  // (slices)
   if constexpr (PUBLISH)
     if (lane == 0) st->npasses = npasses0 + 1;
   if (!good) {  // multi_aligner_impl.cpp:107-111
@@ -2608,19 +2747,19 @@ extern "C" int srrg2_amd_debug_fused_fallbacks(unsigned long long* out, int rese
 #define FUSED_FALLBACK_COUNT() do { } while (0)
 #endif
 
-template <int DIM>
+template <int DIM, bool PRIORS = false>
 __device__ __forceinline__ void fused_control_if_due(const SliceDev& S, ProblemState* __restrict__ states, int prob) {
   if (blockIdx.y != 0 || threadIdx.x >= 64) return;  // (fused launches: x = problem, y = tile)
   const unsigned long long g[1] = {
     pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
   if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) {
     FUSED_STALL();
-    wave_control<DIM == 3 ? 6 : 3, 1>(&S, 1, states, prob, g);
+    wave_control<DIM == 3 ? 6 : 3, 1, true, PRIORS>(&S, 1, states, prob, g);
   }
   PASS_TS(S.fc.epoch, 1);
 }
 
-template <int DIM>
+template <int DIM, bool PRIORS = false>
 __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState* __restrict__ states, int prob, PassView& v) {
   __shared__ unsigned rec_lds[PUB_SLICE_GRANULES];
   const int lane = threadIdx.x & 63;
@@ -2652,7 +2791,7 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
           if (__all((unsigned) (g >> 32) == (unsigned) (S.fc.epoch - 1))) {
             const unsigned long long gv[1] = {g};
             unsigned nv[1];
-            wave_control<DIM == 3 ? 6 : 3, 1, false>(&S, 1, states, prob, gv, &nv);
+            wave_control<DIM == 3 ? 6 : 3, 1, false, PRIORS>(&S, 1, states, prob, gv, &nv);
             g = (unsigned long long) nv[0];
             FUSED_FALLBACK_COUNT();
             break;
@@ -2680,16 +2819,16 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
 // with the control step of the previous iteration in its prologue (round 6).  Without the deferred-search queue: the open points
 // are finished inside the kernel (the queue's kernel and its counters belong to the control LAUNCH: run_compute keeps both for
 // clouds large enough for the queue to pay).  x = problem, y = tile, like the other fused launches.
-template <int DIM, bool PLANE>
+template <int DIM, bool PLANE, bool PRIORS = false>
 __global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const ProblemDev* __restrict__ probs,
                                                         ProblemState* __restrict__ states) {
   const int prob = blockIdx.x + S.prob0;
   const int tile = (int) blockIdx.y;
-  fused_control_if_due<DIM>(S, states, prob);
+  fused_control_if_due<DIM, PRIORS>(S, states, prob);
   const ProblemDev pd = probs[prob];
   if (tile * 256 >= pd.nm && tile != 0) return;
   PassView pv;
-  pass_view_fused<DIM>(S, states, prob, pv);
+  pass_view_fused<DIM, PRIORS>(S, states, prob, pv);
   if (pv.stop || tile * 256 >= pd.nm) return;
   StepView sv;
 #pragma unroll
@@ -2707,7 +2846,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const Proble
 
 // Several slices (the projective kernels: a pack of up to four slices that share one association): the control step of all
 // of them at the top of the iteration's first kernel, and the records of `ns` slices staged in LDS by wave 0.
-template <int MAXS>
+template <int MAXS, bool PRIORS = false>
 __device__ __forceinline__ void fused_control_if_due_multi(const SliceDev* __restrict__ Sv, int ns, ProblemState* __restrict__ states,
                                                            int prob) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
@@ -2723,14 +2862,14 @@ __device__ __forceinline__ void fused_control_if_due_multi(const SliceDev* __res
   }
   if (__any(stale)) {
     FUSED_STALL();
-    wave_control<6, MAXS>(Sv, ns, states, prob, g);  // (projective finders: SE(3))
+    wave_control<6, MAXS, true, PRIORS>(Sv, ns, states, prob, g);  // (projective finders: SE(3))
   }
 }
 // (ns_all: the slices of the aligner -- the control step is one step for all of them, whatever this kernel reads.
 // FIRST = the iteration's first kernel, the one that carries the control step: only there can a record be stale -- the
 // step kernel behind it starts behind a kernel boundary that the designated wave's stores have crossed, reads current
 // records and carries no fallback: wave_control for four slices inside it took it from 98 to 203 registers)
-template <int MAXS, bool FIRST>
+template <int MAXS, bool FIRST, bool PRIORS = false>
 __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, int ns, int prob,
                                               unsigned (&rec)[MAXS][PUB_SLICE_GRANULES], ProblemState* __restrict__ states,
                                               int ns_all) {
@@ -2799,7 +2938,7 @@ __device__ __forceinline__ void records_fused(const SliceDev* __restrict__ Sv, i
           if (z < ns_all) old = old && (unsigned) (ga[z] >> 32) == (unsigned) (F.epoch - 1);
         if (__all(old)) {  // (still whole at the previous epoch: computed here)
           unsigned nv[4];
-          wave_control<6, 4, false>(Sv, ns_all, states, prob, ga, &nv);
+          wave_control<6, 4, false, PRIORS>(Sv, ns_all, states, prob, ga, &nv);
 #pragma unroll
           for (int z = 0; z < MAXS; ++z)
             if (z < ns) g[z] = (unsigned long long) nv[z];
@@ -3032,7 +3171,7 @@ __device__ __forceinline__ float4 ld_stream(const float4* p) {
 // GATHER: the previous neighbour and its normal are gathered from the fixed cloud through prev_pos (batches: the cloud
 // is shared by all alignments and stays in L2; 8 instead of 36 streamed bytes per point) instead of read from prev_f / prev_n
 // (single alignments: no dependent load on the chain).
-template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
+template <int DIM, bool PLANE, int PPT, bool GATHER, int FUSED>  // (FUSED: 0 = control launches, 1 = fused control steps, 2 = ... of an aligner with prior slices)
 __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const ProblemDev* __restrict__ probs,
                                                    ProblemState* __restrict__ states) {
   constexpr int D    = DIM == 3 ? 6 : 3;
@@ -3048,7 +3187,7 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     if (pv.stop) return;
   } else {
     PASS_TS(S.fc.epoch, 0);
-    fused_control_if_due<DIM>(S, states, prob);
+    fused_control_if_due<DIM, FUSED == 2>(S, states, prob);
   }
   const ProblemDev pd = probs[prob];
   // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
@@ -3138,7 +3277,7 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
     }
   }
   if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
-    pass_view_fused<DIM>(S, states, prob, pv);
+    pass_view_fused<DIM, FUSED == 2>(S, states, prob, pv);
     if (pv.stop || tile * (256 * PPT) >= pd.nm) return;
     load_T(pv.T, T);
     load_T(pv.Tprev, Tprev);
@@ -3431,7 +3570,7 @@ __device__ __forceinline__ void icp_step_fast_body(const SliceDev& S, const Prob
   if constexpr (FUSED) PASS_TS(S.fc.epoch, 3);
 }
 
-template <int DIM, bool PLANE, int PPT, bool GATHER, bool FUSED>
+template <int DIM, bool PLANE, int PPT, bool GATHER, int FUSED>  // (FUSED: 0 = control launches, 1 = fused control steps, 2 = ... of an aligner with prior slices)
 __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const ProblemDev* __restrict__ probs,
                                                        ProblemState* __restrict__ states) {
   icp_step_fast_body<DIM, PLANE, PPT, GATHER, FUSED>(S, probs, states);
@@ -3439,7 +3578,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
 // ============================================================================================
 // The search pass over the cell neighbour lists (cnl_search above): TEAM lanes per moving point.
 // ============================================================================================
-template <int DIM, bool PLANE, int TEAM, bool FUSED>
+template <int DIM, bool PLANE, int TEAM, int FUSED>  // (FUSED: as k_icp_step_fast)
 __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, const ProblemDev* __restrict__ probs,
                                                       ProblemState* __restrict__ states) {
   constexpr int NW  = 4;
@@ -3451,7 +3590,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     if (pv.stop) return;
   } else {
     PASS_TS(S.fc.epoch, 0);
-    fused_control_if_due<DIM>(S, states, prob);
+    fused_control_if_due<DIM, FUSED == 2>(S, states, prob);
   }
   const ProblemDev pd = probs[prob];
   const int tile      = FUSED ? blockIdx.y : blockIdx.x;
@@ -3507,7 +3646,7 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     }
   }
   if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
-    pass_view_fused<DIM>(S, states, prob, pv);
+    pass_view_fused<DIM, FUSED == 2>(S, states, prob, pv);
     if (pv.stop || tile * PPB >= pd.nm) return;
     load_T(pv.T, T);
     load_T(pv.Tprev, Tprev);
@@ -4077,17 +4216,20 @@ __global__ __launch_bounds__(256) void k_proj_zbuf_pack(SlicePack P, ProblemStat
 // Fused control steps (projective slices that share their association): the z-buffer pass is the first kernel of an
 // iteration -- wave 0 of workgroup (0, problem) applies the control step of ALL slices of the previous iteration at its top;
 // the transform comes from the record of the first slice.
+// (PRIORS: the instantiation for aligners with prior slices next to the pack -- a motion model beside the projective slices of an
+// RGB-D tracker --, linearised by the control wave: wave_prior)
+template <bool PRIORS>
 __global__ __launch_bounds__(256) void k_proj_zbuf_fz(SlicePack P, int nslices, ProblemState* __restrict__ states) {
   const SliceDev& S = P.s[0];
   const int prob    = blockIdx.y;
-  fused_control_if_due_multi<4>(P.s, nslices, states, prob);
+  fused_control_if_due_multi<4, PRIORS>(P.s, nslices, states, prob);
   const ProblemDev pd = P.probs[0][prob];
   const int i         = blockIdx.x * blockDim.x + threadIdx.x;
   const bool inr      = i < pd.nm;
   float4 p            = make_float4(NAN, 0.f, 0.f, 0.f);
   if (inr) p = S.mpts[pd.moff + i];  // (requested before the record: it does not depend on the state)
   __shared__ unsigned rec[1][PUB_SLICE_GRANULES];
-  records_fused<1, true>(P.s, 1, prob, rec, states, nslices);
+  records_fused<1, true, PRIORS>(P.s, 1, prob, rec, states, nslices);
   PassView pv;
   view_of_record(rec[0], pv);
   if (pv.stop || !inr) return;
@@ -5144,17 +5286,25 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
   if (K <= 0 || max_nm <= 0) return;
   if (S.fc.pub) {  // fused control steps: the record instead of ProblemState, no deferred-search queue
     dim3 fgrid(K, (max_nm + 255) / 256);
-    if (dim == 3) {
-      if (plane)
-        hipLaunchKernelGGL((k_icp_step_fused<3, true>), fgrid, dim3(256), 0, s, S, probs, states);
-      else
-        hipLaunchKernelGGL((k_icp_step_fused<3, false>), fgrid, dim3(256), 0, s, S, probs, states);
-    } else {
-      if (plane)
-        hipLaunchKernelGGL((k_icp_step_fused<2, true>), fgrid, dim3(256), 0, s, S, probs, states);
-      else
-        hipLaunchKernelGGL((k_icp_step_fused<2, false>), fgrid, dim3(256), 0, s, S, probs, states);
-    }
+#define FUSED_GRID_LAUNCH(PRIORS)                                                                              \
+  do {                                                                                                         \
+    if (dim == 3) {                                                                                            \
+      if (plane)                                                                                               \
+        hipLaunchKernelGGL((k_icp_step_fused<3, true, PRIORS>), fgrid, dim3(256), 0, s, S, probs, states);     \
+      else                                                                                                     \
+        hipLaunchKernelGGL((k_icp_step_fused<3, false, PRIORS>), fgrid, dim3(256), 0, s, S, probs, states);    \
+    } else {                                                                                                   \
+      if (plane)                                                                                               \
+        hipLaunchKernelGGL((k_icp_step_fused<2, true, PRIORS>), fgrid, dim3(256), 0, s, S, probs, states);     \
+      else                                                                                                     \
+        hipLaunchKernelGGL((k_icp_step_fused<2, false, PRIORS>), fgrid, dim3(256), 0, s, S, probs, states);    \
+    }                                                                                                          \
+  } while (0)
+    if (S.fc.prior_mask)
+      FUSED_GRID_LAUNCH(true);
+    else
+      FUSED_GRID_LAUNCH(false);
+#undef FUSED_GRID_LAUNCH
     return;
   }
   int bx = (max_nm + 255) / 256;  // one moving point per thread
@@ -5250,20 +5400,25 @@ void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists
     }                                                                                                             \
   } while (0)
   // (fused control steps -- S.fc.pub: the instantiations that read the state from the published record)
-  if (S.fc.pub) {
+  if (S.fc.pub && S.fc.prior_mask) {  // (... of an aligner with prior slices: the control wave linearises them, wave_prior)
     if (team >= 4)
-      CNL_LAUNCH(4, true);
+      CNL_LAUNCH(4, 2);
     else
-      CNL_LAUNCH(1, true);
+      CNL_LAUNCH(1, 2);
+  } else if (S.fc.pub) {
+    if (team >= 4)
+      CNL_LAUNCH(4, 1);
+    else
+      CNL_LAUNCH(1, 1);
   } else {
     if (team >= 4)
-      CNL_LAUNCH(4, false);
+      CNL_LAUNCH(4, 0);
     else
-      CNL_LAUNCH(1, false);
+      CNL_LAUNCH(1, 0);
   }
 #undef CNL_LAUNCH
 }
-template <int PPT, bool GATHER, bool FUSED>
+template <int PPT, bool GATHER, int FUSED>
 static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                             int max_nm, hipStream_t s) {
   dim3 grid((max_nm + 256 * PPT - 1) / (256 * PPT), K);
@@ -5283,34 +5438,41 @@ static void launch_fast_ppt(int dim, bool plane, const SliceDev& S, const Proble
 void launch_icp_step_fast(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                           int max_nm, int ppt, bool gather, hipStream_t s) {
   if (K <= 0 || max_nm <= 0) return;
+  if (S.fc.pub && S.fc.prior_mask) {  // ... of an aligner with prior slices (one point per thread: the instantiations that exist)
+    if (gather)
+      launch_fast_ppt<1, true, 2>(dim, plane, S, probs, states, K, max_nm, s);
+    else
+      launch_fast_ppt<1, false, 2>(dim, plane, S, probs, states, K, max_nm, s);
+    return;
+  }
   if (S.fc.pub) {  // fused control steps (one or two points per thread)
     if (gather) {
       if (ppt >= 2)
-        launch_fast_ppt<2, true, true>(dim, plane, S, probs, states, K, max_nm, s);
+        launch_fast_ppt<2, true, 1>(dim, plane, S, probs, states, K, max_nm, s);
       else
-        launch_fast_ppt<1, true, true>(dim, plane, S, probs, states, K, max_nm, s);
+        launch_fast_ppt<1, true, 1>(dim, plane, S, probs, states, K, max_nm, s);
     } else {
       if (ppt >= 2)
-        launch_fast_ppt<2, false, true>(dim, plane, S, probs, states, K, max_nm, s);
+        launch_fast_ppt<2, false, 1>(dim, plane, S, probs, states, K, max_nm, s);
       else
-        launch_fast_ppt<1, false, true>(dim, plane, S, probs, states, K, max_nm, s);
+        launch_fast_ppt<1, false, 1>(dim, plane, S, probs, states, K, max_nm, s);
     }
     return;
   }
   if (gather) {
     if (ppt >= 4)
-      launch_fast_ppt<4, true, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<4, true, 0>(dim, plane, S, probs, states, K, max_nm, s);
     else if (ppt >= 2)
-      launch_fast_ppt<2, true, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<2, true, 0>(dim, plane, S, probs, states, K, max_nm, s);
     else
-      launch_fast_ppt<1, true, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<1, true, 0>(dim, plane, S, probs, states, K, max_nm, s);
   } else {
     if (ppt >= 4)
-      launch_fast_ppt<4, false, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<4, false, 0>(dim, plane, S, probs, states, K, max_nm, s);
     else if (ppt >= 2)
-      launch_fast_ppt<2, false, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<2, false, 0>(dim, plane, S, probs, states, K, max_nm, s);
     else
-      launch_fast_ppt<1, false, false>(dim, plane, S, probs, states, K, max_nm, s);
+      launch_fast_ppt<1, false, 0>(dim, plane, S, probs, states, K, max_nm, s);
   }
   if (S.queue) launch_icp_queue(dim, plane, S, probs, states, K, max_nm, s);
 }
@@ -5389,7 +5551,10 @@ void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* pro
   }
   dim3 grid(icp_step_blocks(max_nm), K);
   if (P.s[0].fc.pub) {  // fused control steps
-    hipLaunchKernelGGL(k_proj_zbuf_fz, grid, dim3(256), 0, s, P, nslices, states);
+    if (P.s[0].fc.prior_mask)
+      hipLaunchKernelGGL(k_proj_zbuf_fz<true>, grid, dim3(256), 0, s, P, nslices, states);
+    else
+      hipLaunchKernelGGL(k_proj_zbuf_fz<false>, grid, dim3(256), 0, s, P, nslices, states);
     hipLaunchKernelGGL(k_icp_step_proj_fused<true>, grid, dim3(256), 0, s, P, nslices, states);
     return;
   }
@@ -5451,7 +5616,7 @@ __global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, 
   const int prob = blockIdx.x + C.prob0;
   const unsigned long long g[1] = {
     pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
-  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1>(&S, 1, states, prob, g);
+  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1, true, true>(&S, 1, states, prob, g);
   __threadfence();
   icp_finalize_block(C, &states[prob], stats, outs_host, stats_host, prob, with_post != 0);
 }

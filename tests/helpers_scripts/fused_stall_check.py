@@ -17,7 +17,7 @@ except Exception:
     pass
 
 import srrg2_slam_interfaces_amd as product  # noqa: E402
-from helpers import assert_same_run, cue_config, setup_pair  # noqa: E402
+from helpers import assert_same_run, cue_config, prior_config, setup_pair  # noqa: E402
 from oracle import pyoracle as oracle  # noqa: E402
 from srrg2_slam_interfaces_amd import _abi as abi  # noqa: E402
 from srrg2_slam_interfaces_amd import _capi  # noqa: E402
@@ -109,10 +109,45 @@ def projective():
     assert_same_run(runs[0], runs[1], slices=(0, 1))
 
 
+def prior_cue(kind, slice_kind):
+    """a prior slice before and one behind the cue slice: the polling waves linearise the prior factors too (wave_prior)"""
+    if kind == abi.SE2_RIGHT:
+        d = syn.scan_pair_2d(beams=3000, sigma=0.01, seed=1234)
+        gate, thr = 0.5, 0.002
+        Za, Zb = syn.se2(0.03, -0.02, 0.01).astype(np.float32), syn.se2(-0.05, 0.04, -0.02).astype(np.float32)
+        info_a, info_b = [10.0, 10.0, 100.0], [3.0, 5.0, 40.0]
+    else:
+        d = syn.cloud_pair_3d(n=15000, seed=2200, noise_sigma=0.01)
+        gate, thr = 0.25, 0.0005
+        Za = syn.se3(np.array([0.04, -0.02, 0.01]), np.deg2rad([0.5, -1.0, 1.5])).astype(np.float32)
+        Zb = syn.se3(np.array([-0.03, 0.05, 0.02]), np.deg2rad([-1.0, 0.5, -0.7])).astype(np.float32)
+        info_a, info_b = [10, 10, 10, 100, 100, 100], [3, 4, 5, 30, 40, 50]
+    cfg = cue_config(kind, slice_kind, gate, abi.ROBUST_CAUCHY, thr)
+    runs = []
+    for al in (oracle.OracleAligner(kind), product.MultiAligner(kind)):
+        if not isinstance(al, oracle.OracleAligner):
+            al.set_tuning(**FUSED)
+        al.set_params(max_iterations=12, min_num_inliers=10, enable_inlier_only_runs=True)
+        al.set_termination_criteria(abi.default_termination_params())
+        pa = al.add_slice(prior_config(kind, info=info_a, sets_guess=1))
+        cue = setup_pair(al, d, cfg)
+        pb = al.add_slice(prior_config(kind, info=info_b, sets_guess=0))
+        al.set_prior_measurement(pa, Za)
+        al.set_prior_measurement(pb, Zb)
+        al.compute()
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        runs.append(al)
+    assert runs[0].status() == abi.SUCCESS
+    assert_same_run(runs[0], runs[1], slices=(cue,))
+
+
 fallbacks(reset=True)
 counts = {}
 for name, fn in (("se3_plane", lambda: single(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE)), ("se2_p2p", lambda: single(abi.SE2_RIGHT, abi.SLICE_P2P)),
-                 ("batch", batch), ("projective", projective)):
+                 ("batch", batch), ("projective", projective),
+                 ("prior_cue_se3", lambda: prior_cue(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE)),
+                 ("prior_cue_se2", lambda: prior_cue(abi.SE2_RIGHT, abi.SLICE_P2P))):
     fn()
     counts[name] = fallbacks(reset=True)
 print("fused-control fallbacks per scenario:", counts)
