@@ -750,6 +750,24 @@ def main():
                                                 "clipped local map; `upload` (the measurement's host-to-device copy) is not in tracker_frame_ms"}
             except Exception as e:
                 out["tracker_frame"] = {"error": repr(e)}
+            # a tracker's aligner as the reference configures it (S/instances.cpp:35-38): the cue slice NEXT TO a prior slice (odometry
+            # prior / motion model) -- fused control steps there too since round 6 (`launches`: the same aligner with fused_control = 2,
+            # i.e. one control launch per iteration as before)
+            try:
+                import bench_prior_cue
+
+                pc = {}
+                for name, n, three_d in (("laser_1000_beams_se2_p2p", 1000, False), ("c2_100k_se3_p2plane", 100_000, True)):
+                    f = bench_prior_cue.run(n, three_d, True, reps=40)
+                    l = bench_prior_cue.run(n, three_d, True, reps=40, fused_control=2)
+                    c = bench_prior_cue.run(n, three_d, False, reps=40)
+                    pc[name] = {"compute_ms": f["steady_ms"], "new_fixed_cloud_ms": f["new_fixed_cloud_ms"], "status": f["status"],
+                                "with_control_launches_ms": [l["steady_ms"], l["new_fixed_cloud_ms"]],
+                                "cue_slice_alone_ms": [c["steady_ms"], c["new_fixed_cloud_ms"]]}
+                pc["note"] = "ms per compute() (10 iterations), host wall clock; first number steady state (fixed cloud kept), second on a new fixed cloud"
+                out["prior_cue"] = pc
+            except Exception as e:
+                out["prior_cue"] = {"error": repr(e)}
             # BASELINE's second half asks for >= 6x at 8 GPUs on the 256-alignment job: at 8 GPUs every rank runs 32 per
             # launch, so the one-GPU figures bound the strong-scaling ratio from above (no collective on the data path)
             out["projected_8gpu_speedup"] = 8.0 * out["c4_32"]["value"] / out["c4_256"]["value"]

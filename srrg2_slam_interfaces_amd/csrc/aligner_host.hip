@@ -1260,10 +1260,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       if (!last_it && fused_pass(slot0_now, it + 1) && (fused_all || it != probe_it)) return;
     }
     if (last_phase && last_it) {
-      // (the last step on one wave too -- k_icp_final_wave -- measured SLOWER than the 256-thread kernel on C2, 0.191 against
-      // 0.188 ms, neutral on batches (profiles/r6a): the finalize part reads the state back from memory where the big kernel
-      // has it staged in LDS.  Off; SRRG2_AMD_TUNE bit 25 switches it on)
-      if (fuse && !fuse_proj && (C.tune & (1 << 25))) {
+      // (the last step on one wave too, k_icp_final_wave.  Round 5's version let the finalize part read the state back from memory
+      // and measured SLOWER than the 256-thread kernel, which has it staged in LDS (C2 0.191 against 0.188 ms, profiles/r6a);
+      // round 6, late: post and finalize run from the step's REGISTERS and the record for the host is written by the lanes of the
+      // wave, one word each, behind one system-scope fence.  SRRG2_AMD_TUNE bit 25 switches back to the 256-thread kernel)
+      if (fuse && !fuse_proj && !(C.tune & (1 << 25))) {
         SliceDev sd          = sdev[first_cue];
         sd.prob0             = h0[h];
         sd.fc.ctl            = a->ctl_dev.p + h;

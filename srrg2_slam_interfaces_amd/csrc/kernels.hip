@@ -2282,9 +2282,25 @@ __device__ __forceinline__ int wave_prior(const float (&prior_Z)[12], const floa
   return status;
 }
 
-template <int D, int MAXS, bool PUBLISH = true, bool PRIORS = false>
+// What the LAST control step of a compute() leaves in the registers of its wave for the finalize step behind it
+// (k_icp_final_wave): filled only when the step ran in full (`applied`; a run that had already stopped, or stops here for want of
+// correspondences, is finalized from ProblemState as before).
+struct FinalRegs {
+  bool applied;
+  float Xl;        // lanes [0, 12): X after this step
+  double Hl;       // lane r D + c: H(r, c) of this step
+  int nstats;      // IterationStats appended so far, this step's included
+  int num_in;      // inliers of this step (what the post step checks against min_num_inliers)
+  int sw;          // lanes [0, 8): the words of this step's IterationStats record
+  bool stats_written;
+  int nc0, ni0;    // correspondences / inliers of the (first) cue slice
+};
+
+template <int D, int MAXS, bool PUBLISH = true, bool PRIORS = false, bool FINAL = false>
 __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, int ns, ProblemState* __restrict__ states, int prob,
-                                             const unsigned long long (&g)[MAXS], unsigned (*out)[MAXS] = nullptr) {
+                                             const unsigned long long (&g)[MAXS], unsigned (*out)[MAXS] = nullptr,
+                                             FinalRegs* fin = nullptr) {
+  if constexpr (FINAL) fin->applied = false;
   const FusedCtl& F  = Sv[0].fc;
   const int lane     = threadIdx.x & 63;
   ProblemState* st   = &states[prob];
@@ -2436,6 +2452,11 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     const double scaled = (double) v[z] * dm::pow2(-kexp[z]);
     const int nc = (int) rl_ll(v[z], ACC_N_CORR), n_in = (int) rl_ll(v[z], ACC_N_IN), n_out = (int) rl_ll(v[z], ACC_N_OUT);
     good |= nc > Sv[z].fc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
+    if constexpr (FINAL)
+      if (z == 0) {
+        fin->nc0 = nc;
+        fin->ni0 = n_in;
+      }
     Hl = Hl + __shfl(scaled, hsrc);
     bl = bl + __shfl(scaled, (ACC_B + lane) & 31);
     num_in += n_in;
@@ -2592,11 +2613,18 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
   PASS_TS_W(F.epoch, 7, (double) Xl);
   // ---- IterationStats of this iteration (multi_aligner_impl.cpp:113-115): one 4-byte word of the record per lane
   const float chi_in_f = (float) chi_in, chi_out_f = (float) chi_out;
-  if (PUBLISH && nstats0 < F.max_stats && lane < 8) {
-    static_assert(sizeof(srrg2_iteration_stats) == 32, "eight words");
-    const int sw = lane == 0 ? nstats0 : lane == 1 ? num_in : lane == 2 ? num_out : lane == 3 ? num_sup : lane == 4 ? num_corr
-                 : lane == 5 ? (bad ? 1 : 0) : lane == 6 ? __float_as_int(chi_in_f) : __float_as_int(chi_out_f);
-    reinterpret_cast<int*>(F.stats + (size_t) prob * F.max_stats + nstats0)[lane] = sw;
+  static_assert(sizeof(srrg2_iteration_stats) == 32, "eight words");
+  const int sw = lane == 0 ? nstats0 : lane == 1 ? num_in : lane == 2 ? num_out : lane == 3 ? num_sup : lane == 4 ? num_corr
+               : lane == 5 ? (bad ? 1 : 0) : lane == 6 ? __float_as_int(chi_in_f) : __float_as_int(chi_out_f);
+  if (PUBLISH && nstats0 < F.max_stats && lane < 8) reinterpret_cast<int*>(F.stats + (size_t) prob * F.max_stats + nstats0)[lane] = sw;
+  if constexpr (FINAL) {
+    fin->applied = true;
+    fin->Xl = Xl;
+    fin->Hl = Hl;
+    fin->nstats = nstats0 + 1;
+    fin->num_in = num_in;
+    fin->sw = sw;
+    fin->stats_written = nstats0 < F.max_stats;
   }
   if constexpr (PUBLISH)
     if (lane == 0) st->nstats = nstats0 + 1;
@@ -5606,27 +5634,102 @@ void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C
 }
 // The LAST control step of a compute() with fused control steps, on one wave (wave_control) with the post / finalize steps
 // behind it: the 256-thread k_icp_control_final stages the 3.4 KB state through LDS around a 238-register body; this one reads
-// the record + the slot sets, runs the lane-distributed step and lets icp_finalize_block read the state back (its stores are
-// complete behind the fence; this kernel has not loaded those lines before, so no stale copy can be hit).
-template <int D>
+// the record + the slot sets, runs the lane-distributed step and finalizes from what that step left in its registers
+// (FinalRegs); only a run that had stopped earlier lets icp_finalize_block read the state back (its stores are complete
+// behind the fence; this kernel has not loaded those lines before, so no stale copy can be hit).
+template <int D, bool PRIORS>
 __global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, ProblemState* __restrict__ states,
                                                         srrg2_iteration_stats* __restrict__ stats,
                                                         ProblemOut* __restrict__ outs_host,
                                                         srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
   const int prob = blockIdx.x + C.prob0;
+  const int lane = threadIdx.x & 63;
+  ProblemState* st = &states[prob];
   const unsigned long long g[1] = {
-    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + (threadIdx.x & 63))};
-  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1, true, true>(&S, 1, states, prob, g);
-  __threadfence();
-  icp_finalize_block(C, &states[prob], stats, outs_host, stats_host, prob, with_post != 0);
+    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + lane)};
+  // (what the fast path below needs of the state and does not find in the step's registers: the correspondence counts of the
+  // slices the step does not write -- requested with the record)
+  int ncorr_l = 0;
+  if (lane < SRRG2_MAX_SLICES) ncorr_l = st->ncorr[lane];
+  FinalRegs fin;
+  fin.applied = false;
+  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1, true, PRIORS, true>(&S, 1, states, prob, g, nullptr, &fin);
+  if (!fin.applied || !fin.stats_written) {  // (uniform.  A run that had stopped before, or stops here: from the state, as before)
+    __threadfence();
+    icp_finalize_block(C, st, stats, outs_host, stats_host, prob, with_post != 0);
+    return;
+  }
+  // ---- the step ran in full: post (multi_aligner_impl.cpp:75-85) and finalize (:88-94, :214-263) from its registers, the record
+  //      for the host by the lanes of the wave (one 4-byte word each), one system-scope fence in front of the completion flag
+  int status    = SRRG2_SUCCESS;
+  bool finished = false;
+  if (with_post && fin.num_in < C.params.min_num_inliers) {  // icp_post_one: nstats >= 1 here, the last record is this step's
+    status   = SRRG2_NOT_ENOUGH_INLIERS;
+    finished = true;
+  }
+  const int cue = S.slice_idx;
+  int nc_cue    = fin.nc0;
+  float Xa[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Xa[i] = rl_f(fin.Xl, i);
+  if (!finished) {
+    if (C.params.keep_only_inlier_correspondences) nc_cue = fin.ni0;
+    if constexpr (D == 3)
+      dm::se2_fix_transform(Xa);
+    else
+      dm::se3_fix_transform(Xa);
+  }
+  float xl = Xa[0];
+#pragma unroll
+  for (int i = 1; i < 12; ++i) xl = lane == i ? Xa[i] : xl;
+  // the state, for what reads it after compute() (k_icp_outputs, get_information, the next compute() of the handle)
+  if (lane < 12) st->X[lane] = xl;
+  if (lane == 0) {
+    st->status = status;
+    if (finished) st->finished = 1;
+    st->ncorr[cue] = nc_cue;
+  }
+  // ProblemOut: X[12] | status | nstats | ncorr[SRRG2_MAX_SLICES] | H[36] | seq
+  constexpr int W_STATUS = 12, W_NSTATS = 13, W_NCORR = 14, W_H = W_NCORR + SRRG2_MAX_SLICES, W_SEQ = W_H + 36;
+  static_assert(offsetof(ProblemOut, status) == 4 * W_STATUS && offsetof(ProblemOut, ncorr) == 4 * W_NCORR &&
+                  offsetof(ProblemOut, H) == 4 * W_H && offsetof(ProblemOut, seq) == 4 * W_SEQ && W_SEQ < 64,
+                "one word of the record per lane");
+  const int ncorr_w = __shfl(ncorr_l, (lane - W_NCORR) & 63);
+  const float h_w   = (float) __shfl(fin.Hl, (lane - W_H) & 63);
+  int word = __float_as_int(xl);
+  if (lane == W_STATUS) word = status;
+  if (lane == W_NSTATS) word = fin.nstats;
+  if (lane >= W_NCORR && lane < W_H) word = lane - W_NCORR == cue ? nc_cue : ncorr_w;
+  if (lane >= W_H && lane < W_SEQ) word = lane - W_H < D * D ? __float_as_int(h_w) : __float_as_int(0.f);
+  if (lane < W_SEQ) reinterpret_cast<int*>(&outs_host[prob])[lane] = word;
+  {  // the iteration statistics, 8 words each: the earlier records from memory (earlier kernels wrote them), this step's from its lanes
+    const int nrec  = min(fin.nstats, C.max_stats);
+    const int n     = nrec * 8;
+    const int* src  = reinterpret_cast<const int*>(stats + (size_t) prob * C.max_stats);
+    int* dst        = reinterpret_cast<int*>(stats_host + (size_t) prob * C.max_stats);
+    const int lastw = __shfl(fin.sw, lane & 7);
+    for (int k = lane; k < n; k += 64) dst[k] = (k >> 3) == fin.nstats - 1 ? lastw : src[k];
+  }
+  __threadfence_system();
+  if (lane == 0) *reinterpret_cast<volatile int*>(&outs_host[prob].seq) = C.seq;  // the host polls this word
 }
 void launch_icp_final_wave(const CtlParams& C, const SliceDev& S, ProblemState* states, srrg2_iteration_stats* stats,
                            ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
   const dim3 grid(C.nprob > 0 ? C.nprob : C.K);
-  if (C.variable_kind == SRRG2_SE2_RIGHT)
-    hipLaunchKernelGGL(k_icp_final_wave<3>, grid, dim3(64), 0, s, C, S, states, stats, outs_host, stats_host, with_post ? 1 : 0);
-  else
-    hipLaunchKernelGGL(k_icp_final_wave<6>, grid, dim3(64), 0, s, C, S, states, stats, outs_host, stats_host, with_post ? 1 : 0);
+#define FINAL_WAVE_LAUNCH(D_, PRIORS_) \
+  hipLaunchKernelGGL((k_icp_final_wave<D_, PRIORS_>), grid, dim3(64), 0, s, C, S, states, stats, outs_host, stats_host, with_post ? 1 : 0)
+  if (C.variable_kind == SRRG2_SE2_RIGHT) {
+    if (S.fc.prior_mask)
+      FINAL_WAVE_LAUNCH(3, true);
+    else
+      FINAL_WAVE_LAUNCH(3, false);
+  } else {
+    if (S.fc.prior_mask)
+      FINAL_WAVE_LAUNCH(6, true);
+    else
+      FINAL_WAVE_LAUNCH(6, false);
+  }
+#undef FINAL_WAVE_LAUNCH
 }
 void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
                                srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {

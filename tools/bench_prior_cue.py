@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""A laser tracker's aligner: one nearest-neighbour cue slice (2-D scan, SE(2) point-to-point) NEXT TO an odometry prior slice --
-the control steps of such an aligner are launches (no fused control steps).  ms per compute(), steady state and on a new fixed
-scan.   usage: python tools/bench_prior_cue.py [beams ...]"""
+"""A tracker's aligner: one nearest-neighbour cue slice NEXT TO a prior slice (an odometry prior / a motion model: S/instances.cpp:35-38).
+2-D: a laser scan, SE(2) point-to-point; --3d: an SE(3) point-to-plane cloud pair (C2's slice).  ms per compute(), steady state (the
+fixed cloud kept: lists) and on a new fixed cloud (a tracker's frame).  Since round 6 the control steps of such an aligner are fused
+into the pass kernels too (the control wave linearises the prior factor: wave_prior); SRRG2_AMD_FUSED_CONTROL=2 keeps the launches.
+usage: python tools/bench_prior_cue.py [--3d] [--no-prior] [points ...]"""
 import os
 import sys
 import time
@@ -12,71 +14,59 @@ import numpy as np
 import srrg2_slam_interfaces_amd as pkg
 from srrg2_slam_interfaces_amd import _abi as abi, synthetic as syn
 
-with_prior = "--no-prior" not in sys.argv
-if "--3d" in sys.argv:  # a 3-D tracker: 100 000-point SE(3) point-to-plane cue slice (C2) next to a motion-model prior
-    n = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [100000]
-    for npts in n:
-        d = syn.cloud_pair_3d(n=npts, seed=77)
-        al = pkg.MultiAligner(abi.SE3_QUAT_RIGHT)
-        al.set_params(max_iterations=10, min_num_inliers=10)
-        c = abi.default_slice_config(abi.SE3_QUAT_RIGHT)
-        c.kind, c.finder, c.finder_max_distance = abi.SLICE_P2PLANE, abi.FINDER_NN_GATED, 0.25
-        c.robustifier, c.robustifier_chi_threshold = abi.ROBUST_CAUCHY, 0.05
-        si = al.add_slice(c)
-        if with_prior:
-            p = abi.default_slice_config(abi.SE3_QUAT_RIGHT)
-            p.kind, p.finder, p.prior_sets_initial_guess = abi.SLICE_PRIOR, abi.FINDER_NONE, 0
-            for i, v in enumerate([10.0, 10.0, 10.0, 100.0, 100.0, 100.0]):
-                p.prior_information_diag[i] = v
-            pi = al.add_slice(p)
-        al.set_fixed(si, d["fixed"], d["fixed_normals"])
-        al.set_moving(si, d["moving"], d["moving_normals"])
-        if with_prior:
-            al.set_prior_measurement(pi, syn.identity(3).astype(np.float32))
-        steady, fresh = [], []
-        for rep in range(60):
-            al.set_moving_in_fixed(syn.identity(3))
-            t0 = time.perf_counter()
-            st = al.compute()
-            steady.append(time.perf_counter() - t0)
-        for rep in range(40):
-            al.set_fixed(si, d["fixed"], d["fixed_normals"])
-            al.set_moving_in_fixed(syn.identity(3))
-            t0 = time.perf_counter()
-            al.compute()
-            fresh.append(time.perf_counter() - t0)
-        print("%7d 3-D points" % npts + (" + prior" if with_prior else " (cue slice only)") + ": steady %.4f ms per compute(), on a new fixed cloud %.4f ms, status %d"
-              % (1e3 * float(np.median(steady[5:])), 1e3 * float(np.median(fresh[5:])), st), flush=True)
-    sys.exit(0)
-for beams in [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [360, 1000, 3000]:
-    d = syn.scan_pair_2d(beams=beams, sigma=0.01, seed=1234)
-    al = pkg.MultiAligner(abi.SE2_RIGHT)
+
+def run(points, three_d=False, with_prior=True, reps=60, fused_control=None):
+    if three_d:
+        kind, dim = abi.SE3_QUAT_RIGHT, 3
+        d = syn.cloud_pair_3d(n=points, seed=77)
+        cue = (abi.SLICE_P2PLANE, 0.25)
+        info = [10.0, 10.0, 10.0, 100.0, 100.0, 100.0]
+    else:
+        kind, dim = abi.SE2_RIGHT, 2
+        d = syn.scan_pair_2d(beams=points, sigma=0.01, seed=1234)
+        cue = (abi.SLICE_P2P, 0.5)
+        info = [10.0, 10.0, 100.0]
+    al = pkg.MultiAligner(kind)
+    if fused_control is not None:
+        al.set_tuning(fused_control=fused_control)
     al.set_params(max_iterations=10, min_num_inliers=10)
-    c = abi.default_slice_config(abi.SE2_RIGHT)
-    c.kind, c.finder, c.finder_max_distance = abi.SLICE_P2P, abi.FINDER_NN_GATED, 0.5
+    c = abi.default_slice_config(kind)
+    c.kind, c.finder, c.finder_max_distance = cue[0], abi.FINDER_NN_GATED, cue[1]
     c.robustifier, c.robustifier_chi_threshold = abi.ROBUST_CAUCHY, 0.05
     si = al.add_slice(c)
     if with_prior:
-        p = abi.default_slice_config(abi.SE2_RIGHT)
+        p = abi.default_slice_config(kind)
         p.kind, p.finder, p.prior_sets_initial_guess = abi.SLICE_PRIOR, abi.FINDER_NONE, 0
-        for i, v in enumerate([10.0, 10.0, 100.0]):
+        for i, v in enumerate(info):
             p.prior_information_diag[i] = v
         pi = al.add_slice(p)
-    al.set_fixed(si, d["fixed"])
-    al.set_moving(si, d["moving"])
+    al.set_fixed(si, d["fixed"], d.get("fixed_normals"))
+    al.set_moving(si, d["moving"], d.get("moving_normals"))
     if with_prior:
-        al.set_prior_measurement(pi, syn.identity(2).astype(np.float32))
+        al.set_prior_measurement(pi, syn.identity(dim).astype(np.float32))
     steady, fresh = [], []
-    for rep in range(40):
-        al.set_moving_in_fixed(syn.identity(2))
+    st = -1
+    for rep in range(reps):
+        al.set_moving_in_fixed(syn.identity(dim))
         t0 = time.perf_counter()
         st = al.compute()
         steady.append(time.perf_counter() - t0)
-    for rep in range(30):
-        al.set_fixed(si, d["fixed"])
-        al.set_moving_in_fixed(syn.identity(2))
+    for rep in range(max(reps * 2 // 3, 8)):
+        al.set_fixed(si, d["fixed"], d.get("fixed_normals"))
+        al.set_moving_in_fixed(syn.identity(dim))
         t0 = time.perf_counter()
         al.compute()
         fresh.append(time.perf_counter() - t0)
-    print("%5d beams" % beams + (" + prior" if with_prior else " (cue slice only)") + ": steady %.4f ms per compute(), on a new fixed scan %.4f ms, status %d"
-          % (1e3 * float(np.median(steady[5:])), 1e3 * float(np.median(fresh[5:])), st), flush=True)
+    return {"points": points, "dim": dim, "prior": bool(with_prior), "steady_ms": 1e3 * float(np.median(steady[5:])),
+            "new_fixed_cloud_ms": 1e3 * float(np.median(fresh[5:])), "status": int(st)}
+
+
+if __name__ == "__main__":
+    three_d = "--3d" in sys.argv
+    with_prior = "--no-prior" not in sys.argv
+    sizes = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or ([100000] if three_d else [360, 1000, 3000])
+    for n in sizes:
+        r = run(n, three_d, with_prior)
+        print("%7d %s" % (n, "3-D points" if three_d else "beams") + (" + prior" if with_prior else " (cue slice only)") +
+              ": steady %.4f ms per compute(), on a new fixed cloud %.4f ms, status %d" % (r["steady_ms"], r["new_fixed_cloud_ms"], r["status"]),
+              flush=True)
