@@ -591,6 +591,15 @@ int srrg2_aligner_set_tuning(srrg2_aligner_h h, const srrg2_aligner_tuning* t);
 int srrg2_aligner_profile_enable(srrg2_aligner_h h, int enable);
 int srrg2_aligner_profile_get(srrg2_aligner_h h, double* step_kernel_ms, int64_t* step_kernel_launches,
                               int reset);
+/* Which launch path the handle's LAST compute() / compute_batch() took (strategy only: results do not depend on it; what the
+ * tests of those paths assert).  Bits: */
+#define SRRG2_PATH_FUSED_CONTROL 1   /* control steps inside the pass kernels (tuning.fused_control)                       */
+#define SRRG2_PATH_ALL_PASSES_FUSED 2 /* ... of every pass (else: from the first converged pass on)                         */
+#define SRRG2_PATH_FINAL_WAVE 4      /* the last control step + post / finalize on one wave (k_icp_final_wave)             */
+#define SRRG2_PATH_PROLOGUE_IN_PASS 8 /* no k_icp_init launch: compute()'s prologue rode in the first pass kernel           */
+#define SRRG2_PATH_ONE_WORKGROUP 16  /* the whole compute() in one workgroup per problem (k_icp_small)                     */
+#define SRRG2_PATH_PRIORS_FUSED 32   /* prior slices linearised by the control wave                                        */
+int srrg2_aligner_last_compute_path(srrg2_aligner_h h, int32_t* flags_out);
 
 #ifdef __cplusplus
 }

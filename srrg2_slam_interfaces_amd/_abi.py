@@ -157,3 +157,6 @@ def default_slice_config(variable_kind):
         c.prior_information_diag[i] = 100.0 if variable_kind == SE2_RIGHT else 1.0
     c.prior_sets_initial_guess = 1
     return c
+
+# srrg2_aligner_last_compute_path (strategy introspection: what the path tests assert)
+PATH_FUSED_CONTROL, PATH_ALL_PASSES_FUSED, PATH_FINAL_WAVE, PATH_PROLOGUE_IN_PASS, PATH_ONE_WORKGROUP, PATH_PRIORS_FUSED = 1, 2, 4, 8, 16, 32

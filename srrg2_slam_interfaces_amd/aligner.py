@@ -180,6 +180,16 @@ class MultiAligner:
             setattr(t, k, v)
         self._check(self._b.fn("set_tuning")(self._h, C.byref(t)))
 
+    def last_compute_path(self):
+        """SRRG2_PATH_* bits of the launch path the last compute() took (strategy only; 0 for a backend that has no such notion)"""
+        try:
+            f = self._b.fn("last_compute_path")
+        except AttributeError:
+            return 0
+        v = C.c_int32(0)
+        self._check(f(self._h, C.byref(v)))
+        return int(v.value)
+
     def add_slice(self, config):
         idx = C.c_int(-1)
         self._check(self._b.fn("add_slice")(self._h, C.byref(config), C.byref(idx)))

@@ -86,6 +86,10 @@ struct Slice {
   DevBuf<float> corr_resp;
   DevBuf<uint8_t> corr_stat;
   DevBuf<long long> partials;
+  // the slot sets as the handle's last compute() left them: `slots_zeroed` of them, from `slots_zeroed_at` on, are zero
+  // (k_icp_final_wave zeroes the sets of its problems; run_compute clears this before it launches anything)
+  const void* slots_zeroed_at = nullptr;
+  int slots_zeroed = 0;
   DevBuf<unsigned long long> zbuf;  // projective finder: [problem][rows*cols]
   DevBuf<int> queue;                // deferred searches: one 32-byte QEntry per moving point
   DevBuf<int> qcount;               // [problem]
@@ -160,6 +164,7 @@ struct srrg2_aligner_s {
   int last_ncorr[SRRG2_MAX_SLICES]{};
   float last_H[36]{};  // H of the last Gauss-Newton iteration of the last compute() (problem K - 1)
   bool computed = false;
+  int last_path = 0;  // SRRG2_PATH_* of the last compute() (srrg2_aligner_last_compute_path)
   // The nearest-neighbour passes do not store correspondence records; they are derived on demand (k_icp_outputs) from
   // the state of the last compute(): 0 = the arrays are current, 1 = to be derived, 2 = lost (the clouds changed since)
   int records_state = 0;
@@ -1130,6 +1135,9 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // workgroups --, and y stops at 65 535: clouds beyond that many tiles of the four-lanes-per-point first pass, 4.19 M points,
   // keep the control launches and the x = tile grids of the legacy kernels)
   if (((long long) nm_max_cue * 4 + 255) / 256 > 65535) fuse = false;
+  // (no moving point at all: no pass is launched, so nothing would carry the control steps -- without prior slices the run ends at its
+  // first control step anyway, the final one; WITH a prior slice the prior keeps it alive, iteration after iteration: launches)
+  if (prior_mask && nm_max_cue <= 0) fuse = false;
   if (fuse) {
     if ((rc = a->pub.reserve((size_t) K * SRRG2_MAX_SLICES * PUB_SLICE_GRANULES))) return rc;
     if ((rc = a->pub_epoch.reserve((size_t) K * PUB_EPOCH_REPLICAS * PUB_EPOCH_STRIDE))) return rc;
@@ -1185,8 +1193,29 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     }
   if (split && (small || a->reduce_fn || a->profile || !a->timeline_path.empty()))
     return fail(SRRG2_E_STATE, "internal: a pipelined batch on a path that cannot be split");
-  for (int h = 0; h < nhalves; ++h)
-    srrg2amd::launch_icp_init(Ch[h], a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, hstream[h]);
+  // compute()'s prologue INSIDE the first pass (k_icp_step_cnl_init / k_icp_step_fused_init; kernels.hip: pass_view_init) instead of
+  // a k_icp_init launch in front of it (9 us of a 100 k-point compute()'s 164): a single alignment whose every pass carries its
+  // control step, on the list or the fused grid kernel, whose last step is k_icp_final_wave (it leaves the slot sets zeroed: the
+  // one thing of the prologue the first pass cannot do for itself), on a handle whose previous compute() ended that way.
+  // (SRRG2_AMD_TUNE bit 23: always the launch)
+  const bool final_wave = fuse && !fuse_proj && !(C.tune & (1 << 25));
+  bool fold_init = false;
+  InitInline fold_inl{};
+  if (fuse && fused_all && final_wave && K == 1 && !split && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
+      (cnl[(size_t) first_cue] || !(lds_tile > 0)) && !a->profile) {
+    const Slice* s = a->slices[first_cue];
+    fold_init = s->slots_zeroed >= 3 * K && s->slots_zeroed_at == (const void*) s->partials.p;
+    if (fold_init) {
+      fold_init = srrg2amd::make_init_inline(Ch[0], a->probs_host, a->guesses_host, a->tsize, &fold_inl);
+      for (int si = 0; si < nslices && fold_init; ++si)  // (a prior slice that sets the initial guess: k_icp_init's override, here)
+        if (C.slices[si].kind == SRRG2_SLICE_PRIOR && C.slices[si].prior_sets_initial_guess)
+          for (int i = 0; i < a->tsize; ++i) fold_inl.guess[i] = C.slices[si].prior_Z[i];
+    }
+  }
+  for (Slice* sl : a->slices) sl->slots_zeroed = 0;  // (until this compute() has ended the same way)
+  if (!fold_init)
+    for (int h = 0; h < nhalves; ++h)
+      srrg2amd::launch_icp_init(Ch[h], a->probs_host, a->probs.p, a->states.p, a->guesses_host, a->tsize, hstream[h]);
   auto t_init = std::chrono::steady_clock::now();
 
   if (small) {
@@ -1264,7 +1293,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       // and measured SLOWER than the 256-thread kernel, which has it staged in LDS (C2 0.191 against 0.188 ms, profiles/r6a);
       // round 6, late: post and finalize run from the step's REGISTERS and the record for the host is written by the lanes of the
       // wave, one word each, behind one system-scope fence.  SRRG2_AMD_TUNE bit 25 switches back to the 256-thread kernel)
-      if (fuse && !fuse_proj && !(C.tune & (1 << 25))) {
+      if (final_wave) {
         SliceDev sd          = sdev[first_cue];
         sd.prob0             = h0[h];
         sd.fc.ctl            = a->ctl_dev.p + h;
@@ -1388,15 +1417,18 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             const ProblemDev* pt = a->probs.p + (size_t) si * K;
             hipStream_t hs = hstream[h];
             const int Kh   = hn[h];
+            const bool first_pass_init = fold_init && slot0 == 0 && it == 0 && si == first_cue;  // (the prologue rides in this pass)
             if (fast)
               srrg2amd::launch_icp_step_fast(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, fast_ppt_of(Kh), fast_gather, hs);
             else if (cnl[(size_t) si] && !sd.queue)
               srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, s->lists_host, pt, a->states.p, Kh, nm_max,
-                                            search_team_knob > 0 ? search_team_knob : ((K <= 4 && slot0 == 0 && it == 0) ? 4 : 1), hs);
+                                            search_team_knob > 0 ? search_team_knob : ((K <= 4 && slot0 == 0 && it == 0) ? 4 : 1), hs,
+                                            first_pass_init ? &Ch[h] : nullptr, first_pass_init ? &fold_inl : nullptr);
             else if (!sd.queue && lds_tile > 0 && !small)
               srrg2amd::launch_icp_step_tile(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, lds_tile == 2 ? 504 : 416, hs);
             else
-              srrg2amd::launch_icp_step(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, hs);
+              srrg2amd::launch_icp_step(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, hs, first_pass_init ? &Ch[h] : nullptr,
+                                        first_pass_init ? &fold_inl : nullptr);
             if (split) control(it, last_phase, h);
           }
         }
@@ -1505,6 +1537,15 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   for (int si = 0; si < nslices; ++si)
     for (int k = 0; k < K; ++k) a->last_nm_max[(size_t) si] = std::max(a->last_nm_max[(size_t) si], all[(size_t) si * K + k].nm);
   a->records_state = 1;
+  a->last_path = (fuse ? SRRG2_PATH_FUSED_CONTROL : 0) | (fuse && fused_all ? SRRG2_PATH_ALL_PASSES_FUSED : 0) |
+                 (final_wave && final_launched && !small ? SRRG2_PATH_FINAL_WAVE : 0) | (fold_init ? SRRG2_PATH_PROLOGUE_IN_PASS : 0) |
+                 (small ? SRRG2_PATH_ONE_WORKGROUP : 0) | (fuse && prior_mask ? SRRG2_PATH_PRIORS_FUSED : 0);
+  // (k_icp_final_wave has left the slot sets of its problems zeroed: the next compute() of the handle may skip the k_icp_init launch)
+  if (final_wave && final_launched && first_cue >= 0 && !small) {
+    Slice* s           = a->slices[first_cue];
+    s->slots_zeroed    = 3 * K;
+    s->slots_zeroed_at = (const void*) s->partials.p;
+  }
   return 0;
 }
 
@@ -2321,6 +2362,12 @@ int srrg2_aligner_profile_get(srrg2_aligner_h a, double* ms, int64_t* launches, 
     a->prof_ms       = 0.0;
     a->prof_launches = 0;
   }
+  return 0;
+}
+
+int srrg2_aligner_last_compute_path(srrg2_aligner_h a, int32_t* flags_out) {
+  if (!a || !flags_out) return fail(SRRG2_E_INVALID, "last_compute_path: null argument");
+  *flags_out = a->computed ? a->last_path : 0;
   return 0;
 }
 

@@ -22,8 +22,11 @@ void launch_grid_scatter(const GridDev& g, const float4* pts, const float4* nrm,
 void launch_cnl_build(const GridDev& g, const GridLists& L, const int4* offs, int noffs, int* list_start, uint2* box_at,
                       uint4* ent, hipStream_t s);
 // search pass over the cell neighbour lists (any number of alignments per launch; no deferred-search queue)
+// (init_C / init_inl != null: the FIRST pass of a single alignment's compute() with the prologue inside -- no k_icp_init launch;
+// K == 1, fused control steps, the slot sets left zeroed by the previous compute()'s final step: run_compute decides)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
-                         ProblemState* states, int K, int max_nm, int team, hipStream_t s);
+                         ProblemState* states, int K, int max_nm, int team, hipStream_t s, const CtlParams* init_C = nullptr,
+                         const InitInline* init_inl = nullptr);
 // Morton sort of K moving clouds (counts/cursor: (K << kbits) + 1 ints; bb: K*6 keys initialised to
 // {0xffffffff x3, 0 x3}; counts zeroed)
 // kbits = total key bits (2^kbits cells per cloud); aniso != 0: bits dealt to the axes by extent (kernels_prep.hip: KeySpec);
@@ -35,7 +38,7 @@ void launch_msort(const float4* pts, const float4* nrm, const ProblemDev* probs,
                   unsigned* bb, int* counts, int* cursor, int* scan_sums, int* scan_total, float4* out_pts,
                   float4* out_nrm, hipStream_t s);
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                     int max_nm, hipStream_t s);
+                     int max_nm, hipStream_t s, const CtlParams* init_C = nullptr, const InitInline* init_inl = nullptr);
 // search pass of a batch (no deferred-search queue) with every wave's neighbourhood of the fixed cloud staged in LDS
 void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                           int max_nm, int cap, hipStream_t s);
@@ -61,6 +64,8 @@ void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, Pr
                       hipStream_t s);
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
                      const float* guesses_host, int tsize, hipStream_t s);
+// what k_icp_init gets of a single alignment in its arguments (guess, problem table); false: a batch (read from pinned memory)
+bool make_init_inline(const CtlParams& C, const ProblemDev* probs_host, const float* guesses_host, int tsize, InitInline* inl);
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s);
 void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C, const ProblemDev* probs, ProblemState* states,
                       srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s);

@@ -15,6 +15,8 @@
 // exact 64-bit fixed point so that the reduction order (lanes, waves, blocks, GPUs) cannot change
 // a single bit of H, b or the statistics.
 #include <cstdlib>
+#include <algorithm>
+
 #include "kernels.h"
 
 #include <type_traits>
@@ -2146,6 +2148,11 @@ __device__ unsigned long long g_pass_ts[16 * 512 * 8];  // [epoch][workgroup (ti
 namespace {
 
 __device__ float robust_weight(int kind, float thr, float chi, bool& kernelized);  // (defined with the control kernels below)
+__device__ __forceinline__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, int nm, const float* X);
+template <bool ONLY_INLINE>
+__device__ __forceinline__ void init_problem_thread0(const CtlParams& C, int prob, const ProblemDev* probs_host, ProblemDev* probs,
+                                                     ProblemState* states, const float* guesses_host, int tsize,
+                                                     const InitInline& inl, unsigned (*init_gran)[PUB_SLICE_GRANULES]);
 
 __device__ __forceinline__ double rl_d(double v, int k) {  // lane k's value, k wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
@@ -2843,20 +2850,73 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
   v.prior  = (fl & PUB_FLAG_PRIOR) != 0;
 }
 
+// compute()'s prologue INSIDE the first pass kernel of a single alignment (round 6, late; k_icp_init otherwise: a launch of ~9 us
+// in front of every compute()).  The first pass needs three things of that prologue -- the finder transform of the initial guess,
+// the fixed-point exponent of the slice, zeroed slot sets -- and none of the rest (state, records, device copy of the control
+// parameters, problem table: read from the second pass on, behind a kernel boundary).  So every thread of the pass derives the
+// first two from the kernel arguments (the same statements as init_problem_thread0: same bits; two scalar loads of the clouds'
+// norms, a few dozen operations), the slot sets are left zeroed by the final step of the handle's previous compute()
+// (k_icp_final_wave; run_compute takes this path only then), and wave 0 of workgroup (problem, 0) writes the rest on its way.
+template <int DIM>
+__device__ __forceinline__ void pass_view_init(const SliceDev& S, const CtlParams& C, const InitInline& inl, int prob, int nm,
+                                               PassView& v) {
+  const SliceCtl& sc = C.slices[S.slice_idx];
+  float X[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) X[i] = inl.guess[i];  // (run_compute: a prior slice's override of the guess already applied)
+  const int nm_of = sc.nm_global > 0 ? sc.nm_global : nm;
+  v.kexp = slice_exponent(C, sc, prob, nm_of, X);
+  float T[12];
+  finder_transform_of(sc.Sinv, DIM, X, T);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) v.T[i] = v.Tprev[i] = T[i];
+  v.stop = v.phase1 = v.prior = false;
+}
+// ... the rest of the prologue, by wave 0 of workgroup (problem, 0) of that pass (k_icp_init's body without the zeroing)
+__device__ __forceinline__ void fused_init_tail(const CtlParams& C, const InitInline& inl, int prob, ProblemDev* __restrict__ probs,
+                                                ProblemState* __restrict__ states) {
+  __shared__ unsigned init_gran_tail[SRRG2_MAX_SLICES][PUB_SLICE_GRANULES];
+  const int lane = threadIdx.x & 63;
+  if (C.ctl_dev) {
+    const int* src = reinterpret_cast<const int*>(&C);
+    int* dst       = reinterpret_cast<int*>(C.ctl_dev);
+    for (int k = lane; k < (int) (sizeof(CtlParams) / sizeof(int)); k += 64) dst[k] = src[k];
+  }
+  if (lane == 0)
+    init_problem_thread0<true>(C, prob, nullptr, probs, states, nullptr, C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12, inl, init_gran_tail);
+  wave_lds_sync();
+  if (!C.pub) return;
+  for (int s = 0; s < C.nslices; ++s)
+    if (C.slices[s].kind != SRRG2_SLICE_PRIOR)
+      pub_store(C.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane, (unsigned long long) init_gran_tail[s][lane]);
+  pub_write_epoch(C.pub_epoch, prob, lane, 0u);
+}
+
 // The search pass on the GRID (no cell neighbour lists yet: the first compute() on a new fixed cloud, a tracker's every frame)
 // with the control step of the previous iteration in its prologue (round 6).  Without the deferred-search queue: the open points
 // are finished inside the kernel (the queue's kernel and its counters belong to the control LAUNCH: run_compute keeps both for
 // clouds large enough for the queue to pay).  x = problem, y = tile, like the other fused launches.
-template <int DIM, bool PLANE, bool PRIORS = false>
-__global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const ProblemDev* __restrict__ probs,
-                                                        ProblemState* __restrict__ states) {
+// (MODE: 0 = plain, 1 = the aligner has prior slices, 2 = the first pass of a single alignment's compute() with the prologue inside)
+template <int DIM, bool PLANE, int MODE>
+__device__ __forceinline__ void grid_fused_body(const SliceDev& S, const ProblemDev* __restrict__ probs,
+                                                ProblemState* __restrict__ states, const CtlParams* Ci = nullptr,
+                                                const InitInline* inl = nullptr) {
   const int prob = blockIdx.x + S.prob0;
   const int tile = (int) blockIdx.y;
-  fused_control_if_due<DIM, PRIORS>(S, states, prob);
-  const ProblemDev pd = probs[prob];
+  if constexpr (MODE != 2) fused_control_if_due<DIM, MODE == 1>(S, states, prob);
+  ProblemDev pd;
+  if constexpr (MODE == 2)
+    pd = inl->pd[S.slice_idx];
+  else
+    pd = probs[prob];
   if (tile * 256 >= pd.nm && tile != 0) return;
   PassView pv;
-  pass_view_fused<DIM, PRIORS>(S, states, prob, pv);
+  if constexpr (MODE == 2) {
+    pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv);
+    if (tile == 0 && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
+  } else {
+    pass_view_fused<DIM, MODE == 1>(S, states, prob, pv);
+  }
   if (pv.stop || tile * 256 >= pd.nm) return;
   StepView sv;
 #pragma unroll
@@ -2870,6 +2930,16 @@ __global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const Proble
   sv.prior  = pv.prior;
   sv.qmode  = false;
   icp_step_body<DIM, PLANE, 4>(S, pd, sv, prob, tile, (int) gridDim.y, (int) gridDim.x, nullptr);
+}
+template <int DIM, bool PLANE, bool PRIORS = false>
+__global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const ProblemDev* __restrict__ probs,
+                                                        ProblemState* __restrict__ states) {
+  grid_fused_body<DIM, PLANE, PRIORS ? 1 : 0>(S, probs, states);
+}
+template <int DIM, bool PLANE>
+__global__ __launch_bounds__(256) void k_icp_step_fused_init(SliceDev S, CtlParams C, InitInline inl, ProblemDev* __restrict__ probs,
+                                                             ProblemState* __restrict__ states) {
+  grid_fused_body<DIM, PLANE, 2>(S, probs, states, &C, &inl);
 }
 
 // Several slices (the projective kernels: a pack of up to four slices that share one association): the control step of all
@@ -3606,9 +3676,12 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
 // ============================================================================================
 // The search pass over the cell neighbour lists (cnl_search above): TEAM lanes per moving point.
 // ============================================================================================
-template <int DIM, bool PLANE, int TEAM, int FUSED>  // (FUSED: as k_icp_step_fast)
-__global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, const ProblemDev* __restrict__ probs,
-                                                      ProblemState* __restrict__ states) {
+// (FUSED: as k_icp_step_fast; 3 = the FIRST pass of a single alignment's compute() with the prologue inside, k_icp_step_cnl_init:
+// Ci / inl = the kernel's extra arguments, pass_view_init / fused_init_tail)
+template <int DIM, bool PLANE, int TEAM, int FUSED>
+__device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists& GL, const ProblemDev* __restrict__ probs,
+                                              ProblemState* __restrict__ states, const CtlParams* Ci = nullptr,
+                                              const InitInline* inl = nullptr) {
   constexpr int NW  = 4;
   constexpr int PPB = NW * 64 / TEAM;  // moving points per workgroup
   const int prob    = (FUSED ? blockIdx.x : blockIdx.y) + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
@@ -3616,11 +3689,15 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
   if constexpr (!FUSED) {
     pass_view_legacy(S, &states[prob], pv);
     if (pv.stop) return;
-  } else {
+  } else if constexpr (FUSED != 3) {
     PASS_TS(S.fc.epoch, 0);
     fused_control_if_due<DIM, FUSED == 2>(S, states, prob);
   }
-  const ProblemDev pd = probs[prob];
+  ProblemDev pd;
+  if constexpr (FUSED == 3)
+    pd = inl->pd[S.slice_idx];
+  else
+    pd = probs[prob];
   const int tile      = FUSED ? blockIdx.y : blockIdx.x;
   // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
   // iteration whatever its share of the points)
@@ -3674,7 +3751,12 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
     }
   }
   if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
-    pass_view_fused<DIM, FUSED == 2>(S, states, prob, pv);
+    if constexpr (FUSED == 3) {
+      pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv);
+      if (tile == 0 && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
+    } else {
+      pass_view_fused<DIM, FUSED == 2>(S, states, prob, pv);
+    }
     if (pv.stop || tile * PPB >= pd.nm) return;
     load_T(pv.T, T);
     load_T(pv.Tprev, Tprev);
@@ -3856,6 +3938,17 @@ __global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, 
   }
   block_reduce_store_biased<NW>(acc, S.partials, prob, tile, 1);
   if constexpr (FUSED) PASS_TS(S.fc.epoch, 3);
+}
+template <int DIM, bool PLANE, int TEAM, int FUSED>
+__global__ __launch_bounds__(256) void k_icp_step_cnl(SliceDev S, GridLists GL, const ProblemDev* __restrict__ probs,
+                                                      ProblemState* __restrict__ states) {
+  cnl_pass_body<DIM, PLANE, TEAM, FUSED>(S, GL, probs, states);
+}
+// the first pass of a single alignment's compute() with the prologue inside (pass_view_init, fused_init_tail)
+template <int DIM, bool PLANE, int TEAM>
+__global__ __launch_bounds__(256) void k_icp_step_cnl_init(SliceDev S, GridLists GL, CtlParams C, InitInline inl,
+                                                           ProblemDev* __restrict__ probs, ProblemState* __restrict__ states) {
+  cnl_pass_body<DIM, PLANE, TEAM, 3>(S, GL, probs, states, &C, &inl);
 }
 
 // The correspondence records of the nearest-neighbour passes, on demand (get_correspondences, factor status, the scene
@@ -4613,7 +4706,7 @@ __global__ __launch_bounds__(256) void k_icp_step_proj_pack(SlicePack P, Problem
 // ============================================================================================
 namespace {
 
-__device__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, int nm, const float* X) {
+__device__ __forceinline__ int slice_exponent(const CtlParams& C, const SliceCtl& s, int prob, int nm, const float* X) {
   const bool plane = s.kind == SRRG2_SLICE_P2PLANE;
   const bool repro = s.kind == SRRG2_SLICE_REPROJECTION;
   const bool proj  = s.finder == SRRG2_FINDER_PROJECTIVE;
@@ -4914,35 +5007,16 @@ __device__ void control_body(const CtlParams& C, ProblemState* st, srrg2_iterati
 
 }  // namespace
 
-// compute() prologue: term_crit->init, stats clear, _preCompute (prior init overrides the guess).  One block per
-// problem.  The initial guesses and the problem tables are read straight from pinned host memory (no staging copies on
-// the stream), the partial-sum slots and queue counters are zeroed here (no memsets on the stream).
-// (inl.use: a single alignment's guess and problem table travel in the kernel arguments -- 116 bytes -- instead of being read
-// from pinned host memory: one PCIe round trip less at the head of every compute(); batches keep the pinned tables)
-__global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs_host,
-                                                 ProblemDev* __restrict__ probs, ProblemState* __restrict__ states,
-                                                 const float* __restrict__ guesses_host, int tsize, InitInline inl) {
-  const int prob = blockIdx.x + C.prob0;
-  for (int s = 0; s < C.nslices; ++s) {
-    const SliceCtl& sc = C.slices[s];
-    if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
-    for (int buf = 0; buf < (C.pub ? 3 : 1); ++buf) {  // (buffers 1, 2: fused control steps, round k adds into buffer k % 3)
-      long long* p = const_cast<long long*>(sc.partials) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
-      for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += blockDim.x) p[k] = 0;
-    }
-  }
-  if (C.ctl_dev && blockIdx.x == 0) {  // the control parameters where the fused control steps find them
-    static_assert(sizeof(CtlParams) % sizeof(int) == 0, "copied word-wise");
-    const int* src = reinterpret_cast<const int*>(&C);
-    int* dst       = reinterpret_cast<int*>(C.ctl_dev);
-    for (int k = threadIdx.x; k < (int) (sizeof(CtlParams) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
-  }
-  // (fused control steps: the records of epoch 0 are written by all 64 lanes from a staged copy of what thread 0 computes;
-  // one thread storing 64 granules per slice one after the other took k_icp_init from 6 to 25 us)
-  __shared__ unsigned init_gran[SRRG2_MAX_SLICES][PUB_SLICE_GRANULES];
-  if (threadIdx.x == 0) {
+// thread 0 of compute()'s prologue: the state of the problem, the device copy of its problem table and -- fused control steps -- the
+// records of epoch 0, staged in `init_gran` for the wave that publishes them (k_icp_init; fused_init_tail inside a first pass)
+namespace {
+// (ONLY_INLINE: guess and problem table from `inl` whatever inl.use says -- the pinned tables are not even passed)
+template <bool ONLY_INLINE>
+__device__ __forceinline__ void init_problem_thread0(const CtlParams& C, int prob, const ProblemDev* probs_host, ProblemDev* probs,
+                                     ProblemState* states, const float* guesses_host, int tsize, const InitInline& inl,
+                                     unsigned (*init_gran)[PUB_SLICE_GRANULES]) {
   ProblemState* st = &states[prob];
-  for (int i = 0; i < 12; ++i) st->X[i] = i < tsize ? (inl.use ? inl.guess[i] : guesses_host[(size_t) prob * tsize + i]) : 0.f;
+  for (int i = 0; i < 12; ++i) st->X[i] = i < tsize ? ((ONLY_INLINE || inl.use) ? inl.guess[i] : guesses_host[(size_t) prob * tsize + i]) : 0.f;
   for (int i = 0; i < 12; ++i) st->Xprev[i] = st->X[i];
   st->status   = SRRG2_FAIL;
   st->done     = 0;
@@ -4956,7 +5030,12 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
   for (int s = 0; s < C.nslices; ++s) {
     const SliceCtl& sc = C.slices[s];
     nm_of[s]           = 0;
-    const ProblemDev pd = inl.use ? inl.pd[s] : probs_host[(size_t) s * C.K + prob];
+    ProblemDev pd;
+    if constexpr (ONLY_INLINE) {
+      pd = inl.pd[s];
+    } else {
+      pd = inl.use ? inl.pd[s] : probs_host[(size_t) s * C.K + prob];
+    }
     probs[(size_t) s * C.K + prob] = pd;
     st->ncorr[s]       = 0;
     st->ninl[s]        = 0;
@@ -4989,7 +5068,36 @@ __global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* 
       init_gran[s][PUB_G_KEXP] = (unsigned) kx;
     }
   }
-  }  // (thread 0)
+}
+}  // namespace
+
+// compute() prologue: term_crit->init, stats clear, _preCompute (prior init overrides the guess).  One block per
+// problem.  The initial guesses and the problem tables are read straight from pinned host memory (no staging copies on
+// the stream), the partial-sum slots and queue counters are zeroed here (no memsets on the stream).
+// (inl.use: a single alignment's guess and problem table travel in the kernel arguments -- 116 bytes -- instead of being read
+// from pinned host memory: one PCIe round trip less at the head of every compute(); batches keep the pinned tables)
+__global__ __launch_bounds__(64) void k_icp_init(CtlParams C, const ProblemDev* __restrict__ probs_host,
+                                                 ProblemDev* __restrict__ probs, ProblemState* __restrict__ states,
+                                                 const float* __restrict__ guesses_host, int tsize, InitInline inl) {
+  const int prob = blockIdx.x + C.prob0;
+  for (int s = 0; s < C.nslices; ++s) {
+    const SliceCtl& sc = C.slices[s];
+    if (sc.kind == SRRG2_SLICE_PRIOR || !sc.partials) continue;
+    for (int buf = 0; buf < (C.pub ? 3 : 1); ++buf) {  // (buffers 1, 2: fused control steps, round k adds into buffer k % 3)
+      long long* p = const_cast<long long*>(sc.partials) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
+      for (int k = threadIdx.x; k < PARTIAL_SLOTS * ACC_N; k += blockDim.x) p[k] = 0;
+    }
+  }
+  if (C.ctl_dev && blockIdx.x == 0) {  // the control parameters where the fused control steps find them
+    static_assert(sizeof(CtlParams) % sizeof(int) == 0, "copied word-wise");
+    const int* src = reinterpret_cast<const int*>(&C);
+    int* dst       = reinterpret_cast<int*>(C.ctl_dev);
+    for (int k = threadIdx.x; k < (int) (sizeof(CtlParams) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
+  }
+  // (fused control steps: the records of epoch 0 are written by all 64 lanes from a staged copy of what thread 0 computes;
+  // one thread storing 64 granules per slice one after the other took k_icp_init from 6 to 25 us)
+  __shared__ unsigned init_gran[SRRG2_MAX_SLICES][PUB_SLICE_GRANULES];
+  if (threadIdx.x == 0) init_problem_thread0<false>(C, prob, probs_host, probs, states, guesses_host, tsize, inl, init_gran);
   if (!C.pub) return;
   __syncthreads();
   for (int s = 0; s < C.nslices; ++s)
@@ -5310,8 +5418,25 @@ static void launch_icp_queue(int dim, bool plane, const SliceDev& S, const Probl
 }
 
 void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
-                     int max_nm, hipStream_t s) {
-  if (K <= 0 || max_nm <= 0) return;
+                     int max_nm, hipStream_t s, const CtlParams* init_C, const InitInline* init_inl) {
+  if (K <= 0) return;
+  if (S.fc.pub && init_C) {  // the first pass of a single alignment with compute()'s prologue inside (even for an empty cloud)
+    dim3 fgrid(K, std::max((max_nm + 255) / 256, 1));
+    ProblemDev* pw = const_cast<ProblemDev*>(probs);
+    if (dim == 3) {
+      if (plane)
+        hipLaunchKernelGGL((k_icp_step_fused_init<3, true>), fgrid, dim3(256), 0, s, S, *init_C, *init_inl, pw, states);
+      else
+        hipLaunchKernelGGL((k_icp_step_fused_init<3, false>), fgrid, dim3(256), 0, s, S, *init_C, *init_inl, pw, states);
+    } else {
+      if (plane)
+        hipLaunchKernelGGL((k_icp_step_fused_init<2, true>), fgrid, dim3(256), 0, s, S, *init_C, *init_inl, pw, states);
+      else
+        hipLaunchKernelGGL((k_icp_step_fused_init<2, false>), fgrid, dim3(256), 0, s, S, *init_C, *init_inl, pw, states);
+    }
+    return;
+  }
+  if (max_nm <= 0) return;
   if (S.fc.pub) {  // fused control steps: the record instead of ProblemState, no deferred-search queue
     dim3 fgrid(K, (max_nm + 255) / 256);
 #define FUSED_GRID_LAUNCH(PRIORS)                                                                              \
@@ -5409,8 +5534,34 @@ void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemD
 
 // the search pass over the cell neighbour lists of the grid (S.grid.list_R > 0); team = lanes per moving point (1 or 4)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
-                         ProblemState* states, int K, int max_nm, int team, hipStream_t s) {
-  if (K <= 0 || max_nm <= 0) return;
+                         ProblemState* states, int K, int max_nm, int team, hipStream_t s, const CtlParams* init_C,
+                         const InitInline* init_inl) {
+  if (K <= 0) return;
+  if (S.fc.pub && init_C) {  // the first pass of a single alignment with compute()'s prologue inside (even for an empty cloud)
+    ProblemDev* pw = const_cast<ProblemDev*>(probs);
+#define CNL_INIT_LAUNCH(TEAM)                                                                                                   \
+  do {                                                                                                                          \
+    dim3 grid(K, std::max((max_nm * TEAM + 255) / 256, 1));                                                                     \
+    if (dim == 3) {                                                                                                             \
+      if (plane)                                                                                                                \
+        hipLaunchKernelGGL((k_icp_step_cnl_init<3, true, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_inl, pw, states);  \
+      else                                                                                                                      \
+        hipLaunchKernelGGL((k_icp_step_cnl_init<3, false, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_inl, pw, states); \
+    } else {                                                                                                                    \
+      if (plane)                                                                                                                \
+        hipLaunchKernelGGL((k_icp_step_cnl_init<2, true, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_inl, pw, states);  \
+      else                                                                                                                      \
+        hipLaunchKernelGGL((k_icp_step_cnl_init<2, false, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_inl, pw, states); \
+    }                                                                                                                           \
+  } while (0)
+    if (team >= 4)
+      CNL_INIT_LAUNCH(4);
+    else
+      CNL_INIT_LAUNCH(1);
+#undef CNL_INIT_LAUNCH
+    return;
+  }
+  if (max_nm <= 0) return;
 #define CNL_LAUNCH(TEAM, FUSED)                                                                                   \
   do {                                                                                                            \
     dim3 grid((max_nm * TEAM + 255) / 256, K);                                                                    \
@@ -5603,14 +5754,18 @@ void launch_proj_records(const SliceDev& S0, const SliceDev& S, const ProblemDev
   hipLaunchKernelGGL(k_proj_records, grid, dim3(256), 0, s, S0, S, probs, (const ProblemState*) states);
 }
 
+bool make_init_inline(const CtlParams& C, const ProblemDev* probs_host, const float* guesses_host, int tsize, InitInline* inl) {
+  *inl = InitInline{};
+  if (C.K != 1) return false;
+  inl->use = 1;  // (read on the host, sent with the launch)
+  for (int i = 0; i < 12; ++i) inl->guess[i] = i < tsize ? guesses_host[i] : 0.f;
+  for (int sl = 0; sl < C.nslices && sl < SRRG2_MAX_SLICES; ++sl) inl->pd[sl] = probs_host[sl];
+  return true;
+}
 void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDev* probs, ProblemState* states,
                      const float* guesses_host, int tsize, hipStream_t s) {
   InitInline inl{};
-  if (C.K == 1) {  // (read on the host, sent with the launch)
-    inl.use = 1;
-    for (int i = 0; i < 12; ++i) inl.guess[i] = i < tsize ? guesses_host[i] : 0.f;
-    for (int sl = 0; sl < C.nslices && sl < SRRG2_MAX_SLICES; ++sl) inl.pd[sl] = probs_host[sl];
-  }
+  (void) make_init_inline(C, probs_host, guesses_host, tsize, &inl);
   hipLaunchKernelGGL(k_icp_init, dim3(C.nprob > 0 ? C.nprob : C.K), dim3(64), 0, s, C, probs_host, probs, states, guesses_host,
                      tsize, inl);
 }
@@ -5654,6 +5809,17 @@ __global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, 
   FinalRegs fin;
   fin.applied = false;
   if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1, true, PRIORS, true>(&S, 1, states, prob, g, nullptr, &fin);
+  // The slot sets of the slice, all three buffers, are left ZEROED for the handle's next compute(): its first pass may then
+  // carry the prologue (k_icp_step_cnl_init / k_icp_step_fused_init) instead of following a k_icp_init launch that zeroes them.
+  // (this step was the last reader; a run that stopped early leaves sums in the buffers its control steps did not get to)
+  if (const long long* base = C.slices[S.slice_idx].partials) {
+#pragma unroll 1
+    for (int buf = 0; buf < 3; ++buf) {
+      long long* p = const_cast<long long*>(base) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
+#pragma unroll
+      for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+    }
+  }
   if (!fin.applied || !fin.stats_written) {  // (uniform.  A run that had stopped before, or stops here: from the state, as before)
     __threadfence();
     icp_finalize_block(C, st, stats, outs_host, stats_host, prob, with_post != 0);

@@ -387,3 +387,93 @@ def test_prior_slice_next_to_projective_slices_sharing_one_association(oracle, p
     assert ref.status() == abi.SUCCESS
     for run in (fused, launched, unfused):
         assert_same_run(ref, run, slices=ref._cues)
+
+
+@pytest.mark.parametrize("kind,slice_kind", [(abi.SE3_QUAT_RIGHT, abi.SLICE_P2PLANE), (abi.SE2_RIGHT, abi.SLICE_P2P)])
+def test_prologue_inside_the_first_pass(oracle, product, kind, slice_kind, monkeypatch):
+    """Round 6, late: from a handle's second compute() on, a single alignment with fused control steps has NO k_icp_init launch --
+    the first pass derives the finder transform and the exponent from its arguments, wave 0 of its first workgroup writes state,
+    records and tables on its way, and the slot sets were left zeroed by the previous compute()'s final step (k_icp_final_wave).
+    One handle through everything that could leave something behind: a run the termination criterion stops early (sums left in a
+    buffer its control steps never got to), an inlier-only run, a new initial guess, a moving cloud of another size, an EMPTY moving
+    cloud (Fail: no statistics) and the compute() after it, a guess so far off that iteration 0 finds nothing, a new fixed cloud (the
+    grid kernel's first pass), a prior slice that overrides the guess (cue slice at index 1), the launch path forced in between
+    (SRRG2_AMD_TUNE bit 23) -- the oracle's bits after every compute(), and the path asserted where it must be taken."""
+    monkeypatch.setenv("SRRG2_AMD_FUSED_GRID_MAX", "-1")
+    if kind == abi.SE2_RIGHT:
+        d = syn.scan_pair_2d(beams=3000, sigma=0.01, seed=1234)
+        gate, thr = 0.5, 0.002
+        far = syn.se2(40.0, 0.0, 0.0).astype(np.float32)
+        nudge = syn.se2(0.02, -0.01, 0.004).astype(np.float32)
+        Z, info = syn.se2(0.03, -0.02, 0.01).astype(np.float32), [10.0, 10.0, 100.0]
+    else:
+        d = syn.cloud_pair_3d(n=15000, seed=2200, noise_sigma=0.01)
+        gate, thr = 0.25, 0.0005
+        far = syn.se3(np.array([30.0, 0.0, 0.0]), np.zeros(3)).astype(np.float32)
+        nudge = syn.se3(np.array([0.02, -0.01, 0.015]), np.deg2rad([0.3, -0.2, 0.4])).astype(np.float32)
+        Z, info = syn.se3(np.array([0.04, -0.02, 0.01]), np.deg2rad([0.5, -1.0, 1.5])).astype(np.float32), [10, 10, 10, 100, 100, 100]
+    cfg = cue_config(kind, slice_kind, gate, abi.ROBUST_CAUCHY, thr)
+    half = {k: (v[: len(v) // 2] if k.startswith("moving") else v) for k, v in d.items()}
+
+    def script(al, with_prior):
+        """yields after every compute(); the second element: must the prologue have ridden in the first pass?"""
+        al.set_params(max_iterations=12, min_num_inliers=10, enable_inlier_only_runs=True, keep_only_inlier_correspondences=True)
+        al.set_termination_criteria(abi.default_termination_params())
+        if with_prior:
+            pi = al.add_slice(prior_config(kind, info=info, sets_guess=1))
+            al.set_prior_measurement(pi, Z)
+        cue = setup_pair(al, d, cfg)
+        al.compute()
+        yield "first", False, cue
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        yield "second (the criterion stops it early)", True, cue
+        al.set_moving_in_fixed(nudge)
+        al.compute()
+        yield "a new guess", True, cue
+        al.set_moving(cue, half["moving"], half.get("moving_normals"))
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        yield "a smaller moving cloud", True, cue
+        al.set_moving(cue, d["moving"][:0], None if d.get("moving_normals") is None else d["moving_normals"][:0])
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        yield "an empty moving cloud", False, cue
+        al.set_moving(cue, d["moving"], d.get("moving_normals"))
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        yield "after the empty one", None, cue
+        al.set_moving_in_fixed(far)
+        al.compute()
+        yield "nothing within the gate", None, cue
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        yield "after the failure", None, cue
+        al.set_fixed(cue, d["fixed"], d.get("fixed_normals"))
+        al.set_moving_in_fixed(syn.identity(al.dim))
+        al.compute()
+        yield "a new fixed cloud (grid kernel)", True, cue
+        al.set_moving_in_fixed(nudge)
+        al.compute()
+        yield "and again on it", True, cue
+
+    for with_prior in (False, True):
+        for knobs in ({"search_lists": 2, "fused_control": 1}, {"search_lists": 0, "fused_control": 1},
+                      {"search_lists": 2, "fused_control": 1, "strategy_mask": 1 << 23}):
+            ref, got = oracle.OracleAligner(kind), product.MultiAligner(kind)
+            got.set_tuning(**knobs)
+            forced_launch = "strategy_mask" in knobs
+            for (what, must, cue), _ in zip(script(ref, with_prior), script(got, with_prior)):
+                if not with_prior:  # (a prior slice overrides every guess and keeps an empty cue slice's run alive: other statuses)
+                    assert ref.status() == (abi.FAIL if what in ("an empty moving cloud", "nothing within the gate") else abi.SUCCESS), what
+                try:
+                    assert_same_run(ref, got, slices=(cue,))
+                except AssertionError as e:
+                    raise AssertionError("%s | %s | prior %s | path %d | statuses %d %d | stats %d %d" % (
+                        what, knobs, with_prior, got.last_compute_path(), ref.status(), got.status(), len(ref.iteration_stats()),
+                        len(got.iteration_stats()))) from e
+                path = got.last_compute_path()
+                if forced_launch:
+                    assert not path & abi.PATH_PROLOGUE_IN_PASS, (what, knobs)
+                elif must is not None:
+                    assert bool(path & abi.PATH_PROLOGUE_IN_PASS) == must, (what, knobs, with_prior, path)
