@@ -402,7 +402,7 @@ def measure(args, init_dist=True):
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("k_icp_step_cnl<3,true,4|1,fused> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,false,fused> (converged passes): one finder+factor pass of the slice; from the second pass on the launch carries the control step of the previous iteration in its prologue (fused control steps: no control launch between passes)" if args.workload == "c2" else
+            "kernel": ("k_icp_step_cnl_init<3,true,4> (the first pass: compute()'s prologue inside, no k_icp_init launch) / k_icp_step_cnl<3,true,1,fused> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1,false,fused> (converged passes): one finder+factor pass of the slice; from the second pass on the launch carries the control step of the previous iteration in its prologue (fused control steps: no control launch between passes); the last step + finalize: k_icp_final_wave" if args.workload == "c2" else
                        "k_icp_step_cnl<3,true,1,fused> (search passes over the cell neighbour lists) / k_icp_step_fast<3,true,1|2,true,fused> (converged passes): one finder+factor pass over all alignments of the launch, the control steps of the previous iteration in its first workgroups" if args.workload == "c4" else "k_proj_zbuf_fz (+ the control step of the previous iteration) + k_icp_step_proj_fused (both slices share their clouds and their association: one z-buffer pass, one step launch)"),
             "achieved": achieved,
             "peak": 8000.0,
@@ -517,15 +517,20 @@ def measure(args, init_dist=True):
 
 def rocprof_pass_split(workload):
     """mean kernel duration of the pass kernels from the committed rocprofv3 --kernel-trace --stats summary of `bench.py --workload
-    <w>` (profiles/r9/r9final_rocprofv3_<w>_summary.txt; tools/profile_round.sh) and the roofline fraction that goes with it; the
+    <w>` (profiles/r10/r10final_rocprofv3_<w>_summary.txt; tools/profile_round.sh) and the roofline fraction that goes with it; the
     passes from the second on carry the control step of the previous iteration (~3.2 us on one wave, profiles/r6e_pass_timeline_c2.txt)"""
-    path = os.path.join(ROOT, "profiles", "r9", "r9final_rocprofv3_%s_summary.txt" % workload)
-    if not os.path.exists(path):
+    path = None
+    for rel in (("r10", "r10final"), ("r9", "r9final")):  # (the newest committed end-of-round set)
+        cand = os.path.join(ROOT, "profiles", rel[0], "%s_rocprofv3_%s_summary.txt" % (rel[1], workload))
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         return None
     rows = []
     for line in open(path):
         f = [x.strip() for x in line.split("|")]
-        if len(f) == 5 and f[1].isdigit() and any(k in f[0] for k in ("k_icp_step_fast<", "k_icp_step_cnl<", "k_icp_step_proj_fused<", "k_proj_zbuf_fz")):
+        if len(f) == 5 and f[1].isdigit() and any(k in f[0] for k in ("k_icp_step_fast<", "k_icp_step_cnl<", "k_icp_step_cnl_init<", "k_icp_step_proj_fused<", "k_proj_zbuf_fz")):
             rows.append((f[0].replace("void ", "").split("(")[0], int(f[1]), float(f[3])))
     if not rows:
         return None
@@ -536,7 +541,7 @@ def rocprof_pass_split(workload):
     else:  # c3: a pass = z-buffer launch + step launch
         mean_us = sum(r[2] for r in rows)
         alg = None
-    out = {"source": "profiles/r9/" + os.path.basename(path), "kernels_avg_us": {r[0]: r[2] for r in rows}, "mean_pass_us": mean_us,
+    out = {"source": os.path.relpath(path, ROOT), "kernels_avg_us": {r[0]: r[2] for r in rows}, "mean_pass_us": mean_us,
            "note": "kernel time only (no launch gaps); passes from the second on include the previous iteration's control step"}
     if alg:
         out["frac_of_8TBs_on_kernel_time"] = alg / (mean_us * 1e-6) / 8e12

@@ -10,7 +10,7 @@ cur = sqlite3.connect(sys.argv[1]).cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
 sid = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
 rows = [r for r in cur.execute("select name, start, end, %s from kernels order by start" % (sid or "0"))]
-finals = [i for i, r in enumerate(rows) if "k_icp_control_final" in r[0]]
+finals = [i for i, r in enumerate(rows) if "k_icp_control_final" in r[0] or "k_icp_final_wave" in r[0]]  # (the last step of a part)
 # a pipelined batch ends with TWO final control steps on different streams; find the last such pair
 pair = None
 for a, b in zip(finals, finals[1:]):
@@ -26,7 +26,7 @@ seq = [r for r in rows[begin_i:end_i + 1] if not r[0].startswith("__amd")]
 t0 = seq[0][1]
 ivals = []
 for n, s, e, st in seq:
-    short = n.replace("void ", "").split("(")[0]
+    short = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("srrg2amd::", "").split("(")[0]
     print("%9.2f us  %8.2f us  stream %s  %s" % ((s - t0) / 1000.0, (e - s) / 1000.0, st, short))
     ivals.append((s, e))
 ivals.sort()

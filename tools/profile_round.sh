@@ -2,7 +2,7 @@
 # End-of-round measurement on the GPU box: GPU test suite, every bench line, rocprofv3 kernel summaries and the PMC traffic
 # passes (separate --pmc runs, never together with a trace).  Everything lands under gpurun_out/$1/; copy what is to be
 # judged into profiles/.      usage: gpurun -- 'bash tools/profile_round.sh r2final'
-TAG=${1:-round}
+TAG=${1:-round}  # (copy what is to be judged into profiles/r10/)
 cd ${GRAFT_REPO_ROOT:-/root/repo}; GRAFT_REPO_ROOT=$(pwd)
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O

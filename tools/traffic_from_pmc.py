@@ -16,7 +16,8 @@ import json
 import sqlite3
 import sys
 
-KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_fast", "k_icp_step_queue<", "k_icp_step_proj", "k_proj_zbuf")  # (k_icp_step_proj_fused matches k_icp_step_proj)
+KERNELS = ("k_icp_step<", "k_icp_step_tile<", "k_icp_step_cnl<", "k_icp_step_cnl_init<", "k_icp_step_fused", "k_icp_step_fast", "k_icp_step_queue<",
+           "k_icp_step_proj", "k_proj_zbuf")  # (k_icp_step_proj_fused matches k_icp_step_proj; k_icp_step_fused_init matches k_icp_step_fused)
 
 
 def dispatches(db, counter):
@@ -26,10 +27,14 @@ def dispatches(db, counter):
     for name, val, gx, gy, wx in cur.execute("select kernel_name, value, grid_size_x, grid_size_y, workgroup_size_x from "
                                              "counters_collection where counter_name = ? order by dispatch_id", (counter,)):
         if any(k in name for k in KERNELS):
-            short = name.split("(")[0].replace("void ", "")
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("srrg2amd::", "").split("(")[0]
             # alignments the dispatch covers: grid y -- or grid x (in workgroups) for the launches with fused control steps, which
             # walk the problems first (k_icp_step_cnl<..., true> / k_icp_step_fast<..., true>: x = problem, y = tile)
-            fused = short.startswith(("k_icp_step_cnl<", "k_icp_step_fast")) and short.rstrip().endswith(", true>")
+            # (round 6, late: the last template argument is 0 / 1 / 2 -- 1, 2 = fused --; the first pass of a single alignment with
+            # compute()'s prologue inside, k_icp_step_cnl_init / k_icp_step_fused_init, and the fused grid kernel always walk x)
+            s_ = short.rstrip()
+            fused = (s_.startswith(("k_icp_step_cnl<", "k_icp_step_fast")) and s_.endswith((", true>", ", 1>", ", 2>"))) or \
+                    s_.startswith(("k_icp_step_cnl_init<", "k_icp_step_fused"))
             out.append((short, float(val), int(gx) // max(int(wx), 1) if fused else int(gy)))
     return out
 
