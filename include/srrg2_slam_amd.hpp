@@ -208,6 +208,12 @@ public:
     check(srrg2_aligner_num_correspondences(_h, &n));
     return n;
   }
+  // SRRG2_PATH_* bits of the launch path the last compute() took (strategy only: results never depend on it)
+  int lastComputePath() {
+    int32_t f = 0;
+    check(srrg2_aligner_last_compute_path(_h, &f));
+    return (int) f;
+  }
   CorrespondenceVector correspondences(int slice) {
     int n = 0;
     check(srrg2_aligner_get_correspondences(_h, slice, nullptr, &n));

@@ -929,7 +929,11 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
     const bool fast_queue = s->cfg.finder == SRRG2_FINDER_NN_GATED && K > 4 && !small && fast_batch_queue;
     s->fast_queue_only = fast_queue && !use_queue;
     const int nblocks    = PARTIAL_SLOTS;
-    if ((rc = s->partials.reserve((size_t) 3 * K * nblocks * ACC_N))) return rc;  // (three buffers: fused control steps, FusedCtl)
+    {
+      const size_t cap_before = s->partials.cap;
+      if ((rc = s->partials.reserve((size_t) 3 * K * nblocks * ACC_N))) return rc;  // (three buffers: fused control steps, FusedCtl)
+      if (s->partials.cap != cap_before) s->slots_zeroed = 0;  // (a new allocation -- possibly at the old address -- holds anything)
+    }
     if (use_queue || fast_queue) {
       if ((rc = s->queue.reserve((size_t) std::max(s->nm_total, 1) * 10))) return rc;  // QEntry = 10 x 4 bytes
       if ((rc = s->qcount.reserve((size_t) 2 * K))) return rc;  // [problem][near, far]
