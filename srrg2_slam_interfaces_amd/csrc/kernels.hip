@@ -2909,11 +2909,12 @@ __device__ __forceinline__ void grid_fused_body(const SliceDev& S, const Problem
     pd = inl->pd[S.slice_idx];
   else
     pd = probs[prob];
-  if (tile * 256 >= pd.nm && tile != 0) return;
+  const bool tail_wg = MODE == 2 && tile == (int) gridDim.y - 1;  // (one workgroup more than tiles: cnl_pass_body)
+  if (tile * 256 >= pd.nm && (MODE == 2 ? !tail_wg : tile != 0)) return;
   PassView pv;
   if constexpr (MODE == 2) {
     pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv);
-    if (tile == 0 && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
+    if (tail_wg && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
   } else {
     pass_view_fused<DIM, MODE == 1>(S, states, prob, pv);
   }
@@ -2929,7 +2930,7 @@ __device__ __forceinline__ void grid_fused_body(const SliceDev& S, const Problem
   sv.phase1 = pv.phase1;
   sv.prior  = pv.prior;
   sv.qmode  = false;
-  icp_step_body<DIM, PLANE, 4>(S, pd, sv, prob, tile, (int) gridDim.y, (int) gridDim.x, nullptr);
+  icp_step_body<DIM, PLANE, 4>(S, pd, sv, prob, tile, (int) gridDim.y - (MODE == 2 ? 1 : 0), (int) gridDim.x, nullptr);
 }
 template <int DIM, bool PLANE, bool PRIORS = false>
 __global__ __launch_bounds__(256) void k_icp_step_fused(SliceDev S, const ProblemDev* __restrict__ probs,
@@ -3700,8 +3701,11 @@ __device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists
     pd = probs[prob];
   const int tile      = FUSED ? blockIdx.y : blockIdx.x;
   // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
-  // iteration whatever its share of the points)
-  if (tile * PPB >= pd.nm && (!FUSED || tile != 0)) return;
+  // iteration whatever its share of the points.  FUSED = 3: no step is due; the launch has ONE workgroup more than tiles, which
+  // holds no point and writes the rest of the prologue while the others run -- on workgroup 0 that tail sat on the launch's
+  // critical path, ~3 us)
+  const bool tail_wg = FUSED == 3 && tile == (int) gridDim.y - 1;
+  if (tile * PPB >= pd.nm && (!FUSED || (FUSED == 3 ? !tail_wg : tile != 0))) return;
   float T[12], Tprev[12];
   double scale;
   int rk;
@@ -3753,7 +3757,7 @@ __device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists
   if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
     if constexpr (FUSED == 3) {
       pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv);
-      if (tile == 0 && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
+      if (tail_wg && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
     } else {
       pass_view_fused<DIM, FUSED == 2>(S, states, prob, pv);
     }
@@ -5421,7 +5425,7 @@ void launch_icp_step(int dim, bool plane, const SliceDev& S, const ProblemDev* p
                      int max_nm, hipStream_t s, const CtlParams* init_C, const InitInline* init_inl) {
   if (K <= 0) return;
   if (S.fc.pub && init_C) {  // the first pass of a single alignment with compute()'s prologue inside (even for an empty cloud)
-    dim3 fgrid(K, std::max((max_nm + 255) / 256, 1));
+    dim3 fgrid(K, (max_nm + 255) / 256 + 1);  // (+ the workgroup that writes the rest of the prologue)
     ProblemDev* pw = const_cast<ProblemDev*>(probs);
     if (dim == 3) {
       if (plane)
@@ -5541,7 +5545,7 @@ void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists
     ProblemDev* pw = const_cast<ProblemDev*>(probs);
 #define CNL_INIT_LAUNCH(TEAM)                                                                                                   \
   do {                                                                                                                          \
-    dim3 grid(K, std::max((max_nm * TEAM + 255) / 256, 1));                                                                     \
+    dim3 grid(K, (max_nm * TEAM + 255) / 256 + 1); /* (+ the workgroup that writes the rest of the prologue) */                  \
     if (dim == 3) {                                                                                                             \
       if (plane)                                                                                                                \
         hipLaunchKernelGGL((k_icp_step_cnl_init<3, true, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_inl, pw, states);  \
