@@ -1205,15 +1205,23 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   const bool final_wave = fuse && !fuse_proj && !(C.tune & (1 << 25));
   bool fold_init = false;
   InitInline fold_inl{};
-  if (fuse && fused_all && final_wave && K == 1 && !split && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
+  // (small batches too, up to 8 alignments: their first pass reads the problem's rows of the PINNED tables -- like the sort in front
+  // of it -- instead of following a k_icp_init launch: 8 x 50 k points 0.291 -> 0.283 ms.  Every WAVE of that pass reads them, over
+  // PCIe: at 32 alignments -- 12 500 waves per half -- that costs 50 us where the launch costs 12 (0.545 -> 0.60 ms, profiles/r10/r10f):
+  // larger batches keep the launch)
+  if (fuse && fused_all && final_wave && K <= 8 && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
       (cnl[(size_t) first_cue] || !(lds_tile > 0)) && !a->profile) {
     const Slice* s = a->slices[first_cue];
     fold_init = s->slots_zeroed >= 3 * K && s->slots_zeroed_at == (const void*) s->partials.p;
     if (fold_init) {
-      fold_init = srrg2amd::make_init_inline(Ch[0], a->probs_host, a->guesses_host, a->tsize, &fold_inl);
+      const bool single = srrg2amd::make_init_inline(Ch[0], a->probs_host, a->guesses_host, a->tsize, &fold_inl);
       for (int si = 0; si < nslices && fold_init; ++si)  // (a prior slice that sets the initial guess: k_icp_init's override, here)
-        if (C.slices[si].kind == SRRG2_SLICE_PRIOR && C.slices[si].prior_sets_initial_guess)
-          for (int i = 0; i < a->tsize; ++i) fold_inl.guess[i] = C.slices[si].prior_Z[i];
+        if (C.slices[si].kind == SRRG2_SLICE_PRIOR && C.slices[si].prior_sets_initial_guess) {
+          if (single)
+            for (int i = 0; i < a->tsize; ++i) fold_inl.guess[i] = C.slices[si].prior_Z[i];
+          else
+            fold_init = false;  // (a batch: the override per problem stays k_icp_init's)
+        }
     }
   }
   for (Slice* sl : a->slices) sl->slots_zeroed = 0;  // (until this compute() has ended the same way)

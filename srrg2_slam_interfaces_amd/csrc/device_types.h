@@ -229,6 +229,10 @@ struct InitInline {
   int use;
   float guess[12];
   ProblemDev pd[SRRG2_MAX_SLICES];
+  // use == 0 (a batch): the pinned tables themselves, for the prologue inside a first pass (k_icp_step_cnl_init; k_icp_init gets them
+  // as arguments of its own)
+  const ProblemDev* probs_host;  // [slice][K]
+  const float* guesses_host;     // [K][tsize]
 };
 
 struct CtlParams {

@@ -2862,8 +2862,14 @@ __device__ __forceinline__ void pass_view_init(const SliceDev& S, const CtlParam
                                                PassView& v) {
   const SliceCtl& sc = C.slices[S.slice_idx];
   float X[12];
+  if (inl.use) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) X[i] = inl.guess[i];  // (run_compute: a prior slice's override of the guess already applied)
+    for (int i = 0; i < 12; ++i) X[i] = inl.guess[i];  // (run_compute: a prior slice's override of the guess already applied)
+  } else {  // (a batch: the problem's row of the pinned table -- the same address in every lane: scalar loads)
+    const int tsize = C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) X[i] = i < tsize ? inl.guesses_host[(size_t) prob * tsize + i] : 0.f;
+  }
   const int nm_of = sc.nm_global > 0 ? sc.nm_global : nm;
   v.kexp = slice_exponent(C, sc, prob, nm_of, X);
   float T[12];
@@ -2877,13 +2883,18 @@ __device__ __forceinline__ void fused_init_tail(const CtlParams& C, const InitIn
                                                 ProblemState* __restrict__ states) {
   __shared__ unsigned init_gran_tail[SRRG2_MAX_SLICES][PUB_SLICE_GRANULES];
   const int lane = threadIdx.x & 63;
-  if (C.ctl_dev) {
+  if (C.ctl_dev && blockIdx.x == 0) {  // (once per launch: the first problem's tail)
     const int* src = reinterpret_cast<const int*>(&C);
     int* dst       = reinterpret_cast<int*>(C.ctl_dev);
     for (int k = lane; k < (int) (sizeof(CtlParams) / sizeof(int)); k += 64) dst[k] = src[k];
   }
-  if (lane == 0)
-    init_problem_thread0<true>(C, prob, nullptr, probs, states, nullptr, C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12, inl, init_gran_tail);
+  if (lane == 0) {
+    const int tsize = C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
+    if (inl.use)
+      init_problem_thread0<true>(C, prob, nullptr, probs, states, nullptr, tsize, inl, init_gran_tail);
+    else
+      init_problem_thread0<false>(C, prob, inl.probs_host, probs, states, inl.guesses_host, tsize, inl, init_gran_tail);
+  }
   wave_lds_sync();
   if (!C.pub) return;
   for (int s = 0; s < C.nslices; ++s)
@@ -2905,10 +2916,14 @@ __device__ __forceinline__ void grid_fused_body(const SliceDev& S, const Problem
   const int tile = (int) blockIdx.y;
   if constexpr (MODE != 2) fused_control_if_due<DIM, MODE == 1>(S, states, prob);
   ProblemDev pd;
-  if constexpr (MODE == 2)
-    pd = inl->pd[S.slice_idx];
-  else
+  if constexpr (MODE == 2) {
+    if (inl->use)
+      pd = inl->pd[S.slice_idx];
+    else
+      pd = inl->probs_host[(size_t) S.slice_idx * Ci->K + prob];
+  } else {
     pd = probs[prob];
+  }
   const bool tail_wg = MODE == 2 && tile == (int) gridDim.y - 1;  // (one workgroup more than tiles: cnl_pass_body)
   if (tile * 256 >= pd.nm && (MODE == 2 ? !tail_wg : tile != 0)) return;
   PassView pv;
@@ -3695,10 +3710,14 @@ __device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists
     fused_control_if_due<DIM, FUSED == 2>(S, states, prob);
   }
   ProblemDev pd;
-  if constexpr (FUSED == 3)
-    pd = inl->pd[S.slice_idx];
-  else
+  if constexpr (FUSED == 3) {
+    if (inl->use)
+      pd = inl->pd[S.slice_idx];
+    else
+      pd = inl->probs_host[(size_t) S.slice_idx * Ci->K + prob];  // (a batch: from the pinned table, like the sort in front of it)
+  } else {
     pd = probs[prob];
+  }
   const int tile      = FUSED ? blockIdx.y : blockIdx.x;
   // (batches of unequal clouds; fused control steps: workgroup (0, problem) carries the control step of the previous
   // iteration whatever its share of the points.  FUSED = 3: no step is due; the launch has ONE workgroup more than tiles, which
@@ -5760,6 +5779,8 @@ void launch_proj_records(const SliceDev& S0, const SliceDev& S, const ProblemDev
 
 bool make_init_inline(const CtlParams& C, const ProblemDev* probs_host, const float* guesses_host, int tsize, InitInline* inl) {
   *inl = InitInline{};
+  inl->probs_host   = probs_host;
+  inl->guesses_host = guesses_host;
   if (C.K != 1) return false;
   inl->use = 1;  // (read on the host, sent with the launch)
   for (int i = 0; i < 12; ++i) inl->guess[i] = i < tsize ? guesses_host[i] : 0.f;

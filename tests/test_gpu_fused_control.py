@@ -477,3 +477,41 @@ def test_prologue_inside_the_first_pass(oracle, product, kind, slice_kind, monke
                     assert not path & abi.PATH_PROLOGUE_IN_PASS, (what, knobs)
                 elif must is not None:
                     assert bool(path & abi.PATH_PROLOGUE_IN_PASS) == must, (what, knobs, with_prior, path)
+
+
+def test_prologue_inside_the_first_pass_of_a_small_batch(oracle, product):
+    """... and for batches of up to eight alignments (the first pass reads the problems' rows of the pinned tables): two calls on one
+    handle, the second one without a k_icp_init launch, ragged clouds, an empty one, as two halves on two streams and as one launch."""
+    kind = abi.SE3_QUAT_RIGHT
+    probs = syn.batch_3d(K=8, n=9000, seed=8820, shared_fixed_group=64, t_max=0.1, rpy_max_deg=2.0)
+    movs = [p["moving"] for p in probs]
+    nrms = [p["moving_normals"] for p in probs]
+    movs[2], nrms[2] = movs[2][:0], nrms[2][:0]
+    movs[5], nrms[5] = movs[5][:3000], nrms[5][:3000]
+    guesses = [syn.identity(3)] * 8
+    nudged = [syn.se3(np.array([0.01 * k, -0.01, 0.005]), np.deg2rad([0.2, -0.1 * k, 0.3])).astype(np.float32) for k in range(8)]
+    cfg = cue_config(kind, abi.SLICE_P2PLANE, 0.3, abi.ROBUST_CAUCHY, 0.05, 0.7)
+
+    def run(al):
+        al.set_params(max_iterations=7, min_num_inliers=100)
+        al.add_slice(cfg)
+        al.set_fixed(0, probs[0]["fixed"], probs[0]["fixed_normals"])
+        first = al.compute_batch(movs, guesses, nrms)
+        first = [dict(r) for r in first]
+        path1 = al.last_compute_path()
+        second = [dict(r) for r in al.compute_batch(movs, nudged, nrms)]
+        return first, second, path1, al.last_compute_path()
+
+    want = run(oracle.OracleAligner(kind))
+    for knobs in (FUSED, dict(FUSED, batch_pipeline=0), dict(FUSED, strategy_mask=1 << 23)):
+        al = product.MultiAligner(kind)
+        al.set_tuning(**knobs)
+        got = run(al)
+        assert not got[2] & abi.PATH_PROLOGUE_IN_PASS
+        assert bool(got[3] & abi.PATH_PROLOGUE_IN_PASS) == ("strategy_mask" not in knobs), knobs
+        for a, b in ((want[0], got[0]), (want[1], got[1])):
+            for r, g in zip(a, b):
+                assert r["status"] == g["status"] and r["num_iterations"] == g["num_iterations"], knobs
+                assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes(), knobs
+                assert r["last"] == g["last"] and r["num_correspondences"] == g["num_correspondences"], knobs
+                assert np.asarray(r["information"]).tobytes() == np.asarray(g["information"]).tobytes(), knobs
