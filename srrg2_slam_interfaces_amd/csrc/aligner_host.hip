@@ -1205,11 +1205,13 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   const bool final_wave = fuse && !fuse_proj && !(C.tune & (1 << 25));
   bool fold_init = false;
   InitInline fold_inl{};
-  // (small batches too, up to 8 alignments: their first pass reads the problem's rows of the PINNED tables -- like the sort in front
-  // of it -- instead of following a k_icp_init launch: 8 x 50 k points 0.291 -> 0.283 ms.  Every WAVE of that pass reads them, over
-  // PCIe: at 32 alignments -- 12 500 waves per half -- that costs 50 us where the launch costs 12 (0.545 -> 0.60 ms, profiles/r10/r10f):
-  // larger batches keep the launch)
-  if (fuse && fused_all && final_wave && K <= 8 && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
+  std::vector<InitBatch> fold_bat;  // (one per part of a batch)
+  // (batches too, while every launch -- a part of a pipelined batch -- holds at most INIT_BATCH_MAX alignments: their guesses and table
+  // rows ride in the arguments of the part's first pass, InitBatch.  Read from the PINNED tables by the pass itself -- every wave of
+  // it, over PCIe -- 32 alignments lost 50 us where the launch costs 12: 0.545 -> 0.60 ms, profiles/r10/r10f)
+  int part_max = 0;
+  for (int h = 0; h < nhalves; ++h) part_max = std::max(part_max, hn[h]);
+  if (fuse && fused_all && final_wave && (K == 1 || (part_max <= INIT_BATCH_MAX && cnl[(size_t) first_cue])) && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
       (cnl[(size_t) first_cue] || !(lds_tile > 0)) && !a->profile) {
     const Slice* s = a->slices[first_cue];
     fold_init = s->slots_zeroed >= 3 * K && s->slots_zeroed_at == (const void*) s->partials.p;
@@ -1222,6 +1224,17 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
           else
             fold_init = false;  // (a batch: the override per problem stays k_icp_init's)
         }
+      if (fold_init && !single) {
+        fold_bat.assign((size_t) nhalves, InitBatch{});
+        for (int h = 0; h < nhalves; ++h) {
+          InitBatch& B = fold_bat[(size_t) h];
+          B.cue_slice  = first_cue;
+          for (int k = 0; k < hn[h]; ++k) {
+            for (int i = 0; i < 12; ++i) B.guess[k][i] = i < a->tsize ? a->guesses_host[(size_t) (h0[h] + k) * a->tsize + i] : 0.f;
+            B.pd[k] = a->probs_host[(size_t) first_cue * K + h0[h] + k];
+          }
+        }
+      }
     }
   }
   for (Slice* sl : a->slices) sl->slots_zeroed = 0;  // (until this compute() has ended the same way)
@@ -1435,7 +1448,8 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             else if (cnl[(size_t) si] && !sd.queue)
               srrg2amd::launch_icp_step_cnl(a->dim, plane, sd, s->lists_host, pt, a->states.p, Kh, nm_max,
                                             search_team_knob > 0 ? search_team_knob : ((K <= 4 && slot0 == 0 && it == 0) ? 4 : 1), hs,
-                                            first_pass_init ? &Ch[h] : nullptr, first_pass_init ? &fold_inl : nullptr);
+                                            first_pass_init ? &Ch[h] : nullptr, first_pass_init ? &fold_inl : nullptr,
+                                            first_pass_init && !fold_bat.empty() ? &fold_bat[(size_t) h] : nullptr);
             else if (!sd.queue && lds_tile > 0 && !small)
               srrg2amd::launch_icp_step_tile(a->dim, plane, sd, pt, a->states.p, Kh, nm_max, lds_tile == 2 ? 504 : 416, hs);
             else

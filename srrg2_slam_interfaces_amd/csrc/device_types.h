@@ -229,10 +229,15 @@ struct InitInline {
   int use;
   float guess[12];
   ProblemDev pd[SRRG2_MAX_SLICES];
-  // use == 0 (a batch): the pinned tables themselves, for the prologue inside a first pass (k_icp_step_cnl_init; k_icp_init gets them
-  // as arguments of its own)
-  const ProblemDev* probs_host;  // [slice][K]
-  const float* guesses_host;     // [K][tsize]
+};
+
+// the guesses and problem-table rows of up to 16 alignments of ONE launch (a part of a pipelined batch), carried in the arguments of
+// a first pass that has the prologue inside (k_icp_step_cnl_init_batch): no table is read from pinned memory by the pass
+#define INIT_BATCH_MAX 16
+struct InitBatch {
+  float guess[INIT_BATCH_MAX][12];  // [problem - prob0]
+  ProblemDev pd[INIT_BATCH_MAX];    // ... of the cue slice (prior slices have no cloud: {0, 0})
+  int cue_slice;
 };
 
 struct CtlParams {

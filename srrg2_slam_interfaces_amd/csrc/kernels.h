@@ -26,7 +26,7 @@ void launch_cnl_build(const GridDev& g, const GridLists& L, const int4* offs, in
 // K == 1, fused control steps, the slot sets left zeroed by the previous compute()'s final step: run_compute decides)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
                          ProblemState* states, int K, int max_nm, int team, hipStream_t s, const CtlParams* init_C = nullptr,
-                         const InitInline* init_inl = nullptr);
+                         const InitInline* init_inl = nullptr, const InitBatch* init_bat = nullptr);
 // Morton sort of K moving clouds (counts/cursor: (K << kbits) + 1 ints; bb: K*6 keys initialised to
 // {0xffffffff x3, 0 x3}; counts zeroed)
 // kbits = total key bits (2^kbits cells per cloud); aniso != 0: bits dealt to the axes by extent (kernels_prep.hip: KeySpec);

@@ -2859,16 +2859,16 @@ __device__ __forceinline__ void pass_view_fused(const SliceDev& S, ProblemState*
 // (k_icp_final_wave; run_compute takes this path only then), and wave 0 of workgroup (problem, 0) writes the rest on its way.
 template <int DIM>
 __device__ __forceinline__ void pass_view_init(const SliceDev& S, const CtlParams& C, const InitInline& inl, int prob, int nm,
-                                               PassView& v) {
+                                               PassView& v, const InitBatch* bat = nullptr) {
   const SliceCtl& sc = C.slices[S.slice_idx];
   float X[12];
-  if (inl.use) {
+  if (bat) {  // (a part of a batch: the problem's row of the launch's own table)
+    const int lp = prob - C.prob0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) X[i] = bat->guess[lp][i];
+  } else {
 #pragma unroll
     for (int i = 0; i < 12; ++i) X[i] = inl.guess[i];  // (run_compute: a prior slice's override of the guess already applied)
-  } else {  // (a batch: the problem's row of the pinned table -- the same address in every lane: scalar loads)
-    const int tsize = C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) X[i] = i < tsize ? inl.guesses_host[(size_t) prob * tsize + i] : 0.f;
   }
   const int nm_of = sc.nm_global > 0 ? sc.nm_global : nm;
   v.kexp = slice_exponent(C, sc, prob, nm_of, X);
@@ -2878,28 +2878,81 @@ __device__ __forceinline__ void pass_view_init(const SliceDev& S, const CtlParam
   for (int i = 0; i < 12; ++i) v.T[i] = v.Tprev[i] = T[i];
   v.stop = v.phase1 = v.prior = false;
 }
-// ... the rest of the prologue, by wave 0 of workgroup (problem, 0) of that pass (k_icp_init's body without the zeroing)
+// ... the rest of the prologue (k_icp_init's body without the zeroing), by one wave of that pass -- the workgroup behind the last
+// tile, which holds no point.  Lane-distributed stores of what init_problem_thread0 computes with one thread: the transform and
+// the exponent are the ones pass_view_init has just derived (`v`; the aligners that take this path have ONE cue slice, `cue`), the
+// guess and the table rows come from the kernel arguments.  (The one-thread body inlined here took the pass kernel from 74 to
+// 130 registers -- six waves per SIMD to three, and the first pass of a 32-batch is bound by its instruction issue: 0.535 ->
+// 0.58 ms; this form leaves pass_view_init's float64 exponent as the widest point, 91.)
 __device__ __forceinline__ void fused_init_tail(const CtlParams& C, const InitInline& inl, int prob, ProblemDev* __restrict__ probs,
-                                                ProblemState* __restrict__ states) {
-  __shared__ unsigned init_gran_tail[SRRG2_MAX_SLICES][PUB_SLICE_GRANULES];
-  const int lane = threadIdx.x & 63;
+                                                ProblemState* __restrict__ states, const InitBatch* bat, const PassView& v, int cue) {
+  const int lane   = threadIdx.x & 63;
+  const int lp     = prob - C.prob0;
+  ProblemState* st = &states[prob];
   if (C.ctl_dev && blockIdx.x == 0) {  // (once per launch: the first problem's tail)
     const int* src = reinterpret_cast<const int*>(&C);
     int* dst       = reinterpret_cast<int*>(C.ctl_dev);
     for (int k = lane; k < (int) (sizeof(CtlParams) / sizeof(int)); k += 64) dst[k] = src[k];
   }
-  if (lane == 0) {
-    const int tsize = C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12;
-    if (inl.use)
-      init_problem_thread0<true>(C, prob, nullptr, probs, states, nullptr, tsize, inl, init_gran_tail);
-    else
-      init_problem_thread0<false>(C, prob, inl.probs_host, probs, states, inl.guesses_host, tsize, inl, init_gran_tail);
+  // the initial guess (zero-padded beyond the variable's words by the host), element (lane mod 32) -- lanes [0, 12) store it into
+  // the state, lanes [PUB_G_X, PUB_G_X + 12) into the record
+  static_assert(PUB_G_X == 32, "the record's X granules sit one half-wave above the state's");
+  // (selects over statically indexed kernel arguments: a lane-indexed argument array becomes a stack copy, and a kernel that owns
+  // scratch memory pays for it in every wave)
+  float x = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float gi = bat ? bat->guess[lp][i] : inl.guess[i];
+    x              = (lane & 31) == i ? gi : x;
   }
-  wave_lds_sync();
+  // the finder transform, element (lane mod 12) in lanes [0, 24) (taken through readfirstlane: selected straight from the view's
+  // array the compiler moved the view to the stack)
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float ti = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.T[i])));
+    t              = (lane == i || lane == 12 + i) ? ti : t;
+  }
+  if (lane < 12) {
+    st->X[lane]          = x;
+    st->Xprev[lane]      = x;
+    st->Tf[cue][lane]     = t;
+    st->Tfprev[cue][lane] = t;
+  }
+  if (lane == 0) {
+    st->status   = SRRG2_FAIL;
+    st->done     = 0;
+    st->finished = 0;
+    st->nstats   = 0;
+    st->phase    = 0;
+    st->w_count  = 0;
+    st->npasses  = 0;
+  }
+  if (lane < SRRG2_MAX_SLICES) st->qmode[lane] = 1;
+#pragma unroll
+  for (int s = 0; s < SRRG2_MAX_SLICES; ++s) {  // (one slice per lane)
+    if (s >= C.nslices) break;  // (uniform)
+    ProblemDev pd{0, 0};
+    if (bat) {
+      if (s == cue) pd = bat->pd[lp];
+    } else {
+      pd = inl.pd[s];
+    }
+    int* qc = C.slices[s].qcount;
+    if (lane == s) {
+      probs[(size_t) s * C.K + prob] = pd;
+      st->ncorr[s] = 0;
+      st->ninl[s]  = 0;
+      st->kexp[s]  = s == cue ? v.kexp : 0;
+      if (qc) qc[2 * prob] = qc[2 * prob + 1] = 0;
+    }
+  }
   if (!C.pub) return;
-  for (int s = 0; s < C.nslices; ++s)
-    if (C.slices[s].kind != SRRG2_SLICE_PRIOR)
-      pub_store(C.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane, (unsigned long long) init_gran_tail[s][lane]);
+  unsigned gran = 0u;  // (flags, nstats, w_count, npasses: 0)
+  if (lane < 24) gran = __float_as_uint(t);
+  if (lane == PUB_G_KEXP) gran = (unsigned) v.kexp;
+  if (lane >= PUB_G_X && lane < PUB_G_X + 12) gran = __float_as_uint(x);
+  pub_store(C.pub + ((size_t) prob * SRRG2_MAX_SLICES + cue) * PUB_SLICE_GRANULES + lane, (unsigned long long) gran);
   pub_write_epoch(C.pub_epoch, prob, lane, 0u);
 }
 
@@ -2917,10 +2970,7 @@ __device__ __forceinline__ void grid_fused_body(const SliceDev& S, const Problem
   if constexpr (MODE != 2) fused_control_if_due<DIM, MODE == 1>(S, states, prob);
   ProblemDev pd;
   if constexpr (MODE == 2) {
-    if (inl->use)
-      pd = inl->pd[S.slice_idx];
-    else
-      pd = inl->probs_host[(size_t) S.slice_idx * Ci->K + prob];
+    pd = inl->pd[S.slice_idx];
   } else {
     pd = probs[prob];
   }
@@ -2929,7 +2979,8 @@ __device__ __forceinline__ void grid_fused_body(const SliceDev& S, const Problem
   PassView pv;
   if constexpr (MODE == 2) {
     pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv);
-    if (tail_wg && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
+    if (tail_wg && threadIdx.x < 64)  // (probs: the SLICE's table)
+      fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states, nullptr, pv, S.slice_idx);
   } else {
     pass_view_fused<DIM, MODE == 1>(S, states, prob, pv);
   }
@@ -3697,7 +3748,7 @@ __global__ __launch_bounds__(256) void k_icp_step_fast(SliceDev S, const Problem
 template <int DIM, bool PLANE, int TEAM, int FUSED>
 __device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists& GL, const ProblemDev* __restrict__ probs,
                                               ProblemState* __restrict__ states, const CtlParams* Ci = nullptr,
-                                              const InitInline* inl = nullptr) {
+                                              const InitInline* inl = nullptr, const InitBatch* bat = nullptr) {
   constexpr int NW  = 4;
   constexpr int PPB = NW * 64 / TEAM;  // moving points per workgroup
   const int prob    = (FUSED ? blockIdx.x : blockIdx.y) + S.prob0;  // (a launch may cover a sub-range of the batch: SliceDev::prob0)
@@ -3711,10 +3762,10 @@ __device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists
   }
   ProblemDev pd;
   if constexpr (FUSED == 3) {
-    if (inl->use)
-      pd = inl->pd[S.slice_idx];
+    if (bat)
+      pd = bat->pd[prob - Ci->prob0];  // (a part of a batch: the launch's own table)
     else
-      pd = inl->probs_host[(size_t) S.slice_idx * Ci->K + prob];  // (a batch: from the pinned table, like the sort in front of it)
+      pd = inl->pd[S.slice_idx];
   } else {
     pd = probs[prob];
   }
@@ -3775,8 +3826,9 @@ __device__ __forceinline__ void cnl_pass_body(const SliceDev& S, const GridLists
   }
   if constexpr (FUSED) {  // (the points are on their way: now the record, or the control step it still waits for)
     if constexpr (FUSED == 3) {
-      pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv);
-      if (tail_wg && threadIdx.x < 64) fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states);  // (probs: the SLICE's table)
+      pass_view_init<DIM>(S, *Ci, *inl, prob, pd.nm, pv, bat);
+      if (tail_wg && threadIdx.x < 64)  // (probs: the SLICE's table)
+        fused_init_tail(*Ci, *inl, prob, const_cast<ProblemDev*>(probs) - (size_t) S.slice_idx * Ci->K, states, bat, pv, S.slice_idx);
     } else {
       pass_view_fused<DIM, FUSED == 2>(S, states, prob, pv);
     }
@@ -3972,6 +4024,13 @@ template <int DIM, bool PLANE, int TEAM>
 __global__ __launch_bounds__(256) void k_icp_step_cnl_init(SliceDev S, GridLists GL, CtlParams C, InitInline inl,
                                                            ProblemDev* __restrict__ probs, ProblemState* __restrict__ states) {
   cnl_pass_body<DIM, PLANE, TEAM, 3>(S, GL, probs, states, &C, &inl);
+}
+// ... of up to INIT_BATCH_MAX alignments of one launch (a part of a pipelined batch): guesses and table rows in the arguments
+template <int DIM, bool PLANE, int TEAM>
+__global__ __launch_bounds__(256) void k_icp_step_cnl_init_batch(SliceDev S, GridLists GL, CtlParams C, InitBatch B,
+                                                                 ProblemDev* __restrict__ probs, ProblemState* __restrict__ states) {
+  const InitInline none{};
+  cnl_pass_body<DIM, PLANE, TEAM, 3>(S, GL, probs, states, &C, &none, &B);
 }
 
 // The correspondence records of the nearest-neighbour passes, on demand (get_correspondences, factor status, the scene
@@ -5558,8 +5617,32 @@ void launch_icp_step_tile(int dim, bool plane, const SliceDev& S, const ProblemD
 // the search pass over the cell neighbour lists of the grid (S.grid.list_R > 0); team = lanes per moving point (1 or 4)
 void launch_icp_step_cnl(int dim, bool plane, const SliceDev& S, const GridLists& GL, const ProblemDev* probs,
                          ProblemState* states, int K, int max_nm, int team, hipStream_t s, const CtlParams* init_C,
-                         const InitInline* init_inl) {
+                         const InitInline* init_inl, const InitBatch* init_bat) {
   if (K <= 0) return;
+  if (S.fc.pub && init_C && init_bat) {  // a part of a batch (K <= INIT_BATCH_MAX alignments) with the prologue in its first pass
+    ProblemDev* pw = const_cast<ProblemDev*>(probs);
+#define CNL_INITB_LAUNCH(TEAM)                                                                                                        \
+  do {                                                                                                                                \
+    dim3 grid(K, (max_nm * TEAM + 255) / 256 + 1);                                                                                    \
+    if (dim == 3) {                                                                                                                   \
+      if (plane)                                                                                                                      \
+        hipLaunchKernelGGL((k_icp_step_cnl_init_batch<3, true, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_bat, pw, states);  \
+      else                                                                                                                            \
+        hipLaunchKernelGGL((k_icp_step_cnl_init_batch<3, false, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_bat, pw, states); \
+    } else {                                                                                                                          \
+      if (plane)                                                                                                                      \
+        hipLaunchKernelGGL((k_icp_step_cnl_init_batch<2, true, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_bat, pw, states);  \
+      else                                                                                                                            \
+        hipLaunchKernelGGL((k_icp_step_cnl_init_batch<2, false, TEAM>), grid, dim3(256), 0, s, S, GL, *init_C, *init_bat, pw, states); \
+    }                                                                                                                                 \
+  } while (0)
+    if (team >= 4)
+      CNL_INITB_LAUNCH(4);
+    else
+      CNL_INITB_LAUNCH(1);
+#undef CNL_INITB_LAUNCH
+    return;
+  }
   if (S.fc.pub && init_C) {  // the first pass of a single alignment with compute()'s prologue inside (even for an empty cloud)
     ProblemDev* pw = const_cast<ProblemDev*>(probs);
 #define CNL_INIT_LAUNCH(TEAM)                                                                                                   \
@@ -5779,8 +5862,6 @@ void launch_proj_records(const SliceDev& S0, const SliceDev& S, const ProblemDev
 
 bool make_init_inline(const CtlParams& C, const ProblemDev* probs_host, const float* guesses_host, int tsize, InitInline* inl) {
   *inl = InitInline{};
-  inl->probs_host   = probs_host;
-  inl->guesses_host = guesses_host;
   if (C.K != 1) return false;
   inl->use = 1;  // (read on the host, sent with the launch)
   for (int i = 0; i < 12; ++i) inl->guess[i] = i < tsize ? guesses_host[i] : 0.f;
