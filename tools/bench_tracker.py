@@ -20,6 +20,7 @@ from srrg2_slam_interfaces_amd import synthetic as syn  # noqa: E402
 # the scene arrays stay as they are until compute() has returned (the clip of the next frame and the next measurement come after
 # it): SRRG2_MEM_DEVICE_KEPT -- set_moving / set_fixed do not wait for their ingest (SRRG2_TRACKER_KEPT=0: they do)
 KEPT = os.environ.get("SRRG2_TRACKER_KEPT", "1") != "0"
+FIXED_FIRST = os.environ.get("SRRG2_TRACKER_FIXED_FIRST", "0") != "0"  # 1: set_fixed before set_moving, as MultiTrackerBase_::align does (the same frame time: set_fixed 0.15 -> 0.10 ms, compute 0.19 -> 0.25 -- the sort it then waits for)
 
 
 def run(points=100_000, frames=30):
@@ -52,9 +53,15 @@ def run(points=100_000, frames=30):
         cl.set_full_scene(scene); cl.set_clipped_scene_in_robot(clipped); cl.set_robot_in_local_map(est)
         cl.compute(); t2 = time.perf_counter()
         cp, cn, n = clipped.device_arrays()
-        al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n, kept=KEPT); t3 = time.perf_counter()
         mp, mn, m = meas.device_arrays()
-        al.set_cloud_device("set_fixed", si, mp, 16, mn, 16, m, kept=KEPT); t4 = time.perf_counter()
+        if FIXED_FIRST:  # (the reference's order: setFixed, then setMoving -- multi_tracker_impl.cpp:97-98)
+            tm0 = time.perf_counter()
+            al.set_cloud_device("set_fixed", si, mp, 16, mn, 16, m, kept=KEPT); tm1 = time.perf_counter()
+            al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n, kept=KEPT); t4 = time.perf_counter()
+            t3 = t2 + (t4 - tm1)  # (so that t3 - t2 is set_moving's share and t4 - t3 set_fixed's)
+        else:
+            al.set_cloud_device("set_moving", si, cp, 16, cn, 16, n, kept=KEPT); t3 = time.perf_counter()
+            al.set_cloud_device("set_fixed", si, mp, 16, mn, 16, m, kept=KEPT); t4 = time.perf_counter()
         al.set_moving_in_fixed(syn.identity(3))
         al.compute(); t5 = time.perf_counter()
         X = np.vstack([al.moving_in_fixed(), [0, 0, 0, 1]]).astype(np.float64)
