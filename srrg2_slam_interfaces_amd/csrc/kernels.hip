@@ -2109,8 +2109,9 @@ __global__ __launch_bounds__(256) void k_icp_step_tile(SliceDev S, const Problem
 // ============================================================================================
 // Fused control steps (FusedCtl, device_types.h): the control step of an ICP iteration on ONE wave, in the prologue of the
 // first pass kernel of the next iteration.  wave_control() is k_icp_control's body (control_body below: the reference's
-// multi_aligner_impl.cpp:106-126) for aligners whose slices are all cue slices with a nearest-neighbour or projective finder
-// (no prior factors, no given correspondences, no deferred-search queue: those keep the control launch), written so that it
+// multi_aligner_impl.cpp:106-126) for aligners whose cue slices have a nearest-neighbour or projective finder -- with up to two
+// prior slices next to them, wave_prior: the PRIORS instantiations -- (no given correspondences, no deferred-search queue: those
+// keep the control launch), written so that it
 // can live inside a pass kernel: no LDS, no barrier, and matrices spread over the LANES of the wave (H(r, c) in lane
 // r D + c, vectors in lanes 0 .. D - 1) instead of over 238 registers of one thread.  Every arithmetic statement is the one
 // of control_body / dm::solve / dm::box_plus / dm::se3_compose with the same operands in the same order, executed by the
@@ -2218,7 +2219,7 @@ __device__ __forceinline__ void pub_publish_state(const CtlParams& C, const Prob
   }
 }
 
-// The control step on one wave, for an aligner of `ns` <= MAXS cue slices and no prior slices (Sv: their SliceDev records in
+// The control step on one wave, for an aligner of `ns` <= MAXS cue slices (+ prior slices: PRIORS) (Sv: their SliceDev records in
 // slice order -- the calling pass kernel's own argument, or the pack of the projective kernels).  Everything it reads
 // arrives in ONE round trip: the records of the previous epoch (`g[z]`: this lane's granule of slice z's record, already
 // loaded by the caller) carry the state the step needs, the slot sets are addressed from the kernel arguments.  Nothing waits
