@@ -90,6 +90,10 @@ struct Slice {
   // (k_icp_final_wave zeroes the sets of its problems; run_compute clears this before it launches anything)
   const void* slots_zeroed_at = nullptr;
   int slots_zeroed = 0;
+  // set_fixed's bounding box: written into pinned memory by the last block of k_ingest_bbox, word 8 = the sequence number polled for
+  unsigned* bbox_host = nullptr; size_t bbox_host_cap = 0;
+  unsigned bbox_seq = 0;
+  DevBuf<unsigned> bbox_rows;  // [INGEST_BBOX_MAX_BLOCKS][8]: the blocks' partial results of k_ingest_bbox
   DevBuf<unsigned long long> zbuf;  // projective finder: [problem][rows*cols]
   DevBuf<int> queue;                // deferred searches: one 32-byte QEntry per moving point
   DevBuf<int> qcount;               // [problem]
@@ -100,6 +104,9 @@ struct Slice {
     if (qprobe_host) (void) hipHostFree(qprobe_host);
     qprobe_host = nullptr;
     qprobe_cap  = 0;
+    if (bbox_host) (void) hipHostFree(bbox_host);
+    bbox_host     = nullptr;
+    bbox_host_cap = 0;
     if (ms_probs_host) (void) hipHostFree(ms_probs_host);
     ms_probs_host     = nullptr;
     ms_probs_host_cap = 0;
@@ -109,7 +116,7 @@ struct Slice {
     moving.release(); moving_nrm.release(); pinf.release();
     moving_raw.release(); moving_nrm_raw.release(); ms_counts.release(); ms_cursor.release(); ms_sums.release();
     ms_bb.release(); ms_probs.release();
-    corr_fixed.release(); gcorr.release(); gcorr_off.release(); gcorr_stat.release(); prev_n.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release();
+    corr_fixed.release(); gcorr.release(); gcorr_off.release(); gcorr_stat.release(); prev_n.release(); prev_pos.release(); prev_f.release(); prev_m.release(); corr_resp.release(); corr_stat.release(); partials.release(); zbuf.release(); queue.release(); qcount.release(); bbox_rows.release();
   }
 };
 
@@ -280,8 +287,23 @@ int build_grid(srrg2_aligner* a, Slice* s, float force_h = 0.f, bool have_bbox =
     srrg2amd::launch_bbox(s->fixed_raw.p, n, s->scalars.p, s->scalars.p + 3, (int*) (s->scalars.p + 6), a->stream);
   }
   unsigned back[8];
-  HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, a->stream));
-  HIP_TRY(hipStreamSynchronize(a->stream));
+  bool polled = false;
+  if (have_bbox && s->bbox_host) {  // (set_fixed: the last block of k_ingest_bbox has left box and count in pinned memory)
+    volatile unsigned* flag = s->bbox_host + 8;
+    int spins = 0;
+    polled    = true;
+    while (*flag != s->bbox_seq)
+      if ((++spins & 4095) == 0 && hipStreamQuery(a->stream) != hipErrorNotReady) {
+        polled = *flag == s->bbox_seq;  // (drained: the word has just arrived, or the launch failed -- the copy below says which)
+        break;
+      }
+    if (polled)
+      for (int i = 0; i < 7; ++i) back[i] = s->bbox_host[i];
+  }
+  if (!polled) {
+    HIP_TRY(hipMemcpyAsync(back, s->scalars.p, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, a->stream));
+    HIP_TRY(hipStreamSynchronize(a->stream));
+  }
   const int nvalid = (int) back[6];
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   if (nvalid > 0) {
@@ -1851,9 +1873,15 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   const float* dsrc;
   int sf;
   if ((rc = stage_input(a, coords, cs, n, a->dim, mem, &dsrc, &sf, 0))) return rc;
-  if (nn)
+  if (nn) {
+    // (the box comes back through pinned memory: word 8 = this call's sequence number, never 0; scalars[11] = the blocks' ticket)
+    if ((rc = ensure_pinned(s->bbox_host, s->bbox_host_cap, (size_t) 16))) return rc;
+    if ((rc = s->bbox_rows.reserve((size_t) INGEST_BBOX_MAX_BLOCKS * 8))) return rc;
+    if (++s->bbox_seq == 0) s->bbox_seq = 1;
+    s->bbox_host[8] = 0;
     srrg2amd::launch_ingest_bbox(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, s->scalars.p, s->scalars.p + 3,
-                                 (int*) (s->scalars.p + 6), a->stream);
+                                 (int*) (s->scalars.p + 6), a->stream, s->scalars.p + 11, s->bbox_host, s->bbox_seq, s->bbox_rows.p);
+  }
   else
     srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, 1, a->stream);  // [10] = |fixed|inf
   if (normals) {
