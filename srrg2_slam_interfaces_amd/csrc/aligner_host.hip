@@ -134,6 +134,8 @@ struct srrg2_aligner_s {
   int fused_grid_max    = 130000;    // SRRG2_AMD_FUSED_GRID_MAX (read at create): largest cloud whose grid search passes drop the
                                      // deferred-search queue for the fused kernel (run_compute)
   hipEvent_t ev_staged  = nullptr;   // the staging copies of a batch upload (stream) before the other parts' sorts
+  hipEvent_t ev_records = nullptr;   // behind the kernels that materialise the correspondence records (aligner_slice_view)
+  bool records_unsynced = false;     // ... which the host has not waited for yet
   int parts_dirty       = 0;         // pstream[1 .. parts_dirty) may still be running the tail of the last pipelined batch
   int batch_parts       = 0;         // upload_moving -> run_compute: the batch at hand runs as this many parts (0: one)
   int part_begin[MAX_PARTS + 1]{};   // ... part p = alignments [part_begin[p], part_begin[p + 1])
@@ -1598,8 +1600,16 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
 }
 
 // correspondence records of the nearest-neighbour slices of the last compute(), derived on demand
-int materialize_records(srrg2_aligner* a) {
-  if (a->records_state != 1) return 0;
+// (host_wait = false: a consumer on the DEVICE -- the scene merger on its own stream, aligner_slice_view -- waits for the event
+// recorded behind the launches instead of the host waiting for the stream; a host reader that comes later still waits)
+int materialize_records(srrg2_aligner* a, bool host_wait = true) {
+  if (a->records_state != 1) {
+    if (host_wait && a->records_unsynced) {
+      HIP_TRY(hipStreamSynchronize(a->stream));
+      a->records_unsynced = false;
+    }
+    return 0;
+  }
   int rc;
   if ((rc = set_device(a))) return rc;
   if ((rc = quiesce_stream2(a))) return rc;
@@ -1621,7 +1631,12 @@ int materialize_records(srrg2_aligner* a) {
                                  a->states.p, a->K, a->last_nm_max[si], a->stream);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(a->stream));
+  if (host_wait) {
+    HIP_TRY(hipStreamSynchronize(a->stream));
+    a->records_unsynced = false;
+  } else {
+    a->records_unsynced = true;
+  }
   a->records_state = 0;
   return 0;
 }
@@ -1742,6 +1757,7 @@ int srrg2_aligner_create(int variable_kind, int device, srrg2_aligner_h* out) {
   bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) == hipSuccess;
   a->pstream[0] = a->stream;  // (pstream[1 ..]: created by the first pipelined batch that wants them, compute_batch)
   ok = ok && hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&a->ev_records, hipEventDisableTiming) == hipSuccess;
   if (ok && (hipDeviceGetAttribute(&a->cu_count, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || a->cu_count <= 0)) {
     (void) hipGetLastError();
     a->cu_count = 256;
@@ -1777,6 +1793,7 @@ int srrg2_aligner_destroy(srrg2_aligner_h a) {
     (void) hipEventDestroy(ev.second);
   }
   if (a->ev_staged) (void) hipEventDestroy(a->ev_staged);
+  if (a->ev_records) (void) hipEventDestroy(a->ev_records);
   for (int p = srrg2_aligner::MAX_PARTS - 1; p >= 0; --p)
     if (a->pstream[p]) (void) hipStreamDestroy(a->pstream[p]);
   delete a;
@@ -2119,7 +2136,10 @@ int aligner_slice_view(srrg2_aligner_s* a, int si, AlignerSliceView* v) {
   if (!a->computed || a->K != 1 || s->cfg.kind == SRRG2_SLICE_PRIOR || !s->has_moving || !s->has_fixed)
     return fail(SRRG2_E_STATE, "aligner_slice_view: needs a cue slice after a single-problem compute()");
   if (a->records_state == 2) return fail(SRRG2_E_STATE, "aligner_slice_view: the clouds changed since the last compute()");
-  if ((rc = materialize_records(a))) return rc;
+  if ((rc = materialize_records(a, /*host_wait=*/false))) return rc;
+  // (the consumer's stream waits for this event: everything the view points to is complete behind it)
+  HIP_TRY(hipEventRecord(a->ev_records, a->stream));
+  v->ready_event   = (void*) a->ev_records;
   v->moving_sorted = s->moving.p;
   v->corr_fixed    = s->corr_fixed.p;
   v->corr_resp     = s->corr_resp.p;

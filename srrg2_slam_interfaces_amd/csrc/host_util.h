@@ -56,6 +56,8 @@ struct AlignerSliceView {
   int nm, nf;
   bool prune;  // keep_only_inlier_correspondences && Success: only inlier correspondences count
   int device;
+  void* ready_event;  // hipEvent_t recorded on the aligner's stream behind the kernels that wrote the arrays: wait for it on the
+                      // consuming stream (hipStreamWaitEvent) before reading them
 };
 int aligner_slice_view(srrg2_aligner_s* a, int slice_idx, AlignerSliceView* v);
 
