@@ -929,6 +929,14 @@ bool launch_msort_local(const float* src, int sf, const float* nsrc, int nsf, co
   // 146 -> 161 k, 64 alignments 331 -> 345 k with 2; the passes lose 1.4 % of coherence, the sort goes from 118 to ~35 us;
   // 128 alignments 362 -> 372 k with 2 (profiles/archive/r2zs_env_tests.txt); 256: within noise, one workgroup per cloud)
   int G = seg_env > 0 ? seg_env : (K >= 256 ? 1 : (K >= 64 ? 2 : (128 / K < 8 ? 128 / K : 8)));
+  // (round 6, late: a call of one to four clouds -- a tracker's set_moving, every frame -- gets a segment per ~3 Ki points, up to 64
+  // workgroups in all: eight 1024-thread workgroups sorted a 100 k-point cloud in 67 us, a latency chain on eight CUs that the
+  // frame's set_fixed then waits behind; 32 segments: ~20 us.  The passes lose a little coherence -- a tracker's compute() 0.194 ->
+  // 0.198 ms -- the frame gains 30 us: 0.452-0.475 -> 0.423-0.426 ms.  C2 with the fixed cloud kept: unchanged, 0.168 ms)
+  if (seg_env <= 0 && K <= 4) {
+    const int by_size = max_nm / 3072, room = 64 / K;
+    G = G > (by_size < room ? by_size : room) ? G : (by_size < room ? by_size : room);
+  }
   if (G < 1) G = 1;
   if (G > 1) {
     if (!aniso) kbits = kbits < 12 ? kbits : 12;
