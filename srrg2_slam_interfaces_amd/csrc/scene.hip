@@ -113,11 +113,12 @@ __global__ void k_clip_flag(int dim, Xf L, float range2, const float4* __restric
 
 __global__ void k_clip_scatter(int dim, Xf L, float range2, const float4* __restrict__ pts, const float4* __restrict__ nrm,
                                int n, const int* __restrict__ offset, float4* __restrict__ out_pts,
-                               float4* __restrict__ out_nrm, int* __restrict__ gidx) {
+                               float4* __restrict__ out_nrm, int* __restrict__ gidx, int cap) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 q;
     if (!clip_keep(dim, L, range2, pts[i], q)) continue;
     const int k = offset[i];
+    if (k >= cap) continue;  // (a scatter launched before the host knew the total: the caller repeats it with room for all)
     out_pts[k]  = q;
     out_nrm[k]  = nrm ? rotate_normal(dim, L, nrm[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     gidx[k]     = i;
@@ -512,15 +513,36 @@ int srrg2_scene_clip_ball(srrg2_scene_h full, const float* robot_in_local_map, f
   if ((rc = full->flags.reserve((size_t) n + 1))) return rc;
   hipLaunchKernelGGL(k_clip_flag, dim3(blocks_for(n)), dim3(256), 0, st, full->dim, L, range2, full->pts.p, n, full->flags.p);
   int total = 0;
-  if ((rc = scan_flags(full, n, &total))) return rc;
-  if ((rc = scene_reserve(clipped, total > 0 ? total : 1, 0))) return rc;
-  if ((rc = clipped->gidx.reserve((size_t) (total > 0 ? total : 1)))) return rc;
-  if (total > 0)
+  // A clipped scene that has room from the call before (a tracker clips around a pose that moves a little per frame): the scatter
+  // is launched BEHIND the scan without the host having seen the total -- one wait per clip instead of two (0.046 -> ~0.03 ms for a
+  // 100 k-point map); a total beyond the room repeats the scatter the slow way.
+  const int room = (int) std::min<size_t>(std::min(clipped->pts.cap, clipped->nrm.cap), clipped->gidx.cap);
+  bool speculated = false;
+  if (room > 0) {
+    if ((rc = full->scan_sums.reserve((size_t) srrg2amd::scan_num_blocks(n) + 2))) return rc;
+    int* dtotal = full->scan_sums.p + full->scan_sums.cap - 1;
+    srrg2amd::launch_exclusive_scan(full->flags.p, n, full->scan_sums.p, dtotal, st);
     hipLaunchKernelGGL(k_clip_scatter, dim3(blocks_for(n)), dim3(256), 0, st, full->dim, L, range2, full->pts.p,
                        full->has_normals ? full->nrm.p : nullptr, n, full->flags.p, clipped->pts.p, clipped->nrm.p,
-                       clipped->gidx.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(st));
+                       clipped->gidx.p, room);
+    HIP_TRY(hipMemcpyAsync(&full->scalars[0], dtotal, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    total      = full->scalars[0];
+    speculated = total <= room;
+  } else if ((rc = scan_flags(full, n, &total))) {
+    return rc;
+  }
+  if (!speculated) {
+    if ((rc = scene_reserve(clipped, total > 0 ? total : 1, 0))) return rc;
+    if ((rc = clipped->gidx.reserve((size_t) (total > 0 ? total : 1)))) return rc;
+    if (total > 0)
+      hipLaunchKernelGGL(k_clip_scatter, dim3(blocks_for(n)), dim3(256), 0, st, full->dim, L, range2, full->pts.p,
+                         full->has_normals ? full->nrm.p : nullptr, n, full->flags.p, clipped->pts.p, clipped->nrm.p,
+                         clipped->gidx.p, total);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   clipped->n = clipped->ng = total;
   return 0;
 }

@@ -50,6 +50,35 @@ def test_clip_ball_parity(oracle, product, dim):
     assert 1000 < s_gpu.size() < n
 
 
+def test_clip_into_a_scene_that_has_room_or_not(oracle, product):
+    """Round 6, last: a clipped scene with room from the clip before gets its scatter launched behind the scan WITHOUT the host having
+    seen the total (one wait per clip); a total beyond the room repeats the scatter.  One pair of scenes through a small clip, a larger
+    one (beyond the room: repeated), a smaller one again (within the room: speculated), an empty one, and a full one."""
+    rng = np.random.default_rng(77)
+    n = 120_000
+    sp = rng.uniform(-30, 30, (n, 3)).astype(f32)
+    sn = rng.normal(size=(n, 3)).astype(f32)
+    sp[::1013] = np.nan
+    pose = syn.se3(np.array([3.0, -2.0, 0.5]), np.deg2rad(np.array([10.0, 5.0, -20.0]))).astype(f32)
+    pairs = []
+    for b in _bindings(oracle, product):
+        full, clipped = mapping.Scene(b, 3), mapping.Scene(b, 3)
+        full.set(sp, sn)
+        pairs.append((b, full, clipped))
+    sizes = []
+    for r in (4.0, 15.0, 8.0, 0.01, 500.0, 6.0):
+        got = []
+        for b, full, clipped in pairs:
+            cl = mapping.SceneClipperBall(b, range_max=r)
+            cl.set_full_scene(full); cl.set_clipped_scene_in_robot(clipped); cl.set_robot_in_local_map(pose)
+            cl.compute()
+            got.append((cl.global_indices(), clipped))
+        assert np.array_equal(got[0][0], got[1][0]), r
+        _same_scene(got[0][1], got[1][1])
+        sizes.append(got[1][1].size())
+    assert sizes[0] < sizes[2] < sizes[1] < sizes[4] and sizes[3] == 0
+
+
 @pytest.mark.parametrize("target", [200, 20])
 @pytest.mark.parametrize("with_corr", [True, False])
 def test_merge_parity_with_duplicates(oracle, product, target, with_corr):
