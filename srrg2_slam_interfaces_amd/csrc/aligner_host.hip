@@ -93,6 +93,7 @@ struct Slice {
   // set_fixed's bounding box: written into pinned memory by the last block of k_ingest_bbox, word 8 = the sequence number polled for
   unsigned* bbox_host = nullptr; size_t bbox_host_cap = 0;
   unsigned bbox_seq = 0;
+  bool scalars_self_init = false;  // the last set_fixed's k_ingest_bbox left the scalars as the next one needs them
   DevBuf<unsigned> bbox_rows;  // [INGEST_BBOX_MAX_BLOCKS][8]: the blocks' partial results of k_ingest_bbox
   DevBuf<unsigned long long> zbuf;  // projective finder: [problem][rows*cols]
   DevBuf<int> queue;                // deferred searches: one 32-byte QEntry per moving point
@@ -1883,10 +1884,13 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
   // (the scalars: bounding box minima start at all ones, everything else at zero; a nearest-neighbour slice's ingest leaves the box
   // and the count of valid points there on its way -- one pass over the cloud and one launch instead of two, round 6)
   const bool nn = s->cfg.finder == SRRG2_FINDER_NN_GATED;
-  {
+  // (a nearest-neighbour slice whose previous set_fixed went through k_ingest_bbox's last block needs no initialising copy: that block
+  // wrote box, count and norm itself and left the ticket and the normals' norm cleared -- one stream operation less per frame)
+  if (!(nn && n > 0 && s->scalars_self_init)) {
     unsigned init[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(s->scalars.p, init, sizeof(init), hipMemcpyHostToDevice, a->stream));
   }
+  s->scalars_self_init = false;
   const float* dsrc;
   int sf;
   if ((rc = stage_input(a, coords, cs, n, a->dim, mem, &dsrc, &sf, 0))) return rc;
@@ -1897,7 +1901,9 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
     if (++s->bbox_seq == 0) s->bbox_seq = 1;
     s->bbox_host[8] = 0;
     srrg2amd::launch_ingest_bbox(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, s->scalars.p, s->scalars.p + 3,
-                                 (int*) (s->scalars.p + 6), a->stream, s->scalars.p + 11, s->bbox_host, s->bbox_seq, s->bbox_rows.p);
+                                 (int*) (s->scalars.p + 6), a->stream, s->scalars.p + 11, s->bbox_host, s->bbox_seq, s->bbox_rows.p,
+                                 s->scalars.p + 7);
+    s->scalars_self_init = n > 0;
   }
   else
     srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, 1, a->stream);  // [10] = |fixed|inf

@@ -11,7 +11,8 @@ void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* 
 void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s);
 void launch_ingest_bbox(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits, unsigned* mn,
                         unsigned* mx, int* nvalid, hipStream_t s, unsigned* ticket = nullptr, unsigned* host_out = nullptr,
-                        unsigned seq = 0, unsigned* block_out = nullptr /* [INGEST_BBOX_MAX_BLOCKS][8] */);
+                        unsigned seq = 0, unsigned* block_out = nullptr /* [INGEST_BBOX_MAX_BLOCKS][8] */,
+                        unsigned* clear_after = nullptr);
 #define INGEST_BBOX_MAX_BLOCKS 512
 void launch_grid_count(const GridDev& g, const float4* pts, int n, int* counts, hipStream_t s);
 void launch_count_nonzero(const int* counts, int n, int* out, hipStream_t s);

@@ -172,7 +172,7 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
 __global__ void k_ingest_bbox(const float* __restrict__ src, int stride_floats, int n, int dim, float4* __restrict__ dst,
                               unsigned* __restrict__ maxabs_bits, unsigned* __restrict__ mn_out, unsigned* __restrict__ mx_out,
                               int* __restrict__ nvalid, unsigned* __restrict__ ticket, unsigned* __restrict__ host_out, unsigned seq,
-                              unsigned* __restrict__ block_out) {
+                              unsigned* __restrict__ block_out, unsigned* __restrict__ clear_after) {
   // (block_out: [gridDim.x][8] -- every block leaves its minima, maxima, count and max |coordinate| there instead of in 8 atomics
   // on neighbouring words: 256 blocks finishing together serialised 2 048 of them, 20 of this kernel's 24 us on a 100 k-point cloud)
   bbox_body<true>(src, stride_floats, dim, dst, maxabs_bits, nullptr, n, mn_out, mx_out, nvalid, block_out);
@@ -219,6 +219,10 @@ __global__ void k_ingest_bbox(const float* __restrict__ src, int stride_floats, 
     else if (maxabs_bits) *maxabs_bits = r;
     if (d < 7) host_out[d] = r;
   }
+  // (what the NEXT call and the kernels behind this one start from: the ticket back at zero, the normals' norm -- the word behind the
+  // count, accumulated by the normals' ingest that follows on the stream -- cleared: set_fixed queues no initialising copy)
+  if (threadIdx.x == 8) *ticket = 0u;
+  if (threadIdx.x == 9 && clear_after) *clear_after = 0u;
   if (threadIdx.x < 64) {  // (the writers' wave)
     __threadfence_system();
     if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(host_out + 8) = seq;
@@ -834,7 +838,7 @@ void launch_ingest_batch(const float* src, int stride_floats, const ProblemDev* 
 
 void launch_ingest_bbox(const float* src, int stride_floats, int n, int dim, float4* dst, unsigned* maxabs_bits, unsigned* mn,
                         unsigned* mx, int* nvalid, hipStream_t s, unsigned* ticket, unsigned* host_out, unsigned seq,
-                        unsigned* block_out) {
+                        unsigned* block_out, unsigned* clear_after) {
   if (n <= 0) return;
   // (with the rows: few blocks -- every block ends in ONE atomic on the ticket word, and device-scope atomics on one address cost
   // ~80 ns each: on a 100 k-point cloud 48 .. 128 blocks of 256 threads take 9.6 - 10.5 us, 1 024-thread blocks 14 - 15 us; one block
@@ -844,12 +848,12 @@ void launch_ingest_bbox(const float* src, int stride_floats, int n, int dim, flo
     int cap       = n / 8192;
     cap           = cap < 64 ? 64 : (cap > INGEST_BBOX_MAX_BLOCKS ? INGEST_BBOX_MAX_BLOCKS : cap);
     hipLaunchKernelGGL(k_ingest_bbox, dim3(bx < cap ? bx : cap), dim3(256), 0, s, src, stride_floats, n, dim, dst, maxabs_bits, mn, mx, nvalid,
-                       ticket, host_out, seq, block_out);
+                       ticket, host_out, seq, block_out, clear_after);
     return;
   }
   const int bx = (n + 255) / 256;
   hipLaunchKernelGGL(k_ingest_bbox, dim3(bx < 256 ? bx : 256), dim3(256), 0, s, src, stride_floats, n, dim, dst, maxabs_bits, mn, mx, nvalid,
-                     nullptr, nullptr, 0u, nullptr);
+                     nullptr, nullptr, 0u, nullptr, nullptr);
 }
 void launch_bbox(const float4* pts, int n, unsigned* mn, unsigned* mx, int* nvalid, hipStream_t s) {
   if (n <= 0) return;
