@@ -93,6 +93,7 @@ struct Slice {
   // set_fixed's bounding box: written into pinned memory by the last block of k_ingest_bbox, word 8 = the sequence number polled for
   unsigned* bbox_host = nullptr; size_t bbox_host_cap = 0;
   unsigned bbox_seq = 0;
+  bool bbox_polled = false;        // the last k_ingest_bbox writes its result into bbox_host
   bool scalars_self_init = false;  // the last set_fixed's k_ingest_bbox left the scalars as the next one needs them
   DevBuf<unsigned> bbox_rows;  // [INGEST_BBOX_MAX_BLOCKS][8]: the blocks' partial results of k_ingest_bbox
   DevBuf<unsigned long long> zbuf;  // projective finder: [problem][rows*cols]
@@ -291,7 +292,7 @@ int build_grid(srrg2_aligner* a, Slice* s, float force_h = 0.f, bool have_bbox =
   }
   unsigned back[8];
   bool polled = false;
-  if (have_bbox && s->bbox_host) {  // (set_fixed: the last block of k_ingest_bbox has left box and count in pinned memory)
+  if (have_bbox && s->bbox_host && s->bbox_polled) {  // (set_fixed: the last block of k_ingest_bbox has left box and count in pinned memory)
     volatile unsigned* flag = s->bbox_host + 8;
     int spins = 0;
     polled    = true;
@@ -1900,10 +1901,12 @@ int srrg2_aligner_set_fixed(srrg2_aligner_h a, int si, const float* coords, int 
     if ((rc = s->bbox_rows.reserve((size_t) INGEST_BBOX_MAX_BLOCKS * 8))) return rc;
     if (++s->bbox_seq == 0) s->bbox_seq = 1;
     s->bbox_host[8] = 0;
+    const bool rows = !(a->tuning.strategy_mask & (1 << 21));  // (SRRG2_AMD_TUNE bit 21: atomics + a copy + a wait, as before)
     srrg2amd::launch_ingest_bbox(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, s->scalars.p, s->scalars.p + 3,
-                                 (int*) (s->scalars.p + 6), a->stream, s->scalars.p + 11, s->bbox_host, s->bbox_seq, s->bbox_rows.p,
-                                 s->scalars.p + 7);
-    s->scalars_self_init = n > 0;
+                                 (int*) (s->scalars.p + 6), a->stream, rows ? s->scalars.p + 11 : nullptr, rows ? s->bbox_host : nullptr,
+                                 s->bbox_seq, rows ? s->bbox_rows.p : nullptr, s->scalars.p + 7);
+    s->scalars_self_init = rows && n > 0;
+    s->bbox_polled       = rows;
   }
   else
     srrg2amd::launch_ingest(dsrc, sf, n, a->dim, s->fixed_raw.p, s->scalars.p + 10, 1, a->stream);  // [10] = |fixed|inf

@@ -317,8 +317,8 @@ int scan_flags(srrg2_scene* s, int n, int* total) {
   return 0;
 }
 
-int read_scalars(srrg2_scene* s) {
-  HIP_TRY(hipMemcpyAsync(s->scalars, s->dscalars.p, 16 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+int read_scalars(srrg2_scene* s, const int* from = nullptr) {
+  HIP_TRY(hipMemcpyAsync(s->scalars, from ? from : s->dscalars.p, 16 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return 0;
 }
@@ -331,8 +331,9 @@ int check_params(const srrg2_merger_params* p) {
 
 // the tail shared by both merge entry points: count merged points, append if the target was not reached
 // (counted: scalars[1] already holds the number of merged measurement points -- k_merge_from_aligner counts them on its way)
+// (merged_flags: where the flags of this call lie when not at the head of scene->merged)
 int finish_merge(srrg2_scene* scene, srrg2_scene* meas, const Xf& M, bool have_corr, const srrg2_merger_params* p,
-                 srrg2_merge_result* out, bool counted = false) {
+                 srrg2_merge_result* out, bool counted = false, const unsigned char* merged_flags = nullptr) {
   int rc;
   const int n_meas = meas->n;
   int num_merged   = 0;
@@ -348,7 +349,7 @@ int finish_merge(srrg2_scene* scene, srrg2_scene* meas, const Xf& M, bool have_c
   if (!have_corr || (unsigned) num_merged < (unsigned) p->target_number_of_merges) {  // :92
     if (n_meas > 0) {
       if ((rc = scene->flags.reserve((size_t) n_meas + 1))) return rc;
-      const unsigned char* mg = have_corr ? scene->merged.p : nullptr;
+      const unsigned char* mg = have_corr ? (merged_flags ? merged_flags : scene->merged.p) : nullptr;
       hipLaunchKernelGGL(k_append_flag, dim3(blocks_for(n_meas)), dim3(256), 0, scene->stream, scene->dim, meas->pts.p, mg,
                          n_meas, scene->flags.p);
       int total = 0;
@@ -641,22 +642,25 @@ int srrg2_scene_merge_from_aligner(srrg2_scene_h scene, srrg2_scene_h meas, cons
   const Xf M  = load_transform(scene->dim, measurement_in_scene);
   const int n_scene = scene->n, n_meas = meas->n;
   hipStream_t st = scene->stream;
-  if ((rc = scene->merged.reserve((size_t) n_meas + 8))) return rc;  // (whole words: the flags are set through 32-bit atomics)
-  HIP_TRY(hipMemsetAsync(scene->merged.p, 0, ((size_t) n_meas + 4) / 4 * 4, st));
-  HIP_TRY(hipMemsetAsync(scene->dscalars.p, 0, 16 * sizeof(int), st));
+  // (the call's sixteen counters in FRONT of the flags, in one allocation: one memset instead of two; whole words: the flags are set
+  // through 32-bit atomics)
+  if ((rc = scene->merged.reserve((size_t) n_meas + 8 + 64))) return rc;
+  HIP_TRY(hipMemsetAsync(scene->merged.p, 0, 64 + ((size_t) n_meas + 4) / 4 * 4, st));
+  int* const counters         = reinterpret_cast<int*>(scene->merged.p);
+  unsigned char* const flags_ = scene->merged.p + 64;
   if (v.nm > 0) {
     hipLaunchKernelGGL(k_merge_from_aligner, dim3(std::min(blocks_for(v.nm), 256)), dim3(256), 0, st, scene->dim, M, p->maximum_response,
                        p->maximum_distance_geometry_squared, v.moving_sorted, v.corr_fixed, v.corr_resp, v.corr_stat,
                        v.prune ? 1 : 0, v.nm, clipped->gidx.p, n_scene, n_meas, scene->pts.p,
                        scene->nrm.p, meas->pts.p, meas->has_normals ? meas->nrm.p : nullptr,
-                       scene->merged.p, scene->dscalars.p);
-    if ((rc = read_scalars(scene))) return rc;
+                       flags_, counters);
+    if ((rc = read_scalars(scene, counters))) return rc;
     if (scene->scalars[2]) return fail(SRRG2_E_STATE, "scene_merge_from_aligner: index out of range");
   }
-  else if ((rc = read_scalars(scene)))
+  else if ((rc = read_scalars(scene, counters)))
     return rc;
   out->num_correspondences = scene->scalars[4];
-  return finish_merge(scene, meas, M, true, p, out, /*counted=*/true);
+  return finish_merge(scene, meas, M, true, p, out, /*counted=*/true, flags_);
 }
 
 }  // extern "C"
