@@ -542,3 +542,35 @@ def test_ties_and_duplicates(oracle, product, dim):
     cfg = cue_config(kind, abi.SLICE_P2P, 0.3)
     a_ref, a_gpu = _run_both(oracle, product, kind, d, cfg, params=dict(max_iterations=3))
     assert_same_run(a_ref, a_gpu)
+
+
+def test_set_fixed_box_through_rows_and_polled_words(oracle, product):
+    """Round 6, last: set_fixed's bounding box, count and norm come from the rows the blocks of k_ingest_bbox leave and its last block
+    reduces (no atomics on shared words), through pinned words the host polls; SRRG2_AMD_TUNE bit 21 keeps the atomics, the copy and
+    the wait.  One point, a handful, fewer points than a block, a cloud with NaNs, a million points (512 blocks): the same grid either
+    way -- the oracle's bits where the oracle is quick enough to ask -- and twice on the same handle (the kernel re-arms its own
+    ticket and clears the normals' norm for the next call)."""
+    kind = abi.SE3_QUAT_RIGHT
+    for n in (1, 7, 300, 70_000, 1_000_000):
+        d = syn.cloud_pair_3d(n=max(n, 8), seed=5)
+        f, fn = d["fixed"][:n].copy(), d["fixed_normals"][:n]
+        m, mn = d["moving"][:max(n // 3, 1)], d["moving_normals"][:max(n // 3, 1)]
+        if n >= 300:
+            f[::97] = np.nan
+        runs = []
+        makers = [lambda: product.MultiAligner(kind), lambda: product.MultiAligner(kind)]
+        if n <= 70_000:
+            makers.append(lambda: oracle.OracleAligner(kind))
+        for k, make in enumerate(makers):
+            al = make()
+            if k == 1:
+                al.set_tuning(strategy_mask=1 << 21)
+            al.set_params(max_iterations=4, min_num_inliers=0)
+            si = al.add_slice(cue_config(kind, abi.SLICE_P2PLANE, 0.25))
+            for rep in range(2):
+                al.set_fixed(si, f, fn)
+                al.set_moving(si, m, mn)
+                al.set_moving_in_fixed(syn.identity(3))
+                al.compute()
+            runs.append((al.status(), al.moving_in_fixed().tobytes(), al.num_correspondences(), len(al.iteration_stats())))
+        assert all(r == runs[0] for r in runs[1:]), (n, [r[0::2] for r in runs])
