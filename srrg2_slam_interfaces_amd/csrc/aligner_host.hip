@@ -1228,7 +1228,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // control step, on the list or the fused grid kernel, whose last step is k_icp_final_wave (it leaves the slot sets zeroed: the
   // one thing of the prologue the first pass cannot do for itself), on a handle whose previous compute() ended that way.
   // (SRRG2_AMD_TUNE bit 23: always the launch)
-  const bool final_wave = fuse && !fuse_proj && !(C.tune & (1 << 25));
+  const bool final_wave = fuse && !(C.tune & (1 << 25));
   bool fold_init = false;
   InitInline fold_inl{};
   std::vector<InitBatch> fold_bat;  // (one per part of a batch)
@@ -1237,7 +1237,7 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
   // it, over PCIe -- 32 alignments lost 50 us where the launch costs 12: 0.545 -> 0.60 ms, profiles/r10/r10f)
   int part_max = 0;
   for (int h = 0; h < nhalves; ++h) part_max = std::max(part_max, hn[h]);
-  if (fuse && fused_all && final_wave && (K == 1 || (part_max <= INIT_BATCH_MAX && cnl[(size_t) first_cue])) && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
+  if (fuse && !fuse_proj && fused_all && final_wave && (K == 1 || (part_max <= INIT_BATCH_MAX && cnl[(size_t) first_cue])) && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) &&
       (cnl[(size_t) first_cue] || !(lds_tile > 0)) && !a->profile) {
     const Slice* s = a->slices[first_cue];
     fold_init = s->slots_zeroed >= 3 * K && s->slots_zeroed_at == (const void*) s->partials.p;
@@ -1344,7 +1344,22 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       // and measured SLOWER than the 256-thread kernel, which has it staged in LDS (C2 0.191 against 0.188 ms, profiles/r6a);
       // round 6, late: post and finalize run from the step's REGISTERS and the record for the host is written by the lanes of the
       // wave, one word each, behind one system-scope fence.  SRRG2_AMD_TUNE bit 25 switches back to the 256-thread kernel)
-      if (final_wave) {
+      if (final_wave && fuse_proj) {  // (a pack of projective slices: the same wave, the parameters from their device copy)
+        SliceDev pack[4];
+        const ProblemDev* pp[4];
+        for (size_t z = 0; z < proj_group.size(); ++z) {
+          const int si = proj_group[z];
+          Slice* sz    = a->slices[si];
+          pack[z]      = sdev[si];
+          pp[z]        = a->probs.p + (size_t) si * K;
+          pack[z].fc.ctl           = a->ctl_dev.p;
+          pack[z].fc.epoch         = epoch + 1;
+          pack[z].fc.prev_partials = slot_buffer(sz, pround);
+          pack[z].fc.zero_partials = slot_buffer(sz, pround + 2);
+        }
+        srrg2amd::launch_icp_final_wave_pack(pack, pp, (int) proj_group.size(), a->states.p, a->stats.p, a->outs_host, a->stats_host,
+                                             !a->params.enable_inlier_only_runs, hstream[h]);
+      } else if (final_wave) {
         SliceDev sd          = sdev[first_cue];
         sd.prob0             = h0[h];
         sd.fc.ctl            = a->ctl_dev.p + h;

@@ -70,6 +70,11 @@ void launch_icp_init(const CtlParams& C, const ProblemDev* probs_host, ProblemDe
 // what k_icp_init gets of a single alignment in its arguments (guess, problem table); false: a batch (read from pinned memory)
 bool make_init_inline(const CtlParams& C, const ProblemDev* probs_host, const float* guesses_host, int tsize, InitInline* inl);
 void launch_icp_control(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, hipStream_t s);
+// the last control step + post + finalize of a pack of projective slices on one wave (K == 1; the control parameters come from
+// their device copy, FusedCtl::ctl)
+void launch_icp_final_wave_pack(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states,
+                                srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host,
+                                bool with_post, hipStream_t s);
 void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C, const ProblemDev* probs, ProblemState* states,
                       srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host, hipStream_t s);
 // the last control step of a compute() with fused control steps (one nearest-neighbour cue slice): one wave per problem

@@ -2301,7 +2301,7 @@ struct FinalRegs {
   int num_in;      // inliers of this step (what the post step checks against min_num_inliers)
   int sw;          // lanes [0, 8): the words of this step's IterationStats record
   bool stats_written;
-  int nc0, ni0;    // correspondences / inliers of the (first) cue slice
+  int nc[4], ni[4];  // correspondences / inliers of the launch's cue slices
 };
 
 template <int D, int MAXS, bool PUBLISH = true, bool PRIORS = false, bool FINAL = false>
@@ -2461,9 +2461,9 @@ __device__ __forceinline__ void wave_control(const SliceDev* __restrict__ Sv, in
     const int nc = (int) rl_ll(v[z], ACC_N_CORR), n_in = (int) rl_ll(v[z], ACC_N_IN), n_out = (int) rl_ll(v[z], ACC_N_OUT);
     good |= nc > Sv[z].fc.min_num_correspondences;  // aligner_slice_processor_impl.cpp:77-79
     if constexpr (FINAL)
-      if (z == 0) {
-        fin->nc0 = nc;
-        fin->ni0 = n_in;
+      if (z < 4) {
+        fin->nc[z] = nc;
+        fin->ni[z] = n_in;
       }
     Hl = Hl + __shfl(scaled, hsrc);
     bl = bl + __shfl(scaled, (ACC_B + lane) & 31);
@@ -5899,32 +5899,46 @@ void launch_icp_small(int dim, bool plane, const SliceDev& S, const CtlParams& C
 // the record + the slot sets, runs the lane-distributed step and finalizes from what that step left in its registers
 // (FinalRegs); only a run that had stopped earlier lets icp_finalize_block read the state back (its stores are complete
 // behind the fence; this kernel has not loaded those lines before, so no stale copy can be hit).
-template <int D, bool PRIORS>
-__global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, ProblemState* __restrict__ states,
-                                                        srrg2_iteration_stats* __restrict__ stats,
-                                                        ProblemOut* __restrict__ outs_host,
-                                                        srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
+// (MAXS cue slices: one nearest-neighbour slice, or a pack of projective slices that share one association)
+template <int D, int MAXS, bool PRIORS>
+__device__ __forceinline__ void final_wave_body(const CtlParams& C, const SliceDev* __restrict__ Sv, int ns,
+                                                ProblemState* __restrict__ states, srrg2_iteration_stats* __restrict__ stats,
+                                                ProblemOut* __restrict__ outs_host, srrg2_iteration_stats* __restrict__ stats_host,
+                                                int with_post) {
+  const FusedCtl& F = Sv[0].fc;
   const int prob = blockIdx.x + C.prob0;
   const int lane = threadIdx.x & 63;
   ProblemState* st = &states[prob];
-  const unsigned long long g[1] = {
-    pub_load(S.fc.pub + ((size_t) prob * SRRG2_MAX_SLICES + S.slice_idx) * PUB_SLICE_GRANULES + lane)};
+  unsigned long long g[MAXS];
+  bool stale = false;
+#pragma unroll
+  for (int z = 0; z < MAXS; ++z) {
+    g[z] = 0ull;
+    if (z < ns) {
+      g[z]  = pub_load(F.pub + ((size_t) prob * SRRG2_MAX_SLICES + Sv[z].slice_idx) * PUB_SLICE_GRANULES + lane);
+      stale = stale || (unsigned) (g[z] >> 32) != (unsigned) F.epoch;
+    }
+  }
   // (what the fast path below needs of the state and does not find in the step's registers: the correspondence counts of the
-  // slices the step does not write -- requested with the record)
+  // slices the step does not write -- requested with the records)
   int ncorr_l = 0;
   if (lane < SRRG2_MAX_SLICES) ncorr_l = st->ncorr[lane];
   FinalRegs fin;
   fin.applied = false;
-  if (!__all((unsigned) (g[0] >> 32) == (unsigned) S.fc.epoch)) wave_control<D, 1, true, PRIORS, true>(&S, 1, states, prob, g, nullptr, &fin);
-  // The slot sets of the slice, all three buffers, are left ZEROED for the handle's next compute(): its first pass may then
+  if (__any(stale)) wave_control<D, MAXS, true, PRIORS, true>(Sv, ns, states, prob, g, nullptr, &fin);
+  // The slot sets of the slices, all three buffers, are left ZEROED for the handle's next compute(): its first pass may then
   // carry the prologue (k_icp_step_cnl_init / k_icp_step_fused_init) instead of following a k_icp_init launch that zeroes them.
   // (this step was the last reader; a run that stopped early leaves sums in the buffers its control steps did not get to)
-  if (const long long* base = C.slices[S.slice_idx].partials) {
-#pragma unroll 1
-    for (int buf = 0; buf < 3; ++buf) {
-      long long* p = const_cast<long long*>(base) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
 #pragma unroll
-      for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+  for (int z = 0; z < MAXS; ++z) {
+    if (z >= ns) break;
+    if (const long long* base = C.slices[Sv[z].slice_idx].partials) {
+#pragma unroll 1
+      for (int buf = 0; buf < 3; ++buf) {
+        long long* p = const_cast<long long*>(base) + ((size_t) buf * C.K + prob) * PARTIAL_SLOTS * ACC_N;
+#pragma unroll
+        for (int q = 0; q < PARTIAL_SLOTS * ACC_N / 64; ++q) p[q * 64 + lane] = 0;
+      }
     }
   }
   if (!fin.applied || !fin.stats_written) {  // (uniform.  A run that had stopped before, or stops here: from the state, as before)
@@ -5940,13 +5954,11 @@ __global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, 
     status   = SRRG2_NOT_ENOUGH_INLIERS;
     finished = true;
   }
-  const int cue = S.slice_idx;
-  int nc_cue    = fin.nc0;
   float Xa[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) Xa[i] = rl_f(fin.Xl, i);
+  const bool keep_inl = !finished && C.params.keep_only_inlier_correspondences;
   if (!finished) {
-    if (C.params.keep_only_inlier_correspondences) nc_cue = fin.ni0;
     if constexpr (D == 3)
       dm::se2_fix_transform(Xa);
     else
@@ -5955,24 +5967,29 @@ __global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, 
   float xl = Xa[0];
 #pragma unroll
   for (int i = 1; i < 12; ++i) xl = lane == i ? Xa[i] : xl;
+  // the correspondence counts of the cue slices, by slice index (lane = slice): the others keep what the state holds
+  int ncorr_s = ncorr_l;
+#pragma unroll
+  for (int z = 0; z < MAXS; ++z)
+    if (z < ns && lane == Sv[z].slice_idx) ncorr_s = keep_inl ? fin.ni[z] : fin.nc[z];
   // the state, for what reads it after compute() (k_icp_outputs, get_information, the next compute() of the handle)
   if (lane < 12) st->X[lane] = xl;
+  if (lane < SRRG2_MAX_SLICES) st->ncorr[lane] = ncorr_s;
   if (lane == 0) {
     st->status = status;
     if (finished) st->finished = 1;
-    st->ncorr[cue] = nc_cue;
   }
   // ProblemOut: X[12] | status | nstats | ncorr[SRRG2_MAX_SLICES] | H[36] | seq
   constexpr int W_STATUS = 12, W_NSTATS = 13, W_NCORR = 14, W_H = W_NCORR + SRRG2_MAX_SLICES, W_SEQ = W_H + 36;
   static_assert(offsetof(ProblemOut, status) == 4 * W_STATUS && offsetof(ProblemOut, ncorr) == 4 * W_NCORR &&
                   offsetof(ProblemOut, H) == 4 * W_H && offsetof(ProblemOut, seq) == 4 * W_SEQ && W_SEQ < 64,
                 "one word of the record per lane");
-  const int ncorr_w = __shfl(ncorr_l, (lane - W_NCORR) & 63);
+  const int ncorr_w = __shfl(ncorr_s, (lane - W_NCORR) & 63);
   const float h_w   = (float) __shfl(fin.Hl, (lane - W_H) & 63);
   int word = __float_as_int(xl);
   if (lane == W_STATUS) word = status;
   if (lane == W_NSTATS) word = fin.nstats;
-  if (lane >= W_NCORR && lane < W_H) word = lane - W_NCORR == cue ? nc_cue : ncorr_w;
+  if (lane >= W_NCORR && lane < W_H) word = ncorr_w;
   if (lane >= W_H && lane < W_SEQ) word = lane - W_H < D * D ? __float_as_int(h_w) : __float_as_int(0.f);
   if (lane < W_SEQ) reinterpret_cast<int*>(&outs_host[prob])[lane] = word;
   {  // the iteration statistics, 8 words each: the earlier records from memory (earlier kernels wrote them), this step's from its lanes
@@ -5985,6 +6002,23 @@ __global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, 
   }
   __threadfence_system();
   if (lane == 0) *reinterpret_cast<volatile int*>(&outs_host[prob].seq) = C.seq;  // the host polls this word
+}
+template <int D, bool PRIORS>
+__global__ __launch_bounds__(64) void k_icp_final_wave(CtlParams C, SliceDev S, ProblemState* __restrict__ states,
+                                                        srrg2_iteration_stats* __restrict__ stats,
+                                                        ProblemOut* __restrict__ outs_host,
+                                                        srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
+  final_wave_body<D, 1, PRIORS>(C, &S, 1, states, stats, outs_host, stats_host, with_post);
+}
+// ... of a pack of projective slices that share one association (SE(3)).  A four-slice pack and the control parameters do not fit
+// one kernel's 4 KB of arguments: the parameters are read from their device copy (FusedCtl::ctl, written by this compute()'s
+// prologue: the same record but for the fields of the control launches -- epoch, parity --, which this kernel takes from the pack).
+template <bool PRIORS>
+__global__ __launch_bounds__(64) void k_icp_final_wave_pack(SlicePack P, int ns, ProblemState* __restrict__ states,
+                                                             srrg2_iteration_stats* __restrict__ stats,
+                                                             ProblemOut* __restrict__ outs_host,
+                                                             srrg2_iteration_stats* __restrict__ stats_host, int with_post) {
+  final_wave_body<6, 4, PRIORS>(*P.s[0].fc.ctl, P.s, ns, states, stats, outs_host, stats_host, with_post);
 }
 void launch_icp_final_wave(const CtlParams& C, const SliceDev& S, ProblemState* states, srrg2_iteration_stats* stats,
                            ProblemOut* outs_host, srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
@@ -6003,6 +6037,20 @@ void launch_icp_final_wave(const CtlParams& C, const SliceDev& S, ProblemState* 
       FINAL_WAVE_LAUNCH(6, false);
   }
 #undef FINAL_WAVE_LAUNCH
+}
+void launch_icp_final_wave_pack(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states,
+                                srrg2_iteration_stats* stats, ProblemOut* outs_host, srrg2_iteration_stats* stats_host,
+                                bool with_post, hipStream_t s) {
+  if (nslices <= 0 || nslices > 4) return;
+  SlicePack P;
+  for (int z = 0; z < 4; ++z) {
+    P.s[z]     = slices[z < nslices ? z : 0];
+    P.probs[z] = probs[z < nslices ? z : 0];
+  }
+  if (P.s[0].fc.prior_mask)
+    hipLaunchKernelGGL(k_icp_final_wave_pack<true>, dim3(1), dim3(64), 0, s, P, nslices, states, stats, outs_host, stats_host, with_post ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_icp_final_wave_pack<false>, dim3(1), dim3(64), 0, s, P, nslices, states, stats, outs_host, stats_host, with_post ? 1 : 0);
 }
 void launch_icp_control_final(const CtlParams& C, ProblemState* states, srrg2_iteration_stats* stats, ProblemOut* outs_host,
                                srrg2_iteration_stats* stats_host, bool with_post, hipStream_t s) {
