@@ -1263,6 +1263,20 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
       }
     }
   }
+  // (a pack of projective slices: the prologue rides in the z-buffer pass of the first iteration, k_proj_zbuf_fz_init)
+  if (fuse && fuse_proj && final_wave && K == 1 && first_cue >= 0 && nm_max_cue > 0 && !(C.tune & (1 << 23)) && !a->profile) {
+    fold_init = true;
+    for (int si : proj_group) {
+      const Slice* s = a->slices[si];
+      fold_init = fold_init && s->slots_zeroed >= 3 * K && s->slots_zeroed_at == (const void*) s->partials.p;
+    }
+    if (fold_init) {
+      fold_init = srrg2amd::make_init_inline(Ch[0], a->probs_host, a->guesses_host, a->tsize, &fold_inl);
+      for (int si = 0; si < nslices && fold_init; ++si)
+        if (C.slices[si].kind == SRRG2_SLICE_PRIOR && C.slices[si].prior_sets_initial_guess)
+          for (int i = 0; i < a->tsize; ++i) fold_inl.guess[i] = C.slices[si].prior_Z[i];
+    }
+  }
   for (Slice* sl : a->slices) sl->slots_zeroed = 0;  // (until this compute() has ended the same way)
   if (!fold_init)
     for (int h = 0; h < nhalves; ++h)
@@ -1415,7 +1429,10 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
             if (it == 0) pack[z].fc.prior_mask = 0;  // (as for the nearest-neighbour passes below)
           }
         if (proj_fused) {
-          srrg2amd::launch_proj_step_fused(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
+          const bool first_pass_init = fold_init && fuse_proj && slot0 == 0 && it == 0;
+          srrg2amd::launch_proj_step_fused(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream,
+                                           first_pass_init ? &Ch[0] : nullptr, first_pass_init ? &fold_inl : nullptr,
+                                           first_pass_init ? a->probs.p : nullptr);
           sdev[proj_group[0]].zbuf_parity ^= 1;  // (the one z-buffer that is used)
         } else {
           srrg2amd::launch_proj_step_pack(pack, pp, (int) proj_group.size(), a->states.p, K, nm_max, a->stream);
@@ -1609,9 +1626,12 @@ int run_compute(srrg2_aligner* a, int K, const int32_t* offsets /* K+1 or null f
                  (small ? SRRG2_PATH_ONE_WORKGROUP : 0) | (fuse && prior_mask ? SRRG2_PATH_PRIORS_FUSED : 0);
   // (k_icp_final_wave has left the slot sets of its problems zeroed: the next compute() of the handle may skip the k_icp_init launch)
   if (final_wave && final_launched && first_cue >= 0 && !small) {
-    Slice* s           = a->slices[first_cue];
-    s->slots_zeroed    = 3 * K;
-    s->slots_zeroed_at = (const void*) s->partials.p;
+    for (int si = 0; si < nslices; ++si) {  // (the one nearest-neighbour cue slice, or every slice of the projective pack)
+      if (si != first_cue && !(fuse_proj && std::find(proj_group.begin(), proj_group.end(), si) != proj_group.end())) continue;
+      Slice* s           = a->slices[si];
+      s->slots_zeroed    = 3 * K;
+      s->slots_zeroed_at = (const void*) s->partials.p;
+    }
   }
   return 0;
 }

@@ -60,7 +60,8 @@ void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* prob
 void launch_proj_records(const SliceDev& S0, const SliceDev& S, const ProblemDev* probs0, const ProblemDev* probs,
                          ProblemState* states, int K, int max_nm, bool rebuild, hipStream_t s);
 void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
-                            int max_nm, hipStream_t s);
+                            int max_nm, hipStream_t s,
+                            const CtlParams* init_C = nullptr, const InitInline* init_inl = nullptr, ProblemDev* probs_base = nullptr);
 void launch_corr_step(int dim, bool plane, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K,
                       int max_ncorr, hipStream_t s);
 void launch_proj_step(bool repro, const SliceDev& S, const ProblemDev* probs, ProblemState* states, int K, int max_nm,

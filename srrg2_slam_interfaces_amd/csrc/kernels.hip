@@ -2957,6 +2957,27 @@ __device__ __forceinline__ void fused_init_tail(const CtlParams& C, const InitIn
   pub_write_epoch(C.pub_epoch, prob, lane, 0u);
 }
 
+// ... for an aligner of SEVERAL cue slices (a pack of projective slices, k_proj_zbuf_fz_init): k_icp_init's one-thread body as it is
+// (the z-buffer kernel it rides in is not short of registers), the records staged in LDS for the wave that publishes them
+__device__ __forceinline__ void fused_init_tail_full(const CtlParams& C, const InitInline& inl, int prob, ProblemDev* __restrict__ probs,
+                                                     ProblemState* __restrict__ states) {
+  __shared__ unsigned init_gran_tail[SRRG2_MAX_SLICES][PUB_SLICE_GRANULES];
+  const int lane = threadIdx.x & 63;
+  if (C.ctl_dev && blockIdx.y == 0) {
+    const int* src = reinterpret_cast<const int*>(&C);
+    int* dst       = reinterpret_cast<int*>(C.ctl_dev);
+    for (int k = lane; k < (int) (sizeof(CtlParams) / sizeof(int)); k += 64) dst[k] = src[k];
+  }
+  if (lane == 0)
+    init_problem_thread0<true>(C, prob, nullptr, probs, states, nullptr, C.variable_kind == SRRG2_SE2_RIGHT ? 9 : 12, inl, init_gran_tail);
+  wave_lds_sync();
+  if (!C.pub) return;
+  for (int s = 0; s < C.nslices; ++s)
+    if (C.slices[s].kind != SRRG2_SLICE_PRIOR)
+      pub_store(C.pub + ((size_t) prob * SRRG2_MAX_SLICES + s) * PUB_SLICE_GRANULES + lane, (unsigned long long) init_gran_tail[s][lane]);
+  pub_write_epoch(C.pub_epoch, prob, lane, 0u);
+}
+
 // The search pass on the GRID (no cell neighbour lists yet: the first compute() on a new fixed cloud, a tracker's every frame)
 // with the control step of the previous iteration in its prologue (round 6).  Without the deferred-search queue: the open points
 // are finished inside the kernel (the queue's kernel and its counters belong to the control LAUNCH: run_compute keeps both for
@@ -4448,6 +4469,34 @@ __global__ __launch_bounds__(256) void k_proj_zbuf_fz(SlicePack P, int nslices, 
   const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
   atomicMin(&S.zbuf[((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols + pix], key);
 }
+// The z-buffer pass of the FIRST iteration of a compute() with the prologue inside (round 6, last; cnl_pass_body's FUSED = 3 for the
+// projective packs): the finder transform from the kernel arguments, the rest of k_icp_init's work -- all slices' records, state,
+// tables, the device copy of the control parameters -- by one wave of the block behind the last tile; the step kernel that follows
+// reads it behind the kernel boundary.  (One slice's record in the arguments instead of the pack: pack + parameters exceed 4 KB.)
+__global__ __launch_bounds__(256) void k_proj_zbuf_fz_init(SliceDev S, CtlParams C, InitInline inl, ProblemDev* __restrict__ probs,
+                                                          ProblemState* __restrict__ states) {
+  const int prob      = blockIdx.y;
+  const ProblemDev pd = inl.pd[S.slice_idx];
+  const int i         = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inr      = i < pd.nm;
+  float4 p            = make_float4(NAN, 0.f, 0.f, 0.f);
+  if (inr) p = S.mpts[pd.moff + i];
+  float X[12], T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) X[k] = inl.guess[k];
+  finder_transform_of(C.slices[S.slice_idx].Sinv, 3, X, T);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) fused_init_tail_full(C, inl, prob, probs, states);
+  if (!inr) return;
+  if (!finite3(p.x, p.y, p.z)) return;
+  const float qx = ((T[0] * p.x + T[1] * p.y) + T[2] * p.z) + T[3];
+  const float qy = ((T[4] * p.x + T[5] * p.y) + T[6] * p.z) + T[7];
+  const float qz = ((T[8] * p.x + T[9] * p.y) + T[10] * p.z) + T[11];
+  float u, v;
+  const int pix = project_point(S, qx, qy, qz, u, v);
+  if (pix < 0) return;
+  const unsigned long long key = ((unsigned long long) __float_as_uint(qz) << 32) | (unsigned) __float_as_int(p.w);
+  atomicMin(&S.zbuf[((size_t) S.zbuf_parity * gridDim.y + prob) * S.rows * S.cols + pix], key);
+}
 __global__ __launch_bounds__(256) void k_proj_zbuf_last(SliceDev S, const ProblemDev* __restrict__ probs,
                                                         ProblemState* __restrict__ states) {
   proj_zbuf_body<true>(S, probs, states);
@@ -5828,7 +5877,7 @@ void launch_proj_step_pack(const SliceDev* slices, const ProblemDev* const* prob
 
 // the projective slices of one aligner that share clouds and finder parameters: ONE z-buffer pass, ONE step launch
 void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* probs, int nslices, ProblemState* states, int K,
-                            int max_nm, hipStream_t s) {
+                            int max_nm, hipStream_t s, const CtlParams* init_C, const InitInline* init_inl, ProblemDev* probs_base) {
   if (K <= 0 || max_nm <= 0 || nslices <= 0 || nslices > 4) return;
   SlicePack P;
   for (int z = 0; z < 4; ++z) {
@@ -5836,6 +5885,11 @@ void launch_proj_step_fused(const SliceDev* slices, const ProblemDev* const* pro
     P.probs[z] = probs[z < nslices ? z : 0];
   }
   dim3 grid(icp_step_blocks(max_nm), K);
+  if (P.s[0].fc.pub && init_C && init_inl && probs_base) {  // the first iteration of a compute() with the prologue inside
+    hipLaunchKernelGGL(k_proj_zbuf_fz_init, dim3(grid.x + 1, K), dim3(256), 0, s, P.s[0], *init_C, *init_inl, probs_base, states);
+    hipLaunchKernelGGL(k_icp_step_proj_fused<true>, grid, dim3(256), 0, s, P, nslices, states);
+    return;
+  }
   if (P.s[0].fc.pub) {  // fused control steps
     if (P.s[0].fc.prior_mask)
       hipLaunchKernelGGL(k_proj_zbuf_fz<true>, grid, dim3(256), 0, s, P, nslices, states);

@@ -526,3 +526,54 @@ def test_prologue_inside_the_first_pass_of_a_small_batch(oracle, product):
                 assert r["moving_in_fixed"].tobytes() == g["moving_in_fixed"].tobytes(), knobs
                 assert r["last"] == g["last"] and r["num_correspondences"] == g["num_correspondences"], knobs
                 assert np.asarray(r["information"]).tobytes() == np.asarray(g["information"]).tobytes(), knobs
+
+
+@pytest.mark.parametrize("with_prior", [False, True])
+def test_prologue_inside_the_z_buffer_pass_of_a_projective_pack(oracle, product, with_prior):
+    """... and for projective slices that share one association (C3's shape): from the handle's second compute() on the z-buffer pass
+    of the first iteration carries the prologue (k_proj_zbuf_fz_init), and the last step of every compute() is one wave
+    (k_icp_final_wave_pack).  Three computes with different guesses, an inlier-only run, optionally a motion-model prior that overrides
+    the guess: the oracle's bits, the path asserted."""
+    kind = abi.SE3_QUAT_RIGHT
+    r = syn.rgbd_pair(rows=120, cols=160, seed=3100)
+    Z = syn.se3(np.array([0.03, 0.01, -0.02]), np.deg2rad([0.4, 0.9, -0.6])).astype(np.float32)
+    guesses = [syn.identity(3), syn.se3(np.array([0.01, -0.01, 0.0]), np.deg2rad([0.2, 0.0, -0.1])).astype(np.float32), syn.identity(3)]
+
+    def script(al):
+        al.set_params(max_iterations=8, min_num_inliers=10, enable_inlier_only_runs=True)
+        first = None
+        for sk in (abi.SLICE_P2PLANE, abi.SLICE_REPROJECTION):
+            c = abi.default_slice_config(kind)
+            c.kind, c.finder, c.finder_max_distance = sk, abi.FINDER_PROJECTIVE, 0.05
+            c.robustifier, c.robustifier_chi_threshold = abi.ROBUST_CAUCHY, 0.05 if sk == abi.SLICE_P2PLANE else 4.0
+            for i, v in enumerate(r["K"].reshape(-1)):
+                c.camera_matrix[i] = v
+            c.image_rows, c.image_cols, c.depth_min, c.depth_max = r["rows"], r["cols"], r["depth_min"], r["depth_max"]
+            si = al.add_slice(c)
+            if first is None or isinstance(al, oracle.OracleAligner):
+                al.set_fixed(si, r["fixed"], r["fixed_normals"])
+                al.set_moving(si, r["moving"], r["moving_normals"])
+                first = si if first is None else first
+            else:
+                al.share_clouds(si, first)
+        if with_prior:
+            pi = al.add_slice(prior_config(kind, info=[50, 50, 50, 500, 500, 500], sets_guess=1))
+            al.set_prior_measurement(pi, Z)
+        for g in guesses:
+            al.set_moving_in_fixed(g)
+            al.compute()
+            yield (first, first + 1)
+
+    for knobs in ({"fused_control": 1}, {"fused_control": 1, "strategy_mask": 1 << 23}, {"fused_control": 1, "strategy_mask": 1 << 25}):
+        ref, got = oracle.OracleAligner(kind), product.MultiAligner(kind)
+        got.set_tuning(**knobs)
+        for k, (cues, _) in enumerate(zip(script(ref), script(got))):
+            assert ref.status() == abi.SUCCESS
+            assert_same_run(ref, got, slices=cues)
+            assert got.information().tobytes() == ref.information().tobytes()
+            path = got.last_compute_path()
+            if "strategy_mask" not in knobs:
+                assert path & abi.PATH_FINAL_WAVE, (k, path)
+                assert bool(path & abi.PATH_PROLOGUE_IN_PASS) == (k > 0), (k, path)
+            else:
+                assert not path & abi.PATH_PROLOGUE_IN_PASS, (k, knobs, path)
