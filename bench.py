@@ -530,7 +530,8 @@ def rocprof_pass_split(workload):
     rows = []
     for line in open(path):
         f = [x.strip() for x in line.split("|")]
-        if len(f) == 5 and f[1].isdigit() and any(k in f[0] for k in ("k_icp_step_fast<", "k_icp_step_cnl<", "k_icp_step_cnl_init<", "k_icp_step_proj_fused<", "k_proj_zbuf_fz")):
+        if len(f) == 5 and f[1].isdigit() and any(k in f[0] for k in ("k_icp_step_fast<", "k_icp_step_cnl<", "k_icp_step_cnl_init<", "k_icp_step_proj_fused<", "k_proj_zbuf_fz")) \
+                and "k_proj_zbuf_fz_init" not in f[0]:  # (the first iteration's z-buffer pass, prologue inside: one launch of eleven)
             rows.append((f[0].replace("void ", "").split("(")[0], int(f[1]), float(f[3])))
     if not rows:
         return None
